@@ -1,0 +1,224 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  Not product code.
+
+CPU fp32 restatement of the reference's DiT denoise path, written as plain
+functions over a `state_dict`-keyed mapping of tensors.  Only `tests/`,
+`__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this
+module, and only as the checker / the reported CPU baseline.  The product
+(`ditto_tts_amd/`) never imports it and has no CPU fallback.
+
+Parity status: PINNED BY IMPORT.  The reference ships no tests or golden vectors
+(SURVEY.md §4), so this restatement is pinned by executing the reference's own
+modules in the build container on synthetic inputs (tests/golden/make_golden.py,
+which imports /root/reference/src) and committing the outputs under
+tests/golden/*.npz; tests/test_oracle_golden.py checks this file against those
+fixtures everywhere, and tests/test_oracle_vs_reference.py checks it against the
+live reference wherever /root/reference exists.  `SpeechGenerator` cannot be
+imported (torchaudio / BigVGAN missing), so its ~20 lines of sampler arithmetic
+(src/model/SpeechGenerator.py:70-72,130-164) are restated here and pinned only
+through the imported `DiTTO.forward` + this restated update ("parity unpinned by
+the reference" for those 4 elementwise lines).
+
+Third-party arithmetic on the path: torch (reference pins torch==2.5.1,
+requirements.txt:62; this image has 2.10.0) — F.linear, softmax, layer_norm,
+gelu(erf), sigmoid, silu and nn.MultiheadAttention, whose math is restated from
+torch/nn/functional.py `multi_head_attention_forward` (packed in-projection,
+q * sqrt(1/E_head), bmm, softmax, bmm, out-proj).
+
+Every function cites the reference file:line it follows.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Mapping, Optional
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+LN_EPS = 1e-5  # nn.LayerNorm default, src/components/DiT.py:23,84,89,94
+
+
+# --------------------------------------------------------------------------- #
+# RotaryEmbedding                                     src/components/DiT.py:43-72
+# --------------------------------------------------------------------------- #
+def rotary_inv_freq(head_dim: int) -> Tensor:
+    """src/components/DiT.py:49"""
+    return 1.0 / (10000 ** (torch.arange(0, head_dim, 2).float() / head_dim))
+
+
+def rotary_table(inv_freq: Tensor, seq_len: int) -> Tensor:
+    """RotaryEmbedding.forward, src/components/DiT.py:56-59 -> [seq_len, head_dim]."""
+    t = torch.arange(seq_len).type_as(inv_freq)
+    freqs = torch.outer(t, inv_freq)                       # einsum("i,j->ij")
+    return torch.cat((freqs, freqs), dim=-1)
+
+
+def rotate_half(x: Tensor) -> Tensor:
+    """src/components/DiT.py:52-54"""
+    x1, x2 = x.chunk(2, dim=-1)
+    return torch.cat((-x2, x1), dim=-1)
+
+
+def apply_rope(pos: Tensor, t: Tensor) -> Tensor:
+    """src/components/DiT.py:61-72; t is [B, N, H, dh], pos is [N, dh]."""
+    pos = pos.unsqueeze(0).unsqueeze(2)
+    return t * pos.cos() + rotate_half(t) * pos.sin()
+
+
+# --------------------------------------------------------------------------- #
+# GlobalAdaLN                                          src/components/DiT.py:8-40
+# --------------------------------------------------------------------------- #
+def global_adaln(sd: Mapping[str, Tensor], x: Tensor, time_emb: Tensor, text_emb: Tensor,
+                 prefix: str = "ada_ln.") -> Tensor:
+    pooled = torch.mean(text_emb, dim=1)                                              # :27 (no mask)
+    tm = F.linear(F.silu(time_emb), sd[prefix + "time_mlp.1.weight"], sd[prefix + "time_mlp.1.bias"])
+    xm = F.linear(F.silu(pooled), sd[prefix + "text_mlp.1.weight"], sd[prefix + "text_mlp.1.bias"])
+    time_scale, time_shift = tm.chunk(2, dim=-1)                                      # :30
+    text_scale, text_shift = xm.chunk(2, dim=-1)                                      # :31
+    scale = 1 + time_scale + text_scale                                               # :34
+    shift = time_shift + text_shift                                                   # :35
+    x = F.layer_norm(x, (x.shape[-1],), None, None, LN_EPS)                           # :38 (no affine)
+    return x * scale.unsqueeze(1) + shift.unsqueeze(1)                                # :39
+
+
+# --------------------------------------------------------------------------- #
+# DiT block                                          src/components/DiT.py:100-157
+# --------------------------------------------------------------------------- #
+def dit_block(sd: Mapping[str, Tensor], prefix: str, x: Tensor, text_emb: Tensor, rotary_pos: Tensor,
+              num_heads: int, taps: Optional[Dict[str, Tensor]] = None,
+              dropout_p: float = 0.0) -> Tensor:
+    B, N, d = x.shape
+    dh = d // num_heads
+    T = text_emb.shape[1]
+
+    # ---- self-attention with RoPE (:103-139); NO out_proj ----
+    residual = x
+    u = F.layer_norm(x, (d,), sd[prefix + "norm1.weight"], sd[prefix + "norm1.bias"], LN_EPS)
+    w, b = sd[prefix + "attn.in_proj_weight"], sd[prefix + "attn.in_proj_bias"]
+    q = F.linear(u, w[:d], b[:d])                                                     # :112
+    k = F.linear(u, w[d:2 * d], b[d:2 * d])                                           # :113
+    v = F.linear(u, w[2 * d:], b[2 * d:])                                             # :114
+    q = q.view(B, N, num_heads, dh)                                                   # :117-119
+    k = k.view(B, N, num_heads, dh)
+    v = v.view(B, N, num_heads, dh)
+    q = apply_rope(rotary_pos, q)                                                     # :122
+    k = apply_rope(rotary_pos, k)                                                     # :123
+    q, k, v = (z.permute(0, 2, 1, 3) for z in (q, k, v))                              # :126-128
+    scores = torch.matmul(q, k.transpose(-2, -1)) / math.sqrt(dh)                     # :131-132
+    attn = torch.softmax(scores, dim=-1)                                              # :133
+    o = torch.matmul(attn, v)                                                         # :134
+    x = o.permute(0, 2, 1, 3).reshape(B, N, d) + residual                             # :137-139
+    if taps is not None:
+        taps[prefix + "after_self"] = x
+
+    # ---- cross-attention (:141-148) = nn.MultiheadAttention.forward, seq-first ----
+    residual = x
+    u = F.layer_norm(x, (d,), sd[prefix + "norm2.weight"], sd[prefix + "norm2.bias"], LN_EPS)
+    w, b = sd[prefix + "cross_attn.in_proj_weight"], sd[prefix + "cross_attn.in_proj_bias"]
+    qc = F.linear(u, w[:d], b[:d])                       # functional.py _in_projection_packed (q is not k)
+    kc = F.linear(text_emb, w[d:2 * d], b[d:2 * d])
+    vc = F.linear(text_emb, w[2 * d:], b[2 * d:])
+    qc = qc.view(B, N, num_heads, dh).permute(0, 2, 1, 3)
+    kc = kc.view(B, T, num_heads, dh).permute(0, 2, 1, 3)
+    vc = vc.view(B, T, num_heads, dh).permute(0, 2, 1, 3)
+    qc = qc * math.sqrt(1.0 / float(dh))                 # functional.py: q_scaled = q * sqrt(1/E_head)
+    ac = torch.softmax(torch.matmul(qc, kc.transpose(-2, -1)), dim=-1)   # no key-padding mask (SURVEY B-4)
+    if dropout_p > 0.0:
+        ac = F.dropout(ac, p=dropout_p)                  # only in train mode (DiT.py:90-91)
+    oc = torch.matmul(ac, vc).permute(0, 2, 1, 3).reshape(B, N, d)
+    oc = F.linear(oc, sd[prefix + "cross_attn.out_proj.weight"], sd[prefix + "cross_attn.out_proj.bias"])
+    x = oc + residual                                                                 # :148
+    if taps is not None:
+        taps[prefix + "after_cross"] = x
+
+    # ---- gated MLP (:150-155); nn.GELU() default = exact erf form (:96) ----
+    residual = x
+    u = F.layer_norm(x, (d,), sd[prefix + "norm3.weight"], sd[prefix + "norm3.bias"], LN_EPS)
+    h = F.gelu(F.linear(u, sd[prefix + "mlp_fc1.weight"], sd[prefix + "mlp_fc1.bias"]))
+    g = torch.sigmoid(F.linear(u, sd[prefix + "gate.weight"], sd[prefix + "gate.bias"]))
+    x = F.linear(h * g, sd[prefix + "mlp_fc2.weight"], sd[prefix + "mlp_fc2.bias"]) + residual
+    if taps is not None:
+        taps[prefix + "after_mlp"] = x
+    return x
+
+
+# --------------------------------------------------------------------------- #
+# DiTTO.forward                                          src/model/DiTTO.py:66-94
+# --------------------------------------------------------------------------- #
+def time_embedding(sd: Mapping[str, Tensor], t: Tensor) -> Tensor:
+    e = sd["t_embedding.weight"][t]                                                   # :75
+    e = F.linear(e, sd["time_embed.0.weight"], sd["time_embed.0.bias"])               # :76
+    return F.linear(F.silu(e), sd["time_embed.2.weight"], sd["time_embed.2.bias"])
+
+
+def ditto_forward(sd: Mapping[str, Tensor], num_layers: int, num_heads: int, x: Tensor, text_emb: Tensor,
+                  t: Tensor, taps: Optional[Dict[str, Tensor]] = None) -> Tensor:
+    temb = time_embedding(sd, t)                                                      # :75-76
+    rotary_pos = rotary_table(sd["rotary.inv_freq"], x.shape[1])                      # :79-80
+    x_skip = F.linear(x, sd["proj_in.weight"], sd["proj_in.bias"])                    # :83 (RAW input)
+    h = global_adaln(sd, x, temb, text_emb)                                           # :86
+    if taps is not None:
+        taps["after_adaln"] = h
+    for l in range(num_layers):                                                       # :89-90
+        h = dit_block(sd, f"blocks.{l}.", h, text_emb, rotary_pos, num_heads, taps)
+    return x_skip + F.linear(h, sd["proj_out.weight"], sd["proj_out.bias"])           # :93-94
+
+
+# --------------------------------------------------------------------------- #
+# schedule, q_sample                                    src/model/DiTTO.py:96-126
+# --------------------------------------------------------------------------- #
+def cosine_beta_schedule(timesteps: int, s: float = 0.008) -> Tensor:
+    """src/model/DiTTO.py:96-104 (returns CLIPPED BETAS, despite the variable names)."""
+    steps = timesteps + 1
+    x = torch.linspace(0, timesteps, steps)
+    alphas_cumprod = torch.cos(((x / timesteps) + s) / (1 + s) * torch.pi * 0.5) ** 2
+    alphas_cumprod = alphas_cumprod / alphas_cumprod[0]
+    betas = 1 - (alphas_cumprod[1:] / alphas_cumprod[:-1])
+    return torch.clip(betas, 0.0001, 0.9999)
+
+
+def q_sample(alphas_cumprod_buffer: Tensor, x_start: Tensor, t: Tensor, noise: Tensor) -> Tensor:
+    """src/model/DiTTO.py:106-126, bug-for-bug: the buffer holds betas."""
+    t = t.long()
+    a = alphas_cumprod_buffer[t] ** 0.5
+    b = (1 - alphas_cumprod_buffer[t]) ** 0.5
+    return a.reshape(-1, 1, 1) * x_start + b.reshape(-1, 1, 1) * noise
+
+
+# --------------------------------------------------------------------------- #
+# sampler                                   src/model/SpeechGenerator.py:70-72,130-164
+# --------------------------------------------------------------------------- #
+def sampler_tables(timesteps: int):
+    """src/model/SpeechGenerator.py:70-72"""
+    betas = cosine_beta_schedule(timesteps)
+    alphas = 1.0 - betas
+    alphas_cumprod = torch.cumprod(alphas, dim=0)
+    return betas, alphas, alphas_cumprod
+
+
+def p_sample_update(x: Tensor, noise_pred: Tensor, t: Tensor, betas: Tensor, alphas: Tensor,
+                    alphas_cumprod: Tensor, noise: Tensor) -> Tensor:
+    """src/model/SpeechGenerator.py:137-145"""
+    beta_t = betas[t].view(-1, 1, 1)
+    alpha_t = alphas[t].view(-1, 1, 1)
+    alpha_cumprod_t = alphas_cumprod[t].view(-1, 1, 1)
+    mask = (t > 0).float().view(-1, 1, 1)
+    return (1 / torch.sqrt(alpha_t)) * (
+        x - (1 - alpha_t) / torch.sqrt(1 - alpha_cumprod_t) * noise_pred
+    ) + mask * torch.sqrt(beta_t) * noise
+
+
+def sample_latents(sd: Mapping[str, Tensor], num_layers: int, num_heads: int, x_init: Tensor, text_emb: Tensor,
+                   timesteps: int, noises, keep=()):
+    """src/model/SpeechGenerator.py:149-164 with the noise injected: `noises[i]` is the z of the
+    i-th executed step (i = 0 is t = timesteps-1).  Returns (x_final, {i: x after step i})."""
+    betas, alphas, ac = sampler_tables(timesteps)
+    x = x_init
+    kept = {}
+    for i, t_val in enumerate(reversed(range(timesteps))):                            # :161
+        t = torch.full((x.shape[0],), t_val, dtype=torch.long)                        # :162
+        eps = ditto_forward(sd, num_layers, num_heads, x, text_emb, t)                # :135
+        x = p_sample_update(x, eps, t, betas, alphas, ac, noises[i])                  # :137-145
+        if i in keep:
+            kept[i] = x.clone()
+    return x, kept

@@ -1,0 +1,81 @@
+"""Oracle (oracle/ditto_oracle.py) == golden vectors captured from the reference's own code
+(tests/golden/make_golden.py).  Runs everywhere, including the GPU box (no /root/reference needed).
+Tolerance: fp32 restatement vs reference rel-L2 <= 1e-5, max-abs <= 1e-4 at unit scale."""
+import torch
+
+from conftest import max_abs, rel_l2
+from ditto_tts_amd.config import DiTTOConfig
+from ditto_tts_amd.synth import hash_normal, synthetic_inputs, synthetic_state_dict
+from oracle import ditto_oracle as O
+
+RTOL = 1e-5
+
+
+def test_g1_block_segments_and_adaln(golden):
+    g = golden("G1_block_c1.npz")
+    cfg = DiTTOConfig(256, 1, 4, 256, 256, 50)
+    sd = synthetic_state_dict(cfg, seed=1)
+    x, text, t = synthetic_inputs(cfg, 1, 64, 64, seed=11)
+    assert torch.equal(x, g["x"]) and torch.equal(text, g["text"]) and torch.equal(t, g["t"])
+    temb = O.time_embedding(sd, t)
+    assert rel_l2(temb, g["temb"]) < RTOL
+    pos = O.rotary_table(sd["rotary.inv_freq"], 64)
+    assert torch.equal(pos, g["rotary_pos"])
+    h0 = O.global_adaln(sd, x, temb, text)
+    assert rel_l2(h0, g["after_adaln"]) < RTOL
+    taps = {}
+    out = O.ditto_forward(sd, 1, 4, x, text, t, taps)
+    for k in ("after_self", "after_cross", "after_mlp"):
+        assert rel_l2(taps["blocks.0." + k], g[k]) < RTOL, k
+        assert max_abs(taps["blocks.0." + k], g[k]) < 1e-4, k
+    assert rel_l2(out, g["out"]) < RTOL
+
+
+def test_g2_full_ditto_s(golden):
+    g = golden("G2_ditto_s.npz")
+    cfg = DiTTOConfig(768, 12, 12, 256, 768, 50)
+    sd = synthetic_state_dict(cfg, seed=2)
+    x, text, t = synthetic_inputs(cfg, 2, 128, 96, seed=22)
+    assert torch.equal(x.half(), g["x"]) and torch.equal(text.half(), g["text"])
+    taps = {}
+    out = O.ditto_forward(sd, 12, 12, x, text, t, taps)
+    for i in (0, 5, 11):
+        assert rel_l2(taps[f"blocks.{i}.after_mlp"], g[f"block{i}"]) < RTOL, i
+    assert rel_l2(out, g["out"]) < RTOL
+    assert max_abs(out, g["out"]) < 1e-4
+    # the fixture is a meaningful unit-scale signal, not a collapsed one
+    assert 0.3 < float(g["out"].std()) < 10.0
+
+
+def test_g3_shipped_one_head(golden):
+    g = golden("G3_shipped_1head.npz")
+    cfg = DiTTOConfig(768, 5, 1, 256, 768, 1000)
+    sd = synthetic_state_dict(cfg, seed=3)
+    x, text, t = synthetic_inputs(cfg, 1, 64, 64, seed=33)
+    out = O.ditto_forward(sd, 5, 1, x, text, t)
+    assert rel_l2(out, g["out"]) < RTOL
+
+
+def test_g4_schedule_and_qsample(golden):
+    g = golden("G4_schedule_qsample.npz")
+    assert torch.equal(O.cosine_beta_schedule(50), g["betas50"])
+    assert torch.equal(O.cosine_beta_schedule(1000), g["betas1000"])
+    # App. B-1: the `alphas_cumprod` buffer holds the clipped betas
+    assert torch.equal(g["buffer1000"], g["betas1000"])
+    x0, nz = hash_normal((3, 16, 768), "x0", 44), hash_normal((3, 16, 768), "qnoise", 44)
+    qs = O.q_sample(g["buffer1000"], x0, g["t"], nz)
+    assert rel_l2(qs, g["q_sample"]) < 1e-6
+
+
+def test_g5_sampler_trajectory(golden):
+    g = golden("G5_sampler_50.npz")
+    cfg = DiTTOConfig(256, 2, 4, 256, 256, 50)
+    sd = synthetic_state_dict(cfg, seed=5)
+    B, N, T, S = 2, 64, 32, 50
+    betas, alphas, ac = O.sampler_tables(S)
+    assert torch.equal(betas, g["betas"]) and torch.equal(alphas, g["alphas"])
+    assert torch.equal(ac, g["alphas_cumprod"])
+    noises = [hash_normal((B, N, 256), f"z{i}", 55) for i in range(S)]
+    x, kept = O.sample_latents(sd, 2, 4, g["xinit"], g["text"], S, noises, keep=(0, 1, 10, 49))
+    for i in (0, 1, 10, 49):
+        assert rel_l2(kept[i], g[f"x_step{i}"]) < 1e-4, i   # 50 chained steps of fp32 round-off
