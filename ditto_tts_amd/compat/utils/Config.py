@@ -1,0 +1,28 @@
+"""`utils.Config` under the reference's import name (reference src/utils/Config.py): the attribute bag the
+scripts and notebooks read (`ConfigDiTTO.HIDDEN_DIM`, `.DIFFUSION_STEPS`, ...), with the shipped values
+(5 layers, ONE head).  Only the attributes; the dataset paths and printing helpers of the
+reference are not part of the denoise path."""
+import torch
+
+
+class BaseConfig:
+    SAMPLE_RATE = 24000
+    MIN_AUDIO_DURATION = 10
+    MAX_AUDIO_DURATION = 20
+    DEVICE = "cuda" if torch.cuda.is_available() else "cpu"
+    BETAS = [0.9, 0.999]
+
+
+class ConfigDiTTO(BaseConfig):
+    MODEL_NAME = "DiTTO"
+    HIDDEN_DIM = 768
+    NUM_LAYERS = 5
+    NUM_HEADS = 1
+    TIME_DIM = 256
+    TEXT_EMBED_DIM = 768
+    DIFFUSION_STEPS = 1000
+    EPOCHS = 20
+    LEARNING_RATE = 1e-4
+    BATCH_SIZE = 8
+    MAX_TOKEN_LENGTH = 1024
+    NB_SAMPLES = 10000

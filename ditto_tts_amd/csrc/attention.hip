@@ -1,0 +1,355 @@
+// attention.hip — fused (flash-style) attention for gfx950, head_dim 64, bf16 in / fp32 accumulate,
+// plus a generic-head_dim fallback built from the GEMM family.
+//
+// Replaces  softmax(q k^T / sqrt(dh)) v  of the self-attention (reference src/components/DiT.py:131-134,
+// followed by the head merge + residual :137-139, NO out-proj) and of nn.MultiheadAttention's cross
+// attention (src/components/DiT.py:144-148 -> torch F.multi_head_attention_forward: q*sqrt(1/dh), bmm,
+// softmax, bmm).  No masks anywhere in the reference.  The [B,H,N,N] score matrix the
+// reference materialises is never written.
+//
+// Roofline: MFMA-bound; algorithmic FLOPs = 4*B*H*Sq*Skv*dh per launch.  K/V of one head at Skv = 4096 is
+// 1 MiB, so the Sq/128 workgroups of a (batch, head) — placed on ONE XCD by the block remap — re-read it
+// from that XCD's L2, not from HBM.
+//
+// Structure per workgroup (256 threads = 4 waves, 32 query rows per wave, 64-key tiles):
+//   * S^T = K * Q^T with v_mfma_f32_32x32x16_bf16 (K rows as the A operand from LDS, Q^T as the B operand
+//     held in 16 registers for the whole kernel): the accumulator has the QUERY on the lane and 16 keys
+//     in registers, so the row max / row sum are in-lane plus one exchange with lane^32.
+//   * P^T stays in registers: packed to bf16 it IS the B operand of the next product
+//     O^T += V^T * P^T (guide §3 "an accumulator tile as the next MFMA's operand"; the k-order
+//     inside a step is permuted, and V^T is fetched with the same permutation).
+//   * V^T fragments come from the row-major V tile in LDS via ds_read_b64_tr_b16 (hardware transpose).
+//   * K/V tiles: global -> registers (issued before the tile's math) -> LDS (written after it), two LDS
+//     buffers, one barrier per tile (T14 async-STAGE split).
+//   * LDS swizzles: K rows (128 B) chunk ^= (key>>1)&7 -> conflict-free ds_read_b128; V rows chunk ^=
+//     ((key>>1)&1)<<2 -> the 4 rows of a transposed-read block fall in 4 different 64-B bank quarters.
+//   * online softmax in the exp2 domain with fp32 running (max, sum); O^T rescale is a per-lane scalar.
+#include "common.h"
+#include "kernels.h"
+
+namespace ditto {
+
+namespace {
+
+constexpr int DH = 64, QBLK = 128, KBLK = 64;
+constexpr int KV_TILE_BYTES = KBLK * DH * 2;  // 8 KiB
+
+struct AttnParams {
+    const bf16* q; int ldq;
+    const bf16* k; int ldk;
+    const bf16* v; int ldv;
+    bf16* out; int ldo;
+    float* resid; int ldr;
+    int B, H, Sq, Skv, nqb;
+    float scale_log2;  // scale * log2(e)
+};
+
+typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+
+DITTO_DEV bf16x8 cat4(bf16x4 a, bf16x4 b) {
+    bf16x8 r;
+    r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+    r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+    return r;
+}
+
+template <bool RESID>
+__global__ __launch_bounds__(256) void attn64_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KV_TILE_BYTES];  // [buf][K|V]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwg = p.nqb * p.H * p.B;
+    const int id = xcd_remap(blockIdx.x, nwg);
+    const int qb = id % p.nqb, bh = id / p.nqb;
+    const int h = bh % p.H, b = bh / p.H;
+
+    const int ql = lane & 31, hh = lane >> 5;
+    const int q0 = qb * QBLK + wid * 32;
+    int qrow = q0 + ql;
+    const bool qvalid = qrow < p.Sq;
+    qrow = qvalid ? qrow : p.Sq - 1;
+
+    // Q^T B-operand fragments: lane holds Q[query ql][d = 16*ks + 8*hh + 0..7]
+    bf16x8 qf[4];
+    {
+        const bf16* qp = p.q + ((size_t)b * p.Sq + qrow) * p.ldq + h * DH + 8 * hh;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+    }
+
+    // K/V staging: thread owns chunks (key = tid>>3 [+32], c = tid&7)
+    const int skey = tid >> 3, sc = tid & 7;
+    const bf16* kbase = p.k + (size_t)b * p.Skv * p.ldk + h * DH + sc * 8;
+    const bf16* vbase = p.v + (size_t)b * p.Skv * p.ldv + h * DH + sc * 8;
+    u32x4 kreg[2], vreg[2];
+    auto load_kv = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int key = kt * KBLK + skey + 32 * i;
+            key = key < p.Skv ? key : p.Skv - 1;
+            kreg[i] = *reinterpret_cast<const u32x4*>(kbase + (size_t)key * p.ldk);
+            vreg[i] = *reinterpret_cast<const u32x4*>(vbase + (size_t)key * p.ldv);
+        }
+    };
+    auto write_kv = [&](int buf) {
+        char* kb = smem + buf * 2 * KV_TILE_BYTES;
+        char* vb = kb + KV_TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int key = skey + 32 * i;
+            *reinterpret_cast<u32x4*>(kb + key * 128 + ((sc ^ ((key >> 1) & 7)) << 4)) = kreg[i];
+            *reinterpret_cast<u32x4*>(vb + key * 128 + ((sc ^ (((key >> 1) & 1) << 2)) << 4)) = vreg[i];
+        }
+    };
+
+    // K A-operand read offsets: lane reads K[key = kb*32 + ql][chunk = 2*ks + hh]
+    const int k_row_off = ql * 128, k_swz = (ql >> 1) & 7;  // (kb*32 + ql)>>1 & 7 == (ql>>1)&7
+    // V^T transposed-read address pieces: group g = lane>>4 -> d half (g&1), key half hh; i = lane&15
+    const int tr_q = (lane & 15) >> 2, tr_p = lane & 3;
+    const int tr_colbyte = (16 * ((lane >> 4) & 1) + 4 * tr_p) * 2;  // + 64*dblk
+    const int tr_row0 = 4 * hh + tr_q;                               // + 16*s (+8)
+    // rows r = 16*s + {0,8} + 4*hh + tr_q  ->  (r>>1)&1 == (tr_q>>1)&1 (16s, 8, 4hh are multiples of 4)
+    const int tr_swz = ((tr_q >> 1) & 1) << 6;
+
+    f32x16 ot[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { ot[0][i] = 0.f; ot[1][i] = 0.f; }
+    float m_run = -1e30f, l_run = 0.f;
+    const float c = p.scale_log2;
+
+    const int nkt = (p.Skv + KBLK - 1) / KBLK;
+    load_kv(0);
+    write_kv(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const char* kb = smem + (kt & 1) * 2 * KV_TILE_BYTES;
+        const char* vb = kb + KV_TILE_BYTES;
+        if (kt + 1 < nkt) load_kv(kt + 1);
+
+        // ---- S^T[key][query] for the 64 keys of this tile ----
+        f32x16 st[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { st[0][i] = 0.f; st[1][i] = 0.f; }
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + kb2 * 32 * 128 + k_row_off +
+                                                                   (((2 * ks + hh) ^ k_swz) << 4));
+                st[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb2], 0, 0, 0);
+            }
+        if (kt == nkt - 1 && (p.Skv & (KBLK - 1))) {  // ragged last tile: mask keys >= Skv (wave-uniform branch)
+            const int kbase_idx = kt * KBLK + 4 * hh;
+#pragma unroll
+            for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kbase_idx + kb2 * 32 + (r & 3) + 8 * (r >> 2);
+                    if (key >= p.Skv) st[kb2][r] = -1e30f;
+                }
+        }
+
+        // ---- online softmax (this lane = one query; its other 32 keys live in lane^32) ----
+        float mloc = st[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, st[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[1][r]);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        const float mc = m_new * c;
+        m_run = m_new;
+        float psum = 0.f;
+        bf16x8 pf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                e[j] = __builtin_amdgcn_exp2f(st[s >> 1][8 * (s & 1) + j] * c - mc);
+                psum += e[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[s][j] = (bf16)e[j];
+        }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { ot[0][i] *= alpha; ot[1][i] *= alpha; }
+
+        // ---- O^T[d][query] += V^T[d][key] * P^T[key][query] ----
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const int colb = (tr_colbyte + 64 * db) ^ tr_swz;
+                const char* a0 = vb + (16 * s + tr_row0) * 128 + colb;
+                const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0));
+                const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0 + 8 * 128));
+                ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat4(v0, v1), pf[s], ot[db], 0, 0, 0);
+            }
+
+        if (kt + 1 < nkt) write_kv((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: normalise; lane (query ql, half hh) owns d = 32*db + 8*g + 4*hh + 0..3 ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (!qvalid) return;
+    const size_t grow = (size_t)b * p.Sq + qrow;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int col = h * DH + 32 * db + 8 * g + 4 * hh;
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = ot[db][4 * g + e] * inv;
+            if constexpr (RESID) {
+                float* rp = p.resid + grow * p.ldr + col;
+                f32x4 r = *reinterpret_cast<f32x4*>(rp);
+                r += o;  // x = attn_out + residual (src/components/DiT.py:139)
+                *reinterpret_cast<f32x4*>(rp) = r;
+            } else {
+                u32x2 st2;
+                st2[0] = pack_bf16x2(o[0], o[1]);
+                st2[1] = pack_bf16x2(o[2], o[3]);
+                *reinterpret_cast<u32x2*>(p.out + grow * p.ldo + col) = st2;
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic head_dim fallback pieces (e.g. the reference's shipped config: ONE head, dh = 768).
+// scores fp32 [Sq, ldS] -> P bf16 [Sq, ldS] = softmax(scores * scale) over the first Skv columns,
+// zeros in the padding columns.  One wave per row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, bf16* __restrict__ P, int Sq,
+                                                           int Skv, int ld, float scale_log2) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= Sq) return;
+    const float* s = S + (size_t)row * ld;
+    float m = -1e30f;
+    for (int j = lane; j < Skv; j += 64) m = fmaxf(m, s[j]);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int j = lane; j < Skv; j += 64) sum += __builtin_amdgcn_exp2f((s[j] - m) * scale_log2);
+    const float inv = 1.0f / wave_sum(sum);
+    bf16* pr = P + (size_t)row * ld;
+    for (int j = lane; j < ld; j += 64)
+        pr[j] = j < Skv ? (bf16)(__builtin_amdgcn_exp2f((s[j] - m) * scale_log2) * inv) : (bf16)0.f;
+}
+// Vt[dh, ldT] = V[Skv, dh]^T (zero padded to ldT columns); 32x32 LDS tile transpose.
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const bf16* __restrict__ V, int ldv, bf16* __restrict__ Vt,
+                                                            int ldT, int Skv, int dh) {
+    __shared__ bf16 tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int k0 = blockIdx.x * 32, d0 = blockIdx.y * 32;
+    for (int i = ty; i < 32; i += 8) {
+        const int key = k0 + i, dd = d0 + tx;
+        tile[i][tx] = (key < Skv && dd < dh) ? V[(size_t)key * ldv + dd] : (bf16)0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int dd = d0 + i, key = k0 + tx;
+        if (dd < dh && key < ldT) Vt[(size_t)dd * ldT + key] = tile[tx][i];
+    }
+}
+
+// in-place half-split RoPE on bf16 rows (generic head_dim): columns [0, ncols) are heads of width dh.
+__global__ __launch_bounds__(256) void rope_inplace_kernel(bf16* __restrict__ x, int ld, const float* __restrict__ cs,
+                                                           const float* __restrict__ sn, int M, int rpb, int ncols,
+                                                           int dh) {
+    const int half = dh >> 1;
+    const size_t npairs = (size_t)M * (ncols >> 1);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < npairs; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / (ncols >> 1)), pc = (int)(i % (ncols >> 1));
+        const int head = pc / half, j = pc % half;
+        const int pos = row % rpb;
+        bf16* pl = x + (size_t)row * ld + head * dh + j;
+        const float lo = (float)pl[0], hi = (float)pl[half];
+        const float cc = cs[(size_t)pos * half + j], ss = sn[(size_t)pos * half + j];
+        pl[0] = (bf16)(lo * cc - hi * ss);
+        pl[half] = (bf16)(hi * cc + lo * ss);
+    }
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace
+
+size_t attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh) {
+    (void)B; (void)H;
+    if (dh == DH) return 0;
+    const size_t ld = (size_t)((Skv + 63) / 64) * 64;
+    return align256((size_t)Sq * ld * 4) + align256((size_t)Sq * ld * 2) + align256((size_t)dh * ld * 2);
+}
+
+hipError_t launch_rope_inplace(void* x, int ld, const float* cs, const float* sn, int M, int rpb, int ncols, int dh,
+                               hipStream_t s) {
+    const size_t npairs = (size_t)M * (ncols / 2);
+    size_t g = (npairs + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(rope_inplace_kernel, dim3((unsigned)(g ? g : 1)), dim3(256), 0, s, (bf16*)x, ld, cs, sn, M, rpb,
+                       ncols, dh);
+    return hipGetLastError();
+}
+
+hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
+    if (a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Skv <= 0) return hipErrorInvalidValue;
+    const float LOG2E = 1.4426950408889634f;
+    if (a.dh == DH) {
+        if ((a.ldq | a.ldk | a.ldv) % 8) return hipErrorInvalidValue;
+        AttnParams p;
+        p.q = (const bf16*)a.q; p.ldq = a.ldq; p.k = (const bf16*)a.k; p.ldk = a.ldk;
+        p.v = (const bf16*)a.v; p.ldv = a.ldv; p.out = (bf16*)a.out_bf16; p.ldo = a.ldo;
+        p.resid = a.resid_f32; p.ldr = a.ldr; p.B = a.B; p.H = a.H; p.Sq = a.Sq; p.Skv = a.Skv;
+        p.nqb = (a.Sq + QBLK - 1) / QBLK;
+        p.scale_log2 = a.scale * LOG2E;
+        const dim3 grid(p.nqb * a.H * a.B), block(256);
+        if (a.resid_f32) hipLaunchKernelGGL((attn64_kernel<true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((attn64_kernel<false>), grid, block, 0, s, p);
+        return hipGetLastError();
+    }
+    // ---- generic head_dim: per (batch, head)  S = Q K^T (GEMM) -> row softmax -> O = P V (GEMM on V^T) ----
+    if (a.dh % 64) return hipErrorInvalidValue;
+    const int ld = ((a.Skv + 63) / 64) * 64;
+    if (a.workspace_bytes < attention_workspace_bytes(a.B, a.H, a.Sq, a.Skv, a.dh) || !a.workspace)
+        return hipErrorInvalidValue;
+    char* ws = (char*)a.workspace;
+    float* S = (float*)ws;
+    bf16* P = (bf16*)(ws + align256((size_t)a.Sq * ld * 4));
+    bf16* Vt = (bf16*)((char*)P + align256((size_t)a.Sq * ld * 2));
+    for (int b = 0; b < a.B; ++b)
+        for (int h = 0; h < a.H; ++h) {
+            const bf16* q = (const bf16*)a.q + (size_t)b * a.Sq * a.ldq + h * a.dh;
+            const bf16* k = (const bf16*)a.k + (size_t)b * a.Skv * a.ldk + h * a.dh;
+            const bf16* v = (const bf16*)a.v + (size_t)b * a.Skv * a.ldv + h * a.dh;
+            GemmArgs g1{};
+            g1.A = q; g1.lda = a.ldq; g1.W = k; g1.ldw = a.ldk; g1.out = S; g1.ldo = ld;
+            g1.M = a.Sq; g1.N = ld; g1.K = a.dh; g1.w_rows = a.Skv;
+            hipError_t e = launch_gemm(g1, EPI_BIAS_F32, s);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(softmax_rows_kernel, dim3((a.Sq + 3) / 4), dim3(256), 0, s, S, P, a.Sq, a.Skv, ld,
+                               a.scale * LOG2E);
+            hipLaunchKernelGGL(transpose_pad_kernel, dim3(ld / 32, (a.dh + 31) / 32), dim3(256), 0, s, v, a.ldv, Vt,
+                               ld, a.Skv, a.dh);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            GemmArgs g2{};
+            g2.A = P; g2.lda = ld; g2.W = Vt; g2.ldw = ld; g2.M = a.Sq; g2.N = a.dh; g2.K = ld; g2.w_rows = a.dh;
+            if (a.resid_f32) {
+                float* r = a.resid_f32 + (size_t)b * a.Sq * a.ldr + h * a.dh;
+                g2.residual = r; g2.ldr = a.ldr; g2.out = r; g2.ldo = a.ldr;
+                e = launch_gemm(g2, EPI_BIAS_RES_F32, s);
+            } else {
+                g2.out = (bf16*)a.out_bf16 + (size_t)b * a.Sq * a.ldo + h * a.dh; g2.ldo = a.ldo;
+                e = launch_gemm(g2, EPI_BIAS_BF16, s);
+            }
+            if (e != hipSuccess) return e;
+        }
+    return hipSuccess;
+}
+
+}  // namespace ditto

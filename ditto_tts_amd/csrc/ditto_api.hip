@@ -1,0 +1,586 @@
+// ditto_api.hip — the C-ABI of libditto_hip.so (include/ditto_hip.h): model handle, weight packing,
+// the stream-ordered launch sequence of one DiTTO.forward, the sampler update.
+//
+// HBM layout (one contiguous caller-owned arena per model, one workspace per (B,N,T), one cond buffer
+// per utterance batch).  All offsets 256-byte aligned.
+//   arena     : per layer { Wqkv bf16[3d,d] | Wcq bf16[d,d] | Wco bf16[d,d] | W1g bf16[8d,d] (fc1/gate rows
+//               interleaved in blocks of 16) | W2 bf16[d,4d] | biases + LN gamma/beta fp32 },
+//               Wkv_all bf16[L*2d, d] (cross-attn K,V projections of every layer), Wfin bf16[d, 2d]
+//               ([proj_in | proj_out] along K), time table fp32[steps, 2d], text_mlp fp32, inv_freq.
+//   cond      : kv_cache bf16[B*T, L*2d] (layer l: K at cols l*2d.., V at l*2d+d..) | tmod fp32[B, 2d]
+//   workspace : h fp32[M,d] (residual stream) | u bf16[M,d] | qkv bf16[M,3d] | act bf16[M,4d] |
+//               xcat bf16[M,2d] ([bf16(x_raw) | bf16(h_L)]) | eps fp32[M,d] | attention scratch
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <vector>
+
+#include "../../include/ditto_hip.h"
+#include "kernels.h"
+
+using namespace ditto;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) return fail(DITTO_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e));      \
+    } while (0)
+
+inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct LayerPack {
+    const void *Wqkv, *Wcq, *Wco, *W1g, *W2;
+    const float *bqkv, *bcq, *bco, *b1g, *b2;
+    const float *g1, *be1, *g2, *be2, *g3, *be3;
+};
+
+struct ArenaPlan {
+    size_t total = 0;
+    struct L { size_t Wqkv, Wcq, Wco, W1g, W2, bqkv, bcq, bco, b1g, b2, g1, be1, g2, be2, g3, be3; };
+    std::vector<L> layers;
+    size_t Wkv, bkv, Wfin, bfin, ttab, wx, bx, invf;
+};
+
+ArenaPlan plan_arena(const ditto_config& c) {
+    ArenaPlan p;
+    const size_t d = c.hidden_dim, L = c.num_layers;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
+    p.layers.resize(L);
+    for (size_t l = 0; l < L; ++l) {
+        auto& q = p.layers[l];
+        q.Wqkv = take(3 * d * d * 2); q.Wcq = take(d * d * 2); q.Wco = take(d * d * 2);
+        q.W1g = take(8 * d * d * 2); q.W2 = take(4 * d * d * 2);
+        q.bqkv = take(3 * d * 4); q.bcq = take(d * 4); q.bco = take(d * 4); q.b1g = take(8 * d * 4); q.b2 = take(d * 4);
+        q.g1 = take(d * 4); q.be1 = take(d * 4); q.g2 = take(d * 4); q.be2 = take(d * 4); q.g3 = take(d * 4);
+        q.be3 = take(d * 4);
+    }
+    p.Wkv = take(L * 2 * d * d * 2); p.bkv = take(L * 2 * d * 4);
+    p.Wfin = take(d * 2 * d * 2); p.bfin = take(d * 4);
+    p.ttab = take((size_t)c.diffusion_steps * 2 * d * 4);
+    p.wx = take(2 * d * (size_t)c.text_dim * 4); p.bx = take(2 * d * 4);
+    p.invf = take((d / c.num_heads / 2) * 4);
+    p.total = off;
+    return p;
+}
+
+struct WsPlan { size_t h, u, qkv, act, xcat, eps, attn, attn_bytes, total; };
+
+// ditto_text_precompute scratch (front of the same workspace): bf16(text) | pooled fp32
+inline size_t text_scratch_bytes(const ditto_config& c, int B, int T) {
+    return al((size_t)B * T * c.text_dim * 2) + al((size_t)B * c.text_dim * 4);
+}
+
+WsPlan plan_ws(const ditto_config& c, int B, int N, int T) {
+    WsPlan w;
+    const size_t d = c.hidden_dim, M = (size_t)B * N, dh = d / c.num_heads;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
+    w.h = take(M * d * 4); w.u = take(M * d * 2); w.qkv = take(M * 3 * d * 2); w.act = take(M * 4 * d * 2);
+    w.xcat = take(M * 2 * d * 2); w.eps = take(M * d * 4);
+    const size_t a1 = attention_workspace_bytes(B, c.num_heads, N, N, (int)dh);
+    const size_t a2 = attention_workspace_bytes(B, c.num_heads, N, T, (int)dh);
+    w.attn_bytes = a1 > a2 ? a1 : a2;
+    w.attn = take(w.attn_bytes);
+    const size_t tneed = text_scratch_bytes(c, B, T);
+    w.total = off > tneed ? off : tneed;
+    return w;
+}
+
+int check_cfg(const ditto_config* c) {
+    if (!c) return fail(DITTO_ERR_ARG, "config is null");
+    if (c->hidden_dim <= 0 || c->num_layers <= 0 || c->num_heads <= 0 || c->time_dim <= 0 || c->diffusion_steps <= 0)
+        return fail(DITTO_ERR_SHAPE, "non-positive config field");
+    if (c->hidden_dim % c->num_heads) return fail(DITTO_ERR_SHAPE, "hidden_dim %% num_heads != 0");
+    if (c->text_dim != c->hidden_dim)
+        return fail(DITTO_ERR_SHAPE, "text_dim (%d) must equal hidden_dim (%d): reference cross-attn has no kdim/vdim",
+                    c->text_dim, c->hidden_dim);
+    if (c->hidden_dim % 64) return fail(DITTO_ERR_SHAPE, "hidden_dim must be a multiple of 64 (MFMA K tile)");
+    if (c->hidden_dim > 2048) return fail(DITTO_ERR_SHAPE, "hidden_dim > 2048 not supported by the LayerNorm kernel");
+    const int dh = c->hidden_dim / c->num_heads;
+    if (dh % 64) return fail(DITTO_ERR_SHAPE, "head_dim (%d) must be a multiple of 64", dh);
+    return DITTO_OK;
+}
+
+}  // namespace
+
+struct ditto_model {
+    ditto_config cfg;
+    ArenaPlan plan;
+    char* arena;
+    std::vector<LayerPack> layers;
+    const void* Wkv; const float* bkv; const void* Wfin; const float* bfin;
+    const float* ttab; const float* wx; const float* bx; const float* invf;
+    bool blocks_only = false;    // created without the model-level weights: only ditto_block_forward works
+    // profiling
+    bool prof = false;
+    struct Rec { hipEvent_t a, b; int kc; };
+    std::vector<Rec> recs;       // pending, un-synchronised
+    std::vector<hipEvent_t> pool;
+    int32_t launches[DITTO_KC_COUNT] = {0};
+    float ms[DITTO_KC_COUNT] = {0};
+};
+
+namespace {
+
+struct ProfScope {
+    ditto_model* m; hipStream_t s; int kc; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(ditto_model* m_, hipStream_t s_, int kc_) : m(m_), s(s_), kc(kc_) {
+        if (!m->prof) return;
+        a = take(); b = take();
+        if (a) (void)hipEventRecord(a, s);
+    }
+    hipEvent_t take() {
+        if (!m->pool.empty()) { hipEvent_t e = m->pool.back(); m->pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
+    ~ProfScope() {
+        if (!m->prof || !a || !b) return;
+        (void)hipEventRecord(b, s);
+        m->recs.push_back({a, b, kc});
+    }
+};
+
+}  // namespace
+
+// One DiT block (reference src/components/DiT.py:100-157) on the fp32 residual stream `h`, in place.
+static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* act, char* xcat_or_null,
+                     void* attn_ws, size_t attn_ws_bytes, const char* kv, int kv_layer, int kv_ld,
+                     const float* rope_cos, const float* rope_sin, int B, int N, int T, hipStream_t s) {
+    const ditto_config& c = m->cfg;
+    const int d = c.hidden_dim, H = c.num_heads, dh = d / H, M = B * N;
+    const float scale = 1.0f / sqrtf((float)dh);
+    const bool fused_rope = (dh == 64);
+    const LayerPack& lp = m->layers[l];
+        // ---- self-attention (src/components/DiT.py:103-139) ----
+        { ProfScope ps(m, s, DITTO_KC_LAYERNORM); HIP_TRY(launch_layernorm(h, lp.g1, lp.be1, u, d, M, d, s)); }
+        {
+            ProfScope ps(m, s, DITTO_KC_GEMM_QKV);
+            GemmArgs g{};
+            g.A = u; g.lda = d; g.W = lp.Wqkv; g.bias = lp.bqkv; g.out = qkv; g.ldo = 3 * d;
+            g.M = M; g.N = 3 * d; g.K = d;
+            g.rope_cos = rope_cos; g.rope_sin = rope_sin; g.rope_rows_per_batch = N; g.rope_cols = 2 * d;
+            HIP_TRY(launch_gemm(g, fused_rope ? EPI_QKV_ROPE : EPI_BIAS_BF16, s));
+            if (!fused_rope) HIP_TRY(launch_rope_inplace(qkv, 3 * d, rope_cos, rope_sin, M, N, 2 * d, dh, s));
+        }
+        {
+            ProfScope ps(m, s, DITTO_KC_ATTN_SELF);
+            AttnArgs a{};
+            a.q = qkv; a.ldq = 3 * d; a.k = qkv + (size_t)d * 2; a.ldk = 3 * d; a.v = qkv + (size_t)2 * d * 2;
+            a.ldv = 3 * d; a.resid_f32 = h; a.ldr = d; a.B = B; a.H = H; a.Sq = N; a.Skv = N; a.dh = dh;
+            a.scale = scale; a.workspace = attn_ws; a.workspace_bytes = attn_ws_bytes;
+            HIP_TRY(launch_attention(a, s));
+        }
+        // ---- cross-attention (src/components/DiT.py:141-148), K/V from the per-utterance cache ----
+        { ProfScope ps(m, s, DITTO_KC_LAYERNORM); HIP_TRY(launch_layernorm(h, lp.g2, lp.be2, u, d, M, d, s)); }
+        {
+            ProfScope ps(m, s, DITTO_KC_GEMM_D);
+            GemmArgs g{};
+            g.A = u; g.lda = d; g.W = lp.Wcq; g.bias = lp.bcq; g.out = qkv; g.ldo = d; g.M = M; g.N = d; g.K = d;
+            HIP_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
+        }
+        {
+            ProfScope ps(m, s, DITTO_KC_ATTN_CROSS);
+            AttnArgs a{};
+            a.q = qkv; a.ldq = d; a.k = kv + (size_t)kv_layer * 2 * d * 2; a.ldk = kv_ld;
+            a.v = kv + ((size_t)kv_layer * 2 * d + d) * 2; a.ldv = kv_ld; a.out_bf16 = u; a.ldo = d;
+            a.B = B; a.H = H; a.Sq = N; a.Skv = T; a.dh = dh; a.scale = scale;
+            a.workspace = attn_ws; a.workspace_bytes = attn_ws_bytes;
+            HIP_TRY(launch_attention(a, s));
+        }
+        {
+            ProfScope ps(m, s, DITTO_KC_GEMM_D);
+            GemmArgs g{};
+            g.A = u; g.lda = d; g.W = lp.Wco; g.bias = lp.bco; g.residual = h; g.ldr = d; g.out = h; g.ldo = d;
+            g.M = M; g.N = d; g.K = d;
+            HIP_TRY(launch_gemm(g, EPI_BIAS_RES_F32, s));
+        }
+        // ---- gated MLP (src/components/DiT.py:150-155) ----
+        { ProfScope ps(m, s, DITTO_KC_LAYERNORM); HIP_TRY(launch_layernorm(h, lp.g3, lp.be3, u, d, M, d, s)); }
+        {
+            ProfScope ps(m, s, DITTO_KC_GEMM_GATED);
+            GemmArgs g{};
+            g.A = u; g.lda = d; g.W = lp.W1g; g.bias = lp.b1g; g.out = act; g.ldo = 4 * d; g.M = M; g.N = 8 * d;
+            g.K = d;
+            HIP_TRY(launch_gemm(g, EPI_GATED, s));
+        }
+        {
+            ProfScope ps(m, s, DITTO_KC_GEMM_FC2);
+            GemmArgs g{};
+            g.A = act; g.lda = 4 * d; g.W = lp.W2; g.bias = lp.b2; g.residual = h; g.ldr = d; g.out = h; g.ldo = d;
+            g.M = M; g.N = d; g.K = 4 * d;
+            if (xcat_or_null) { g.out2_bf16 = xcat_or_null + (size_t)d * 2; g.ldo2 = 2 * d; }  // bf16(h_L) for proj_out
+            HIP_TRY(launch_gemm(g, EPI_BIAS_RES_F32, s));
+        }
+    return DITTO_OK;
+}
+
+extern "C" {
+
+int ditto_abi_version(void) { return DITTO_ABI_VERSION; }
+const char* ditto_last_error(void) { return g_err; }
+
+const char* ditto_kernel_class_name(int kc) {
+    static const char* names[DITTO_KC_COUNT] = {"layernorm", "gemm_qkv_rope", "gemm_d_x_d", "gemm_gated_mlp",
+                                                "gemm_fc2", "gemm_final", "attn_self", "attn_cross", "adaln",
+                                                "p_sample_update"};
+    return (kc >= 0 && kc < DITTO_KC_COUNT) ? names[kc] : "?";
+}
+
+size_t ditto_arena_bytes(const ditto_config* cfg) {
+    if (check_cfg(cfg) != DITTO_OK) return 0;
+    return plan_arena(*cfg).total;
+}
+size_t ditto_cond_bytes(const ditto_config* cfg, int B, int T) {
+    if (check_cfg(cfg) != DITTO_OK || B <= 0 || T <= 0) return 0;
+    const size_t d = cfg->hidden_dim;
+    return al((size_t)B * T * cfg->num_layers * 2 * d * 2) + al((size_t)B * 2 * d * 4);
+}
+size_t ditto_workspace_bytes(const ditto_config* cfg, int B, int N, int T) {
+    if (check_cfg(cfg) != DITTO_OK || B <= 0 || N <= 0 || T <= 0) return 0;
+    return plan_ws(*cfg, B, N, T).total;
+}
+size_t ditto_attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh) {
+    return attention_workspace_bytes(B, H, Sq, Skv, dh);
+}
+
+int ditto_model_create(const ditto_config* cfg, const ditto_weights* w, void* arena, size_t arena_bytes,
+                       ditto_stream_t stream, ditto_model_t* out) {
+    if (int rc = check_cfg(cfg)) return rc;
+    if (!w || !arena || !out || !w->layers) return fail(DITTO_ERR_ARG, "null argument to ditto_model_create");
+    const ArenaPlan plan = plan_arena(*cfg);
+    if (arena_bytes < plan.total)
+        return fail(DITTO_ERR_SIZE, "arena too small: %zu < %zu", arena_bytes, plan.total);
+    if ((uintptr_t)arena % 256) return fail(DITTO_ERR_ARG, "arena must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int d = cfg->hidden_dim, L = cfg->num_layers, td = cfg->time_dim, dt = cfg->text_dim;
+    char* A = (char*)arena;
+    std::unique_ptr<ditto_model> guard(new (std::nothrow) ditto_model());
+    ditto_model* m = guard.get();
+    if (!m) return fail(DITTO_ERR_ARG, "out of host memory");
+    m->cfg = *cfg; m->plan = plan; m->arena = A; m->layers.resize(L);
+    const int BIG = 1 << 30;
+    for (int l = 0; l < L; ++l) {
+        const ditto_layer_weights& lw = w->layers[l];
+        const auto& q = plan.layers[l];
+        const float* need[] = {lw.norm1_weight, lw.norm1_bias, lw.attn_in_proj_weight, lw.attn_in_proj_bias,
+                               lw.norm2_weight, lw.norm2_bias, lw.cross_in_proj_weight, lw.cross_in_proj_bias,
+                               lw.cross_out_proj_weight, lw.cross_out_proj_bias, lw.norm3_weight, lw.norm3_bias,
+                               lw.mlp_fc1_weight, lw.mlp_fc1_bias, lw.gate_weight, lw.gate_bias, lw.mlp_fc2_weight,
+                               lw.mlp_fc2_bias};
+        for (const float* p : need)
+            if (!p) return fail(DITTO_ERR_ARG, "null weight pointer in layer %d", l);
+        // self-attention in_proj [3d, d] (q | k | v rows), reference src/components/DiT.py:110-114
+        HIP_TRY(launch_pack_bf16(lw.attn_in_proj_weight, A + q.Wqkv, 3 * d, d, d, 0, BIG, 1, 0, s));
+        HIP_TRY(hipMemcpyAsync(A + q.bqkv, lw.attn_in_proj_bias, 3 * d * 4, hipMemcpyDeviceToDevice, s));
+        // cross-attention: q rows [0,d) per layer; k,v rows [d,3d) go to the all-layer Wkv
+        HIP_TRY(launch_pack_bf16(lw.cross_in_proj_weight, A + q.Wcq, d, d, d, 0, BIG, 1, 0, s));
+        HIP_TRY(hipMemcpyAsync(A + q.bcq, lw.cross_in_proj_bias, d * 4, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(launch_pack_bf16(lw.cross_in_proj_weight + (size_t)d * d, A + plan.Wkv, 2 * d, d, d, 0, BIG, 1,
+                                 l * 2 * d, s));
+        HIP_TRY(hipMemcpyAsync(A + plan.bkv + (size_t)l * 2 * d * 4, lw.cross_in_proj_bias + d, 2 * d * 4,
+                               hipMemcpyDeviceToDevice, s));
+        HIP_TRY(launch_pack_bf16(lw.cross_out_proj_weight, A + q.Wco, d, d, d, 0, BIG, 1, 0, s));
+        HIP_TRY(hipMemcpyAsync(A + q.bco, lw.cross_out_proj_bias, d * 4, hipMemcpyDeviceToDevice, s));
+        // gated MLP: rows interleaved [16 x fc1 | 16 x gate] so both halves of a product meet in one lane
+        HIP_TRY(launch_pack_bf16(lw.mlp_fc1_weight, A + q.W1g, 4 * d, d, d, 0, 16, 2, 0, s));
+        HIP_TRY(launch_pack_bf16(lw.gate_weight, A + q.W1g, 4 * d, d, d, 0, 16, 2, 16, s));
+        HIP_TRY(launch_pack_vec(lw.mlp_fc1_bias, (float*)(A + q.b1g), 4 * d, 16, 2, 0, s));
+        HIP_TRY(launch_pack_vec(lw.gate_bias, (float*)(A + q.b1g), 4 * d, 16, 2, 16, s));
+        HIP_TRY(launch_pack_bf16(lw.mlp_fc2_weight, A + q.W2, d, 4 * d, 4 * d, 0, BIG, 1, 0, s));
+        HIP_TRY(hipMemcpyAsync(A + q.b2, lw.mlp_fc2_bias, d * 4, hipMemcpyDeviceToDevice, s));
+        const float* lnsrc[6] = {lw.norm1_weight, lw.norm1_bias, lw.norm2_weight, lw.norm2_bias, lw.norm3_weight,
+                                 lw.norm3_bias};
+        const size_t lndst[6] = {q.g1, q.be1, q.g2, q.be2, q.g3, q.be3};
+        for (int i = 0; i < 6; ++i)
+            HIP_TRY(hipMemcpyAsync(A + lndst[i], lnsrc[i], d * 4, hipMemcpyDeviceToDevice, s));
+        LayerPack& lp = m->layers[l];
+        lp.Wqkv = A + q.Wqkv; lp.Wcq = A + q.Wcq; lp.Wco = A + q.Wco; lp.W1g = A + q.W1g; lp.W2 = A + q.W2;
+        lp.bqkv = (const float*)(A + q.bqkv); lp.bcq = (const float*)(A + q.bcq); lp.bco = (const float*)(A + q.bco);
+        lp.b1g = (const float*)(A + q.b1g); lp.b2 = (const float*)(A + q.b2);
+        lp.g1 = (const float*)(A + q.g1); lp.be1 = (const float*)(A + q.be1); lp.g2 = (const float*)(A + q.g2);
+        lp.be2 = (const float*)(A + q.be2); lp.g3 = (const float*)(A + q.g3); lp.be3 = (const float*)(A + q.be3);
+    }
+    const float* gneed[] = {w->t_embedding_weight, w->time_embed_0_weight, w->time_embed_0_bias,
+                            w->time_embed_2_weight, w->time_embed_2_bias, w->ada_time_mlp_weight,
+                            w->ada_time_mlp_bias, w->ada_text_mlp_weight, w->ada_text_mlp_bias, w->proj_in_weight,
+                            w->proj_in_bias, w->proj_out_weight, w->proj_out_bias, w->rotary_inv_freq};
+    int nnull = 0;
+    for (const float* p : gneed) nnull += (p == nullptr);
+    if (nnull == (int)(sizeof(gneed) / sizeof(gneed[0]))) {
+        // standalone DiT blocks (reference src/components/DiT.py:75-157 used without a DiTTO around them)
+        m->blocks_only = true;
+        m->Wkv = A + plan.Wkv; m->bkv = (const float*)(A + plan.bkv);
+        m->Wfin = nullptr; m->bfin = nullptr; m->ttab = nullptr; m->wx = nullptr; m->bx = nullptr; m->invf = nullptr;
+        *out = guard.release();
+        return DITTO_OK;
+    }
+    if (nnull) return fail(DITTO_ERR_ARG, "null global weight pointer (pass ALL of them, or none for a blocks-only handle)");
+    // eps = x W_in^T + h_L W_out^T + (b_in + b_out): one GEMM with K = 2d (src/model/DiTTO.py:83,93-94)
+    HIP_TRY(launch_pack_bf16(w->proj_in_weight, A + plan.Wfin, d, d, 2 * d, 0, BIG, 1, 0, s));
+    HIP_TRY(launch_pack_bf16(w->proj_out_weight, A + plan.Wfin, d, d, 2 * d, d, BIG, 1, 0, s));
+    HIP_TRY(launch_add_vec(w->proj_in_bias, w->proj_out_bias, (float*)(A + plan.bfin), d, s));
+    HIP_TRY(launch_time_table(w->t_embedding_weight, w->time_embed_0_weight, w->time_embed_0_bias,
+                              w->time_embed_2_weight, w->time_embed_2_bias, w->ada_time_mlp_weight,
+                              w->ada_time_mlp_bias, (float*)(A + plan.ttab), cfg->diffusion_steps, td, d, s));
+    HIP_TRY(hipMemcpyAsync(A + plan.wx, w->ada_text_mlp_weight, (size_t)2 * d * dt * 4, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(A + plan.bx, w->ada_text_mlp_bias, (size_t)2 * d * 4, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(A + plan.invf, w->rotary_inv_freq, (size_t)(d / cfg->num_heads / 2) * 4,
+                           hipMemcpyDeviceToDevice, s));
+    m->Wkv = A + plan.Wkv; m->bkv = (const float*)(A + plan.bkv); m->Wfin = A + plan.Wfin;
+    m->bfin = (const float*)(A + plan.bfin); m->ttab = (const float*)(A + plan.ttab);
+    m->wx = (const float*)(A + plan.wx); m->bx = (const float*)(A + plan.bx); m->invf = (const float*)(A + plan.invf);
+    *out = guard.release();
+    return DITTO_OK;
+}
+
+int ditto_model_destroy(ditto_model_t m) {
+    if (!m) return DITTO_OK;
+    for (auto& r : m->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : m->pool) (void)hipEventDestroy(e);
+    delete m;
+    return DITTO_OK;
+}
+
+int ditto_rope_tables(ditto_model_t m, int N, float* cos_out, float* sin_out, ditto_stream_t stream) {
+    if (!m || !cos_out || !sin_out || N <= 0) return fail(DITTO_ERR_ARG, "bad argument to ditto_rope_tables");
+    if (m->blocks_only) return fail(DITTO_ERR_ARG, "blocks-only handle has no rotary.inv_freq");
+    HIP_TRY(launch_rope_tables(m->invf, cos_out, sin_out, N, m->cfg.hidden_dim / m->cfg.num_heads / 2,
+                               (hipStream_t)stream));
+    return DITTO_OK;
+}
+
+int ditto_text_precompute(ditto_model_t m, const float* text, int B, int T, void* cond, size_t cond_bytes,
+                          void* workspace, size_t workspace_bytes, ditto_stream_t stream) {
+    if (!m || !text || !cond || !workspace || B <= 0 || T <= 0)
+        return fail(DITTO_ERR_ARG, "bad argument to ditto_text_precompute");
+    const ditto_config& c = m->cfg;
+    if (cond_bytes < ditto_cond_bytes(&c, B, T)) return fail(DITTO_ERR_SIZE, "cond buffer too small");
+    const size_t need = text_scratch_bytes(c, B, T);
+    if (workspace_bytes < need) return fail(DITTO_ERR_SIZE, "workspace too small for text precompute: %zu < %zu",
+                                            workspace_bytes, need);
+    hipStream_t s = (hipStream_t)stream;
+    const int d = c.hidden_dim, L = c.num_layers;
+    char* ws = (char*)workspace;
+    void* textbf = ws;
+    float* pooled = (float*)(ws + al((size_t)B * T * c.text_dim * 2));
+    char* kv = (char*)cond;
+    float* tmod = (float*)(kv + al((size_t)B * T * L * 2 * d * 2));
+    HIP_TRY(launch_cast_bf16(text, textbf, (size_t)B * T * c.text_dim, s));
+    GemmArgs g{};
+    g.A = textbf; g.lda = c.text_dim; g.W = m->Wkv; g.bias = m->bkv; g.out = kv; g.ldo = L * 2 * d;
+    g.M = B * T; g.N = L * 2 * d; g.K = d;
+    HIP_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
+    if (!m->blocks_only) HIP_TRY(launch_text_mod(text, m->wx, m->bx, pooled, tmod, B, T, c.text_dim, d, s));
+    return DITTO_OK;
+}
+
+int ditto_forward(ditto_model_t m, const float* x, const void* cond, const int64_t* t, int B, int N, int T,
+                  const float* rope_cos, const float* rope_sin, float* eps_out, void* workspace,
+                  size_t workspace_bytes, ditto_stream_t stream) {
+    if (!m || !x || !cond || !t || !rope_cos || !rope_sin || !eps_out || !workspace || B <= 0 || N <= 0 || T <= 0)
+        return fail(DITTO_ERR_ARG, "bad argument to ditto_forward");
+    const ditto_config& c = m->cfg;
+    if (m->blocks_only) return fail(DITTO_ERR_ARG, "ditto_forward on a blocks-only handle");
+    const WsPlan w = plan_ws(c, B, N, T);
+    if (workspace_bytes < w.total)
+        return fail(DITTO_ERR_SIZE, "workspace too small: %zu < %zu", workspace_bytes, w.total);
+    if ((uintptr_t)workspace % 256) return fail(DITTO_ERR_ARG, "workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int d = c.hidden_dim, L = c.num_layers, M = B * N;
+    char* ws = (char*)workspace;
+    float* h = (float*)(ws + w.h);
+    void* u = ws + w.u;
+    char* qkv = ws + w.qkv;
+    void* act = ws + w.act;
+    char* xcat = ws + w.xcat;
+    void* attn_ws = ws + w.attn;
+    const char* kv = (const char*)cond;
+    const float* tmod = (const float*)(kv + al((size_t)B * T * L * 2 * d * 2));
+
+    {   // GlobalAdaLN (src/components/DiT.py:25-40) + bf16 copy of the raw input for proj_in
+        ProfScope ps(m, s, DITTO_KC_ADALN);
+        HIP_TRY(launch_adaln(x, m->ttab, tmod, t, c.diffusion_steps, h, xcat, 2 * d, B, N, d, s));
+    }
+    for (int l = 0; l < L; ++l)
+        if (int rc = run_block(m, l, h, u, qkv, act, l == L - 1 ? xcat : nullptr, attn_ws, w.attn_bytes, kv, l,
+                               L * 2 * d, rope_cos, rope_sin, B, N, T, s))
+            return rc;
+    {   // eps = proj_in(x_raw) + proj_out(h_L)  (src/model/DiTTO.py:83,93-94), one K = 2d GEMM
+        ProfScope ps(m, s, DITTO_KC_GEMM_FINAL);
+        GemmArgs g{};
+        g.A = xcat; g.lda = 2 * d; g.W = m->Wfin; g.bias = m->bfin; g.out = eps_out; g.ldo = d; g.M = M; g.N = d;
+        g.K = 2 * d;
+        HIP_TRY(launch_gemm(g, EPI_BIAS_F32, s));
+    }
+    return DITTO_OK;
+}
+
+
+int ditto_block_forward(ditto_model_t m, int layer, float* h, const void* cond, int cond_layer, int B, int N, int T,
+                        const float* rope_cos, const float* rope_sin, void* workspace, size_t workspace_bytes,
+                        ditto_stream_t stream) {
+    if (!m || !h || !cond || !rope_cos || !rope_sin || !workspace || B <= 0 || N <= 0 || T <= 0)
+        return fail(DITTO_ERR_ARG, "bad argument to ditto_block_forward");
+    const ditto_config& c = m->cfg;
+    if (layer < 0 || layer >= c.num_layers || cond_layer < 0 || cond_layer >= c.num_layers)
+        return fail(DITTO_ERR_ARG, "layer index out of range");
+    const WsPlan w = plan_ws(c, B, N, T);
+    if (workspace_bytes < w.total) return fail(DITTO_ERR_SIZE, "workspace too small: %zu < %zu", workspace_bytes, w.total);
+    char* ws = (char*)workspace;
+    return run_block(m, layer, h, ws + w.u, ws + w.qkv, ws + w.act, nullptr, ws + w.attn, w.attn_bytes,
+                     (const char*)cond, cond_layer, c.num_layers * 2 * c.hidden_dim, rope_cos, rope_sin, B, N, T,
+                     (hipStream_t)stream);
+}
+
+
+size_t ditto_global_adaln_scratch_bytes(int B, int d, int time_dim, int text_dim) {
+    return al((size_t)B * time_dim * 4) + al((size_t)B * text_dim * 4) + 2 * al((size_t)B * 2 * d * 4);
+}
+
+int ditto_global_adaln(const float* x, const float* time_emb, const float* text_emb, const float* time_w,
+                       const float* time_b, const float* text_w, const float* text_b, int B, int N, int T, int d,
+                       int time_dim, int text_dim, float* out, void* scratch, size_t scratch_bytes,
+                       ditto_stream_t stream) {
+    if (!x || !time_emb || !text_emb || !time_w || !time_b || !text_w || !text_b || !out || !scratch || B <= 0 ||
+        N <= 0 || T <= 0)
+        return fail(DITTO_ERR_ARG, "bad argument to ditto_global_adaln");
+    if (d % 4 || d > 2048) return fail(DITTO_ERR_SHAPE, "d must be a multiple of 4 and <= 2048");
+    if (scratch_bytes < ditto_global_adaln_scratch_bytes(B, d, time_dim, text_dim))
+        return fail(DITTO_ERR_SIZE, "scratch too small for ditto_global_adaln");
+    hipStream_t s = (hipStream_t)stream;
+    char* sc = (char*)scratch;
+    float* pooled_t = (float*)sc;                 sc += al((size_t)B * time_dim * 4);
+    float* pooled_x = (float*)sc;                 sc += al((size_t)B * text_dim * 4);
+    float* mod_t = (float*)sc;                    sc += al((size_t)B * 2 * d * 4);
+    float* mod_x = (float*)sc;
+    // time half: Linear(SiLU(time_emb)) == the text-mod kernel with a "sequence" of length 1
+    HIP_TRY(launch_text_mod(time_emb, time_w, time_b, pooled_t, mod_t, B, 1, time_dim, d, s));
+    HIP_TRY(launch_text_mod(text_emb, text_w, text_b, pooled_x, mod_x, B, T, text_dim, d, s));
+    HIP_TRY(launch_adaln(x, mod_t, mod_x, nullptr, B, out, nullptr, 0, B, N, d, s));
+    return DITTO_OK;
+}
+
+int ditto_apply_rope_f32(const float* pos, const float* t, float* out, int B, int N, int H, int dh,
+                         ditto_stream_t stream) {
+    if (!pos || !t || !out || B <= 0 || N <= 0 || H <= 0 || dh <= 0 || (dh & 1))
+        return fail(DITTO_ERR_ARG, "bad argument to ditto_apply_rope_f32");
+    if (t == out) return fail(DITTO_ERR_ARG, "ditto_apply_rope_f32 is not in-place");
+    HIP_TRY(launch_apply_rope_f32(pos, t, out, B, N, H, dh, (hipStream_t)stream));
+    return DITTO_OK;
+}
+
+int ditto_p_sample_update(float* x, const float* eps, const float* noise, const int64_t* t, const float* betas,
+                          const float* alphas, const float* alphas_cumprod, int B, size_t elems_per_utt,
+                          ditto_stream_t stream) {
+    if (!x || !eps || !t || !betas || !alphas || !alphas_cumprod || B <= 0 || elems_per_utt == 0)
+        return fail(DITTO_ERR_ARG, "bad argument to ditto_p_sample_update");
+    if (elems_per_utt % 4) return fail(DITTO_ERR_SHAPE, "elems_per_utt must be a multiple of 4");
+    HIP_TRY(launch_p_sample_update(x, eps, noise, t, betas, alphas, alphas_cumprod, B, elems_per_utt,
+                                   (hipStream_t)stream));
+    return DITTO_OK;
+}
+
+int ditto_p_sample(ditto_model_t m, float* x, const void* cond, const int64_t* t, const float* noise,
+                   const float* betas, const float* alphas, const float* alphas_cumprod, int B, int N, int T,
+                   const float* rope_cos, const float* rope_sin, void* workspace, size_t workspace_bytes,
+                   ditto_stream_t stream) {
+    if (!m || !workspace) return fail(DITTO_ERR_ARG, "bad argument to ditto_p_sample");
+    const WsPlan w = plan_ws(m->cfg, B, N, T);
+    if (workspace_bytes < w.total) return fail(DITTO_ERR_SIZE, "workspace too small: %zu < %zu", workspace_bytes, w.total);
+    float* eps = (float*)((char*)workspace + w.eps);
+    if (int rc = ditto_forward(m, x, cond, t, B, N, T, rope_cos, rope_sin, eps, workspace, workspace_bytes, stream))
+        return rc;
+    ProfScope ps(m, (hipStream_t)stream, DITTO_KC_UPDATE);
+    return ditto_p_sample_update(x, eps, noise, t, betas, alphas, alphas_cumprod, B,
+                                 (size_t)N * m->cfg.hidden_dim, stream);
+}
+
+int ditto_q_sample(const float* x_start, const float* noise, const int64_t* t, const float* buffer, float* out, int B,
+                   size_t elems_per_utt, ditto_stream_t stream) {
+    if (!x_start || !noise || !t || !buffer || !out || B <= 0) return fail(DITTO_ERR_ARG, "bad argument to ditto_q_sample");
+    if (elems_per_utt % 4) return fail(DITTO_ERR_SHAPE, "elems_per_utt must be a multiple of 4");
+    HIP_TRY(launch_q_sample(x_start, noise, t, buffer, out, B, elems_per_utt, (hipStream_t)stream));
+    return DITTO_OK;
+}
+
+int ditto_layernorm_bf16(const float* x, const float* gamma, const float* beta, void* out_bf16, int M, int d,
+                         ditto_stream_t stream) {
+    if (!x || !out_bf16 || M <= 0 || d <= 0 || (gamma == nullptr) != (beta == nullptr))
+        return fail(DITTO_ERR_ARG, "bad argument to ditto_layernorm_bf16");
+    if (d % 4 || d > 2048) return fail(DITTO_ERR_SHAPE, "d must be a multiple of 4 and <= 2048");
+    HIP_TRY(launch_layernorm(x, gamma, beta, out_bf16, d, M, d, (hipStream_t)stream));
+    return DITTO_OK;
+}
+
+int ditto_gemm_bf16(const void* A, int lda, const void* W, const float* bias, const float* residual, void* out,
+                    int ldo, int M, int N, int K, int epilogue, ditto_stream_t stream) {
+    if (!A || !W || !out) return fail(DITTO_ERR_ARG, "null pointer to ditto_gemm_bf16");
+    if (K % 64 || N % 16 || lda % 8) return fail(DITTO_ERR_SHAPE, "need K %% 64 == 0, N %% 16 == 0, lda %% 8 == 0");
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.W = W; g.bias = bias; g.residual = residual; g.ldr = ldo; g.out = out; g.ldo = ldo;
+    g.M = M; g.N = N; g.K = K;
+    if (epilogue != 0 && epilogue != 1) return fail(DITTO_ERR_ARG, "epilogue must be 0 or 1");
+    HIP_TRY(launch_gemm(g, epilogue == 0 ? EPI_BIAS_BF16 : EPI_BIAS_RES_F32, (hipStream_t)stream));
+    return DITTO_OK;
+}
+
+int ditto_attention_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo,
+                         int B, int H, int Sq, int Skv, int dh, float scale, void* workspace, size_t workspace_bytes,
+                         ditto_stream_t stream) {
+    if (!q || !k || !v || !out) return fail(DITTO_ERR_ARG, "null pointer to ditto_attention_bf16");
+    if (dh % 64) return fail(DITTO_ERR_SHAPE, "head_dim must be a multiple of 64");
+    if (workspace_bytes < attention_workspace_bytes(B, H, Sq, Skv, dh))
+        return fail(DITTO_ERR_SIZE, "attention workspace too small");
+    AttnArgs a{};
+    a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.out_bf16 = out; a.ldo = ldo;
+    a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.dh = dh; a.scale = scale;
+    a.workspace = workspace; a.workspace_bytes = workspace_bytes;
+    HIP_TRY(launch_attention(a, (hipStream_t)stream));
+    return DITTO_OK;
+}
+
+int ditto_profile_enable(ditto_model_t m, int enable) {
+    if (!m) return fail(DITTO_ERR_ARG, "null model");
+    m->prof = enable != 0;
+    return DITTO_OK;
+}
+
+int ditto_profile_read(ditto_model_t m, int32_t* launches, float* ms) {
+    if (!m || !launches || !ms) return fail(DITTO_ERR_ARG, "null argument to ditto_profile_read");
+    for (auto& r : m->recs) {
+        HIP_TRY(hipEventSynchronize(r.b));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, r.a, r.b));
+        m->launches[r.kc] += 1;
+        m->ms[r.kc] += t;
+        m->pool.push_back(r.a);
+        m->pool.push_back(r.b);
+    }
+    m->recs.clear();
+    for (int i = 0; i < DITTO_KC_COUNT; ++i) {
+        launches[i] = m->launches[i]; ms[i] = m->ms[i];
+        m->launches[i] = 0; m->ms[i] = 0.f;
+    }
+    return DITTO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,256 @@
+// gemm.hip — bf16 MFMA GEMM family for gfx950:  out[M,N] = A[M,K] * W[N,K]^T (+ fused epilogue)
+//
+// Replaces every F.linear on the DiT path (reference src/components/DiT.py:112-114,153-155,
+// src/model/DiTTO.py:83,93 and torch MHA's in/out projections).  W is nn.Linear.weight as stored
+// ([out, in], K-contiguous = "B^T input" form), so both operands are read along K.
+//
+// Roofline: MFMA-bound (dense bf16 ~2.5 PFLOP/s).  Algorithmic FLOPs = 2*M*N*K per launch.
+//
+// Structure (v1, "128^2 two-barrier" of cdna_hip_programming.md §5):
+//   * tile 128(M) x 128(N) x 64(K), 256 threads = 4 waves in 2x2, each wave a 64x64 sub-tile as
+//     4x4 v_mfma_f32_16x16x32_bf16 accumulators (64 fp32 regs).
+//   * staging by LDS-DMA: __builtin_amdgcn_global_load_lds, 16 B per lane, two LDS buffers
+//     (2 x (16 KiB A + 16 KiB W) = 64 KiB -> 2 workgroups / CU); tile kt+1 is in flight while
+//     tile kt is multiplied.
+//   * LDS image is lane-linear (DMA writes base + lane*16), so the bank swizzle is applied to the
+//     per-lane SOURCE address and again on the ds_read_b128 (rule 21): 16-B chunk c of row r is
+//     stored at chunk position c ^ ((r>>1)&7) of its 128-B row -> every ds_read_b128 lane group
+//     hits 16 distinct 16-B slots of the 256-B bank row (conflict-free).
+//   * operands are SWAPPED in the MFMA (weights as the instruction's A, activations as B), so the
+//     accumulator holds C^T: a lane owns 4 CONSECUTIVE output columns of one row -> 8/16-byte
+//     stores, and the RoPE partner (col +-32) and the fc1/gate partner (col +-16) of a value are in
+//     the same lane (no cross-lane traffic in the fused epilogues).
+//   * XCD-aware, bijective block->tile map: each XCD (private 4 MiB L2) walks a contiguous range of
+//     M-panels, sweeping N inside a panel, so an A panel is fetched from HBM once per XCD.
+#include "common.h"
+#include "kernels.h"
+
+namespace ditto {
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile
+constexpr int BUF_BYTES = 2 * TILE_BYTES;        // A + W
+constexpr int GEMM_LDS = 2 * BUF_BYTES;          // double buffered: 64 KiB
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+struct GemmParams {
+    const bf16* A; int lda;
+    const bf16* W; int ldw; int w_rows;
+    const float* bias;
+    const float* residual; int ldr;
+    void* out; int ldo;
+    bf16* out2; int ldo2;
+    const float* rope_cos; const float* rope_sin; int rope_rpb; int rope_cols;
+    int M, N, K;
+    int tiles_m, tiles_n;
+};
+
+// Issue the LDS-DMA loads of one (A, W) K-tile.  Lane -> (row, chunk position) is linear in LDS;
+// the source chunk is the swizzled one.
+DITTO_DEV void stage_tile(const GemmParams& p, char* buf, int m0, int n0, int k0, int wid, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = wid * 4 + i;                    // 1 KiB piece = 8 rows x 128 B
+        const int row = piece * 8 + (lane >> 3);
+        const int cpos = lane & 7;
+        const int c = cpos ^ ((row >> 1) & 7);
+        int ar = m0 + row; ar = ar < p.M ? ar : p.M - 1;  // clamp: rows past M are computed, never stored
+        int wr = n0 + row; wr = wr < p.w_rows ? wr : p.w_rows - 1;
+        const bf16* ga = p.A + (size_t)ar * p.lda + k0 + c * 8;
+        const bf16* gw = p.W + (size_t)wr * p.ldw + k0 + c * 8;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)ga, (lds_ptr_t)(buf + piece * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)gw, (lds_ptr_t)(buf + TILE_BYTES + piece * 1024), 16, 0, 0);
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int tile = xcd_remap(blockIdx.x, nwg);
+    const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = p.K / BK;
+    stage_tile(p, smem, m0, n0, 0, wid, lane);
+    __syncthreads();  // (hipcc drains the LDS-DMA with vmcnt(0) here)
+
+    // per-lane fragment addressing: row (lane&15) of a 16-row block, k-chunk (lane>>4) of a 32-wide k-step
+    const int frow = lane & 15, fq = lane >> 4, fswz = frow >> 1;
+    const int a_row_off = (wr * 64 + frow) * 128;
+    const int w_row_off = TILE_BYTES + (wc * 64 + frow) * 128;
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        char* cur = smem + (kt & 1) * BUF_BYTES;
+        if (kt + 1 < nkt) stage_tile(p, smem + ((kt + 1) & 1) * BUF_BYTES, m0, n0, (kt + 1) * BK, wid, lane);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int coff = ((kk * 4 + fq) ^ fswz) << 4;
+            bf16x8 af[4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8*>(cur + a_row_off + i * 16 * 128 + coff);
+                wf[i] = *reinterpret_cast<const bf16x8*>(cur + w_row_off + i * 16 * 128 + coff);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], af[m], acc[m][n], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---------------- epilogue: lane owns rows (lane&15) and 4 consecutive columns per (m, n) ----------------
+    const int col_in_wave = fq * 4;  // + n*16
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int row = m0 + wr * 64 + m * 16 + frow;
+        if (row >= p.M) continue;
+        if constexpr (EPI == EPI_GATED) {
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const int pc = n0 + wc * 64 + pr * 32 + col_in_wave;  // packed column of the fc1 half
+                if (pc >= p.N) continue;
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + pc);
+                const f32x4 bg = *reinterpret_cast<const f32x4*>(p.bias + pc + 16);
+                const f32x4 h = acc[m][2 * pr], g = acc[m][2 * pr + 1];
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = gelu_erf_f(h[e] + b1[e]) * sigmoid_f(g[e] + bg[e]);
+                const int oc = (n0 + wc * 64) / 2 + pr * 16 + col_in_wave;
+                u32x2 st;
+                st[0] = pack_bf16x2(o[0], o[1]);
+                st[1] = pack_bf16x2(o[2], o[3]);
+                *reinterpret_cast<u32x2*>((bf16*)p.out + (size_t)row * p.ldo + oc) = st;
+            }
+        } else if constexpr (EPI == EPI_QKV_ROPE) {
+            const int cbase = n0 + wc * 64;  // 64-aligned: exactly one head of width 64
+            float v[4][4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int c = cbase + n * 16 + col_in_wave;
+                f32x4 b = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias && c < p.N) b = *reinterpret_cast<const f32x4*>(p.bias + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[n][e] = acc[m][n][e] + b[e];
+            }
+            if (cbase < p.rope_cols) {  // q or k head: half-split RoPE, pair (j, j+32); src/components/DiT.py:52-72
+                const int pos = row % p.rope_rpb;
+                float r[4][4];
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const f32x4 cs = *reinterpret_cast<const f32x4*>(p.rope_cos + (size_t)pos * 32 + n * 16 + col_in_wave);
+                    const f32x4 sn = *reinterpret_cast<const f32x4*>(p.rope_sin + (size_t)pos * 32 + n * 16 + col_in_wave);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float lo = v[n][e], hi = v[n + 2][e];
+                        r[n][e] = lo * cs[e] - hi * sn[e];      // t*cos + (-t[j+32])*sin
+                        r[n + 2][e] = hi * cs[e] + lo * sn[e];  // t*cos + ( t[j-32])*sin
+                    }
+                }
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[n][e] = r[n][e];
+            }
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int c = cbase + n * 16 + col_in_wave;
+                if (c >= p.N) continue;
+                u32x2 st;
+                st[0] = pack_bf16x2(v[n][0], v[n][1]);
+                st[1] = pack_bf16x2(v[n][2], v[n][3]);
+                *reinterpret_cast<u32x2*>((bf16*)p.out + (size_t)row * p.ldo + c) = st;
+            }
+        } else {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int c = n0 + wc * 64 + n * 16 + col_in_wave;
+                if (c >= p.N) continue;
+                f32x4 v = acc[m][n];
+                if (p.bias) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + c);
+                    v += b;
+                }
+                if constexpr (EPI == EPI_BIAS_BF16) {
+                    u32x2 st;
+                    st[0] = pack_bf16x2(v[0], v[1]);
+                    st[1] = pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<u32x2*>((bf16*)p.out + (size_t)row * p.ldo + c) = st;
+                } else {
+                    if constexpr (EPI == EPI_BIAS_RES_F32) {
+                        if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)row * p.ldr + c);
+                    }
+                    *reinterpret_cast<f32x4*>((float*)p.out + (size_t)row * p.ldo + c) = v;
+                    if constexpr (EPI == EPI_BIAS_RES_F32) {
+                        if (p.out2) {
+                            u32x2 st;
+                            st[0] = pack_bf16x2(v[0], v[1]);
+                            st[1] = pack_bf16x2(v[2], v[3]);
+                            *reinterpret_cast<u32x2*>(p.out2 + (size_t)row * p.ldo2 + c) = st;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int EPI>
+hipError_t launch_t(const GemmParams& p, hipStream_t s) {
+    static bool attr_set = false;  // idempotent; races are benign (same value)
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm128_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm128_kernel<EPI>), dim3(p.tiles_m * p.tiles_n), dim3(256), GEMM_LDS, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0) return hipErrorInvalidValue;
+    if (a.K % BK || a.N % 16 || a.lda % 8 || (a.ldw % 8)) return hipErrorInvalidValue;
+    GemmParams p;
+    p.A = (const bf16*)a.A; p.lda = a.lda; p.W = (const bf16*)a.W; p.bias = a.bias;
+    p.ldw = a.ldw ? a.ldw : a.K; p.w_rows = a.w_rows ? a.w_rows : a.N;
+    p.residual = a.residual; p.ldr = a.ldr; p.out = a.out; p.ldo = a.ldo;
+    p.out2 = (bf16*)a.out2_bf16; p.ldo2 = a.ldo2;
+    p.rope_cos = a.rope_cos; p.rope_sin = a.rope_sin; p.rope_rpb = a.rope_rows_per_batch; p.rope_cols = a.rope_cols;
+    p.M = a.M; p.N = a.N; p.K = a.K;
+    p.tiles_m = (a.M + BM - 1) / BM;
+    p.tiles_n = (a.N + BN - 1) / BN;
+    switch (epi) {
+        case EPI_BIAS_BF16: return launch_t<EPI_BIAS_BF16>(p, s);
+        case EPI_BIAS_RES_F32: return launch_t<EPI_BIAS_RES_F32>(p, s);
+        case EPI_QKV_ROPE:
+            if (a.N % 64 || a.rope_cols % 64 || !a.rope_cos || !a.rope_sin || a.rope_rows_per_batch <= 0)
+                return hipErrorInvalidValue;
+            return launch_t<EPI_QKV_ROPE>(p, s);
+        case EPI_GATED:
+            if (a.N % 32 || !a.bias) return hipErrorInvalidValue;
+            return launch_t<EPI_GATED>(p, s);
+        case EPI_BIAS_F32: return launch_t<EPI_BIAS_F32>(p, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace ditto

@@ -1,0 +1,78 @@
+// kernels.h — internal launch interface between the C-ABI (ditto_api.hip) and the kernel files.
+// Every launcher enqueues on `s` and returns hipGetLastError(); none allocates or synchronises.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ditto {
+
+// ---------------- rowwise.hip : HBM-bound row / elementwise kernels ----------------
+// LayerNorm over the last dim (eps 1e-5), one wave per row.
+//   gamma/beta: affine (both or neither).  out_bf16 [M, ldo] bf16.
+hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, void* out_bf16, int ldo,
+                            int M, int d, hipStream_t s);
+// GlobalAdaLN apply: h = LN_noaffine(x) * (1 + ttab[t[b]][j] + tmod[b][j]) + (ttab[t[b]][d+j] + tmod[b][d+j]);
+// also writes bf16(x) (the RAW input) to raw_bf16 [M, ldraw] for the fused proj_in.
+hipError_t launch_adaln(const float* x, const float* ttab, const float* tmod, const int64_t* t, int steps,
+                        float* h_out, void* raw_bf16, int ldraw, int B, int N, int d, hipStream_t s);
+hipError_t launch_cast_bf16(const float* src, void* dst_bf16, size_t n, hipStream_t s);
+hipError_t launch_p_sample_update(float* x, const float* eps, const float* noise, const int64_t* t,
+                                  const float* betas, const float* alphas, const float* acp, int B,
+                                  size_t elems_per_utt, hipStream_t s);
+hipError_t launch_q_sample(const float* x0, const float* noise, const int64_t* t, const float* buffer, float* out,
+                           int B, size_t elems_per_utt, hipStream_t s);
+// ttab[step, 0:2d] = time_mlp(time_embed(t_embedding[step]))
+hipError_t launch_time_table(const float* emb, const float* w0, const float* b0, const float* w2, const float* b2,
+                             const float* wt, const float* bt, float* ttab, int steps, int td, int d, hipStream_t s);
+// pooled[b, :] = mean_T text[b, :, :]   then   tmod[b, 0:2d] = Wx * silu(pooled[b]) + bx
+hipError_t launch_text_mod(const float* text, const float* wx, const float* bx, float* pooled_scratch, float* tmod,
+                           int B, int T, int dt, int d, hipStream_t s);
+hipError_t launch_apply_rope_f32(const float* pos, const float* x, float* out, int B, int N, int H, int dh,
+                                 hipStream_t s);
+hipError_t launch_rope_tables(const float* inv_freq, float* cos_out, float* sin_out, int N, int half, hipStream_t s);
+// dst[(r/blk)*(blk*mult) + r%blk + row_off][col_off + c] = bf16(src[r][c])
+hipError_t launch_pack_bf16(const float* src, void* dst_bf16, int rows, int cols, int dst_ld, int col_off, int blk,
+                            int mult, int row_off, hipStream_t s);
+// same row map for an fp32 vector (bias)
+hipError_t launch_pack_vec(const float* src, float* dst, int rows, int blk, int mult, int row_off, hipStream_t s);
+hipError_t launch_add_vec(const float* a, const float* b, float* dst, int n, hipStream_t s);
+
+// ---------------- gemm.hip : bf16 MFMA GEMM family  out = A[M,K] * W[N,K]^T + bias ... ----------------
+enum GemmEpilogue {
+    EPI_BIAS_BF16 = 0,    // out bf16 [M, ldo] = acc + bias
+    EPI_BIAS_RES_F32 = 1, // out fp32 [M, ldo] = acc + bias + residual (may alias out); optional bf16 copy
+    EPI_QKV_ROPE = 2,     // out bf16 [M, ldo]; columns < 2*d_model get half-split RoPE (head_dim 64 only)
+    EPI_GATED = 3,        // W rows interleaved [fc1 x16 | gate x16]; out bf16 [M, N/2] = gelu(a) * sigmoid(g)
+    EPI_BIAS_F32 = 4      // out fp32 [M, ldo] = acc + bias
+};
+struct GemmArgs {
+    const void* A; int lda;          // bf16 [M, K], row stride lda (elements)
+    const void* W; int ldw;          // bf16 [N, K], K-contiguous rows (nn.Linear.weight layout); ldw = row stride, 0 -> K
+    int w_rows;                      // valid rows of W (rows >= w_rows are clamped, their outputs are don't-care); 0 -> N
+    const float* bias;               // fp32 [N] (may be null)
+    const float* residual; int ldr;  // fp32 [M, ldr] (EPI_BIAS_RES_F32)
+    void* out; int ldo;              // bf16 or fp32
+    void* out2_bf16; int ldo2;       // optional bf16 copy of the fp32 result (EPI_BIAS_RES_F32)
+    const float* rope_cos; const float* rope_sin; int rope_rows_per_batch; int rope_cols;  // EPI_QKV_ROPE
+    int M, N, K;
+};
+hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s);
+
+// ---------------- attention.hip ----------------
+struct AttnArgs {
+    const void* q; int ldq;   // bf16, head h at columns [h*dh, (h+1)*dh)
+    const void* k; int ldk;
+    const void* v; int ldv;
+    void* out_bf16; int ldo;         // used when resid_f32 == nullptr
+    float* resid_f32; int ldr;       // if set: resid[row, h*dh + c] += O   (self-attention, no out-proj)
+    int B, H, Sq, Skv, dh;
+    float scale;                     // 1/sqrt(dh)
+    void* workspace; size_t workspace_bytes;   // generic (dh != 64) path only
+};
+hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+size_t attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh);
+// in-place half-split RoPE on bf16 [M, ld] for `nheads` heads of width dh starting at column 0 (generic path)
+hipError_t launch_rope_inplace(void* qk_bf16, int ld, const float* cosT, const float* sinT, int M,
+                               int rows_per_batch, int ncols, int dh, hipStream_t s);
+
+}  // namespace ditto

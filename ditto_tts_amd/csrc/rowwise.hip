@@ -1,0 +1,398 @@
+// rowwise.hip — HBM-bound kernels of the DiT denoise path (gfx950).
+//
+// Roofline: every kernel here moves each byte once (algorithmic bytes == HBM traffic) and is judged
+// against HBM (~6.3 TB/s achievable of 8 TB/s).  Rules applied (cdna_hip_programming.md G2/G11/G13):
+// 16-byte per-lane accesses, one wave64 per row with shuffle reductions (no LDS round trip needed at
+// d <= 2048: the row lives in registers between the statistics and the normalise pass), grids of
+// >= 4 rows per 256-thread block so that >= 8k blocks cover M = 32k rows.
+#include "common.h"
+#include "kernels.h"
+
+namespace ditto {
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm / GlobalAdaLN.  Reference: nn.LayerNorm(d) (biased variance, eps 1e-5)
+//   src/components/DiT.py:84,89,94 (affine), :23,:38-39 (no affine + scale/shift).
+// One wave per row; lane i owns float4 chunks i, i+64, ... (CH of them) => coalesced 1 KiB per
+// wave-instruction.  Two-pass statistics on the register copy (mean, then sum (x-mean)^2).
+// MODE 0: affine (gamma/beta may be null) -> bf16.   MODE 1: AdaLN modulation -> fp32 + bf16(raw x).
+// ------------------------------------------------------------------------------------------------
+template <int CH, int MODE>
+__global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, const float* __restrict__ ttab,
+                                                 const float* __restrict__ tmod, const int64_t* __restrict__ t,
+                                                 int steps, int rows_per_batch, bf16* __restrict__ out_bf16, int ldo,
+                                                 float* __restrict__ out_f32, int M, int d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = d >> 2;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * d);
+    f32x4 v[CH];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int i = lane + 64 * c;
+        if (i < nv) {
+            v[c] = xr[i];
+            s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+        } else {
+            v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int i = lane + 64 * c;
+        if (i < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dlt = v[c][e] - mean;
+                q += dlt * dlt;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
+
+    if constexpr (MODE == 0) {
+        bf16* orow = out_bf16 + (size_t)row * ldo;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int i = lane + 64 * c;
+            if (i < nv) {
+                f32x4 g = {1.f, 1.f, 1.f, 1.f}, b = {0.f, 0.f, 0.f, 0.f};
+                if (gamma) {
+                    g = reinterpret_cast<const f32x4*>(gamma)[i];
+                    b = reinterpret_cast<const f32x4*>(beta)[i];
+                }
+                u32x2 o;
+                o[0] = pack_bf16x2((v[c][0] - mean) * rstd * g[0] + b[0], (v[c][1] - mean) * rstd * g[1] + b[1]);
+                o[1] = pack_bf16x2((v[c][2] - mean) * rstd * g[2] + b[2], (v[c][3] - mean) * rstd * g[3] + b[3]);
+                *reinterpret_cast<u32x2*>(orow + 4 * i) = o;
+            }
+        }
+    } else {
+        const int b_idx = row / rows_per_batch;
+        long long ts = t ? t[b_idx] : b_idx;               // t == nullptr: table row = batch index
+        ts = ts < 0 ? 0 : (ts >= steps ? steps - 1 : ts);  // nn.Embedding would raise; clamp instead of faulting
+        const f32x4* tt = reinterpret_cast<const f32x4*>(ttab + (size_t)ts * 2 * d);
+        const f32x4* tm = reinterpret_cast<const f32x4*>(tmod + (size_t)b_idx * 2 * d);
+        bf16* orow = out_bf16 + (size_t)row * ldo;
+        f32x4* hrow = reinterpret_cast<f32x4*>(out_f32 + (size_t)row * d);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int i = lane + 64 * c;
+            if (i < nv) {
+                const f32x4 sc_t = tt[i], sc_x = tm[i], sh_t = tt[nv + i], sh_x = tm[nv + i];
+                f32x4 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float scale = 1.f + sc_t[e] + sc_x[e];          // DiT.py:34
+                    const float shift = sh_t[e] + sh_x[e];                // DiT.py:35
+                    h[e] = (v[c][e] - mean) * rstd * scale + shift;       // DiT.py:38-39
+                }
+                hrow[i] = h;
+                if (out_bf16) {
+                    u32x2 o;
+                    o[0] = pack_bf16x2(v[c][0], v[c][1]);
+                    o[1] = pack_bf16x2(v[c][2], v[c][3]);
+                    *reinterpret_cast<u32x2*>(orow + 4 * i) = o;
+                }
+            }
+        }
+    }
+}
+
+template <int MODE>
+static hipError_t ln_dispatch(const float* x, const float* gamma, const float* beta, const float* ttab,
+                              const float* tmod, const int64_t* t, int steps, int rpb, bf16* ob, int ldo, float* of,
+                              int M, int d, hipStream_t s) {
+    const int ch = (d / 4 + 63) / 64;
+    dim3 grid((M + 3) / 4), block(256);
+#define LN_CASE(C)                                                                                             \
+    case C:                                                                                                    \
+        hipLaunchKernelGGL((ln_kernel<C, MODE>), grid, block, 0, s, x, gamma, beta, ttab, tmod, t, steps, rpb, \
+                           ob, ldo, of, M, d);                                                                 \
+        break;
+    switch (ch) {
+        LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8)
+        default: return hipErrorInvalidValue;  // d > 2048 (checked with a message in the API layer)
+    }
+#undef LN_CASE
+    return hipGetLastError();
+}
+
+hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, void* out_bf16, int ldo, int M,
+                            int d, hipStream_t s) {
+    return ln_dispatch<0>(x, gamma, beta, nullptr, nullptr, nullptr, 0, 1, (bf16*)out_bf16, ldo, nullptr, M, d, s);
+}
+
+hipError_t launch_adaln(const float* x, const float* ttab, const float* tmod, const int64_t* t, int steps,
+                        float* h_out, void* raw_bf16, int ldraw, int B, int N, int d, hipStream_t s) {
+    return ln_dispatch<1>(x, nullptr, nullptr, ttab, tmod, t, steps, N, (bf16*)raw_bf16, ldraw, h_out, B * N, d, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 -> bf16 cast (text_emb before the cross-attention K/V projection).  8 elements per thread.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16* __restrict__ dst,
+                                                        size_t n8) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(src)[2 * i];
+        const f32x4 b = reinterpret_cast<const f32x4*>(src)[2 * i + 1];
+        u32x4 o;
+        o[0] = pack_bf16x2(a[0], a[1]);
+        o[1] = pack_bf16x2(a[2], a[3]);
+        o[2] = pack_bf16x2(b[0], b[1]);
+        o[3] = pack_bf16x2(b[2], b[3]);
+        reinterpret_cast<u32x4*>(dst)[i] = o;
+    }
+}
+hipError_t launch_cast_bf16(const float* src, void* dst, size_t n, hipStream_t s) {
+    if (n % 8) return hipErrorInvalidValue;
+    const size_t n8 = n / 8;
+    const int grid = (int)((n8 + 255) / 256 < 2048 ? (n8 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, s, src, (bf16*)dst, n8);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// DDPM ancestral update, in place.  Reference: src/model/SpeechGenerator.py:137-145.
+// Same operation order as the torch expression; __f*_rn keep hipcc from contracting to FMA so the
+// fp32 result is the IEEE sequence torch's CPU kernels produce.
+// grid = (blocks per utterance, B): the per-utterance coefficients are wave-uniform.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void p_sample_update_kernel(float* __restrict__ x, const float* __restrict__ eps,
+                                                              const float* __restrict__ noise,
+                                                              const int64_t* __restrict__ t,
+                                                              const float* __restrict__ betas,
+                                                              const float* __restrict__ alphas,
+                                                              const float* __restrict__ acp, size_t n4_per_utt) {
+    const int b = blockIdx.y;
+    const long long ts = t[b];
+    const float beta = betas[ts], alpha = alphas[ts], ac = acp[ts];
+    const float inv_sqrt_alpha = __fdiv_rn(1.0f, __fsqrt_rn(alpha));                 // 1 / sqrt(alpha_t)
+    const float c_eps = __fdiv_rn(__fsub_rn(1.0f, alpha), __fsqrt_rn(__fsub_rn(1.0f, ac)));  // (1-a)/sqrt(1-acp)
+    const float sigma = (ts > 0 ? 1.0f : 0.0f) * __fsqrt_rn(beta);                   // mask * sqrt(beta_t)
+    const bool use_noise = (noise != nullptr) && (ts > 0);
+    const size_t base = (size_t)b * n4_per_utt;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4_per_utt;
+         i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 xv = reinterpret_cast<f32x4*>(x)[base + i];
+        const f32x4 ev = reinterpret_cast<const f32x4*>(eps)[base + i];
+        f32x4 zv = {0.f, 0.f, 0.f, 0.f};
+        if (use_noise) zv = reinterpret_cast<const f32x4*>(noise)[base + i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float mean = __fmul_rn(inv_sqrt_alpha, __fsub_rn(xv[e], __fmul_rn(c_eps, ev[e])));
+            xv[e] = __fadd_rn(mean, __fmul_rn(sigma, zv[e]));
+        }
+        reinterpret_cast<f32x4*>(x)[base + i] = xv;
+    }
+}
+hipError_t launch_p_sample_update(float* x, const float* eps, const float* noise, const int64_t* t,
+                                  const float* betas, const float* alphas, const float* acp, int B,
+                                  size_t elems_per_utt, hipStream_t s) {
+    if (elems_per_utt % 4) return hipErrorInvalidValue;
+    const size_t n4 = elems_per_utt / 4;
+    size_t gx = (n4 + 255) / 256;
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(p_sample_update_kernel, dim3((unsigned)gx, B), dim3(256), 0, s, x, eps, noise, t, betas,
+                       alphas, acp, n4);
+    return hipGetLastError();
+}
+
+// q_sample, reference src/model/DiTTO.py:106-126 (bug-for-bug: `buffer` holds clipped betas).
+__global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise,
+                                                       const int64_t* __restrict__ t,
+                                                       const float* __restrict__ buffer, float* __restrict__ out,
+                                                       size_t n4_per_utt) {
+    const int b = blockIdx.y;
+    const float c = buffer[t[b]];
+    const float a = __fsqrt_rn(c), s1 = __fsqrt_rn(__fsub_rn(1.0f, c));
+    const size_t base = (size_t)b * n4_per_utt;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4_per_utt;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 xv = reinterpret_cast<const f32x4*>(x0)[base + i];
+        const f32x4 zv = reinterpret_cast<const f32x4*>(noise)[base + i];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = __fadd_rn(__fmul_rn(a, xv[e]), __fmul_rn(s1, zv[e]));
+        reinterpret_cast<f32x4*>(out)[base + i] = o;
+    }
+}
+hipError_t launch_q_sample(const float* x0, const float* noise, const int64_t* t, const float* buffer, float* out,
+                           int B, size_t elems_per_utt, hipStream_t s) {
+    if (elems_per_utt % 4) return hipErrorInvalidValue;
+    const size_t n4 = elems_per_utt / 4;
+    size_t gx = (n4 + 255) / 256;
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(q_sample_kernel, dim3((unsigned)gx, B), dim3(256), 0, s, x0, noise, t, buffer, out, n4);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Timestep -> AdaLN (scale, shift) table, built once per checkpoint at model-create time:
+//   ttab[s] = time_mlp( time_embed( t_embedding[s] ) )
+// Reference: src/model/DiTTO.py:75-76 (Embedding, Linear, SiLU, Linear) + src/components/DiT.py:14-17,30
+// (SiLU, Linear).  One block per timestep; fp32 FMA; vectors staged in LDS.  Init-time only.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void time_table_kernel(const float* __restrict__ emb, const float* __restrict__ w0,
+                                                         const float* __restrict__ b0, const float* __restrict__ w2,
+                                                         const float* __restrict__ b2, const float* __restrict__ wt,
+                                                         const float* __restrict__ bt, float* __restrict__ ttab,
+                                                         int td, int d) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* e = sm;           // [td]
+    float* a = sm + td;      // [td]
+    float* c = sm + 2 * td;  // [td]
+    const int step = blockIdx.x;
+    for (int j = threadIdx.x; j < td; j += blockDim.x) e[j] = emb[(size_t)step * td + j];
+    __syncthreads();
+    for (int j = threadIdx.x; j < td; j += blockDim.x) {
+        float acc = 0.f;
+        const float* wr = w0 + (size_t)j * td;
+        for (int k = 0; k < td; ++k) acc = fmaf(wr[k], e[k], acc);
+        a[j] = silu_f(acc + b0[j]);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < td; j += blockDim.x) {
+        float acc = 0.f;
+        const float* wr = w2 + (size_t)j * td;
+        for (int k = 0; k < td; ++k) acc = fmaf(wr[k], a[k], acc);
+        c[j] = silu_f(acc + b2[j]);  // SiLU of GlobalAdaLN.time_mlp[0]
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 2 * d; j += blockDim.x) {
+        float acc = 0.f;
+        const float* wr = wt + (size_t)j * td;
+        for (int k = 0; k < td; ++k) acc = fmaf(wr[k], c[k], acc);
+        ttab[(size_t)step * 2 * d + j] = acc + bt[j];
+    }
+}
+hipError_t launch_time_table(const float* emb, const float* w0, const float* b0, const float* w2, const float* b2,
+                             const float* wt, const float* bt, float* ttab, int steps, int td, int d, hipStream_t s) {
+    hipLaunchKernelGGL(time_table_kernel, dim3(steps), dim3(256), 3 * td * sizeof(float), s, emb, w0, b0, w2, b2, wt,
+                       bt, ttab, td, d);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Text half of GlobalAdaLN, once per utterance batch (step-invariant):
+//   pooled = mean_T(text)  (no mask, src/components/DiT.py:27);  tmod = Linear(SiLU(pooled)) (:19-22,31)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void text_pool_kernel(const float* __restrict__ text, float* __restrict__ pooled,
+                                                        int T, int dt) {
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6, b = blockIdx.y;
+    float acc = 0.f;
+    if (col < dt)
+        for (int r = g; r < T; r += 4) acc += text[((size_t)b * T + r) * dt + col];
+    red[g][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (g == 0 && col < dt)
+        pooled[(size_t)b * dt + col] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) +
+                                        (red[2][threadIdx.x] + red[3][threadIdx.x])) / (float)T;
+}
+// one wave per output row j of the [2d, dt] matrix
+__global__ __launch_bounds__(256) void text_mod_kernel(const float* __restrict__ pooled, const float* __restrict__ wx,
+                                                       const float* __restrict__ bx, float* __restrict__ tmod, int dt,
+                                                       int d2) {
+    const int lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+    if (j >= d2) return;
+    const float* p = pooled + (size_t)b * dt;
+    const float* w = wx + (size_t)j * dt;
+    float acc = 0.f;
+    for (int k = lane; k < dt; k += 64) acc = fmaf(w[k], silu_f(p[k]), acc);
+    acc = wave_sum(acc);
+    if (lane == 0) tmod[(size_t)b * d2 + j] = acc + bx[j];
+}
+hipError_t launch_text_mod(const float* text, const float* wx, const float* bx, float* pooled, float* tmod, int B,
+                           int T, int dt, int d, hipStream_t s) {
+    hipLaunchKernelGGL(text_pool_kernel, dim3((dt + 63) / 64, B), dim3(256), 0, s, text, pooled, T, dt);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(text_mod_kernel, dim3((2 * d + 3) / 4, B), dim3(256), 0, s, pooled, wx, bx, tmod, dt, 2 * d);
+    return hipGetLastError();
+}
+
+// RotaryEmbedding.forward tables (src/components/DiT.py:56-59): angle = float(n) * inv_freq[j] in fp32.
+__global__ __launch_bounds__(256) void rope_table_kernel(const float* __restrict__ inv_freq, float* __restrict__ c,
+                                                         float* __restrict__ sn, int N, int half) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * half) return;
+    const float ang = __fmul_rn((float)(i / half), inv_freq[i % half]);
+    c[i] = cosf(ang);
+    sn[i] = sinf(ang);
+}
+hipError_t launch_rope_tables(const float* inv_freq, float* c, float* sn, int N, int half, hipStream_t s) {
+    hipLaunchKernelGGL(rope_table_kernel, dim3((N * half + 255) / 256), dim3(256), 0, s, inv_freq, c, sn, N, half);
+    return hipGetLastError();
+}
+
+// RotaryEmbedding.apply_rope on fp32 [B,N,H,dh] with the ANGLE table pos [N,dh] the reference passes around
+// (src/components/DiT.py:61-72).  Component-level surface only; the model path fuses RoPE into the QKV GEMM.
+__global__ __launch_bounds__(256) void apply_rope_f32_kernel(const float* __restrict__ pos, const float* __restrict__ x,
+                                                             float* __restrict__ out, size_t total, int N, int H,
+                                                             int dh) {
+    const int half = dh >> 1;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % dh);
+        const int n = (int)((i / ((size_t)dh * H)) % N);
+        const float a = pos[(size_t)n * dh + j];
+        const float rot = j < half ? -x[i + half] : x[i - half];   // _rotate_half: cat(-x2, x1)
+        out[i] = x[i] * cosf(a) + rot * sinf(a);
+    }
+}
+hipError_t launch_apply_rope_f32(const float* pos, const float* x, float* out, int B, int N, int H, int dh,
+                                 hipStream_t s) {
+    const size_t total = (size_t)B * N * H * dh;
+    size_t g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(apply_rope_f32_kernel, dim3((unsigned)(g ? g : 1)), dim3(256), 0, s, pos, x, out, total, N, H, dh);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight packing (model-create time): fp32 [rows, cols] -> bf16 with a block row map.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ src, bf16* __restrict__ dst,
+                                                        int rows, int cols, int dst_ld, int col_off, int blk,
+                                                        int mult, int row_off) {
+    const size_t n = (size_t)rows * cols;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cols), c = (int)(i % cols);
+        const size_t dr = (size_t)(r / blk) * ((size_t)blk * mult) + (r % blk) + row_off;
+        dst[dr * dst_ld + col_off + c] = (bf16)src[i];
+    }
+}
+hipError_t launch_pack_bf16(const float* src, void* dst, int rows, int cols, int dst_ld, int col_off, int blk,
+                            int mult, int row_off, hipStream_t s) {
+    const size_t n = (size_t)rows * cols;
+    size_t g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)(g ? g : 1)), dim3(256), 0, s, src, (bf16*)dst, rows, cols,
+                       dst_ld, col_off, blk, mult, row_off);
+    return hipGetLastError();
+}
+__global__ void pack_vec_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int blk, int mult,
+                                int row_off) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < rows) dst[(size_t)(r / blk) * ((size_t)blk * mult) + (r % blk) + row_off] = src[r];
+}
+hipError_t launch_pack_vec(const float* src, float* dst, int rows, int blk, int mult, int row_off, hipStream_t s) {
+    hipLaunchKernelGGL(pack_vec_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, src, dst, rows, blk, mult, row_off);
+    return hipGetLastError();
+}
+__global__ void add_vec_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ dst,
+                               int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = a[i] + b[i];
+}
+hipError_t launch_add_vec(const float* a, const float* b, float* dst, int n, hipStream_t s) {
+    hipLaunchKernelGGL(add_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, dst, n);
+    return hipGetLastError();
+}
+
+}  // namespace ditto

@@ -1,0 +1,96 @@
+"""Batch-parallel sampling over the GPUs of one node: one process per GPU, RCCL over xGMI for the
+scatter of conditioning / gather of latents ONLY.  There is no collective inside the
+step loop: every utterance's trajectory depends only on its own (x_T, text_emb, noise) and the
+replicated weights.
+
+xGMI is point-to-point (7 links x ~153 GB/s per GPU), so root<->peer transfers are issued as one batch of
+send/recv pairs (`torch.distributed.batch_isend_irecv` = grouped ncclSend/ncclRecv on RCCL): each peer's
+shard rides its own direct link instead of a ring bound by one link.
+
+Works on any backend: "nccl" (= RCCL on ROCm) on the GPU node, "gloo" in the CPU tests.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(total: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous shard [lo, hi) of `total` utterances for `rank`; the first (total % world) ranks get one more."""
+    q, r = divmod(total, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def scatter_batch(full: Optional[torch.Tensor], shape_tail, dtype, device, root: int = 0, group=None) -> torch.Tensor:
+    """Root holds `full` [B_total, *shape_tail]; every rank returns its contiguous shard (root keeps a view)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    meta = torch.zeros(1, dtype=torch.int64, device=device)
+    if rank == root:
+        meta[0] = full.shape[0]
+    dist.broadcast(meta, src=root, group=group)
+    total = int(meta.item())
+    lo, hi = shard_bounds(total, world, rank)
+    if rank == root:
+        ops = []
+        for r in range(world):
+            if r == root:
+                continue
+            a, b = shard_bounds(total, world, r)
+            if b > a:
+                ops.append(dist.P2POp(dist.isend, full[a:b].contiguous(), r, group))
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        return full[lo:hi]
+    out = torch.empty((hi - lo, *shape_tail), dtype=dtype, device=device)
+    if hi > lo:
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, out, root, group)]):
+            w.wait()
+    return out
+
+
+def gather_batch(shard: torch.Tensor, total: int, root: int = 0, group=None) -> Optional[torch.Tensor]:
+    """Inverse of scatter_batch: root returns [total, ...], the others None."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if rank == root:
+        full = torch.empty((total, *shard.shape[1:]), dtype=shard.dtype, device=shard.device)
+        lo, hi = shard_bounds(total, world, rank)
+        full[lo:hi] = shard
+        ops, bufs = [], []
+        for r in range(world):
+            if r == root:
+                continue
+            a, b = shard_bounds(total, world, r)
+            if b > a:
+                buf = torch.empty((b - a, *shard.shape[1:]), dtype=shard.dtype, device=shard.device)
+                bufs.append((a, b, buf))
+                ops.append(dist.P2POp(dist.irecv, buf, r, group))
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        for a, b, buf in bufs:
+            full[a:b] = buf
+        return full
+    if shard.shape[0] > 0:
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, shard.contiguous(), root, group)]):
+            w.wait()
+    return None
+
+
+def sample_sharded(sample_fn: Callable[[torch.Tensor, torch.Tensor, int], torch.Tensor],
+                   text_full: Optional[torch.Tensor], xT_full: Optional[torch.Tensor], text_tail, x_tail,
+                   device, root: int = 0, group=None) -> Optional[torch.Tensor]:
+    """Scatter (text_emb, x_T) from root, run `sample_fn(text_shard, xT_shard, first_global_index)` on every
+    rank (the whole denoise loop — no communication inside), gather the final latents on root."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    text = scatter_batch(text_full, text_tail, torch.float32, device, root, group)
+    xT = scatter_batch(xT_full, x_tail, torch.float32, device, root, group)
+    meta = torch.zeros(1, dtype=torch.int64, device=device)
+    if rank == root:
+        meta[0] = text_full.shape[0]
+    dist.broadcast(meta, src=root, group=group)
+    total = int(meta.item())
+    lo, _ = shard_bounds(total, world, rank)
+    out = sample_fn(text, xT, lo) if text.shape[0] > 0 else xT
+    return gather_batch(out, total, root, group)

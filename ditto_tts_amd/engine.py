@@ -1,0 +1,188 @@
+"""DenoiseEngine — host-side owner of one packed model on one GPU.
+
+PyTorch is plumbing here: it owns device memory (arena / workspace / cond buffers are uint8 tensors) and
+the stream; every FLOP of the path runs in libditto_hip.so.  One engine per process per GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Mapping, Optional, Tuple
+
+import torch
+
+from . import hip
+from .config import DiTTOConfig
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class TextCond:
+    """Step-invariant conditioning of one utterance batch: cached cross-attention K/V of every layer and the
+    text half of the AdaLN modulation (ditto_text_precompute)."""
+
+    def __init__(self, buf: torch.Tensor, B: int, T: int):
+        self.buf, self.B, self.T = buf, B, T
+
+
+class DenoiseEngine:
+    def __init__(self, cfg: DiTTOConfig, state: Mapping[str, torch.Tensor], device: Optional[torch.device] = None):
+        """`state`: reference state_dict keys -> tensors; fp32 CUDA copies are made as needed.
+        `nac.*`, `blocks.i.attn.out_proj.*`, `blocks.i.rotary.inv_freq` and `alphas_cumprod` are ignored here."""
+        self.lib = hip.lib()
+        if not torch.cuda.is_available():
+            raise RuntimeError("DenoiseEngine needs an MI355X (torch.cuda.is_available() is False); "
+                               "ditto_tts_amd has no CPU path")
+        self.cfg = cfg
+        self.device = torch.device(device if device is not None else "cuda")
+        self._ccfg = hip.make_config(cfg)
+        nbytes = self.lib.ditto_arena_bytes(C.byref(self._ccfg))
+        if nbytes == 0:
+            raise hip.DittoHipError(hip.ERR_SHAPE, self.lib.ditto_last_error().decode())
+        self.arena = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self.handle = C.c_void_p()
+        self._ws: Optional[torch.Tensor] = None
+        self._rope: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._pack(state)
+
+    # ------------------------------------------------------------------ weights
+    def _pack(self, state: Mapping[str, torch.Tensor]):
+        keep = []  # fp32 device staging copies must outlive the (stream-ordered) pack kernels
+
+        def dev(key):
+            if key not in state:
+                raise KeyError(f"state_dict is missing '{key}'")
+            t = state[key].detach().to(device=self.device, dtype=torch.float32).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        L = self.cfg.num_layers
+        layers = (hip.LayerWeights * L)()
+        for l in range(L):
+            for f, k in hip.LAYER_KEY.items():
+                setattr(layers[l], f, dev(f"blocks.{l}.{k}"))
+        w = hip.Weights()
+        for f, k in hip.GLOBAL_KEY.items():
+            setattr(w, f, dev(k))
+        w.layers = layers
+        with torch.cuda.device(self.device):
+            if self.handle:
+                hip.check(self.lib.ditto_model_destroy(self.handle))
+                self.handle = C.c_void_p()
+            hip.check(self.lib.ditto_model_create(C.byref(self._ccfg), C.byref(w), self.arena.data_ptr(),
+                                                  self.arena.numel(), _stream(), C.byref(self.handle)))
+            torch.cuda.current_stream().synchronize()  # staging copies may now be freed
+        self._rope.clear()
+
+    def repack(self, state: Mapping[str, torch.Tensor]):
+        self._pack(state)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.ditto_model_destroy(self.handle)
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ buffers
+    def workspace(self, B: int, N: int, T: int) -> torch.Tensor:
+        need = self.lib.ditto_workspace_bytes(C.byref(self._ccfg), B, N, T)
+        if need == 0:
+            raise hip.DittoHipError(hip.ERR_SHAPE, self.lib.ditto_last_error().decode())
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def rope_tables(self, N: int):
+        if N not in self._rope:
+            half = self.cfg.head_dim // 2
+            c = torch.empty(N, half, dtype=torch.float32, device=self.device)
+            s = torch.empty_like(c)
+            hip.check(self.lib.ditto_rope_tables(self.handle, N, c.data_ptr(), s.data_ptr(), _stream()))
+            self._rope[N] = (c, s)
+        return self._rope[N]
+
+    # ------------------------------------------------------------------ path
+    def _f32(self, t: torch.Tensor, name: str) -> torch.Tensor:
+        if not t.is_cuda:
+            raise RuntimeError(f"{name} must be a CUDA (ROCm) tensor: ditto_tts_amd has no CPU path")
+        return t.to(dtype=torch.float32).contiguous()
+
+    def prepare_text(self, text_emb: torch.Tensor, N_hint: int = 1) -> TextCond:
+        """text_emb [B, T, text_dim] -> TextCond (K/V cache of all layers + text modulation)."""
+        text = self._f32(text_emb, "text_emb")
+        B, T, dt = text.shape
+        if dt != self.cfg.text_dim:
+            raise ValueError(f"text_emb last dim {dt} != text_dim {self.cfg.text_dim}")
+        nb = self.lib.ditto_cond_bytes(C.byref(self._ccfg), B, T)
+        buf = torch.empty(nb, dtype=torch.uint8, device=self.device)
+        ws = self.workspace(B, max(N_hint, 1), T)
+        hip.check(self.lib.ditto_text_precompute(self.handle, text.data_ptr(), B, T, buf.data_ptr(), nb,
+                                                 ws.data_ptr(), ws.numel(), _stream()))
+        return TextCond(buf, B, T)
+
+    def _t64(self, t: torch.Tensor, B: int) -> torch.Tensor:
+        if t.shape != (B,):
+            raise ValueError(f"t must have shape [{B}]")
+        return t.to(device=self.device, dtype=torch.int64).contiguous()
+
+    def forward(self, x: torch.Tensor, cond: TextCond, t: torch.Tensor, out: Optional[torch.Tensor] = None):
+        """DiTTO.forward(x, text_emb, t) with text_emb pre-digested into `cond` -> eps fp32 [B,N,d]."""
+        xf = self._f32(x, "x")
+        B, N, d = xf.shape
+        if d != self.cfg.hidden_dim or B != cond.B:
+            raise ValueError("x shape does not match the model / the conditioning batch")
+        tt = self._t64(t, B)
+        if out is None:
+            out = torch.empty_like(xf)
+        ws = self.workspace(B, N, cond.T)
+        c, s = self.rope_tables(N)
+        hip.check(self.lib.ditto_forward(self.handle, xf.data_ptr(), cond.buf.data_ptr(), tt.data_ptr(), B, N, cond.T,
+                                         c.data_ptr(), s.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                         _stream()))
+        return out
+
+    def p_sample_(self, x: torch.Tensor, cond: TextCond, t: torch.Tensor, noise: Optional[torch.Tensor],
+                  betas: torch.Tensor, alphas: torch.Tensor, alphas_cumprod: torch.Tensor):
+        """One reverse-diffusion step IN PLACE on the fp32 CUDA state x [B,N,d]."""
+        if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()):
+            raise ValueError("p_sample_ needs a contiguous fp32 CUDA state tensor (it is updated in place)")
+        B, N, d = x.shape
+        tt = self._t64(t, B)
+        ws = self.workspace(B, N, cond.T)
+        c, s = self.rope_tables(N)
+        if noise is not None:
+            noise = self._f32(noise, "noise")
+        hip.check(self.lib.ditto_p_sample(self.handle, x.data_ptr(), cond.buf.data_ptr(), tt.data_ptr(), _ptr(noise),
+                                          betas.data_ptr(), alphas.data_ptr(), alphas_cumprod.data_ptr(), B, N, cond.T,
+                                          c.data_ptr(), s.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+        return x
+
+    def block_forward_(self, layer: int, h: torch.Tensor, cond: TextCond, cond_layer: Optional[int] = None,
+                       rope: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+        """DiT block `layer` in place on the fp32 residual stream h [B,N,d]."""
+        if not (h.is_cuda and h.dtype == torch.float32 and h.is_contiguous()):
+            raise ValueError("block_forward_ needs a contiguous fp32 CUDA tensor")
+        B, N, _ = h.shape
+        ws = self.workspace(B, N, cond.T)
+        c, s = rope if rope is not None else self.rope_tables(N)
+        hip.check(self.lib.ditto_block_forward(self.handle, layer, h.data_ptr(), cond.buf.data_ptr(),
+                                               layer if cond_layer is None else cond_layer, B, N, cond.T,
+                                               c.data_ptr(), s.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+        return h
+
+    # ------------------------------------------------------------------ profiling (bench.py)
+    def profile_enable(self, on: bool):
+        hip.check(self.lib.ditto_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_read(self):
+        n = (C.c_int32 * hip.KC_COUNT)()
+        ms = (C.c_float * hip.KC_COUNT)()
+        hip.check(self.lib.ditto_profile_read(self.handle, n, ms))
+        return {hip.KERNEL_CLASSES[i]: (int(n[i]), float(ms[i])) for i in range(hip.KC_COUNT)}

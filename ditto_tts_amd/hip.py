@@ -1,0 +1,129 @@
+"""ctypes binding of libditto_hip.so (include/ditto_hip.h).
+
+There is NO fallback: if the library is missing or a call fails this module raises.
+Build it with `python -m ditto_tts_amd.build` (hipcc, gfx950).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libditto_hip.so")
+
+OK, ERR_ARG, ERR_SHAPE, ERR_HIP, ERR_SIZE = range(5)
+
+KERNEL_CLASSES = ["layernorm", "gemm_qkv_rope", "gemm_d_x_d", "gemm_gated_mlp", "gemm_fc2", "gemm_final",
+                  "attn_self", "attn_cross", "adaln", "p_sample_update"]
+KC_COUNT = len(KERNEL_CLASSES)
+
+
+class DittoHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libditto_hip error {code}: {msg}")
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("hidden_dim", "num_layers", "num_heads", "time_dim", "text_dim", "diffusion_steps")]
+
+
+_LAYER_FIELDS = ["norm1_weight", "norm1_bias", "attn_in_proj_weight", "attn_in_proj_bias",
+                 "norm2_weight", "norm2_bias", "cross_in_proj_weight", "cross_in_proj_bias",
+                 "cross_out_proj_weight", "cross_out_proj_bias", "norm3_weight", "norm3_bias",
+                 "mlp_fc1_weight", "mlp_fc1_bias", "gate_weight", "gate_bias", "mlp_fc2_weight", "mlp_fc2_bias"]
+_GLOBAL_FIELDS = ["t_embedding_weight", "time_embed_0_weight", "time_embed_0_bias", "time_embed_2_weight",
+                  "time_embed_2_bias", "ada_time_mlp_weight", "ada_time_mlp_bias", "ada_text_mlp_weight",
+                  "ada_text_mlp_bias", "proj_in_weight", "proj_in_bias", "proj_out_weight", "proj_out_bias",
+                  "rotary_inv_freq"]
+
+# struct field -> reference state_dict key (layer keys are relative to "blocks.{i}.")
+LAYER_KEY = {
+    "norm1_weight": "norm1.weight", "norm1_bias": "norm1.bias",
+    "attn_in_proj_weight": "attn.in_proj_weight", "attn_in_proj_bias": "attn.in_proj_bias",
+    "norm2_weight": "norm2.weight", "norm2_bias": "norm2.bias",
+    "cross_in_proj_weight": "cross_attn.in_proj_weight", "cross_in_proj_bias": "cross_attn.in_proj_bias",
+    "cross_out_proj_weight": "cross_attn.out_proj.weight", "cross_out_proj_bias": "cross_attn.out_proj.bias",
+    "norm3_weight": "norm3.weight", "norm3_bias": "norm3.bias",
+    "mlp_fc1_weight": "mlp_fc1.weight", "mlp_fc1_bias": "mlp_fc1.bias",
+    "gate_weight": "gate.weight", "gate_bias": "gate.bias",
+    "mlp_fc2_weight": "mlp_fc2.weight", "mlp_fc2_bias": "mlp_fc2.bias",
+}
+GLOBAL_KEY = {
+    "t_embedding_weight": "t_embedding.weight",
+    "time_embed_0_weight": "time_embed.0.weight", "time_embed_0_bias": "time_embed.0.bias",
+    "time_embed_2_weight": "time_embed.2.weight", "time_embed_2_bias": "time_embed.2.bias",
+    "ada_time_mlp_weight": "ada_ln.time_mlp.1.weight", "ada_time_mlp_bias": "ada_ln.time_mlp.1.bias",
+    "ada_text_mlp_weight": "ada_ln.text_mlp.1.weight", "ada_text_mlp_bias": "ada_ln.text_mlp.1.bias",
+    "proj_in_weight": "proj_in.weight", "proj_in_bias": "proj_in.bias",
+    "proj_out_weight": "proj_out.weight", "proj_out_bias": "proj_out.bias",
+    "rotary_inv_freq": "rotary.inv_freq",
+}
+
+
+class LayerWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _LAYER_FIELDS]
+
+
+class Weights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _GLOBAL_FIELDS] + [("layers", C.POINTER(LayerWeights))]
+
+
+# every symbol include/ditto_hip.h declares: name -> (restype, argtypes)
+_vp, _i, _sz, _f = C.c_void_p, C.c_int, C.c_size_t, C.c_float
+SYMBOLS = {
+    "ditto_abi_version": (_i, []),
+    "ditto_last_error": (C.c_char_p, []),
+    "ditto_arena_bytes": (_sz, [C.POINTER(Config)]),
+    "ditto_cond_bytes": (_sz, [C.POINTER(Config), _i, _i]),
+    "ditto_workspace_bytes": (_sz, [C.POINTER(Config), _i, _i, _i]),
+    "ditto_model_create": (_i, [C.POINTER(Config), C.POINTER(Weights), _vp, _sz, _vp, C.POINTER(_vp)]),
+    "ditto_model_destroy": (_i, [_vp]),
+    "ditto_rope_tables": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "ditto_text_precompute": (_i, [_vp, _vp, _i, _i, _vp, _sz, _vp, _sz, _vp]),
+    "ditto_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ditto_block_forward": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "ditto_global_adaln_scratch_bytes": (_sz, [_i, _i, _i, _i]),
+    "ditto_global_adaln": (_i, [_vp] * 7 + [_i] * 6 + [_vp, _vp, _sz, _vp]),
+    "ditto_apply_rope_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ditto_p_sample_update": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _sz, _vp]),
+    "ditto_p_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "ditto_q_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _sz, _vp]),
+    "ditto_layernorm_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "ditto_gemm_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ditto_attention_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
+    "ditto_attention_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "ditto_profile_enable": (_i, [_vp, _i]),
+    "ditto_profile_read": (_i, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
+    "ditto_kernel_class_name": (C.c_char_p, [_i]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libditto_hip.so (once).  Raises if it has not been built — there is no other path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension is the only compute path of ditto_tts_amd. "
+                "Build it with `python -m ditto_tts_amd.build` (needs hipcc).")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        if l.ditto_abi_version() != 1:
+            raise RuntimeError("libditto_hip.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(rc: int):
+    if rc != OK:
+        raise DittoHipError(rc, lib().ditto_last_error().decode(errors="replace"))
+
+
+def make_config(cfg) -> Config:
+    return Config(cfg.hidden_dim, cfg.num_layers, cfg.num_heads, cfg.time_dim, cfg.text_dim, cfg.diffusion_steps)

@@ -1,0 +1,148 @@
+"""The DDPM sampling loop over the HIP denoise path.
+
+Mirrors the sampling surface of the reference's `SpeechGenerator`
+(reference src/model/SpeechGenerator.py): constructor arguments `:18-27`, attributes `ditto_model`, `betas`,
+`alphas`, `alphas_cumprod`, `device` `:70-72`, and the two (name-mangled) methods the notebooks reach,
+`_SpeechGenerator__p_sample` `:130-147` and `_SpeechGenerator__sample_latents` `:149-164`.
+
+Out of scope: the EnCodec / GPT-2 / BigVGAN / SLP pieces around the loop.  They are taken from
+`ditto_model.nac` and from injected `vocoder` / `text_tokenizer` / `audio_processor` objects when present and
+raise a clear error otherwise; nothing here re-implements them.
+
+Differences from the reference, both deliberate and documented in SURVEY.md App. B:
+  * B-8: the loop length comes from this object's own tables (`len(self.betas)`), not from a mutable global
+    read at call time;
+  * B-9: RoPE tables and the cross-attention K/V of the unchanging text are computed once per call to
+    `__sample_latents`, not once per step.
+RNG: `torch.randn_like` on the state's device, in the reference's call order (one draw for x_T unless
+`cond_by_audio`, then one draw per step).
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+
+from .modules import DiTTO
+
+
+class SpeechGenerator:
+    def __init__(self, lambda_factor=0.1, nac_model_path=None, ditto_model_path=None, slp_path=None,
+                 sample_rate=24000, device="cuda", *, ditto_model: Optional[DiTTO] = None, config=None,
+                 diffusion_steps: Optional[int] = None, vocoder=None, mel_fn: Optional[Callable] = None,
+                 text_tokenizer=None, audio_processor=None, slp=None):
+        self.device = device
+        if ditto_model is None:
+            if config is None:
+                from .compat.utils.Config import ConfigDiTTO as config  # the reference's shipped values
+            ditto_model = DiTTO(hidden_dim=config.HIDDEN_DIM, num_layers=config.NUM_LAYERS,
+                                num_heads=config.NUM_HEADS, time_dim=config.TIME_DIM,
+                                text_dim=config.TEXT_EMBED_DIM, diffusion_steps=config.DIFFUSION_STEPS,
+                                lambda_factor=lambda_factor, nac_model_path=nac_model_path)
+            if ditto_model_path is not None:
+                info = torch.load(ditto_model_path, map_location="cpu")
+                ditto_model.load_state_dict(info["model_state_dict"], strict=ditto_model.nac is not None)
+        self.ditto_model = ditto_model.to(self.device).eval()
+        self.sample_rate = sample_rate
+        self.vocoder, self.mel_fn, self.slp = vocoder, mel_fn, slp
+        self.text_tokenizer, self.audio_processor = text_tokenizer, audio_processor
+        steps = diffusion_steps if diffusion_steps is not None else self.ditto_model.cfg.diffusion_steps
+        if steps > self.ditto_model.cfg.diffusion_steps:
+            raise ValueError("diffusion_steps exceeds the rows of the model's t_embedding")
+        # reference src/model/SpeechGenerator.py:70-72
+        self.betas = self.ditto_model.cosine_beta_schedule(steps).to(self.device)
+        self.alphas = (1.0 - self.betas).to(self.device)
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0).to(self.device)
+
+    @property
+    def diffusion_steps(self) -> int:
+        return int(self.betas.shape[0])
+
+    # ---------------------------------------------------------------- the hot loop
+    @torch.no_grad()
+    def __p_sample(self, x, t, text_emb, noise=None):
+        """Reverse diffusion step (reference :130-147).  Returns a new tensor, like the reference."""
+        m = self.ditto_model
+        cond = m.text_cond(text_emb, x.shape[1])
+        if noise is None:
+            noise = torch.randn_like(x)
+        x_prev = x.detach().float().contiguous().clone()
+        m.engine().p_sample_(x_prev, cond, t, noise, self.betas, self.alphas, self.alphas_cumprod)
+        return x_prev
+
+    @torch.no_grad()
+    def __sample_latents(self, text_emb, audio_emb, text_prompt=None, audio=None, is_slp=False, cond_by_audio=False,
+                         noises=None, keep=None):
+        """All reverse diffusion steps (reference :149-164).
+
+        `noises` (optional): a sequence / callable giving the z of executed step i, for parity tests;
+        `keep` (optional): dict filled with {i: state after step i} for the i it already has as keys."""
+        if is_slp:
+            raise NotImplementedError("the speech-length-predictor branch is broken in the reference "
+                                      "(SURVEY.md App. B-6) and out of scope")
+        m = self.ditto_model
+        x = torch.randn_like(audio_emb) if not cond_by_audio else audio_emb.clone()
+        x = x.to(self.device).float().contiguous()
+        eng = m.engine(x.device)
+        cond = m.text_cond(text_emb.to(x.device), x.shape[1])
+        B = x.shape[0]
+        t_tensor = torch.empty(B, device=x.device, dtype=torch.long)
+        for i, t_val in enumerate(reversed(range(self.diffusion_steps))):
+            t_tensor.fill_(t_val)
+            if noises is None:
+                z = torch.randn_like(x)
+            else:
+                z = (noises(i) if callable(noises) else noises[i]).to(x.device)
+            eng.p_sample_(x, cond, t_tensor, z, self.betas, self.alphas, self.alphas_cumprod)
+            if keep is not None and i in keep:
+                keep[i] = x.clone()
+        return x
+
+    # public aliases (the mangled names above are what the reference's own code reaches)
+    def p_sample(self, x, t, text_emb, noise=None):
+        return self.__p_sample(x, t, text_emb, noise)
+
+    def sample_latents(self, text_emb, audio_emb, **kw):
+        return self.__sample_latents(text_emb, audio_emb, **kw)
+
+    # ---------------------------------------------------------------- around the loop (out of scope: delegated)
+    def _need(self, what, obj):
+        if obj is None:
+            raise RuntimeError(f"SpeechGenerator.{what} is not available: the codec / vocoder / tokenizer stack is "
+                               "outside the MI355X denoise path (SURVEY.md §2) and was not injected")
+        return obj
+
+    @torch.no_grad()
+    def generate_speech_from_audio_tensor(self, audio_tensor, padding_mask_audio, text_prompt, is_tokenized=False,
+                                          is_slp=False, cond_by_audio=False):
+        """Reference :93-111, using the caller-provided codec (`ditto_model.nac`) and vocoder."""
+        nac = self._need("ditto_model.nac", self.ditto_model.nac)
+        audio_latents, audio_scales = nac.audio_encoder(audio_tensor, padding_mask_audio)
+        max_length = nac.language_model.config.n_positions
+        audio_latents = audio_latents[:, :, :max_length].mean(dim=1)
+        if not is_tokenized:
+            tok = self._need("text_tokenizer", self.text_tokenizer)
+            text_tokens = tok(text_prompt, return_tensors="pt").input_ids.to(self.device)
+        else:
+            text_tokens = text_prompt
+        text_tokens = text_tokens[:, :max_length]
+        text_embeddings = nac.language_model.transformer.wte(text_tokens)
+        t = torch.full((audio_latents.size(0),), self.diffusion_steps - 1, device=self.device, dtype=torch.long)
+        audio_latents = self.ditto_model.q_sample(audio_latents, t)
+        refined = self.__sample_latents(text_embeddings, audio_latents, text_tokens, audio_tensor, is_slp, cond_by_audio)
+        return self.__generate_speech_from_latents(refined, audio_scales, padding_mask_audio)
+
+    @torch.no_grad()
+    def __generate_speech_from_latents(self, audio_latents, audio_scales, padding_mask_audio):
+        """Reference :114-128 (VQ -> EnCodec decode -> mel -> vocoder), all delegated."""
+        nac = self._need("ditto_model.nac", self.ditto_model.nac)
+        vocoder, mel_fn = self._need("vocoder", self.vocoder), self._need("mel_fn", self.mel_fn)
+        audio_latents = audio_latents.unsqueeze(1).repeat(1, 2, 1, 1)
+        q = nac.vector_quantizer(audio_latents)
+        waveform = nac.audio_decoder.decode(q.unsqueeze(0).detach(), audio_scales=audio_scales,
+                                            padding_mask=padding_mask_audio)[0].squeeze(1)
+        return vocoder(mel_fn(waveform, vocoder.h).to(self.device)).squeeze(0)
+
+    def generate_speech_from_file(self, file_path, text_prompt, cond_by_audio=False):
+        raise RuntimeError("generate_speech_from_file needs torchaudio + the EnCodec processor, which are outside the "
+                           "denoise path; load the audio yourself and call generate_speech_from_audio_tensor")

@@ -1,0 +1,202 @@
+/* ditto_hip.h — C-ABI of libditto_hip.so: the MI355X (gfx950) DiT denoise path.
+ *
+ * The reference (Tikai7/DiTTO-TTS) is pure Python with no FFI or operator registry;
+ * its boundary for this path is the nn.Module surface.  This header
+ * is the *new* boundary underneath that surface: each entry point names the reference
+ * Python function (file:line, relative to the reference repo) whose arithmetic it
+ * replaces.  The Python binding a maintainer adds is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no C++/torch types, no exceptions.
+ *  - Every function returns a ditto_status (0 = ok) and never aborts;
+ *    ditto_last_error() returns a thread-local message for the last failure.
+ *  - All tensor pointers are DEVICE pointers owned by the caller.  The library
+ *    allocates no device memory and never synchronises: one call = one
+ *    stream-ordered enqueue on `stream` (a hipStream_t; NULL = the default stream),
+ *    so a caller may capture any call into a hipGraph.
+ *  - Row-major, contiguous.  B = batch, N = latent length, T = text length,
+ *    d = hidden_dim, H = num_heads, dh = d / H, L = num_layers, M = B*N.
+ *  - fp32 in / fp32 out at the model boundary (what the reference's callers hold);
+ *    bf16 operands with fp32 accumulation inside (MFMA).
+ */
+#ifndef DITTO_HIP_H
+#define DITTO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DITTO_ABI_VERSION 1
+
+typedef enum ditto_status {
+    DITTO_OK = 0,
+    DITTO_ERR_ARG = 1,        /* null pointer / bad enum */
+    DITTO_ERR_SHAPE = 2,      /* unsupported shape (message says which constraint) */
+    DITTO_ERR_HIP = 3,        /* a HIP runtime call failed */
+    DITTO_ERR_SIZE = 4        /* caller-provided arena / workspace / cond buffer too small */
+} ditto_status;
+
+typedef void* ditto_stream_t;            /* hipStream_t */
+typedef struct ditto_model* ditto_model_t;
+
+/* DiTTO.__init__ keyword arguments, reference src/model/DiTTO.py:10-19 */
+typedef struct ditto_config {
+    int32_t hidden_dim;        /* d        (768)  */
+    int32_t num_layers;        /* L        (12)   */
+    int32_t num_heads;         /* H        (12)   */
+    int32_t time_dim;          /*          (256)  */
+    int32_t text_dim;          /* must equal hidden_dim: reference src/components/DiT.py:90-91 */
+    int32_t diffusion_steps;   /* rows of t_embedding (1000; 50 for the benchmark loop) */
+} ditto_config;
+
+/* fp32 device pointers, named after the reference state_dict keys.
+ * `blocks.i.attn.out_proj.*` and `blocks.i.rotary.inv_freq` are intentionally absent:
+ * the reference never reads them on this path (src/components/DiT.py:134-139). */
+typedef struct ditto_layer_weights {
+    const float* norm1_weight;  const float* norm1_bias;                 /* blocks.i.norm1.*            [d]      */
+    const float* attn_in_proj_weight;  const float* attn_in_proj_bias;   /* blocks.i.attn.in_proj_*     [3d,d],[3d] */
+    const float* norm2_weight;  const float* norm2_bias;                 /* blocks.i.norm2.*                     */
+    const float* cross_in_proj_weight; const float* cross_in_proj_bias;  /* blocks.i.cross_attn.in_proj_*        */
+    const float* cross_out_proj_weight; const float* cross_out_proj_bias;/* blocks.i.cross_attn.out_proj.* [d,d],[d] */
+    const float* norm3_weight;  const float* norm3_bias;                 /* blocks.i.norm3.*                     */
+    const float* mlp_fc1_weight; const float* mlp_fc1_bias;              /* blocks.i.mlp_fc1.*          [4d,d],[4d] */
+    const float* gate_weight;    const float* gate_bias;                 /* blocks.i.gate.*             [4d,d],[4d] */
+    const float* mlp_fc2_weight; const float* mlp_fc2_bias;              /* blocks.i.mlp_fc2.*          [d,4d],[d]  */
+} ditto_layer_weights;
+
+typedef struct ditto_weights {
+    const float* t_embedding_weight;                                     /* [steps, time_dim] */
+    const float* time_embed_0_weight; const float* time_embed_0_bias;    /* [td,td],[td] */
+    const float* time_embed_2_weight; const float* time_embed_2_bias;
+    const float* ada_time_mlp_weight; const float* ada_time_mlp_bias;    /* ada_ln.time_mlp.1.* [2d,td],[2d] */
+    const float* ada_text_mlp_weight; const float* ada_text_mlp_bias;    /* ada_ln.text_mlp.1.* [2d,dt],[2d] */
+    const float* proj_in_weight;  const float* proj_in_bias;             /* [d,d],[d] */
+    const float* proj_out_weight; const float* proj_out_bias;
+    const float* rotary_inv_freq;                                        /* rotary.inv_freq [dh/2] */
+    const ditto_layer_weights* layers;                                   /* HOST array [num_layers] */
+} ditto_weights;
+
+/* ---- library ---------------------------------------------------------------------- */
+int         ditto_abi_version(void);
+const char* ditto_last_error(void);
+
+/* ---- sizes (host-only arithmetic, no GPU needed) ------------------------------------ */
+/* bytes of device arena ditto_model_create packs the weights into */
+size_t ditto_arena_bytes(const ditto_config* cfg);
+/* bytes of the per-batch conditioning buffer: cached cross-attention K/V of every layer
+ * [B*T, L*2d] bf16 + the text half of the AdaLN modulation [B, 2d] fp32 */
+size_t ditto_cond_bytes(const ditto_config* cfg, int B, int T);
+/* bytes of scratch ditto_forward / ditto_text_precompute need for (B, N, T) */
+size_t ditto_workspace_bytes(const ditto_config* cfg, int B, int N, int T);
+
+/* ---- model handle --------------------------------------------------------------------
+ * Packs DiTTO's parameters (reference src/model/DiTTO.py:36-64, src/components/DiT.py:78-98)
+ * for the kernels: bf16 weights, fused [W_fc1;W_gate] interleave, all layers' cross-attention
+ * K/V projections concatenated, [W_proj_in | W_proj_out] concatenated along K, and the
+ * timestep -> AdaLN (scale,shift) table  time_mlp(time_embed(t_embedding[t]))  for every t
+ * (src/model/DiTTO.py:75-76 + src/components/DiT.py:30: depends on t and weights only).
+ * The handle is immutable afterwards; concurrent calls on different streams are safe.
+ * If EVERY model-level pointer of `w` (everything except `layers`) is NULL the handle is "blocks-only":
+ * ditto_block_forward and ditto_text_precompute (K/V only) work, ditto_forward / ditto_rope_tables refuse. */
+int ditto_model_create(const ditto_config* cfg, const ditto_weights* w, void* arena, size_t arena_bytes,
+                       ditto_stream_t stream, ditto_model_t* out);
+int ditto_model_destroy(ditto_model_t m);
+
+/* RotaryEmbedding.forward (src/components/DiT.py:56-59): cos/sin of n*inv_freq[j],
+ * cos_out/sin_out fp32 [N, dh/2] */
+int ditto_rope_tables(ditto_model_t m, int N, float* cos_out, float* sin_out, ditto_stream_t stream);
+
+/* Step-invariant text work, once per batch of utterances (the reference redoes it every step,
+ * SURVEY.md App. B-9): the text half of GlobalAdaLN (src/components/DiT.py:27,31: mean-pool over T,
+ * SiLU, Linear) and every layer's cross-attention K/V in-projection of text_emb
+ * (src/components/DiT.py:144-148 -> torch F.multi_head_attention_forward packed in-projection).
+ * text fp32 [B,T,text_dim] -> cond (ditto_cond_bytes). */
+int ditto_text_precompute(ditto_model_t m, const float* text, int B, int T, void* cond, size_t cond_bytes,
+                          void* workspace, size_t workspace_bytes, ditto_stream_t stream);
+
+/* DiTTO.forward(x, text_emb, t)  (src/model/DiTTO.py:66-94) with text_emb given as `cond`.
+ * x fp32 [B,N,d], t int64 [B] (device), rope_cos/sin from ditto_rope_tables(N), eps_out fp32 [B,N,d]. */
+int ditto_forward(ditto_model_t m, const float* x, const void* cond, const int64_t* t, int B, int N, int T,
+                  const float* rope_cos, const float* rope_sin, float* eps_out,
+                  void* workspace, size_t workspace_bytes, ditto_stream_t stream);
+
+/* One DiT block, DiT.forward(x, text_emb, time_emb, rotary_pos) (src/components/DiT.py:100-157), in place on the
+ * fp32 residual stream h [B,N,d].  `layer` selects the packed weights, `cond_layer` the K/V slice of `cond`
+ * (a standalone block uses a 1-layer handle and cond_layer = 0).  time_emb is not an input: the reference's
+ * block ignores it. */
+int ditto_block_forward(ditto_model_t m, int layer, float* h, const void* cond, int cond_layer, int B, int N, int T,
+                        const float* rope_cos, const float* rope_sin, void* workspace, size_t workspace_bytes,
+                        ditto_stream_t stream);
+
+/* GlobalAdaLN.forward(x, time_emb, text_emb) as a standalone module (src/components/DiT.py:25-40): explicit
+ * time_emb fp32 [B,time_dim] instead of a timestep; weights are the module's own fp32 device tensors
+ * (time_mlp.1.*, text_mlp.1.*).  out fp32 [B,N,d]. */
+size_t ditto_global_adaln_scratch_bytes(int B, int d, int time_dim, int text_dim);
+int ditto_global_adaln(const float* x, const float* time_emb, const float* text_emb, const float* time_w,
+                       const float* time_b, const float* text_w, const float* text_b, int B, int N, int T, int d,
+                       int time_dim, int text_dim, float* out, void* scratch, size_t scratch_bytes,
+                       ditto_stream_t stream);
+
+/* RotaryEmbedding.apply_rope(pos, t) (src/components/DiT.py:61-72): pos fp32 [N,dh] ANGLES (the tensor
+ * RotaryEmbedding.forward returns), t fp32 [B,N,H,dh] -> out (not in place). */
+int ditto_apply_rope_f32(const float* pos, const float* t, float* out, int B, int N, int H, int dh,
+                         ditto_stream_t stream);
+
+/* SpeechGenerator.__p_sample's update (src/model/SpeechGenerator.py:137-145), in place on x:
+ *   x <- (x - (1-alpha_t)/sqrt(1-acp_t) * eps)/sqrt(alpha_t) + [t>0]*sqrt(beta_t)*noise
+ * betas/alphas/alphas_cumprod fp32 [steps] (device), t int64 [B] (device), noise may be NULL only
+ * if every t == 0 is guaranteed by the caller (it is then never read). */
+int ditto_p_sample_update(float* x, const float* eps, const float* noise, const int64_t* t,
+                          const float* betas, const float* alphas, const float* alphas_cumprod,
+                          int B, size_t elems_per_utt, ditto_stream_t stream);
+
+/* One reverse-diffusion step = ditto_forward + ditto_p_sample_update (SpeechGenerator.__p_sample,
+ * src/model/SpeechGenerator.py:130-147); eps scratch lives in the workspace. */
+int ditto_p_sample(ditto_model_t m, float* x, const void* cond, const int64_t* t, const float* noise,
+                   const float* betas, const float* alphas, const float* alphas_cumprod,
+                   int B, int N, int T, const float* rope_cos, const float* rope_sin,
+                   void* workspace, size_t workspace_bytes, ditto_stream_t stream);
+
+/* DiTTO.q_sample (src/model/DiTTO.py:106-126), bug-for-bug: `buffer` is the module's
+ * `alphas_cumprod` buffer, which holds clipped betas.  out may alias x_start. */
+int ditto_q_sample(const float* x_start, const float* noise, const int64_t* t, const float* buffer,
+                   float* out, int B, size_t elems_per_utt, ditto_stream_t stream);
+
+/* ---- single kernels, exported for unit parity tests ------------------------------------ */
+/* nn.LayerNorm(d) eps=1e-5 (src/components/DiT.py:84,89,94,105,143,152): x fp32 [M,d] -> bf16 [M,d];
+ * gamma/beta may both be NULL (elementwise_affine=False, src/components/DiT.py:23). */
+int ditto_layernorm_bf16(const float* x, const float* gamma, const float* beta, void* out_bf16,
+                         int M, int d, ditto_stream_t stream);
+
+/* out[M,N] = A[M,K](bf16, row stride lda) * W[N,K]^T(bf16) + bias[N](fp32) — F.linear.
+ * epilogue: 0 = bf16 out; 1 = fp32 out = acc + bias + residual (residual may alias out; may be NULL). */
+int ditto_gemm_bf16(const void* A, int lda, const void* W, const float* bias, const float* residual,
+                    void* out, int ldo, int M, int N, int K, int epilogue, ditto_stream_t stream);
+
+/* softmax(q k^T * scale) v per (batch, head), no mask (src/components/DiT.py:131-134;
+ * torch functional.py MHA math).  q/k/v/out bf16, element strides given per row; head h occupies
+ * columns [h*dh, (h+1)*dh) of each row; rows of batch b start at b*Sq (q,out) / b*Skv (k,v). */
+int ditto_attention_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
+                         void* out, int ldo, int B, int H, int Sq, int Skv, int dh, float scale,
+                         void* workspace, size_t workspace_bytes, ditto_stream_t stream);
+/* scratch bytes ditto_attention_bf16 needs (0 for the fused dh = 64 kernel) */
+size_t ditto_attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh);
+
+/* ---- profiling aid (bench.py): per-kernel-class HIP-event timing -------------------------
+ * When enabled on a handle, ditto_forward brackets every launch with hipEvents on `stream`
+ * (eager only; do not enable while capturing a graph).  ditto_profile_read synchronises the
+ * recorded events and returns, per class, launches and summed milliseconds since the last reset. */
+enum { DITTO_KC_LAYERNORM = 0, DITTO_KC_GEMM_QKV, DITTO_KC_GEMM_D, DITTO_KC_GEMM_GATED, DITTO_KC_GEMM_FC2,
+       DITTO_KC_GEMM_FINAL, DITTO_KC_ATTN_SELF, DITTO_KC_ATTN_CROSS, DITTO_KC_ADALN, DITTO_KC_UPDATE,
+       DITTO_KC_COUNT };
+int ditto_profile_enable(ditto_model_t m, int enable);
+int ditto_profile_read(ditto_model_t m, int32_t* launches /*[DITTO_KC_COUNT]*/, float* ms /*[DITTO_KC_COUNT]*/);
+const char* ditto_kernel_class_name(int kc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DITTO_HIP_H */

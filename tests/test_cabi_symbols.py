@@ -1,0 +1,72 @@
+"""The C-ABI library loads on a GPU-less host and exports every symbol include/ditto_hip.h declares.
+No compute call is made here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from ditto_tts_amd import hip
+from ditto_tts_amd.config import PRESETS, DiTTOConfig
+
+
+def declared_functions():
+    txt = open(os.path.join(ROOT, "include", "ditto_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ditto_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_exported_and_bound():
+    names = declared_functions()
+    assert len(names) >= 20
+    lib = hip.lib()
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in ditto_hip.h but not exported by libditto_hip.so"
+        assert n in hip.SYMBOLS, f"{n} has no ctypes prototype in ditto_tts_amd/hip.py"
+    assert sorted(hip.SYMBOLS) == names
+    assert lib.ditto_abi_version() == 1
+
+
+def test_struct_layout_matches_header():
+    # 14 model-level pointers + layers pointer; 18 per-layer pointers; 6 int32 config fields
+    assert C.sizeof(hip.Config) == 24
+    assert C.sizeof(hip.LayerWeights) == 18 * 8
+    assert C.sizeof(hip.Weights) == 15 * 8
+
+
+def test_size_queries_and_errors():
+    lib = hip.lib()
+    c = hip.make_config(PRESETS["C2"]["cfg"])
+    arena = lib.ditto_arena_bytes(C.byref(c))
+    # bf16 live parameters of 12L/768 = 137.83 M -> ~276 MB, plus fp32 vectors and the time table
+    assert 270e6 < arena < 285e6
+    ws = lib.ditto_workspace_bytes(C.byref(c), 32, 1024, 1024)
+    cond = lib.ditto_cond_bytes(C.byref(c), 32, 1024)
+    assert cond >= 32 * 1024 * 12 * 2 * 768 * 2
+    assert ws >= 32 * 1024 * 768 * (4 + 2 + 6 + 8 + 4 + 4)
+    bad = hip.Config(768, 12, 12, 256, 512, 50)             # text_dim != hidden_dim
+    assert lib.ditto_arena_bytes(C.byref(bad)) == 0
+    assert b"text_dim" in lib.ditto_last_error()
+    bad = hip.Config(96, 1, 1, 64, 96, 10)                   # not a multiple of 64
+    assert lib.ditto_arena_bytes(C.byref(bad)) == 0
+    for kc, name in enumerate(hip.KERNEL_CLASSES):
+        assert lib.ditto_kernel_class_name(kc).decode() == name
+    assert lib.ditto_attention_workspace_bytes(1, 1, 64, 64, 64) == 0
+    assert lib.ditto_attention_workspace_bytes(1, 1, 64, 64, 768) > 0
+
+
+def test_null_arguments_are_refused_not_crashed():
+    lib = hip.lib()
+    assert lib.ditto_model_create(None, None, None, 0, None, None) == hip.ERR_ARG
+    assert lib.ditto_forward(None, None, None, None, 1, 1, 1, None, None, None, None, 0, None) == hip.ERR_ARG
+    assert lib.ditto_p_sample_update(None, None, None, None, None, None, None, 1, 4, None) == hip.ERR_ARG
+    with pytest.raises(hip.DittoHipError):
+        hip.check(lib.ditto_gemm_bf16(None, 0, None, None, None, None, 0, 1, 1, 1, 0, None))
+
+
+def test_config_rejects_what_the_reference_cannot_run():
+    with pytest.raises(ValueError):
+        DiTTOConfig(768, 12, 12, 256, 512, 50)
+    with pytest.raises(ValueError):
+        DiTTOConfig(770, 12, 12, 256, 770, 50)
