@@ -110,8 +110,9 @@ class RotaryEmbedding(nn.Module):
         B, N, H, dh = t.shape
         tf = t.float().contiguous()
         out = torch.empty_like(tf)
-        hip.check(hip.lib().ditto_apply_rope_f32(pos.to(t.device).float().contiguous().data_ptr(), tf.data_ptr(),
-                                                 out.data_ptr(), B, N, H, dh, _stream()))
+        posf = pos.to(t.device).float().contiguous()
+        hip.check(hip.lib().ditto_apply_rope_f32(posf.data_ptr(), tf.data_ptr(), out.data_ptr(), B, N, H, dh,
+                                                 _stream()))
         return out.to(t.dtype)
 
 

@@ -1,0 +1,158 @@
+"""Each HIP kernel against a plain fp32 reference of the same op, through the C-ABI (libditto_hip.so).
+Tolerances: fp32 outputs of bf16-operand products: rel-L2 <= 2e-3 against an fp32 product of the SAME
+bf16-rounded operands (only accumulation order differs); bf16 outputs add one bf16 rounding (2^-9 relative)."""
+import math
+
+import pytest
+import torch
+
+from ditto_tts_amd import hip
+from gpu_util import asym, bf16, max_abs, rel_l2, stream
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return hip.lib()
+
+
+@pytest.mark.parametrize("M,d,affine", [(7, 256, True), (130, 768, True), (33, 1024, False), (5, 64, True),
+                                        (9, 2048, True)])
+def test_layernorm(lib, M, d, affine):
+    x = (asym((M, d), 1) * 1.7 + 0.3).to(DEV)
+    g = (1 + 0.1 * asym((d,), 2)).to(DEV) if affine else None
+    b = (0.1 * asym((d,), 3)).to(DEV) if affine else None
+    out = torch.empty(M, d, dtype=torch.bfloat16, device=DEV)
+    hip.check(lib.ditto_layernorm_bf16(x.data_ptr(), g.data_ptr() if affine else None,
+                                       b.data_ptr() if affine else None, out.data_ptr(), M, d, stream()))
+    want = torch.nn.functional.layer_norm(x, (d,), g, b, 1e-5)
+    assert max_abs(out.float(), want) < 3e-2           # bf16 output: |y| < ~6 -> half-ulp 1.6e-2
+    assert rel_l2(out.float(), want) < 4e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 192, 128), (1, 64, 64), (300, 2304, 768), (257, 768, 3072),
+                                   (64, 16, 64)])
+@pytest.mark.parametrize("epi", [0, 1])
+def test_gemm(lib, M, N, K, epi):
+    A = bf16(asym((M, K), 4).to(DEV))
+    W = bf16((asym((N, K), 5) / math.sqrt(K)).to(DEV))
+    bias = (0.1 * asym((N,), 6)).to(DEV)
+    res = asym((M, N), 7).to(DEV)
+    want = A.float() @ W.float().T + bias
+    if epi == 0:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        hip.check(lib.ditto_gemm_bf16(A.data_ptr(), K, W.data_ptr(), bias.data_ptr(), None, out.data_ptr(), N, M, N, K,
+                                      0, stream()))
+        assert rel_l2(out.float(), want) < 4e-3
+    else:
+        out = res.clone()   # residual aliases out (the in-place residual-stream update of the model path)
+        hip.check(lib.ditto_gemm_bf16(A.data_ptr(), K, W.data_ptr(), bias.data_ptr(), out.data_ptr(), out.data_ptr(), N,
+                                      M, N, K, 1, stream()))
+        assert rel_l2(out, want + res) < 1e-5
+        assert max_abs(out, want + res) < 1e-4
+
+
+def test_gemm_identity_asymmetric(lib):
+    """A = I with an asymmetric W catches a transposed C-write (guide §3)."""
+    K = N = 128
+    A = bf16(torch.eye(K, device=DEV))
+    W = bf16((torch.arange(N * K, device=DEV).reshape(N, K) % 251).float() - 125)   # exact in bf16
+    out = torch.empty(K, N, dtype=torch.float32, device=DEV)
+    hip.check(lib.ditto_gemm_bf16(A.data_ptr(), K, W.data_ptr(), None, None, out.data_ptr(), N, K, N, K, 1, stream()))
+    assert torch.equal(out, W.float().T)
+
+
+def _attn_ref(q, k, v, B, H, Sq, Skv, dh, scale):
+    qh = q.float().view(B, Sq, H, dh).permute(0, 2, 1, 3)
+    kh = k.float().view(B, Skv, H, dh).permute(0, 2, 1, 3)
+    vh = v.float().view(B, Skv, H, dh).permute(0, 2, 1, 3)
+    a = torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1)
+    return (a @ vh).permute(0, 2, 1, 3).reshape(B * Sq, H * dh)
+
+
+@pytest.mark.parametrize("B,H,Sq,Skv,dh", [(1, 1, 32, 64, 64), (2, 3, 200, 96, 64), (1, 2, 128, 128, 64),
+                                           (1, 4, 64, 1, 64), (2, 12, 256, 320, 64), (1, 1, 40, 50, 128),
+                                           (1, 2, 70, 33, 192)])
+def test_attention(lib, B, H, Sq, Skv, dh):
+    d = H * dh
+    q = bf16(asym((B * Sq, d), 8).to(DEV))
+    k = bf16(asym((B * Skv, d), 9).to(DEV))
+    v = bf16(asym((B * Skv, d), 10).to(DEV))
+    scale = 1.0 / math.sqrt(dh)
+    out = torch.empty(B * Sq, d, dtype=torch.bfloat16, device=DEV)
+    nws = lib.ditto_attention_workspace_bytes(B, H, Sq, Skv, dh)
+    ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=DEV)
+    hip.check(lib.ditto_attention_bf16(q.data_ptr(), d, k.data_ptr(), d, v.data_ptr(), d, out.data_ptr(), d, B, H, Sq,
+                                       Skv, dh, scale, ws.data_ptr(), ws.numel(), stream()))
+    want = _attn_ref(q, k, v, B, H, Sq, Skv, dh, scale)
+    assert rel_l2(out.float(), want) < 1.5e-2     # P is rounded to bf16 before the PV product
+    assert max_abs(out.float(), want) < 6e-2
+
+
+def test_attention_forced_rescale(lib):
+    """Rule 26: force the online-softmax rescale branch — one key in the LAST tile dominates one query row."""
+    B, H, Sq, Skv, dh = 1, 1, 64, 256, 64
+    q = asym((Sq, dh), 11) * 0.5
+    k = asym((Skv, dh), 12) * 0.5
+    v = asym((Skv, dh), 13)
+    k[Skv - 3] = q[5] * 40.0          # score ~ 40*|q5|^2*0.125 >> all others, arrives in tile 3
+    k[70] = q[9] * 30.0               # and one in tile 1 for another row
+    q, k, v = bf16(q.to(DEV)), bf16(k.to(DEV)), bf16(v.to(DEV))
+    out = torch.empty(Sq, dh, dtype=torch.bfloat16, device=DEV)
+    hip.check(hip.lib().ditto_attention_bf16(q.data_ptr(), dh, k.data_ptr(), dh, v.data_ptr(), dh, out.data_ptr(), dh,
+                                             B, H, Sq, Skv, dh, 0.125, None, 0, stream()))
+    want = _attn_ref(q, k, v, B, H, Sq, Skv, dh, 0.125)
+    assert max_abs(out.float(), want) < 6e-2
+    assert max_abs(out.float()[5], v.float()[Skv - 3]) < 6e-2   # row 5 is (almost) exactly that value row
+
+
+def test_p_sample_update_and_q_sample(lib):
+    from oracle import ditto_oracle as O
+    B, n = 3, 16 * 768
+    betas, alphas, acp = O.sampler_tables(50)
+    x, eps, z = asym((B, 16, 768), 14), asym((B, 16, 768), 15), asym((B, 16, 768), 16)
+    t = torch.tensor([49, 0, 17])
+    want = O.p_sample_update(x, eps, t, betas, alphas, acp, z)
+    # keep every device tensor referenced until the launch has been checked (a freed temporary's memory is
+    # handed to the next allocation)
+    xd, epsd, zd, td = x.to(DEV).clone(), eps.to(DEV), z.to(DEV), t.to(DEV)
+    bd, ad, cd = betas.to(DEV), alphas.to(DEV), acp.to(DEV)
+    hip.check(lib.ditto_p_sample_update(xd.data_ptr(), epsd.data_ptr(), zd.data_ptr(), td.data_ptr(), bd.data_ptr(),
+                                        ad.data_ptr(), cd.data_ptr(), B, n, stream()))
+    assert rel_l2(xd, want) < 1e-6
+    assert max_abs(xd[1], want[1]) < 1e-6   # t == 0: no noise term
+    buf = O.cosine_beta_schedule(1000)
+    tq = torch.tensor([0, 500, 999])
+    wantq = O.q_sample(buf, x, tq, z)
+    out = torch.empty_like(xd)
+    x0d, tqd, bufd = x.to(DEV), tq.to(DEV), buf.to(DEV)
+    hip.check(lib.ditto_q_sample(x0d.data_ptr(), zd.data_ptr(), tqd.data_ptr(), bufd.data_ptr(), out.data_ptr(), B, n,
+                                 stream()))
+    assert rel_l2(out, wantq) < 1e-6
+    torch.cuda.synchronize()
+
+
+def test_component_modules_adaln_and_rope(golden):
+    """GlobalAdaLN / RotaryEmbedding facade modules == golden G1 (reference outputs)."""
+    from ditto_tts_amd.modules import GlobalAdaLN, RotaryEmbedding
+    from ditto_tts_amd.config import DiTTOConfig
+    from ditto_tts_amd.synth import synthetic_state_dict
+    g = golden("G1_block_c1.npz")
+    sd = synthetic_state_dict(DiTTOConfig(256, 1, 4, 256, 256, 50), seed=1)
+    ada = GlobalAdaLN(256, 256, 256)
+    ada.load_state_dict({k[len("ada_ln."):]: v for k, v in sd.items() if k.startswith("ada_ln.")})
+    ada = ada.to(DEV)
+    with torch.no_grad():
+        h0 = ada(g["x"].to(DEV), g["temb"].to(DEV), g["text"].to(DEV))
+    assert rel_l2(h0, g["after_adaln"]) < 1e-5          # all-fp32 kernel
+    rot = RotaryEmbedding(64).to(DEV)
+    pos = rot(64, DEV)
+    assert rel_l2(pos, g["rotary_pos"]) < 1e-6
+    from oracle import ditto_oracle as O
+    tq = asym((2, 64, 4, 64), 17)
+    want = O.apply_rope(g["rotary_pos"], tq)
+    got = rot.apply_rope(pos, tq.to(DEV))
+    assert rel_l2(got, want) < 1e-5
