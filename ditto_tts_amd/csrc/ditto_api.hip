@@ -538,8 +538,17 @@ int ditto_gemm_bf16(const void* A, int lda, const void* W, const float* bias, co
     GemmArgs g{};
     g.A = A; g.lda = lda; g.W = W; g.bias = bias; g.residual = residual; g.ldr = ldo; g.out = out; g.ldo = ldo;
     g.M = M; g.N = N; g.K = K;
-    if (epilogue != 0 && epilogue != 1) return fail(DITTO_ERR_ARG, "epilogue must be 0 or 1");
-    HIP_TRY(launch_gemm(g, epilogue == 0 ? EPI_BIAS_BF16 : EPI_BIAS_RES_F32, (hipStream_t)stream));
+    GemmEpilogue e;
+    switch (epilogue) {
+        case 0: e = EPI_BIAS_BF16; break;
+        case 1: e = EPI_BIAS_RES_F32; break;
+        case 3:
+            if (!bias || N % 32) return fail(DITTO_ERR_ARG, "gated epilogue needs a bias and N %% 32 == 0");
+            e = EPI_GATED; break;
+        case 4: e = EPI_BIAS_F32; break;
+        default: return fail(DITTO_ERR_ARG, "epilogue must be 0, 1, 3 or 4");
+    }
+    HIP_TRY(launch_gemm(g, e, (hipStream_t)stream));
     return DITTO_OK;
 }
 
@@ -556,6 +565,16 @@ int ditto_attention_bf16(const void* q, int ldq, const void* k, int ldk, const v
     a.workspace = workspace; a.workspace_bytes = workspace_bytes;
     HIP_TRY(launch_attention(a, (hipStream_t)stream));
     return DITTO_OK;
+}
+
+int ditto_set_option(const char* name, int value) {
+    if (!name) return fail(DITTO_ERR_ARG, "null option name");
+    if (!strcmp(name, "gemm_tile")) {
+        if (value != 0 && value != 128 && value != 256) return fail(DITTO_ERR_ARG, "gemm_tile must be 0, 128 or 256");
+        g_gemm_tile = value;
+        return DITTO_OK;
+    }
+    return fail(DITTO_ERR_ARG, "unknown option '%s'", name);
 }
 
 int ditto_profile_enable(ditto_model_t m, int enable) {

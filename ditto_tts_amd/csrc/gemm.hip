@@ -22,10 +22,14 @@
 //     the same lane (no cross-lane traffic in the fused epilogues).
 //   * XCD-aware, bijective block->tile map: each XCD (private 4 MiB L2) walks a contiguous range of
 //     M-panels, sweeping N inside a panel, so an A panel is fetched from HBM once per XCD.
-#include "common.h"
-#include "kernels.h"
+#include <cstdlib>
+
+#include "gemm_common.h"
 
 namespace ditto {
+
+// 0 = automatic, 128 / 256 = force that tile structure (ditto_set_option("gemm_tile", v); env DITTO_GEMM seeds it)
+int g_gemm_tile = [] { const char* e = getenv("DITTO_GEMM"); return e ? atoi(e) : 0; }();
 
 namespace {
 
@@ -33,21 +37,6 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile
 constexpr int BUF_BYTES = 2 * TILE_BYTES;        // A + W
 constexpr int GEMM_LDS = 2 * BUF_BYTES;          // double buffered: 64 KiB
-
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-
-struct GemmParams {
-    const bf16* A; int lda;
-    const bf16* W; int ldw; int w_rows;
-    const float* bias;
-    const float* residual; int ldr;
-    void* out; int ldo;
-    bf16* out2; int ldo2;
-    const float* rope_cos; const float* rope_sin; int rope_rpb; int rope_cols;
-    int M, N, K;
-    int tiles_m, tiles_n;
-};
 
 // Issue the LDS-DMA loads of one (A, W) K-tile.  Lane -> (row, chunk position) is linear in LDS;
 // the source chunk is the swizzled one.
@@ -115,99 +104,13 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmParams p) {
         __syncthreads();
     }
 
-    // ---------------- epilogue: lane owns rows (lane&15) and 4 consecutive columns per (m, n) ----------------
-    const int col_in_wave = fq * 4;  // + n*16
+    // ---------------- epilogue (gemm_common.h): lane owns row (lane&15) of each 16-row block ----------------
+    f32x4 bias4[4];
+    load_bias(p, n0 + wc * 64, fq, bias4);
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const int row = m0 + wr * 64 + m * 16 + frow;
-        if (row >= p.M) continue;
-        if constexpr (EPI == EPI_GATED) {
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                const int pc = n0 + wc * 64 + pr * 32 + col_in_wave;  // packed column of the fc1 half
-                if (pc >= p.N) continue;
-                const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + pc);
-                const f32x4 bg = *reinterpret_cast<const f32x4*>(p.bias + pc + 16);
-                const f32x4 h = acc[m][2 * pr], g = acc[m][2 * pr + 1];
-                float o[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = gelu_erf_f(h[e] + b1[e]) * sigmoid_f(g[e] + bg[e]);
-                const int oc = (n0 + wc * 64) / 2 + pr * 16 + col_in_wave;
-                u32x2 st;
-                st[0] = pack_bf16x2(o[0], o[1]);
-                st[1] = pack_bf16x2(o[2], o[3]);
-                *reinterpret_cast<u32x2*>((bf16*)p.out + (size_t)row * p.ldo + oc) = st;
-            }
-        } else if constexpr (EPI == EPI_QKV_ROPE) {
-            const int cbase = n0 + wc * 64;  // 64-aligned: exactly one head of width 64
-            float v[4][4];
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const int c = cbase + n * 16 + col_in_wave;
-                f32x4 b = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias && c < p.N) b = *reinterpret_cast<const f32x4*>(p.bias + c);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[n][e] = acc[m][n][e] + b[e];
-            }
-            if (cbase < p.rope_cols) {  // q or k head: half-split RoPE, pair (j, j+32); src/components/DiT.py:52-72
-                const int pos = row % p.rope_rpb;
-                float r[4][4];
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    const f32x4 cs = *reinterpret_cast<const f32x4*>(p.rope_cos + (size_t)pos * 32 + n * 16 + col_in_wave);
-                    const f32x4 sn = *reinterpret_cast<const f32x4*>(p.rope_sin + (size_t)pos * 32 + n * 16 + col_in_wave);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float lo = v[n][e], hi = v[n + 2][e];
-                        r[n][e] = lo * cs[e] - hi * sn[e];      // t*cos + (-t[j+32])*sin
-                        r[n + 2][e] = hi * cs[e] + lo * sn[e];  // t*cos + ( t[j-32])*sin
-                    }
-                }
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[n][e] = r[n][e];
-            }
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const int c = cbase + n * 16 + col_in_wave;
-                if (c >= p.N) continue;
-                u32x2 st;
-                st[0] = pack_bf16x2(v[n][0], v[n][1]);
-                st[1] = pack_bf16x2(v[n][2], v[n][3]);
-                *reinterpret_cast<u32x2*>((bf16*)p.out + (size_t)row * p.ldo + c) = st;
-            }
-        } else {
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const int c = n0 + wc * 64 + n * 16 + col_in_wave;
-                if (c >= p.N) continue;
-                f32x4 v = acc[m][n];
-                if (p.bias) {
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + c);
-                    v += b;
-                }
-                if constexpr (EPI == EPI_BIAS_BF16) {
-                    u32x2 st;
-                    st[0] = pack_bf16x2(v[0], v[1]);
-                    st[1] = pack_bf16x2(v[2], v[3]);
-                    *reinterpret_cast<u32x2*>((bf16*)p.out + (size_t)row * p.ldo + c) = st;
-                } else {
-                    if constexpr (EPI == EPI_BIAS_RES_F32) {
-                        if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)row * p.ldr + c);
-                    }
-                    *reinterpret_cast<f32x4*>((float*)p.out + (size_t)row * p.ldo + c) = v;
-                    if constexpr (EPI == EPI_BIAS_RES_F32) {
-                        if (p.out2) {
-                            u32x2 st;
-                            st[0] = pack_bf16x2(v[0], v[1]);
-                            st[1] = pack_bf16x2(v[2], v[3]);
-                            *reinterpret_cast<u32x2*>(p.out2 + (size_t)row * p.ldo2 + c) = st;
-                        }
-                    }
-                }
-            }
-        }
+        if (row < p.M) epilogue_row<EPI>(p, row, n0 + wc * 64, acc[m], bias4, fq);
     }
 }
 
@@ -236,18 +139,32 @@ hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s) {
     p.out2 = (bf16*)a.out2_bf16; p.ldo2 = a.ldo2;
     p.rope_cos = a.rope_cos; p.rope_sin = a.rope_sin; p.rope_rpb = a.rope_rows_per_batch; p.rope_cols = a.rope_cols;
     p.M = a.M; p.N = a.N; p.K = a.K;
+    switch (epi) {
+        case EPI_QKV_ROPE:
+            if (a.N % 64 || a.rope_cols % 64 || !a.rope_cos || !a.rope_sin || a.rope_rows_per_batch <= 0)
+                return hipErrorInvalidValue;
+            break;
+        case EPI_GATED:
+            if (a.N % 32 || !a.bias) return hipErrorInvalidValue;
+            break;
+        default: break;
+    }
+    // Structure choice: the 256x256 eight-phase kernel (1 workgroup / CU) once its grid covers the chip;
+    // the 128x128 kernel for small problems.  DITTO_GEMM=128|256 forces one (experiments).
+    const int forced = g_gemm_tile;
+    const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+    if (forced == 256 || (forced != 128 && t256 >= 192)) {
+        p.tiles_m = (a.M + 255) / 256;
+        p.tiles_n = (a.N + 255) / 256;
+        return launch_gemm256(p, epi, s);
+    }
     p.tiles_m = (a.M + BM - 1) / BM;
     p.tiles_n = (a.N + BN - 1) / BN;
     switch (epi) {
         case EPI_BIAS_BF16: return launch_t<EPI_BIAS_BF16>(p, s);
         case EPI_BIAS_RES_F32: return launch_t<EPI_BIAS_RES_F32>(p, s);
-        case EPI_QKV_ROPE:
-            if (a.N % 64 || a.rope_cols % 64 || !a.rope_cos || !a.rope_sin || a.rope_rows_per_batch <= 0)
-                return hipErrorInvalidValue;
-            return launch_t<EPI_QKV_ROPE>(p, s);
-        case EPI_GATED:
-            if (a.N % 32 || !a.bias) return hipErrorInvalidValue;
-            return launch_t<EPI_GATED>(p, s);
+        case EPI_QKV_ROPE: return launch_t<EPI_QKV_ROPE>(p, s);
+        case EPI_GATED: return launch_t<EPI_GATED>(p, s);
         case EPI_BIAS_F32: return launch_t<EPI_BIAS_F32>(p, s);
     }
     return hipErrorInvalidValue;

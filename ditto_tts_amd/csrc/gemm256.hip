@@ -1,0 +1,272 @@
+// gemm256.hip — 256x256x64 eight-phase bf16 MFMA GEMM for gfx950 (1 workgroup of 8 waves per CU).
+//
+// Same contract and epilogues as gemm.hip (out = A[M,K] * W[N,K]^T, fused epilogue); this is the structure
+// for problems whose 256x256 grid covers the chip.  It follows the recipe of cdna_hip_programming.md §5
+// ("The 256^2 8-phase template": LDS-DMA staging that stays in flight across raw s_barriers behind a COUNTED
+// vmcnt, two wave groups staggered by one barrier so that on every SIMD one wave is in its MFMA segment while
+// its partner is in its LDS/DMA segment, st_16x32-style source-side swizzle), re-derived for this layout:
+//
+//   waves     8 = 2 (M) x 4 (N); wave (wm, wn) owns C rows [128 wm, +128) x cols [64 wn, +64):
+//             8 x 4 accumulators of v_mfma_f32_16x16x32_bf16 = 128 fp32 registers.
+//   LDS       128 KiB = 2 K-tile buffers x 4 half-tiles (A_lo, A_hi, B_lo, B_hi; 128 rows x 128 B = 16 KiB each).
+//             Row r keeps 16-B chunk c at position c ^ ((r>>1)&7)  (conflict-free ds_read_b128; the swizzle is
+//             applied to the DMA's per-lane SOURCE address, the LDS image itself is lane-linear).
+//   K-tile    = 4 phases, one 64x32 quadrant of the wave tile (16 MFMAs) each:
+//               P1: read B0 (4) + A0 (8 ds_read_b128) -> C00     P2: read B1 (4) -> C01
+//               P3: read A1 (8)                        -> C11     P4: no reads     -> C10 (A1, B0 still in registers)
+//             so a buffer's B halves are last read in P2 and its A halves in P3.
+//   phase     = { ds_reads ; issue this phase's DMA (global_load_lds_dwordx4, 2 per wave per half-tile) ;
+//                 [P4/P8: s_waitcnt vmcnt(4)] ; s_barrier ; 16 MFMA ; s_barrier }.
+//   DMA order (tile e = even buffer, o = odd buffer), each half restaged >= 2 phases after its last read and
+//   issued >= 2 phases before the wait that retires it (a first version with one half-tile per phase and
+//   vmcnt(2) left the last half one phase of lead and ran at half the MFMA rate):
+//               P8: o.B_lo+o.B_hi  P1: o.A_lo  P2: o.A_hi  P3: -  | P4: vmcnt(4) -> o complete, read in P5..P7
+//               P4: e.B_lo+e.B_hi  P5: e.A_lo  P6: e.A_hi  P7: -  | P8: vmcnt(4) -> e complete, read in P1..P3
+//             (vmcnt(4) leaves exactly the phase's own two half-tiles in flight; vmcnt(0) once the look-ahead
+//             tile does not exist).
+//   persistent: gridDim = #CUs; a workgroup walks tiles b, b+grid, ... and issues the NEXT tile's first DMA
+//             before the current tile's epilogue, so the cold-start latency hides under the stores.
+//   stagger   waves 4-7 (wm = 1) run one barrier behind waves 0-3: every barrier interval has one group in
+//             its MFMA segment and the other in its read/DMA segment.  Visibility of DMA data is by
+//             {every issuing wave's vmcnt ; a barrier the reader has passed}: the readers' phase comes two
+//             barriers after both groups' waits.
+//   tails     rows past M / N are clamped on load and masked on store; K-tiles past the end are neither
+//             loaded nor multiplied.
+#include "gemm_common.h"
+
+namespace ditto {
+
+namespace {
+
+constexpr int HALF_BYTES = 128 * 64 * 2;  // 16 KiB
+constexpr int KT_BYTES = 4 * HALF_BYTES;  // 64 KiB: A_lo | A_hi | B_lo | B_hi
+constexpr int LDS256 = 2 * KT_BYTES;      // 128 KiB
+
+template <int V>
+struct IC { static constexpr int value = V; };
+
+#define DITTO_BAR() asm volatile("s_barrier" ::: "memory")
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int nkt = p.K / 64;
+
+    // ---- DMA source addressing: this wave moves pieces 2*wid, 2*wid+1 (1 KiB = 8 rows) of every half-tile ----
+    const int srow = lane >> 3;   // row inside a piece
+    const int scpos = lane & 7;   // chunk position inside the 128-B row
+    int m0 = 0, n0 = 0;           // origin of the tile whose DMA is being issued
+    auto stage = [&](int buf, auto HALF, int kt) {
+        constexpr int half = decltype(HALF)::value;
+        if (kt >= nkt) return;    // wave-uniform; the waits below account for it
+        const int k0 = kt * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int piece = wid * 2 + i;
+            const int row = piece * 8 + srow;  // 0..127 inside the half
+            const int c = scpos ^ ((row >> 1) & 7);
+            const bf16* src;
+            if constexpr (half < 2) {
+                int gr = m0 + half * 128 + row;
+                gr = gr < p.M ? gr : p.M - 1;
+                src = p.A + (size_t)gr * p.lda + k0 + c * 8;
+            } else {
+                int gr = n0 + (half - 2) * 128 + row;
+                gr = gr < p.w_rows ? gr : p.w_rows - 1;
+                src = p.W + (size_t)gr * p.ldw + k0 + c * 8;
+            }
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src,
+                                             (lds_ptr_t)(smem + buf * KT_BYTES + half * HALF_BYTES + piece * 1024), 16, 0,
+                                             0);
+        }
+    };
+    // tile 0 -> buffer 0 (all four halves), tile 1's B halves -> buffer 1: the state the loop's P1 expects
+    auto prologue = [&](int tile) {
+        const int t = xcd_remap(tile, ntiles);
+        m0 = (t / p.tiles_n) * 256;
+        n0 = (t % p.tiles_n) * 256;
+        stage(0, IC<2>{}, 0);
+        stage(0, IC<3>{}, 0);
+        stage(0, IC<0>{}, 0);
+        stage(0, IC<1>{}, 0);
+        stage(1, IC<2>{}, 1);
+        stage(1, IC<3>{}, 1);
+    };
+
+    // ---- fragment addressing ----
+    const int frow = lane & 15, fq = lane >> 4, fswz = frow >> 1;
+    const int a_base = wm * HALF_BYTES + frow * 128;                                 // + (ai*64 + m*16)*128
+    const int b_base = (2 + (wn >> 1)) * HALF_BYTES + ((wn & 1) * 64 + frow) * 128;  // + (bj*32 + n*16)*128
+    const int coff0 = ((0 + fq) ^ fswz) << 4, coff1 = ((4 + fq) ^ fswz) << 4;
+
+    bf16x8 af[8], b0f[4], b1f[4];
+    f32x4 acc[8][4];
+
+    auto read_A = [&](int buf, auto AI) {
+        constexpr int ai = decltype(AI)::value;
+        const char* base = smem + buf * KT_BYTES + a_base + ai * 64 * 128;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            af[m * 2 + 0] = *reinterpret_cast<const bf16x8*>(base + m * 16 * 128 + coff0);
+            af[m * 2 + 1] = *reinterpret_cast<const bf16x8*>(base + m * 16 * 128 + coff1);
+        }
+    };
+    auto read_B = [&](int buf, auto BJ, bf16x8(&bf)[4]) {
+        constexpr int bj = decltype(BJ)::value;
+        const char* base = smem + buf * KT_BYTES + b_base + bj * 32 * 128;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            bf[n * 2 + 0] = *reinterpret_cast<const bf16x8*>(base + n * 16 * 128 + coff0);
+            bf[n * 2 + 1] = *reinterpret_cast<const bf16x8*>(base + n * 16 * 128 + coff1);
+        }
+    };
+    auto mma = [&](auto AI, auto BJ, const bf16x8(&bf)[4]) {
+        constexpr int ai = decltype(AI)::value, bj = decltype(BJ)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[ai * 4 + m][bj * 2 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        bf[n * 2 + kk], af[m * 2 + kk], acc[ai * 4 + m][bj * 2 + n], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // counted wait: `ahead` = the DMA this phase issued itself exists (4 loads stay in flight), else drain
+    auto wait_dma = [&](bool ahead) {
+        if (ahead) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
+    const int niter = (nkt + 1) / 2;
+    int tile = blockIdx.x;
+    if (tile < ntiles) prologue(tile);
+
+    for (; tile < ntiles; tile += p.tile_stride) {
+        const int cur_m0 = m0, cur_n0 = n0;
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // buffer 0 complete (everything older than the newest 4 loads: tile 1's B halves, or the previous
+        // tile's epilogue stores, which were issued AFTER this tile's prologue DMA)
+        wait_dma(nkt > 1);
+        DITTO_BAR();
+        if (wm == 1) DITTO_BAR();  // stagger the second wave group by one barrier
+
+        for (int it = 0; it < niter; ++it) {
+            const int te = 2 * it, to = te + 1;
+            const bool odd_valid = to < nkt;
+            // ---------------- K-tile te from buffer 0 ----------------
+            read_B(0, IC<0>{}, b0f);
+            read_A(0, IC<0>{});
+            stage(1, IC<0>{}, to);                    // P1: o.A_lo   (buffer 1's A halves were last read in P7)
+            DITTO_BAR();
+            mma(IC<0>{}, IC<0>{}, b0f);
+            DITTO_BAR();
+
+            read_B(0, IC<1>{}, b1f);
+            stage(1, IC<1>{}, to);                    // P2: o.A_hi
+            DITTO_BAR();
+            mma(IC<0>{}, IC<1>{}, b1f);
+            DITTO_BAR();
+
+            read_A(0, IC<1>{});                       // P3: no DMA
+            DITTO_BAR();
+            mma(IC<1>{}, IC<1>{}, b1f);
+            DITTO_BAR();
+
+            stage(0, IC<2>{}, te + 2);                // P4: e.B_lo + e.B_hi (buffer 0's B halves were last read in P2)
+            stage(0, IC<3>{}, te + 2);
+            wait_dma(te + 2 < nkt);                   // buffer 1 (tile to: issued P8, P1, P2) has landed
+            DITTO_BAR();
+            mma(IC<1>{}, IC<0>{}, b0f);
+            DITTO_BAR();
+
+            // ---------------- K-tile to from buffer 1 ----------------
+            read_B(1, IC<0>{}, b0f);
+            read_A(1, IC<0>{});
+            stage(0, IC<0>{}, te + 2);                // P5: e.A_lo   (buffer 0's A halves were last read in P3)
+            DITTO_BAR();
+            if (odd_valid) mma(IC<0>{}, IC<0>{}, b0f);
+            DITTO_BAR();
+
+            read_B(1, IC<1>{}, b1f);
+            stage(0, IC<1>{}, te + 2);                // P6: e.A_hi
+            DITTO_BAR();
+            if (odd_valid) mma(IC<0>{}, IC<1>{}, b1f);
+            DITTO_BAR();
+
+            read_A(1, IC<1>{});                       // P7: no DMA
+            DITTO_BAR();
+            if (odd_valid) mma(IC<1>{}, IC<1>{}, b1f);
+            DITTO_BAR();
+
+            stage(1, IC<2>{}, to + 2);                // P8: o.B_lo + o.B_hi of the next odd tile
+            stage(1, IC<3>{}, to + 2);
+            wait_dma(to + 2 < nkt);                   // buffer 0 (tile te+2: issued P4, P5, P6) has landed
+            DITTO_BAR();
+            if (odd_valid) mma(IC<1>{}, IC<0>{}, b0f);
+            DITTO_BAR();
+        }
+        if (wm == 0) DITTO_BAR();  // balance the stagger barrier: every LDS read of this tile has retired
+
+        // next tile's first K-tiles start streaming in now, under this tile's epilogue
+        const int next = tile + p.tile_stride;
+        if (next < ntiles) prologue(next);
+
+        // ---------------- epilogue ----------------
+        f32x4 bias4[4];
+        load_bias(p, cur_n0 + wn * 64, fq, bias4);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int row = cur_m0 + wm * 128 + m * 16 + frow;
+            if (row < p.M) epilogue_row<EPI>(p, row, cur_n0 + wn * 64, acc[m], bias4, fq);
+        }
+    }
+}
+
+template <int EPI>
+hipError_t launch256_t(const GemmParams& p, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS256);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3(p.tile_stride), dim3(512), LDS256, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_gemm256(const GemmParams& p_in, GemmEpilogue epi, hipStream_t s) {
+    // persistent grid: one workgroup per CU (128 KiB LDS each), walking tiles b, b + grid, ...
+    static int n_cu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        return n;
+    }();
+    GemmParams p = p_in;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    p.tile_stride = ntiles < n_cu ? ntiles : n_cu;
+    switch (epi) {
+        case EPI_BIAS_BF16: return launch256_t<EPI_BIAS_BF16>(p, s);
+        case EPI_BIAS_RES_F32: return launch256_t<EPI_BIAS_RES_F32>(p, s);
+        case EPI_QKV_ROPE: return launch256_t<EPI_QKV_ROPE>(p, s);
+        case EPI_GATED: return launch256_t<EPI_GATED>(p, s);
+        case EPI_BIAS_F32: return launch256_t<EPI_BIAS_F32>(p, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace ditto

@@ -57,6 +57,7 @@ struct GemmArgs {
     int M, N, K;
 };
 hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s);
+extern int g_gemm_tile;  // 0 auto | 128 | 256
 
 // ---------------- attention.hip ----------------
 struct AttnArgs {

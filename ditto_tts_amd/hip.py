@@ -94,6 +94,7 @@ SYMBOLS = {
     "ditto_gemm_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ditto_attention_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
     "ditto_attention_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "ditto_set_option": (_i, [C.c_char_p, _i]),
     "ditto_profile_enable": (_i, [_vp, _i]),
     "ditto_profile_read": (_i, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     "ditto_kernel_class_name": (C.c_char_p, [_i]),

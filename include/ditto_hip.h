@@ -172,7 +172,10 @@ int ditto_layernorm_bf16(const float* x, const float* gamma, const float* beta, 
                          int M, int d, ditto_stream_t stream);
 
 /* out[M,N] = A[M,K](bf16, row stride lda) * W[N,K]^T(bf16) + bias[N](fp32) — F.linear.
- * epilogue: 0 = bf16 out; 1 = fp32 out = acc + bias + residual (residual may alias out; may be NULL). */
+ * epilogue: 0 = bf16 out; 1 = fp32 out = acc + bias + residual (residual may alias out; may be NULL);
+ *           4 = fp32 out = acc + bias;
+ *           3 = gated MLP (src/components/DiT.py:153-155): W/bias rows interleaved in blocks of 16
+ *               [16 x mlp_fc1 | 16 x gate | ...], out bf16 [M, N/2] = gelu_erf(a) * sigmoid(g), ldo = N/2 or more. */
 int ditto_gemm_bf16(const void* A, int lda, const void* W, const float* bias, const float* residual,
                     void* out, int ldo, int M, int N, int K, int epilogue, ditto_stream_t stream);
 
@@ -184,6 +187,10 @@ int ditto_attention_bf16(const void* q, int ldq, const void* k, int ldk, const v
                          void* workspace, size_t workspace_bytes, ditto_stream_t stream);
 /* scratch bytes ditto_attention_bf16 needs (0 for the fused dh = 64 kernel) */
 size_t ditto_attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh);
+
+/* Process-wide tuning switches (tests / experiments).  "gemm_tile": 0 = automatic choice between the two GEMM
+ * tile structures, 128 / 256 = force one.  Results are identical up to fp32 summation order. */
+int ditto_set_option(const char* name, int value);
 
 /* ---- profiling aid (bench.py): per-kernel-class HIP-event timing -------------------------
  * When enabled on a handle, ditto_forward brackets every launch with hipEvents on `stream`

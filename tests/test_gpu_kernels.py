@@ -55,6 +55,50 @@ def test_gemm(lib, M, N, K, epi):
         assert max_abs(out, want + res) < 1e-4
 
 
+@pytest.fixture
+def tile256(lib):
+    hip.check(lib.ditto_set_option(b"gemm_tile", 256))
+    yield
+    hip.check(lib.ditto_set_option(b"gemm_tile", 0))
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 320, 64), (1000, 768, 768), (513, 2304, 192),
+                                   (260, 272, 3072), (1, 16, 64), (2048, 1024, 320)])
+@pytest.mark.parametrize("epi", [0, 1])
+def test_gemm_256_tile_structure(lib, tile256, M, N, K, epi):
+    """The eight-phase 256x256 kernel forced on ragged M / N and odd / even K-tile counts (K = 64, 192, 320)."""
+    A = bf16(asym((M, K), 4).to(DEV))
+    W = bf16((asym((N, K), 5) / math.sqrt(K)).to(DEV))
+    bias = (0.1 * asym((N,), 6)).to(DEV)
+    res = asym((M, N), 7).to(DEV)
+    want = A.float() @ W.float().T + bias
+    for rep in range(3):   # repeat: a DMA/ds_read race would show as run-to-run differences
+        if epi == 0:
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+            hip.check(lib.ditto_gemm_bf16(A.data_ptr(), K, W.data_ptr(), bias.data_ptr(), None, out.data_ptr(), N, M, N,
+                                          K, 0, stream()))
+            assert rel_l2(out.float(), want) < 4e-3
+        else:
+            out = res.clone()
+            hip.check(lib.ditto_gemm_bf16(A.data_ptr(), K, W.data_ptr(), bias.data_ptr(), out.data_ptr(), out.data_ptr(),
+                                          N, M, N, K, 1, stream()))
+            assert rel_l2(out, want + res) < 1e-5
+            assert max_abs(out, want + res) < 2e-4
+        if rep == 0:
+            first = out.clone()
+        else:
+            assert torch.equal(out, first)
+
+
+def test_gemm_identity_asymmetric_256(lib, tile256):
+    K = N = 256
+    A = bf16(torch.eye(K, device=DEV))
+    W = bf16((torch.arange(N * K, device=DEV).reshape(N, K) % 251).float() - 125)
+    out = torch.empty(K, N, dtype=torch.float32, device=DEV)
+    hip.check(lib.ditto_gemm_bf16(A.data_ptr(), K, W.data_ptr(), None, None, out.data_ptr(), N, K, N, K, 1, stream()))
+    assert torch.equal(out, W.float().T)
+
+
 def test_gemm_identity_asymmetric(lib):
     """A = I with an asymmetric W catches a transposed C-write (guide §3)."""
     K = N = 128

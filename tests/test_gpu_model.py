@@ -60,6 +60,25 @@ def test_g2_full_ditto_s(golden):
 
 
 @torch.no_grad()
+@pytest.mark.parametrize("tile", [128, 256])
+def test_g2_with_forced_gemm_structure(golden, tile):
+    """Every fused epilogue (RoPE, gated MLP, residual, K-concatenated final) through BOTH GEMM tile structures."""
+    from ditto_tts_amd import hip
+    g = golden("G2_ditto_s.npz")
+    cfg = DiTTOConfig(768, 12, 12, 256, 768, 50)
+    m = build(cfg, 2)
+    x, text, t = synthetic_inputs(cfg, 2, 128, 96, seed=22)
+    hip.check(hip.lib().ditto_set_option(b"gemm_tile", tile))
+    try:
+        out = m(x.to(DEV), text.to(DEV), t.to(DEV))
+        out2 = m(x.to(DEV), text.to(DEV).clone(), t.to(DEV))
+    finally:
+        hip.check(hip.lib().ditto_set_option(b"gemm_tile", 0))
+    close(out, g["out"])
+    assert torch.equal(out, out2)
+
+
+@torch.no_grad()
 def test_g2_intermediate_blocks(golden):
     """Per-block parity: run blocks through the C-ABI block entry point and compare blocks 0, 5, 11."""
     g = golden("G2_ditto_s.npz")
