@@ -574,6 +574,10 @@ int ditto_set_option(const char* name, int value) {
         g_gemm_tile = value;
         return DITTO_OK;
     }
+    if (!strcmp(name, "gemm_flags")) {
+        g_gemm_flags = value;
+        return DITTO_OK;
+    }
     return fail(DITTO_ERR_ARG, "unknown option '%s'", name);
 }
 

@@ -29,6 +29,7 @@
 namespace ditto {
 
 // 0 = automatic, 128 / 256 = force that tile structure (ditto_set_option("gemm_tile", v); env DITTO_GEMM seeds it)
+int g_gemm_flags = GF_RELAXED_WAIT | GF_STAGGER_START | GF_STORE_NT;
 int g_gemm_tile = [] { const char* e = getenv("DITTO_GEMM"); return e ? atoi(e) : 0; }();
 
 namespace {
@@ -149,17 +150,20 @@ hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s) {
             break;
         default: break;
     }
-    // Structure choice: the 256x256 eight-phase kernel (1 workgroup / CU) once its grid covers the chip;
-    // the 128x128 kernel for small problems.  DITTO_GEMM=128|256 forces one (experiments).
+    // Structure choice (measured in-model on MI355X, tools/step_ab.py, one device): the persistent 256x256
+    // eight-phase kernel wins once every CU gets >= 4 tiles (QKV: 145 vs 166 us, gated MLP: 307 vs 424 us);
+    // at 1.5 tiles per CU (the N = 768 GEMMs) its tile quantisation loses to the 128x128 kernel (d x d 84 vs
+    // 69 us, fc2 218 vs 205 us).  DITTO_GEMM=128|256 / ditto_set_option("gemm_tile") force one.
     const int forced = g_gemm_tile;
     const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-    if (forced == 256 || (forced != 128 && t256 >= 192)) {
+    if (forced == 256 || (forced != 128 && t256 >= 4 * 256)) {
         p.tiles_m = (a.M + 255) / 256;
         p.tiles_n = (a.N + 255) / 256;
         return launch_gemm256(p, epi, s);
     }
     p.tiles_m = (a.M + BM - 1) / BM;
     p.tiles_n = (a.N + BN - 1) / BN;
+    p.flags = g_gemm_flags & ~(GF_DIAG_NO_STORE | GF_DIAG_NO_EPILOGUE | GF_DIAG_LINEAR_STORE);
     switch (epi) {
         case EPI_BIAS_BF16: return launch_t<EPI_BIAS_BF16>(p, s);
         case EPI_BIAS_RES_F32: return launch_t<EPI_BIAS_RES_F32>(p, s);

@@ -143,9 +143,25 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
 
+    // VMEM instructions one wave issues in the epilogue of a fully interior tile AFTER the next tile's prologue
+    // DMA (stores; the compiler's own waits retire the loads).  vmcnt retires in order, so the tile-start wait may
+    // leave these (younger) stores in flight and still guarantee the (older) prologue DMA has landed: the store
+    // drain of the previous tile then overlaps the first phases instead of stalling the whole workgroup.
+    constexpr int EPI_STORES = EPI == EPI_BIAS_BF16 ? 16 : EPI == EPI_QKV_ROPE ? 16 : EPI == EPI_GATED ? 8 : 32;
+    bool prev_interior = false;   // previous tile of this workgroup was interior (its store count is exact)
+
     const int niter = (nkt + 1) / 2;
     int tile = blockIdx.x;
     if (tile < ntiles) prologue(tile);
+    if ((p.flags & GF_STAGGER_START) && ntiles >= 8 * p.tile_stride) {   // pays only with many rounds per CU
+        // All CUs run identical tiles, so without this they alternate in lockstep between an HBM-idle multiply
+        // phase and a chip-wide store burst.  Offsetting 4 groups of workgroups by a quarter tile each spreads the
+        // stores of some CUs under the MFMA work of the others.  (blockIdx>>3 walks the CUs of one XCD.)
+        const int g = (blockIdx.x >> 3) & 3;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long wait = (unsigned long long)g * (unsigned)p.stagger_ticks;
+        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
 
     for (; tile < ntiles; tile += p.tile_stride) {
         const int cur_m0 = m0, cur_n0 = n0;
@@ -156,7 +172,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 
         // buffer 0 complete (everything older than the newest 4 loads: tile 1's B halves, or the previous
         // tile's epilogue stores, which were issued AFTER this tile's prologue DMA)
-        wait_dma(nkt > 1);
+        if (prev_interior && nkt > 1 && (p.flags & GF_RELAXED_WAIT)) {
+            if constexpr (EPI_STORES == 8) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if constexpr (EPI_STORES == 16) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+        } else {
+            wait_dma(nkt > 1);
+        }
         DITTO_BAR();
         if (wm == 1) DITTO_BAR();  // stagger the second wave group by one barrier
 
@@ -222,6 +244,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         if (next < ntiles) prologue(next);
 
         // ---------------- epilogue ----------------
+        prev_interior = (cur_m0 + 256 <= p.M) && (cur_n0 + 256 <= p.N) && !(EPI == EPI_BIAS_RES_F32 && p.out2) &&
+                        !(p.flags & (GF_DIAG_NO_STORE | GF_DIAG_NO_EPILOGUE));
+        if (p.flags & GF_DIAG_NO_EPILOGUE) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) asm volatile("" ::"v"(acc[m][n]));   // keep the accumulators live
+            continue;
+        }
         f32x4 bias4[4];
         load_bias(p, cur_n0 + wn * 64, fq, bias4);
 #pragma unroll
@@ -259,6 +290,9 @@ hipError_t launch_gemm256(const GemmParams& p_in, GemmEpilogue epi, hipStream_t 
     GemmParams p = p_in;
     const int ntiles = p.tiles_m * p.tiles_n;
     p.tile_stride = ntiles < n_cu ? ntiles : n_cu;
+    p.flags = g_gemm_flags;
+    // quarter of the expected tile time: ~1.5 us per K-tile + ~8 us fixed, in 10 ns ticks
+    p.stagger_ticks = (int)((p.K / 64 * 1.5 + 8.0) * 100.0 / 4.0);
     switch (epi) {
         case EPI_BIAS_BF16: return launch256_t<EPI_BIAS_BF16>(p, s);
         case EPI_BIAS_RES_F32: return launch256_t<EPI_BIAS_RES_F32>(p, s);

@@ -21,7 +21,17 @@ struct GemmParams {
     int M, N, K;
     int tiles_m, tiles_n;
     int tile_stride;   // gemm256: persistent workgroups walk tiles b, b + stride, ...
+    int stagger_ticks; // GF_STAGGER_START: s_memrealtime ticks (100 MHz) per quarter tile
+    int flags;         // experiment switches (ditto_set_option("gemm_flags")): see GF_* below
 };
+
+enum { GF_RELAXED_WAIT = 1,   // tile-start wait skips over the previous tile's epilogue stores
+       GF_DIAG_NO_STORE = 2,  // DIAGNOSTIC (wrong results): epilogue computes but does not store
+       GF_DIAG_NO_EPILOGUE = 4,    // DIAGNOSTIC (wrong results): no epilogue at all
+       GF_STAGGER_START = 8,
+       GF_DIAG_LINEAR_STORE = 16,    // DIAGNOSTIC (wrong results): bf16 stores go to lane-linear addresses
+       GF_STORE_SC1 = 32,            // output stores write-through, line dropped from L2 (sc1)
+       GF_STORE_NT = 64 };           // output stores non-temporal (nt)  // DIAGNOSTIC (wrong results): bf16 stores go to lane-linear addresses     // de-synchronise the persistent workgroups: group g of 4 starts g/4 tile late
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -37,6 +47,47 @@ DITTO_DEV void load_bias(const GemmParams& p, int cbase, int fq, f32x4 (&b)[4]) 
     }
 }
 
+// 16-byte global store with a cache policy: plain, sc1 (write-through, no L2 residency) or nt.
+// Measured on MI355X (tools/gemm_bench.py, same-process A/B): nt on the fp32 in-place residual epilogue
+// (d x d out-proj, fc2) -20..-26 % kernel time; on bf16 outputs nt / sc1 are within +-3 %, so nt applies to
+// fp32 outputs only.
+template <bool F32_OUT>
+DITTO_DEV void store16(void* ptr, u32x4 v, int flags) {
+    if (flags & GF_STORE_SC1) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
+    } else if (F32_OUT && (flags & GF_STORE_NT)) {
+        asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
+    } else {
+        *reinterpret_cast<u32x4*>(ptr) = v;
+    }
+}
+
+// Widened bf16 row store (guide T21, with v_permlane16_swap): a lane holds 4 packed bf16 (8 B) of two adjacent
+// 16-column blocks (pa = block nb, pb = block nb+1).  Lanes l and l^16 (fq and fq^1: same row, neighbouring
+// 4-column groups) trade halves, after which the even-fq lane owns 8 CONSECUTIVE columns of block nb and the
+// odd-fq lane 8 consecutive columns of block nb+1: one 16-B store per lane instead of two 8-B stores.  The tile
+// epilogue is store-ISSUE-bound (32 dwordx2 per lane measured ~10 us per 256x256 tile), so halving the
+// instruction count at equal bytes is what matters.  Must be called by both lanes of every (l, l^16) pair.
+DITTO_DEV void store_bf16_pair(bf16* rowp, int col0 /* column of block nb */, u32x2 pa, u32x2 pb, int fq, int ncols,
+                                int flags = 0, int ld = 0) {
+    const auto r0 = __builtin_amdgcn_permlane16_swap(pa[0], pb[0], false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(pa[1], pb[1], false, false);
+    // even fq: [own nb | partner's nb]      odd fq: [partner's nb+1 | own nb+1]
+    const int odd = fq & 1;
+    int c = col0 + odd * 16 + 4 * (fq - odd);
+    if (flags & GF_DIAG_LINEAR_STORE) {   // same instruction, same bytes, 1 KiB contiguous per wave-instruction
+        rowp -= (size_t)(threadIdx.x & 15) * ld;
+        c = (col0 & ~63) + (threadIdx.x & 63) * 8;
+        if (c + 8 > ncols) c = ncols - 8;
+    }
+    if (c < ncols) {
+        u32x4 st;
+        st[0] = r0[0]; st[1] = r1[0]; st[2] = r0[1]; st[3] = r1[1];
+        if (flags & GF_DIAG_NO_STORE) asm volatile("" ::"v"(st));   // computed, kept live, not stored
+        else store16<false>(rowp + c, st, flags);
+    }
+}
+
 // One output row x the wave's 64-column span.  `row` < M is checked by the caller.
 template <int EPI>
 DITTO_DEV void epilogue_row(const GemmParams& p, int row, int cbase, const f32x4 (&acc)[4], const f32x4 (&bias)[4],
@@ -44,21 +95,18 @@ DITTO_DEV void epilogue_row(const GemmParams& p, int row, int cbase, const f32x4
     const int c4 = fq * 4;
     if constexpr (EPI == EPI_GATED) {
         // packed columns: 16 x fc1 | 16 x gate | 16 x fc1 | 16 x gate  (reference src/components/DiT.py:153-155)
+        u32x2 pk[2];
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
-            const int pc = cbase + pr * 32 + c4;
-            if (pc >= p.N) continue;
             const f32x4 b1 = bias[2 * pr], bg = bias[2 * pr + 1];
             const f32x4 h = acc[2 * pr], g = acc[2 * pr + 1];
             float o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = fast_gelu_erf(h[e] + b1[e]) * fast_sigmoid(g[e] + bg[e]);
-            const int oc = cbase / 2 + pr * 16 + c4;
-            u32x2 st;
-            st[0] = pack_bf16x2(o[0], o[1]);
-            st[1] = pack_bf16x2(o[2], o[3]);
-            *reinterpret_cast<u32x2*>((bf16*)p.out + (size_t)row * p.ldo + oc) = st;
+            pk[pr][0] = pack_bf16x2(o[0], o[1]);
+            pk[pr][1] = pack_bf16x2(o[2], o[3]);
         }
+        store_bf16_pair((bf16*)p.out + (size_t)row * p.ldo, cbase / 2, pk[0], pk[1], fq, p.N / 2, p.flags, p.ldo);
     } else if constexpr (EPI == EPI_QKV_ROPE) {
         float v[4][4];
 #pragma unroll
@@ -85,38 +133,43 @@ DITTO_DEV void epilogue_row(const GemmParams& p, int row, int cbase, const f32x4
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[n][e] = r[n][e];
         }
+        u32x2 pk[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-            const int c = cbase + n * 16 + c4;
-            if (c >= p.N) continue;
-            u32x2 st;
-            st[0] = pack_bf16x2(v[n][0], v[n][1]);
-            st[1] = pack_bf16x2(v[n][2], v[n][3]);
-            *reinterpret_cast<u32x2*>((bf16*)p.out + (size_t)row * p.ldo + c) = st;
+            pk[n][0] = pack_bf16x2(v[n][0], v[n][1]);
+            pk[n][1] = pack_bf16x2(v[n][2], v[n][3]);
         }
+        bf16* rowp = (bf16*)p.out + (size_t)row * p.ldo;
+        store_bf16_pair(rowp, cbase, pk[0], pk[1], fq, p.N, p.flags, p.ldo);
+        store_bf16_pair(rowp, cbase + 32, pk[2], pk[3], fq, p.N, p.flags, p.ldo);
+    } else if constexpr (EPI == EPI_BIAS_BF16) {
+        u32x2 pk[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const f32x4 v = acc[n] + bias[n];
+            pk[n][0] = pack_bf16x2(v[0], v[1]);
+            pk[n][1] = pack_bf16x2(v[2], v[3]);
+        }
+        bf16* rowp = (bf16*)p.out + (size_t)row * p.ldo;
+        store_bf16_pair(rowp, cbase, pk[0], pk[1], fq, p.N, p.flags, p.ldo);
+        store_bf16_pair(rowp, cbase + 32, pk[2], pk[3], fq, p.N, p.flags, p.ldo);
     } else {
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             const int c = cbase + n * 16 + c4;
             if (c >= p.N) continue;
             f32x4 v = acc[n] + bias[n];
-            if constexpr (EPI == EPI_BIAS_BF16) {
-                u32x2 st;
-                st[0] = pack_bf16x2(v[0], v[1]);
-                st[1] = pack_bf16x2(v[2], v[3]);
-                *reinterpret_cast<u32x2*>((bf16*)p.out + (size_t)row * p.ldo + c) = st;
-            } else {
-                if constexpr (EPI == EPI_BIAS_RES_F32) {
-                    if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)row * p.ldr + c);
-                }
-                *reinterpret_cast<f32x4*>((float*)p.out + (size_t)row * p.ldo + c) = v;
-                if constexpr (EPI == EPI_BIAS_RES_F32) {
-                    if (p.out2) {
-                        u32x2 st;
-                        st[0] = pack_bf16x2(v[0], v[1]);
-                        st[1] = pack_bf16x2(v[2], v[3]);
-                        *reinterpret_cast<u32x2*>(p.out2 + (size_t)row * p.ldo2 + c) = st;
-                    }
+            if constexpr (EPI == EPI_BIAS_RES_F32) {
+                if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)row * p.ldr + c);
+            }
+            if (p.flags & GF_DIAG_NO_STORE) asm volatile("" ::"v"(v));
+            else store16<true>((float*)p.out + (size_t)row * p.ldo + c, __builtin_bit_cast(u32x4, v), p.flags);
+            if constexpr (EPI == EPI_BIAS_RES_F32) {
+                if (p.out2) {   // bf16 side copy (last layer only): plain 8-B stores, off the hot path
+                    u32x2 st;
+                    st[0] = pack_bf16x2(v[0], v[1]);
+                    st[1] = pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<u32x2*>(p.out2 + (size_t)row * p.ldo2 + c) = st;
                 }
             }
         }

@@ -189,7 +189,9 @@ int ditto_attention_bf16(const void* q, int ldq, const void* k, int ldk, const v
 size_t ditto_attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh);
 
 /* Process-wide tuning switches (tests / experiments).  "gemm_tile": 0 = automatic choice between the two GEMM
- * tile structures, 128 / 256 = force one.  Results are identical up to fp32 summation order. */
+ * tile structures, 128 / 256 = force one.  Results are identical up to fp32 summation order.
+ * "gemm_flags": bit mask for kernel experiments (bit 0 = relaxed tile-start wait, default on; bits 1, 2 are
+ * DIAGNOSTIC timing switches that skip stores / the epilogue and produce WRONG results — tools/ only). */
 int ditto_set_option(const char* name, int value);
 
 /* ---- profiling aid (bench.py): per-kernel-class HIP-event timing -------------------------

@@ -15,8 +15,9 @@ from ditto_tts_amd import hip  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--m", type=int, default=32768)
 ap.add_argument("--iters", type=int, default=20)
-ap.add_argument("--tiles", default="128,256")
+ap.add_argument("--tiles", default="128,256", help="variants: tile[/flags], e.g. 128,256/0,256/1,256/3")
 ap.add_argument("--shapes", default="qkv,dxd,gated,fc2,final")
+ap.add_argument("--custom", default="", help="extra shapes 'M,N,K;M,N,K' (epilogue 0)")
 a = ap.parse_args()
 lib = hip.lib()
 dev = "cuda"
@@ -28,8 +29,16 @@ SHAPES = {  # name: (N, K, epilogue, ldo)
 }
 st = torch.cuda.current_stream().cuda_stream
 bufs = {}
-for name in a.shapes.split(","):
+MS = {}
+names = [n for n in a.shapes.split(",") if n]
+for c in [c for c in a.custom.split(";") if c]:
+    cm, cn, ck = (int(v) for v in c.split(","))
+    SHAPES[f"c{cm}x{cn}x{ck}"] = (cn, ck, 0, cn)
+    MS[f"c{cm}x{cn}x{ck}"] = cm
+    names.append(f"c{cm}x{cn}x{ck}")
+for name in names:
     N, K, epi, ldo = SHAPES[name]
+    M = MS.get(name, a.m)
     A = torch.randn(M, K, device=dev).to(torch.bfloat16)
     W = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
     bias = torch.randn(N, device=dev) * 0.1
@@ -39,20 +48,27 @@ for name in a.shapes.split(","):
 def run(name):
     N, K, epi, ldo = SHAPES[name]
     A, W, bias, out = bufs[name]
+    M = A.shape[0]
     hip.check(lib.ditto_gemm_bf16(A.data_ptr(), K, W.data_ptr(), bias.data_ptr(), out.data_ptr() if epi == 1 else None,
                                   out.data_ptr(), ldo, M, N, K, epi, st))
 
-tiles = [int(t) for t in a.tiles.split(",")]
+tiles = a.tiles.split(",")
+
+
+def select(v):
+    t, _, f = v.partition("/")
+    hip.check(lib.ditto_set_option(b"gemm_tile", int(t)))
+    hip.check(lib.ditto_set_option(b"gemm_flags", int(f) if f else 73))
 res = {(n, t): [] for n in bufs for t in tiles}
 for n in bufs:
     for t in tiles:
-        hip.check(lib.ditto_set_option(b"gemm_tile", t))
+        select(t)
         run(n)
 torch.cuda.synchronize()
 for it in range(a.iters):
     for n in bufs:
         for t in tiles:
-            hip.check(lib.ditto_set_option(b"gemm_tile", t))
+            select(t)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             run(n)
@@ -61,7 +77,8 @@ for it in range(a.iters):
             res[(n, t)].append(e0.elapsed_time(e1))
 for n in bufs:
     N, K, epi, _ = SHAPES[n]
+    M = bufs[n][0].shape[0]
     fl = 2.0 * M * N * K
     print(n, f"M={M} N={N} K={K}", "  ".join(
-        f"tile{t}: {statistics.median(res[(n, t)]) * 1e3:7.1f} us {fl / statistics.median(res[(n, t)]) / 1e9:7.1f} TF"
+        f"[{t}] {statistics.median(res[(n, t)]) * 1e3:7.1f} us {fl / statistics.median(res[(n, t)]) / 1e9:7.1f} TF"
         f" (min {min(res[(n, t)]) * 1e3:.1f})" for t in tiles), flush=True)
