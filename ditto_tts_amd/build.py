@@ -16,6 +16,9 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libditto_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# per-file extras.  attention.hip: without -fno-honor-nans hipcc canonicalises every MFMA output (v_max x,x)
+# before the row-max fmaxf chain (+32 VALU per KV tile); the softmax has no NaN semantics to preserve.
+EXTRA = {"attention.hip": ["-fno-honor-nans"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC,
          "-Wall", "-Wno-unused-function"]
 
@@ -44,7 +47,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         o = s[:-4] + ".o"
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([HIPCC, *FLAGS, "-c", s, "-o", o])
+            jobs.append([HIPCC, *FLAGS, *EXTRA.get(os.path.basename(s), []), "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

@@ -24,6 +24,8 @@
 //   * LDS swizzles: K rows (128 B) chunk ^= (key>>1)&7 -> conflict-free ds_read_b128; V rows chunk ^=
 //     ((key>>1)&1)<<2 -> the 4 rows of a transposed-read block fall in 4 different 64-B bank quarters.
 //   * online softmax in the exp2 domain with fp32 running (max, sum); O^T rescale is a per-lane scalar.
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -53,8 +55,16 @@ DITTO_DEV bf16x8 cat4(bf16x4 a, bf16x4 b) {
     return r;
 }
 
+// online-softmax rescale threshold (guide T13), in log2 units of the exp2 domain: the running max is only raised
+// (and O^T / l rescaled) when some row's new maximum exceeds it by more than this, so P stays <= 2^8 — exact in
+// bf16's exponent range, accumulated in fp32 — and the 32-register O^T rescale is skipped on most tiles.
+constexpr float RESCALE_THR_LOG2 = 8.0f;
+
+// __launch_bounds__(256, 2): 2 waves per SIMD => a 256-register budget, so the MFMA accumulators (S^T, O^T: 64
+// registers) stay in VGPRs.  With the default budget hipcc parks them in AGPRs and moves all 64 through
+// v_accvgpr_read/write around every softmax (127 extra VALU per tile, as much as the softmax itself).
 template <bool RESID>
-__global__ __launch_bounds__(256) void attn64_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn64_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KV_TILE_BYTES];  // [buf][K|V]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -122,7 +132,7 @@ __global__ __launch_bounds__(256) void attn64_kernel(AttnParams p) {
     write_kv(0);
     __syncthreads();
 
-    for (int kt = 0; kt < nkt; ++kt) {
+    auto tile_body = [&](int kt, auto MASKED) {
         const char* kb = smem + (kt & 1) * 2 * KV_TILE_BYTES;
         const char* vb = kb + KV_TILE_BYTES;
         if (kt + 1 < nkt) load_kv(kt + 1);
@@ -139,7 +149,7 @@ __global__ __launch_bounds__(256) void attn64_kernel(AttnParams p) {
                                                                    (((2 * ks + hh) ^ k_swz) << 4));
                 st[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb2], 0, 0, 0);
             }
-        if (kt == nkt - 1 && (p.Skv & (KBLK - 1))) {  // ragged last tile: mask keys >= Skv (wave-uniform branch)
+        if constexpr (decltype(MASKED)::value) {  // ragged last tile only: keys >= Skv never contribute
             const int kbase_idx = kt * KBLK + 4 * hh;
 #pragma unroll
             for (int kb2 = 0; kb2 < 2; ++kb2)
@@ -151,48 +161,56 @@ __global__ __launch_bounds__(256) void attn64_kernel(AttnParams p) {
         }
 
         // ---- online softmax (this lane = one query; its other 32 keys live in lane^32) ----
-        float mloc = st[0][0];
+        float mloc = fmaxf(st[0][0], st[1][0]);
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, st[0][r]);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[1][r]);
+        for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, fmaxf(st[0][r], st[1][r]));
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run, mloc);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-        const float mc = m_new * c;
-        m_run = m_new;
+        // raise the running max only if some query of the wave needs it (wave-uniform decision, taken BEFORE
+        // any P of this tile is exponentiated and with the previous tile's P*V complete: guide T13 safe order)
+        if (!__all((mloc - m_run) * c <= RESCALE_THR_LOG2)) {
+            const float m_new = fmaxf(m_run, mloc);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { ot[0][i] *= alpha; ot[1][i] *= alpha; }
+        }
+        const float mc = m_run * c;
         float psum = 0.f;
         bf16x8 pf[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s2 = 0; s2 < 4; ++s2) {
             float e[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                e[j] = __builtin_amdgcn_exp2f(st[s >> 1][8 * (s & 1) + j] * c - mc);
+                e[j] = __builtin_amdgcn_exp2f(st[s2 >> 1][8 * (s2 & 1) + j] * c - mc);
                 psum += e[j];
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pf[s][j] = (bf16)e[j];
+            for (int j = 0; j < 8; ++j) pf[s2][j] = (bf16)e[j];
         }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { ot[0][i] *= alpha; ot[1][i] *= alpha; }
+        l_run += psum;
 
         // ---- O^T[d][query] += V^T[d][key] * P^T[key][query] ----
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int s2 = 0; s2 < 4; ++s2)
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
                 const int colb = (tr_colbyte + 64 * db) ^ tr_swz;
-                const char* a0 = vb + (16 * s + tr_row0) * 128 + colb;
+                const char* a0 = vb + (16 * s2 + tr_row0) * 128 + colb;
                 const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0));
                 const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0 + 8 * 128));
-                ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat4(v0, v1), pf[s], ot[db], 0, 0, 0);
+                ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat4(v0, v1), pf[s2], ot[db], 0, 0, 0);
             }
 
         if (kt + 1 < nkt) write_kv((kt + 1) & 1);
         __syncthreads();
-    }
+    };
+
+    const bool ragged = (p.Skv & (KBLK - 1)) != 0;
+    const int nfull = ragged ? nkt - 1 : nkt;
+    for (int kt = 0; kt < nfull; ++kt) tile_body(kt, std::false_type{});
+    if (ragged) tile_body(nkt - 1, std::true_type{});
 
     // ---- epilogue: normalise; lane (query ql, half hh) owns d = 32*db + 8*g + 4*hh + 0..3 ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
