@@ -570,7 +570,8 @@ int ditto_attention_bf16(const void* q, int ldq, const void* k, int ldk, const v
 int ditto_set_option(const char* name, int value) {
     if (!name) return fail(DITTO_ERR_ARG, "null option name");
     if (!strcmp(name, "gemm_tile")) {
-        if (value != 0 && value != 128 && value != 256) return fail(DITTO_ERR_ARG, "gemm_tile must be 0, 128 or 256");
+        if (value != 0 && value != 128 && value != 256 && value != 129)
+            return fail(DITTO_ERR_ARG, "gemm_tile must be 0, 128, 129 (256x128 ring) or 256");
         g_gemm_tile = value;
         return DITTO_OK;
     }

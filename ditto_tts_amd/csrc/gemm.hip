@@ -156,10 +156,18 @@ hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s) {
     // 69 us, fc2 218 vs 205 us).  DITTO_GEMM=128|256 / ditto_set_option("gemm_tile") force one.
     const int forced = g_gemm_tile;
     const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-    if (forced == 256 || (forced != 128 && t256 >= 4 * 256)) {
+    if (forced == 256 || (forced == 0 && t256 >= 4 * 256)) {
         p.tiles_m = (a.M + 255) / 256;
         p.tiles_n = (a.N + 255) / 256;
         return launch_gemm256(p, epi, s);
+    }
+    // 256x128 ring kernel (gemm_p128.hip): built for the N = d GEMMs (exactly 3 tiles per CU at M = 32768, N = 768),
+    // correct and tested, but measured in-model (tools/step_ab.py, one device) it does NOT beat the 128x128 kernel
+    // there (d x d 71.8 vs 66.4 us, fc2 219 vs 198 us), so it is selectable (gemm_tile = 129) and not automatic.
+    if (forced == 129) {
+        p.tiles_m = (a.M + 255) / 256;
+        p.tiles_n = (a.N + 127) / 128;
+        return launch_gemm_p128(p, epi, s);
     }
     p.tiles_m = (a.M + BM - 1) / BM;
     p.tiles_n = (a.N + BN - 1) / BN;

@@ -1,5 +1,6 @@
-// gemm_common.h — parameters and fused epilogues shared by the two GEMM tile structures
-// (gemm.hip: 128x128 two-barrier; gemm256.hip: 256x256 eight-phase).
+// gemm_common.h — parameters and fused epilogues shared by the three GEMM tile structures
+// (gemm.hip: 128x128 two-barrier; gemm256.hip: persistent 256x256 eight-phase; gemm_p128.hip: persistent
+// 256x128 with a 3-slot LDS ring).
 //
 // Both structures compute C^T with swapped MFMA operands (weights as the instruction's A operand), so a
 // lane holds, for ONE output row, 4 consecutive columns of each of the 4 16-column blocks of its wave's
@@ -25,13 +26,13 @@ struct GemmParams {
     int flags;         // experiment switches (ditto_set_option("gemm_flags")): see GF_* below
 };
 
-enum { GF_RELAXED_WAIT = 1,   // tile-start wait skips over the previous tile's epilogue stores
-       GF_DIAG_NO_STORE = 2,  // DIAGNOSTIC (wrong results): epilogue computes but does not store
+enum { GF_RELAXED_WAIT = 1,        // tile-start wait skips over the previous tile's epilogue stores
+       GF_DIAG_NO_STORE = 2,       // DIAGNOSTIC (wrong results): epilogue computes but does not store
        GF_DIAG_NO_EPILOGUE = 4,    // DIAGNOSTIC (wrong results): no epilogue at all
-       GF_STAGGER_START = 8,
-       GF_DIAG_LINEAR_STORE = 16,    // DIAGNOSTIC (wrong results): bf16 stores go to lane-linear addresses
-       GF_STORE_SC1 = 32,            // output stores write-through, line dropped from L2 (sc1)
-       GF_STORE_NT = 64 };           // output stores non-temporal (nt)  // DIAGNOSTIC (wrong results): bf16 stores go to lane-linear addresses     // de-synchronise the persistent workgroups: group g of 4 starts g/4 tile late
+       GF_STAGGER_START = 8,       // de-synchronise the persistent workgroups: group g of 4 starts g/4 tile late
+       GF_DIAG_LINEAR_STORE = 16,  // DIAGNOSTIC (wrong results): bf16 stores go to lane-linear addresses
+       GF_STORE_SC1 = 32,          // output stores write-through, line dropped from L2 (sc1)
+       GF_STORE_NT = 64 };         // fp32 output stores non-temporal (nt)
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -178,5 +179,7 @@ DITTO_DEV void epilogue_row(const GemmParams& p, int row, int cbase, const f32x4
 
 // gemm256.hip
 hipError_t launch_gemm256(const GemmParams& p, GemmEpilogue epi, hipStream_t s);
+// gemm_p128.hip
+hipError_t launch_gemm_p128(const GemmParams& p, GemmEpilogue epi, hipStream_t s);
 
 }  // namespace ditto

@@ -188,8 +188,8 @@ int ditto_attention_bf16(const void* q, int ldq, const void* k, int ldk, const v
 /* scratch bytes ditto_attention_bf16 needs (0 for the fused dh = 64 kernel) */
 size_t ditto_attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh);
 
-/* Process-wide tuning switches (tests / experiments).  "gemm_tile": 0 = automatic choice between the two GEMM
- * tile structures, 128 / 256 = force one.  Results are identical up to fp32 summation order.
+/* Process-wide tuning switches (tests / experiments).  "gemm_tile": 0 = automatic choice between the three GEMM
+ * tile structures, 128 (128x128) / 129 (persistent 256x128 ring) / 256 (persistent 256x256) = force one.  Results are identical up to fp32 summation order.
  * "gemm_flags": bit mask for kernel experiments (bit 0 = relaxed tile-start wait, default on; bits 1, 2 are
  * DIAGNOSTIC timing switches that skip stores / the epilogue and produce WRONG results — tools/ only). */
 int ditto_set_option(const char* name, int value);

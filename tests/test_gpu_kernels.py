@@ -55,15 +55,16 @@ def test_gemm(lib, M, N, K, epi):
         assert max_abs(out, want + res) < 1e-4
 
 
-@pytest.fixture
-def tile256(lib):
-    hip.check(lib.ditto_set_option(b"gemm_tile", 256))
+@pytest.fixture(params=[256, 129])
+def tile256(lib, request):
+    """forces one of the two persistent structures: 256x256 eight-phase, 256x128 ring"""
+    hip.check(lib.ditto_set_option(b"gemm_tile", request.param))
     yield
     hip.check(lib.ditto_set_option(b"gemm_tile", 0))
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 320, 64), (1000, 768, 768), (513, 2304, 192),
-                                   (260, 272, 3072), (1, 16, 64), (2048, 1024, 320)])
+                                   (260, 272, 3072), (1, 16, 64), (2048, 1024, 320), (777, 144, 128)])
 @pytest.mark.parametrize("epi", [0, 1])
 def test_gemm_256_tile_structure(lib, tile256, M, N, K, epi):
     """The eight-phase 256x256 kernel forced on ragged M / N and odd / even K-tile counts (K = 64, 192, 320)."""
