@@ -71,11 +71,30 @@ def kernel_bytes(cfg, B, N, T):
     }
 
 
+def usable_cores():
+    """CPUs this process may actually use: the scheduler affinity capped by the cgroup CPU quota (the GPU box
+    shows 256 hardware threads behind a 16-CPU quota; running 256 torch threads there is 70x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, -(-q // per)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(cfg, N, T, steps=3):
     """fp32 oracle on the host cores: B = 1, `steps` timed steps after 1 warm-up (bounded sample)."""
     from ditto_tts_amd.synth import hash_normal, synthetic_inputs, synthetic_state_dict
     from oracle import ditto_oracle as O
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     sd = synthetic_state_dict(cfg, seed=1234)
     x, text, _ = synthetic_inputs(cfg, 1, N, T, seed=7)
