@@ -65,8 +65,8 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmParams p) {
     const int wr = wid >> 1, wc = wid & 1;
 
     const int nwg = p.tiles_m * p.tiles_n;
-    const int tile = xcd_remap(blockIdx.x, nwg);
-    const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+    int tm, tn;
+    tile_to_mn(xcd_remap(blockIdx.x, nwg), p.tiles_m, p.tiles_n, p.group_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     f32x4 acc[4][4];
@@ -161,10 +161,12 @@ hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s) {
         p.tiles_n = (a.N + 255) / 256;
         return launch_gemm256(p, epi, s);
     }
-    // 256x128 ring kernel (gemm_p128.hip): built for the N = d GEMMs (exactly 3 tiles per CU at M = 32768, N = 768),
-    // correct and tested, but measured in-model (tools/step_ab.py, one device) it does NOT beat the 128x128 kernel
-    // there (d x d 71.8 vs 66.4 us, fc2 219 vs 198 us), so it is selectable (gemm_tile = 129) and not automatic.
-    if (forced == 129) {
+    // 256x128 ring kernel (gemm_p128.hip): N = d GEMMs, exactly 3 tiles per CU at M = 32768, N = 768.  Measured
+    // in-model (tools/step_ab.py, one device, after the asm-DMA fix): fc2 (K = 3072) 194 vs 201 us and the final
+    // K = 1536 projection 96 vs 104 us against the 128x128 kernel, but the K = 768 d x d GEMMs 70 vs 69 us:
+    // automatic only for K >= 1536.
+    const long tp128 = (long)((a.M + 255) / 256) * ((a.N + 127) / 128);
+    if (forced == 129 || (forced == 0 && tp128 >= 2 * 256 && a.K >= 1536)) {
         p.tiles_m = (a.M + 255) / 256;
         p.tiles_n = (a.N + 127) / 128;
         return launch_gemm_p128(p, epi, s);
@@ -172,6 +174,7 @@ hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s) {
     p.tiles_m = (a.M + BM - 1) / BM;
     p.tiles_n = (a.N + BN - 1) / BN;
     p.flags = g_gemm_flags & ~(GF_DIAG_NO_STORE | GF_DIAG_NO_EPILOGUE | GF_DIAG_LINEAR_STORE);
+    p.group_n = pick_group_n(p.tiles_n, p.flags);
     switch (epi) {
         case EPI_BIAS_BF16: return launch_t<EPI_BIAS_BF16>(p, s);
         case EPI_BIAS_RES_F32: return launch_t<EPI_BIAS_RES_F32>(p, s);

@@ -57,6 +57,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     const int nkt = p.K / 64;
 
     // ---- DMA source addressing: this wave moves pieces 2*wid, 2*wid+1 (1 KiB = 8 rows) of every half-tile ----
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;   // LDS byte address of the dynamic region
     const int srow = lane >> 3;   // row inside a piece
     const int scpos = lane & 7;   // chunk position inside the 128-B row
     int m0 = 0, n0 = 0;           // origin of the tile whose DMA is being issued
@@ -79,16 +80,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
                 gr = gr < p.w_rows ? gr : p.w_rows - 1;
                 src = p.W + (size_t)gr * p.ldw + k0 + c * 8;
             }
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src,
-                                             (lds_ptr_t)(smem + buf * KT_BYTES + half * HALF_BYTES + piece * 1024), 16, 0,
-                                             0);
+            glds16(src, lds_base + (unsigned)(buf * KT_BYTES + half * HALF_BYTES + piece * 1024));
         }
     };
     // tile 0 -> buffer 0 (all four halves), tile 1's B halves -> buffer 1: the state the loop's P1 expects
     auto prologue = [&](int tile) {
-        const int t = xcd_remap(tile, ntiles);
-        m0 = (t / p.tiles_n) * 256;
-        n0 = (t % p.tiles_n) * 256;
+        int tm, tn;
+        tile_to_mn(xcd_remap(tile, ntiles), p.tiles_m, p.tiles_n, p.group_n, tm, tn);
+        m0 = tm * 256;
+        n0 = tn * 256;
         stage(0, IC<2>{}, 0);
         stage(0, IC<3>{}, 0);
         stage(0, IC<0>{}, 0);
@@ -291,6 +291,7 @@ hipError_t launch_gemm256(const GemmParams& p_in, GemmEpilogue epi, hipStream_t 
     const int ntiles = p.tiles_m * p.tiles_n;
     p.tile_stride = ntiles < n_cu ? ntiles : n_cu;
     p.flags = g_gemm_flags;
+    p.group_n = pick_group_n(p.tiles_n, p.flags);
     // quarter of the expected tile time: ~1.5 us per K-tile + ~8 us fixed, in 10 ns ticks
     p.stagger_ticks = (int)((p.K / 64 * 1.5 + 8.0) * 100.0 / 4.0);
     switch (epi) {

@@ -21,6 +21,7 @@ struct GemmParams {
     const float* rope_cos; const float* rope_sin; int rope_rpb; int rope_cols;
     int M, N, K;
     int tiles_m, tiles_n;
+    int group_n;       // super-column width in column tiles (tile order, see tile_to_mn)
     int tile_stride;   // gemm256: persistent workgroups walk tiles b, b + stride, ...
     int stagger_ticks; // GF_STAGGER_START: s_memrealtime ticks (100 MHz) per quarter tile
     int flags;         // experiment switches (ditto_set_option("gemm_flags")): see GF_* below
@@ -32,10 +33,50 @@ enum { GF_RELAXED_WAIT = 1,        // tile-start wait skips over the previous ti
        GF_STAGGER_START = 8,       // de-synchronise the persistent workgroups: group g of 4 starts g/4 tile late
        GF_DIAG_LINEAR_STORE = 16,  // DIAGNOSTIC (wrong results): bf16 stores go to lane-linear addresses
        GF_STORE_SC1 = 32,          // output stores write-through, line dropped from L2 (sc1)
-       GF_STORE_NT = 64 };         // fp32 output stores non-temporal (nt)
+       GF_STORE_NT = 64,           // fp32 output stores non-temporal (nt)
+       GF_ROWMAJOR_TILES = 128 };  // A/B switch: plain row-major tile order instead of super-columns
+
+// Tile order.  An XCD (private 4 MiB L2) receives a contiguous range of the linear tile index (xcd_remap); within it
+// the tiles run down M inside a SUPER-COLUMN of `G` column tiles, so the tiles an XCD works on at one time are a
+// few row panels x G column tiles and the weight rows of the super-column stay L2-resident while the XCD walks
+// down M.  With the plain row-major order an XCD sweeps all N/BN column tiles of a row panel: for the gated MLP
+// GEMM that working set is the whole 9.4 MB weight matrix, and rocprofv3 FETCH_SIZE showed ~1 GB of L2-miss
+// traffic per launch against 60 MB of algorithmic input.
+DITTO_DEV void tile_to_mn(int t, int tiles_m, int tiles_n, int G, int& tm, int& tn) {
+    const int per_sc = tiles_m * G;
+    const int sc = t / per_sc;
+    const int r = t - sc * per_sc;
+    const int w = (tiles_n - sc * G) < G ? (tiles_n - sc * G) : G;   // last super-column may be narrower
+    tm = r / w;
+    tn = sc * G + r % w;
+}
+// host side: split tiles_n into ceil(tiles_n / 8) super-columns of (nearly) equal width
+inline int pick_group_n(int tiles_n, int flags) {
+    // measured in-model: with <= 12 column tiles the weights fit the 4 MiB L2 and row-major is ~5 % faster (QKV)
+    if ((flags & GF_ROWMAJOR_TILES) || tiles_n <= 12) return tiles_n;
+    const int nsc = (tiles_n + 7) / 8;
+    return (tiles_n + nsc - 1) / nsc;
+}
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+// LDS-DMA (global_load_lds_dwordx4) through inline asm: 64 lanes x 16 B land at LDS byte address
+// `lds_dst` (wave-uniform) + lane*16.  Why not the builtin: in the PERSISTENT kernels the next tile's first DMA is
+// issued into buffer 0 at the end of the tile loop, and hipcc — which tracks the builtin as a pending LDS write —
+// then cannot prove that it does not alias the first ds_reads of the K-loop and drains the whole DMA pipeline
+// with s_waitcnt vmcnt(0) at the top of EVERY iteration (seen in the .s).  An asm DMA is invisible to that pass;
+// every wait on DMA data in those kernels is hand-counted (s_waitcnt vmcnt(N) + s_barrier before the reader).
+// hipcc's own counted waits stay safe: its loads (epilogue bias / residual / RoPE tables) are issued after the
+// asm DMAs, and vmcnt retires in order, so extra OLDER operations only make its waits stricter.
+// M0 holds the LDS base for the instruction and is compiler-reserved: saved and restored in the same statement.
+DITTO_DEV void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
 
 // Bias of the lane's 4 x 4 columns, loaded ONCE per wave (the same for every row of the tile): keeps the row
 // loop free of dependent global loads.

@@ -39,11 +39,12 @@ __global__ __launch_bounds__(512, 2) void gemm_p128_kernel(GemmParams p) {
     const int ntiles = p.tiles_m * p.tiles_n;
     const int nkt = p.K / 64;
 
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;   // LDS byte address of the dynamic region
     const int srow = lane >> 3, scpos = lane & 7;
     int m0 = 0, n0 = 0;   // origin of the tile whose DMA is being issued
     // half: 0 = A rows 0..127, 1 = A rows 128..255, 2 = B rows 0..127 (of the 128-column tile)
-    auto stage = [&](int buf, auto HALF, int kt) {
-        constexpr int half = decltype(HALF)::value;
+    auto stage = [&](auto BUF, auto HALF, int kt) {
+        constexpr int half = decltype(HALF)::value, buf = decltype(BUF)::value;
         if (kt >= nkt) return;
         const int k0 = kt * 64;
 #pragma unroll
@@ -61,22 +62,21 @@ __global__ __launch_bounds__(512, 2) void gemm_p128_kernel(GemmParams p) {
                 gr = gr < p.w_rows ? gr : p.w_rows - 1;
                 src = p.W + (size_t)gr * p.ldw + k0 + c * 8;
             }
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src,
-                                             (lds_ptr_t)(smem + buf * KTB + half * HB + piece * 1024), 16, 0, 0);
+            glds16(src, lds_base + (unsigned)(buf * KTB + half * HB + piece * 1024));
         }
     };
-    auto stage_tile = [&](int kt) {   // all three halves of K-tile kt into ring slot kt % 3
-        const int buf = kt % 3;
-        stage(buf, ICp<0>{}, kt);
-        stage(buf, ICp<1>{}, kt);
-        stage(buf, ICp<2>{}, kt);
+    auto stage_tile = [&](auto BUF, int kt) {   // all three halves of K-tile kt into ring slot BUF
+        stage(BUF, ICp<0>{}, kt);
+        stage(BUF, ICp<1>{}, kt);
+        stage(BUF, ICp<2>{}, kt);
     };
     auto prologue = [&](int tile) {
-        const int t = xcd_remap(tile, ntiles);
-        m0 = (t / p.tiles_n) * 256;
-        n0 = (t % p.tiles_n) * 128;
-        stage_tile(0);
-        stage_tile(1);
+        int tm, tn;
+        tile_to_mn(xcd_remap(tile, ntiles), p.tiles_m, p.tiles_n, p.group_n, tm, tn);
+        m0 = tm * 256;
+        n0 = tn * 128;
+        stage_tile(ICp<0>{}, 0);
+        stage_tile(ICp<1>{}, 1);
     };
 
     const int frow = lane & 15, fq = lane >> 4, fswz = frow >> 1;
@@ -87,7 +87,8 @@ __global__ __launch_bounds__(512, 2) void gemm_p128_kernel(GemmParams p) {
     bf16x8 af[8], bfr[4];
     f32x4 acc[4][4];
 
-    auto read_A = [&](int buf) {
+    auto read_A = [&](auto BUF) {
+        constexpr int buf = decltype(BUF)::value;
         const char* base = smem + buf * KTB + a_base;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -95,8 +96,8 @@ __global__ __launch_bounds__(512, 2) void gemm_p128_kernel(GemmParams p) {
             af[m * 2 + 1] = *reinterpret_cast<const bf16x8*>(base + m * 16 * 128 + coff1);
         }
     };
-    auto read_B = [&](int buf, auto BJ) {
-        constexpr int bj = decltype(BJ)::value;
+    auto read_B = [&](auto BUF, auto BJ) {
+        constexpr int bj = decltype(BJ)::value, buf = decltype(BUF)::value;
         const char* base = smem + buf * KTB + b_base + bj * 32 * 128;
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
@@ -147,26 +148,32 @@ __global__ __launch_bounds__(512, 2) void gemm_p128_kernel(GemmParams p) {
         DITTO_BAR();
         if (wid >= 4) DITTO_BAR();   // stagger the second wave group by one barrier
 
-        int buf = 0;                 // ring slot of K-tile kt
-        for (int kt = 0; kt < nkt; ++kt) {
-            const int buf2 = buf == 0 ? 2 : buf - 1;   // (kt + 2) % 3
+        // One K-tile from ring slot BUF; its DMA look-ahead (K-tile kt+2) goes to slot BUF2 = (BUF + 2) % 3.
+        // The slots are COMPILE-TIME constants on purpose: with a run-time ring index hipcc cannot prove that
+        // the in-flight LDS-DMA does not alias the ds_reads and drains it with s_waitcnt vmcnt(0) before the
+        // first read of every K-tile (seen in the .s; the kernel then ran at a third of the MFMA rate).
+        auto ktile = [&](int kt, auto BUF, auto BUF2) {
             // P1
-            read_B(buf, ICp<0>{});
-            read_A(buf);
-            stage(buf2, ICp<0>{}, kt + 2);
-            stage(buf2, ICp<1>{}, kt + 2);
+            read_B(BUF, ICp<0>{});
+            read_A(BUF);
+            stage(BUF2, ICp<0>{}, kt + 2);
+            stage(BUF2, ICp<1>{}, kt + 2);
             DITTO_BAR();
             mma(ICp<0>{});
             DITTO_BAR();
             // P2
-            read_B(buf, ICp<1>{});
-            stage(buf2, ICp<2>{}, kt + 2);
+            read_B(BUF, ICp<1>{});
+            stage(BUF2, ICp<2>{}, kt + 2);
             if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // K-tile kt+1 has landed
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             DITTO_BAR();
             mma(ICp<1>{});
             DITTO_BAR();
-            buf = buf == 2 ? 0 : buf + 1;
+        };
+        for (int kt = 0; kt < nkt; kt += 3) {
+            ktile(kt, ICp<0>{}, ICp<2>{});
+            if (kt + 1 < nkt) ktile(kt + 1, ICp<1>{}, ICp<0>{});
+            if (kt + 2 < nkt) ktile(kt + 2, ICp<2>{}, ICp<1>{});
         }
         if (wid < 4) DITTO_BAR();    // balance the stagger barrier: every LDS read of this tile has retired
 
@@ -219,6 +226,7 @@ hipError_t launch_gemm_p128(const GemmParams& p_in, GemmEpilogue epi, hipStream_
     const int ntiles = p.tiles_m * p.tiles_n;
     p.tile_stride = ntiles < n_cu ? ntiles : n_cu;
     p.flags = g_gemm_flags;
+    p.group_n = pick_group_n(p.tiles_n, p.flags);
     p.stagger_ticks = 0;
     switch (epi) {
         case EPI_BIAS_BF16: return launch_p128_t<EPI_BIAS_BF16>(p, s);
