@@ -127,6 +127,18 @@ class DenoiseEngine:
                                                  ws.data_ptr(), ws.numel(), _stream()))
         return TextCond(buf, B, T)
 
+    def prepare_text_into(self, text_emb: torch.Tensor, N_hint: int, cond: TextCond) -> TextCond:
+        """Recompute the conditioning of a new utterance batch into an EXISTING TextCond buffer (same B, T), so
+        captured graphs bound to that buffer stay valid."""
+        text = self._f32(text_emb, "text_emb")
+        B, T, _ = text.shape
+        if (B, T) != (cond.B, cond.T):
+            raise ValueError("prepare_text_into needs the same (B, T) as the existing conditioning")
+        ws = self.workspace(B, max(N_hint, 1), T)
+        hip.check(self.lib.ditto_text_precompute(self.handle, text.data_ptr(), B, T, cond.buf.data_ptr(),
+                                                 cond.buf.numel(), ws.data_ptr(), ws.numel(), _stream()))
+        return cond
+
     def _t64(self, t: torch.Tensor, B: int) -> torch.Tensor:
         if t.shape != (B,):
             raise ValueError(f"t must have shape [{B}]")
@@ -163,6 +175,28 @@ class DenoiseEngine:
                                           betas.data_ptr(), alphas.data_ptr(), alphas_cumprod.data_ptr(), B, N, cond.T,
                                           c.data_ptr(), s.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
         return x
+
+    def capture_p_sample(self, x: torch.Tensor, cond: TextCond, t: torch.Tensor, noise: torch.Tensor,
+                         betas: torch.Tensor, alphas: torch.Tensor, alphas_cumprod: torch.Tensor):
+        """Capture ONE reverse-diffusion step (the ~122 stream-ordered launches of ditto_p_sample) into a HIP
+        graph bound to these exact tensors; returns the graph.  Replaying it advances `x` in place using whatever
+        `t` and `noise` hold at replay time, so a sampling loop is: fill t, draw noise, graph.replay().
+        Worth it when the step is launch-bound (small batches); the library calls neither allocate nor
+        synchronise, so they are capturable as they are."""
+        for name, v in (("x", x), ("noise", noise)):
+            if not (v.is_cuda and v.dtype == torch.float32 and v.is_contiguous()):
+                raise ValueError(f"{name} must be a contiguous fp32 CUDA tensor")
+        if t.dtype != torch.int64 or not t.is_cuda:
+            raise ValueError("t must be an int64 CUDA tensor")
+        B, N, _ = x.shape
+        self.workspace(B, N, cond.T)      # allocate outside the capture
+        self.rope_tables(N)
+        self.p_sample_(x, cond, t, noise, betas, alphas, alphas_cumprod)   # warm-up (lazy kernel attributes)
+        torch.cuda.current_stream().synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.p_sample_(x, cond, t, noise, betas, alphas, alphas_cumprod)
+        return g
 
     def block_forward_(self, layer: int, h: torch.Tensor, cond: TextCond, cond_layer: Optional[int] = None,
                        rope: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):

@@ -72,11 +72,13 @@ class SpeechGenerator:
 
     @torch.no_grad()
     def __sample_latents(self, text_emb, audio_emb, text_prompt=None, audio=None, is_slp=False, cond_by_audio=False,
-                         noises=None, keep=None):
+                         noises=None, keep=None, use_graph=None):
         """All reverse diffusion steps (reference :149-164).
 
         `noises` (optional): a sequence / callable giving the z of executed step i, for parity tests;
-        `keep` (optional): dict filled with {i: state after step i} for the i it already has as keys."""
+        `keep` (optional): dict filled with {i: state after step i} for the i it already has as keys;
+        `use_graph`: replay the step from a HIP graph (default off: measured no gain even at B = 1, the step is
+        bound by per-kernel latency, not by its 122 launches; bit-identical to eager either way)."""
         if is_slp:
             raise NotImplementedError("the speech-length-predictor branch is broken in the reference "
                                       "(SURVEY.md App. B-6) and out of scope")
@@ -87,13 +89,25 @@ class SpeechGenerator:
         cond = m.text_cond(text_emb.to(x.device), x.shape[1])
         B = x.shape[0]
         t_tensor = torch.empty(B, device=x.device, dtype=torch.long)
+        use_graph = bool(use_graph)
+        z = torch.empty_like(x)
+        graph = None
+        if use_graph:
+            t_tensor.fill_(self.diffusion_steps - 1)
+            keep_x = x.clone()                      # capture runs one warm-up step on x: restore it afterwards
+            z.zero_()
+            graph = eng.capture_p_sample(x, cond, t_tensor, z, self.betas, self.alphas, self.alphas_cumprod)
+            x.copy_(keep_x)
         for i, t_val in enumerate(reversed(range(self.diffusion_steps))):
             t_tensor.fill_(t_val)
             if noises is None:
-                z = torch.randn_like(x)
+                z.normal_()                          # same generator stream as randn_like(x)
             else:
-                z = (noises(i) if callable(noises) else noises[i]).to(x.device)
-            eng.p_sample_(x, cond, t_tensor, z, self.betas, self.alphas, self.alphas_cumprod)
+                z.copy_((noises(i) if callable(noises) else noises[i]).to(x.device))
+            if graph is not None:
+                graph.replay()
+            else:
+                eng.p_sample_(x, cond, t_tensor, z, self.betas, self.alphas, self.alphas_cumprod)
             if keep is not None and i in keep:
                 keep[i] = x.clone()
         return x

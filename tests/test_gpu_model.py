@@ -127,6 +127,22 @@ def test_g5_sampler_trajectory(golden):
 
 
 @torch.no_grad()
+def test_graph_replay_equals_eager(golden):
+    """The HIP-graph sampling loop (one captured step replayed 50 times) is bit-identical to eager launches."""
+    g = golden("G5_sampler_50.npz")
+    cfg = DiTTOConfig(256, 2, 4, 256, 256, 50)
+    m = build(cfg, 5)
+    sg = SpeechGenerator(ditto_model=m, device=DEV)
+    noises = lambda i: hash_normal((2, 64, 256), f"z{i}", 55)
+    outs = []
+    for use_graph in (False, True):
+        outs.append(sg._SpeechGenerator__sample_latents(g["text"].to(DEV), g["xinit"].to(DEV), cond_by_audio=True,
+                                                        noises=noises, use_graph=use_graph))
+    assert torch.equal(outs[0], outs[1])
+    assert rel_l2(outs[1], g["x_step49"]) < RTOL
+
+
+@torch.no_grad()
 def test_ragged_lengths_against_oracle():
     """N and T that are multiples of nothing (row clamps, key masking, partial tiles)."""
     from oracle import ditto_oracle as O
