@@ -29,7 +29,7 @@
 namespace ditto {
 
 // 0 = automatic, 128 / 256 = force that tile structure (ditto_set_option("gemm_tile", v); env DITTO_GEMM seeds it)
-int g_gemm_flags = GF_RELAXED_WAIT | GF_STAGGER_START | GF_STORE_NT;
+int g_gemm_flags = GF_RELAXED_WAIT | GF_STAGGER_START | GF_STORE_NT | GF_WIDE_PHASE;
 int g_gemm_tile = [] { const char* e = getenv("DITTO_GEMM"); return e ? atoi(e) : 0; }();
 
 namespace {
@@ -173,7 +173,7 @@ hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s) {
     }
     p.tiles_m = (a.M + BM - 1) / BM;
     p.tiles_n = (a.N + BN - 1) / BN;
-    p.flags = g_gemm_flags & ~(GF_DIAG_NO_STORE | GF_DIAG_NO_EPILOGUE | GF_DIAG_LINEAR_STORE);
+    p.flags = g_gemm_flags & ~(GF_DIAG_NO_STORE | GF_DIAG_NO_EPILOGUE | GF_DIAG_LINEAR_STORE | GF_DIAG_SMALL_OUT);
     p.group_n = pick_group_n(p.tiles_n, p.flags);
     switch (epi) {
         case EPI_BIAS_BF16: return launch_t<EPI_BIAS_BF16>(p, s);

@@ -47,7 +47,7 @@ struct IC { static constexpr int value = V; };
 
 #define DITTO_BAR() asm volatile("s_barrier" ::: "memory")
 
-template <int EPI>
+template <int EPI, bool WIDE>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -182,60 +182,117 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         DITTO_BAR();
         if (wm == 1) DITTO_BAR();  // stagger the second wave group by one barrier
 
-        for (int it = 0; it < niter; ++it) {
-            const int te = 2 * it, to = te + 1;
-            const bool odd_valid = to < nkt;
-            // ---------------- K-tile te from buffer 0 ----------------
-            read_B(0, IC<0>{}, b0f);
-            read_A(0, IC<0>{});
-            stage(1, IC<0>{}, to);                    // P1: o.A_lo   (buffer 1's A halves were last read in P7)
-            DITTO_BAR();
-            mma(IC<0>{}, IC<0>{}, b0f);
-            DITTO_BAR();
+        if constexpr (WIDE) {
+            // Wide-phase schedule: 2 phases of 32 MFMAs per K-tile (half the barriers).  The phase's ds_reads are
+            // RETIRED (lgkmcnt(0)) before its first barrier, so (a) the MFMA segment starts the moment the barrier
+            // opens and (b) an LDS half may be restaged ONE phase after its last read (guide: WAR rule, second form):
+            //   W1: read e.{B0,B1,A0}; DMA o.A      W2: read e.A1; DMA e'.B; vmcnt -> o complete (read in W3, W4)
+            //   W3: read o.{B0,B1,A0}; DMA e'.A     W4: read o.A1; DMA o'.B; vmcnt -> e' complete (read in W1', W2')
+            for (int it = 0; it < niter; ++it) {
+                const int te = 2 * it, to = te + 1;
+                const bool odd_valid = to < nkt;
+                read_B(0, IC<0>{}, b0f);
+                read_B(0, IC<1>{}, b1f);
+                read_A(0, IC<0>{});
+                stage(1, IC<0>{}, to);
+                stage(1, IC<1>{}, to);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                DITTO_BAR();
+                mma(IC<0>{}, IC<0>{}, b0f);
+                mma(IC<0>{}, IC<1>{}, b1f);
+                DITTO_BAR();
 
-            read_B(0, IC<1>{}, b1f);
-            stage(1, IC<1>{}, to);                    // P2: o.A_hi
-            DITTO_BAR();
-            mma(IC<0>{}, IC<1>{}, b1f);
-            DITTO_BAR();
+                read_A(0, IC<1>{});
+                stage(0, IC<2>{}, te + 2);
+                stage(0, IC<3>{}, te + 2);
+                wait_dma(te + 2 < nkt);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                DITTO_BAR();
+                mma(IC<1>{}, IC<1>{}, b1f);
+                mma(IC<1>{}, IC<0>{}, b0f);
+                DITTO_BAR();
 
-            read_A(0, IC<1>{});                       // P3: no DMA
-            DITTO_BAR();
-            mma(IC<1>{}, IC<1>{}, b1f);
-            DITTO_BAR();
+                read_B(1, IC<0>{}, b0f);
+                read_B(1, IC<1>{}, b1f);
+                read_A(1, IC<0>{});
+                stage(0, IC<0>{}, te + 2);
+                stage(0, IC<1>{}, te + 2);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                DITTO_BAR();
+                if (odd_valid) {
+                    mma(IC<0>{}, IC<0>{}, b0f);
+                    mma(IC<0>{}, IC<1>{}, b1f);
+                }
+                DITTO_BAR();
 
-            stage(0, IC<2>{}, te + 2);                // P4: e.B_lo + e.B_hi (buffer 0's B halves were last read in P2)
-            stage(0, IC<3>{}, te + 2);
-            wait_dma(te + 2 < nkt);                   // buffer 1 (tile to: issued P8, P1, P2) has landed
-            DITTO_BAR();
-            mma(IC<1>{}, IC<0>{}, b0f);
-            DITTO_BAR();
+                read_A(1, IC<1>{});
+                stage(1, IC<2>{}, to + 2);
+                stage(1, IC<3>{}, to + 2);
+                wait_dma(to + 2 < nkt);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                DITTO_BAR();
+                if (odd_valid) {
+                    mma(IC<1>{}, IC<1>{}, b1f);
+                    mma(IC<1>{}, IC<0>{}, b0f);
+                }
+                DITTO_BAR();
+            }
+        } else {
+            for (int it = 0; it < niter; ++it) {
+                const int te = 2 * it, to = te + 1;
+                const bool odd_valid = to < nkt;
+                // ---------------- K-tile te from buffer 0 ----------------
+                read_B(0, IC<0>{}, b0f);
+                read_A(0, IC<0>{});
+                stage(1, IC<0>{}, to);                    // P1: o.A_lo   (buffer 1's A halves were last read in P7)
+                DITTO_BAR();
+                mma(IC<0>{}, IC<0>{}, b0f);
+                DITTO_BAR();
 
-            // ---------------- K-tile to from buffer 1 ----------------
-            read_B(1, IC<0>{}, b0f);
-            read_A(1, IC<0>{});
-            stage(0, IC<0>{}, te + 2);                // P5: e.A_lo   (buffer 0's A halves were last read in P3)
-            DITTO_BAR();
-            if (odd_valid) mma(IC<0>{}, IC<0>{}, b0f);
-            DITTO_BAR();
+                read_B(0, IC<1>{}, b1f);
+                stage(1, IC<1>{}, to);                    // P2: o.A_hi
+                DITTO_BAR();
+                mma(IC<0>{}, IC<1>{}, b1f);
+                DITTO_BAR();
 
-            read_B(1, IC<1>{}, b1f);
-            stage(0, IC<1>{}, te + 2);                // P6: e.A_hi
-            DITTO_BAR();
-            if (odd_valid) mma(IC<0>{}, IC<1>{}, b1f);
-            DITTO_BAR();
+                read_A(0, IC<1>{});                       // P3: no DMA
+                DITTO_BAR();
+                mma(IC<1>{}, IC<1>{}, b1f);
+                DITTO_BAR();
 
-            read_A(1, IC<1>{});                       // P7: no DMA
-            DITTO_BAR();
-            if (odd_valid) mma(IC<1>{}, IC<1>{}, b1f);
-            DITTO_BAR();
+                stage(0, IC<2>{}, te + 2);                // P4: e.B_lo + e.B_hi (buffer 0's B halves were last read in P2)
+                stage(0, IC<3>{}, te + 2);
+                wait_dma(te + 2 < nkt);                   // buffer 1 (tile to: issued P8, P1, P2) has landed
+                DITTO_BAR();
+                mma(IC<1>{}, IC<0>{}, b0f);
+                DITTO_BAR();
 
-            stage(1, IC<2>{}, to + 2);                // P8: o.B_lo + o.B_hi of the next odd tile
-            stage(1, IC<3>{}, to + 2);
-            wait_dma(to + 2 < nkt);                   // buffer 0 (tile te+2: issued P4, P5, P6) has landed
-            DITTO_BAR();
-            if (odd_valid) mma(IC<1>{}, IC<0>{}, b0f);
-            DITTO_BAR();
+                // ---------------- K-tile to from buffer 1 ----------------
+                read_B(1, IC<0>{}, b0f);
+                read_A(1, IC<0>{});
+                stage(0, IC<0>{}, te + 2);                // P5: e.A_lo   (buffer 0's A halves were last read in P3)
+                DITTO_BAR();
+                if (odd_valid) mma(IC<0>{}, IC<0>{}, b0f);
+                DITTO_BAR();
+
+                read_B(1, IC<1>{}, b1f);
+                stage(0, IC<1>{}, te + 2);                // P6: e.A_hi
+                DITTO_BAR();
+                if (odd_valid) mma(IC<0>{}, IC<1>{}, b1f);
+                DITTO_BAR();
+
+                read_A(1, IC<1>{});                       // P7: no DMA
+                DITTO_BAR();
+                if (odd_valid) mma(IC<1>{}, IC<1>{}, b1f);
+                DITTO_BAR();
+
+                stage(1, IC<2>{}, to + 2);                // P8: o.B_lo + o.B_hi of the next odd tile
+                stage(1, IC<3>{}, to + 2);
+                wait_dma(to + 2 < nkt);                   // buffer 0 (tile te+2: issued P4, P5, P6) has landed
+                DITTO_BAR();
+                if (odd_valid) mma(IC<1>{}, IC<0>{}, b0f);
+                DITTO_BAR();
+            }
         }
         if (wm == 0) DITTO_BAR();  // balance the stagger barrier: every LDS read of this tile has retired
 
@@ -258,22 +315,27 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             const int row = cur_m0 + wm * 128 + m * 16 + frow;
-            if (row < p.M) epilogue_row<EPI>(p, row, cur_n0 + wn * 64, acc[m], bias4, fq);
+            if (row < p.M)
+                epilogue_row<EPI>(p, (p.flags & GF_DIAG_SMALL_OUT) ? (row & 255) : row, cur_n0 + wn * 64, acc[m], bias4, fq);
         }
     }
 }
 
-template <int EPI>
-hipError_t launch256_t(const GemmParams& p, hipStream_t s) {
+template <int EPI, bool WIDE>
+hipError_t launch256_tw(const GemmParams& p, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI, WIDE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS256);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3(p.tile_stride), dim3(512), LDS256, s, p);
+    hipLaunchKernelGGL((gemm256_kernel<EPI, WIDE>), dim3(p.tile_stride), dim3(512), LDS256, s, p);
     return hipGetLastError();
+}
+template <int EPI>
+hipError_t launch256_t(const GemmParams& p, hipStream_t s) {
+    return (p.flags & GF_WIDE_PHASE) ? launch256_tw<EPI, true>(p, s) : launch256_tw<EPI, false>(p, s);
 }
 
 }  // namespace

@@ -34,7 +34,9 @@ enum { GF_RELAXED_WAIT = 1,        // tile-start wait skips over the previous ti
        GF_DIAG_LINEAR_STORE = 16,  // DIAGNOSTIC (wrong results): bf16 stores go to lane-linear addresses
        GF_STORE_SC1 = 32,          // output stores write-through, line dropped from L2 (sc1)
        GF_STORE_NT = 64,           // fp32 output stores non-temporal (nt)
-       GF_ROWMAJOR_TILES = 128 };  // A/B switch: plain row-major tile order instead of super-columns
+       GF_ROWMAJOR_TILES = 128,    // A/B switch: plain row-major tile order instead of super-columns
+       GF_WIDE_PHASE = 256,        // gemm256: 32 MFMAs per barrier pair, LDS reads retired before the barrier
+       GF_DIAG_SMALL_OUT = 512 };  // DIAGNOSTIC (wrong results): every tile stores into rows 0..255 (stays in L2)
 
 // Tile order.  An XCD (private 4 MiB L2) receives a contiguous range of the linear tile index (xcd_remap); within it
 // the tiles run down M inside a SUPER-COLUMN of `G` column tiles, so the tiles an XCD works on at one time are a

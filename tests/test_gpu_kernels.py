@@ -55,12 +55,14 @@ def test_gemm(lib, M, N, K, epi):
         assert max_abs(out, want + res) < 1e-4
 
 
-@pytest.fixture(params=[256, 129])
+@pytest.fixture(params=[(256, 73), (256, 73 + 256), (129, 73)])
 def tile256(lib, request):
-    """forces one of the two persistent structures: 256x256 eight-phase, 256x128 ring"""
-    hip.check(lib.ditto_set_option(b"gemm_tile", request.param))
+    """forces one persistent structure: 256x256 eight-phase, 256x256 wide-phase, 256x128 ring"""
+    hip.check(lib.ditto_set_option(b"gemm_tile", request.param[0]))
+    hip.check(lib.ditto_set_option(b"gemm_flags", request.param[1]))
     yield
     hip.check(lib.ditto_set_option(b"gemm_tile", 0))
+    hip.check(lib.ditto_set_option(b"gemm_flags", 329))
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 320, 64), (1000, 768, 768), (513, 2304, 192),

@@ -46,7 +46,7 @@ wall = {v: [] for v in variants}
 def select(v):
     tile, _, fl = v.partition("/")
     hip.check(lib.ditto_set_option(b"gemm_tile", int(tile)))
-    hip.check(lib.ditto_set_option(b"gemm_flags", int(fl) if fl else 73))
+    hip.check(lib.ditto_set_option(b"gemm_flags", int(fl) if fl else 329))
 
 
 with torch.no_grad():
