@@ -575,6 +575,10 @@ int ditto_set_option(const char* name, int value) {
         g_gemm_tile = value;
         return DITTO_OK;
     }
+    if (!strcmp(name, "attn_flags")) {
+        g_attn_flags = value;
+        return DITTO_OK;
+    }
     if (!strcmp(name, "gemm_flags")) {
         g_gemm_flags = value;
         return DITTO_OK;

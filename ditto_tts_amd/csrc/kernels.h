@@ -59,6 +59,7 @@ struct GemmArgs {
 hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s);
 extern int g_gemm_tile;  // 0 auto | 128 | 256
 extern int g_gemm_flags; // GF_* (gemm_common.h)
+extern int g_attn_flags; // attention.hip
 
 // ---------------- attention.hip ----------------
 struct AttnArgs {

@@ -121,9 +121,12 @@ def _attn_ref(q, k, v, B, H, Sq, Skv, dh, scale):
 
 
 @pytest.mark.parametrize("B,H,Sq,Skv,dh", [(1, 1, 32, 64, 64), (2, 3, 200, 96, 64), (1, 2, 128, 128, 64),
+                                           (2, 2, 300, 200, 64), (1, 3, 1024, 1024, 64),
                                            (1, 4, 64, 1, 64), (2, 12, 256, 320, 64), (1, 1, 40, 50, 128),
                                            (1, 2, 70, 33, 192)])
-def test_attention(lib, B, H, Sq, Skv, dh):
+@pytest.mark.parametrize("attn_flags", [0, 1, 3, 7])
+def test_attention(lib, B, H, Sq, Skv, dh, attn_flags):
+    hip.check(lib.ditto_set_option(b"attn_flags", attn_flags))   # 1: K/V tiles by LDS-DMA
     d = H * dh
     q = bf16(asym((B * Sq, d), 8).to(DEV))
     k = bf16(asym((B * Skv, d), 9).to(DEV))
@@ -134,6 +137,7 @@ def test_attention(lib, B, H, Sq, Skv, dh):
     ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=DEV)
     hip.check(lib.ditto_attention_bf16(q.data_ptr(), d, k.data_ptr(), d, v.data_ptr(), d, out.data_ptr(), d, B, H, Sq,
                                        Skv, dh, scale, ws.data_ptr(), ws.numel(), stream()))
+    hip.check(lib.ditto_set_option(b"attn_flags", 3))
     want = _attn_ref(q, k, v, B, H, Sq, Skv, dh, scale)
     assert rel_l2(out.float(), want) < 1.5e-2     # P is rounded to bf16 before the PV product
     assert max_abs(out.float(), want) < 6e-2

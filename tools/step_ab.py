@@ -44,6 +44,8 @@ wall = {v: [] for v in variants}
 
 
 def select(v):
+    v, _, af = v.partition("@")          # tile/gemm_flags@attn_flags
+    hip.check(lib.ditto_set_option(b"attn_flags", int(af) if af else 0))
     tile, _, fl = v.partition("/")
     hip.check(lib.ditto_set_option(b"gemm_tile", int(tile)))
     hip.check(lib.ditto_set_option(b"gemm_flags", int(fl) if fl else 329))
