@@ -74,6 +74,20 @@ def kernel_bytes(cfg, B, N, T):
     }
 
 
+def pmc_traffic(kernel_class, B, N, T, cfg):
+    """HBM bytes per launch of `kernel_class` from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json:
+    separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 x2 correction on the read side).
+    bench.py cannot run under the counter collector itself, so the figure is the offline one; it is only reported
+    when the workload is the one those passes measured (C2, B=32), else null."""
+    if not (B == 32 and N == 1024 and T == 1024 and cfg.hidden_dim == 768 and cfg.num_layers == 12):
+        return None
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        return d[kernel_class]["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def usable_cores():
     """CPUs this process may actually use: the scheduler affinity capped by the cgroup CPU quota (the GPU box
     shows 256 hardware threads behind a 16-CPU quota; running 256 torch threads there is 70x slower)."""
@@ -228,11 +242,11 @@ def main():
             e = classes[dom]
             if "tflops" in e:
                 roof = {"bound": "mfma", "kernel": dom, "achieved": e["tflops"], "peak": PEAK_BF16_TFLOPS,
-                        "unit": "TFLOP/s", "frac": e["frac_mfma"], "traffic": None,
+                        "unit": "TFLOP/s", "frac": e["frac_mfma"], "traffic": pmc_traffic(dom, B, N, T, cfg),
                         "avg_launch_ms": e["avg_ms"], "flops_per_launch": kf[dom]}
             else:
                 roof = {"bound": "hbm", "kernel": dom, "achieved": e["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": e["frac_hbm"], "traffic": None, "avg_launch_ms": e["avg_ms"],
+                        "frac": e["frac_hbm"], "traffic": pmc_traffic(dom, B, N, T, cfg), "avg_launch_ms": e["avg_ms"],
                         "bytes_per_launch": kb[dom]}
 
     ms_per_step = elapsed / args.steps * 1e3
