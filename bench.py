@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="C2", choices=["C1", "C2", "C4", "C5", "shipped"])
+    ap.add_argument("--config", default="C2", choices=["C1", "C2", "C4", "C5", "C5_bf16", "shipped"])
     ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default: the preset's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5)
@@ -160,7 +160,8 @@ def main():
     B = args.batch or p["B"]
     S = cfg.diffusion_steps
 
-    model = DiTTO(cfg.hidden_dim, cfg.num_layers, cfg.num_heads, cfg.time_dim, cfg.text_dim, S)
+    model = DiTTO(cfg.hidden_dim, cfg.num_layers, cfg.num_heads, cfg.time_dim, cfg.text_dim, S,
+                  fp8_linear=cfg.fp8_linear)
     model.load_state_dict(synthetic_state_dict(cfg, seed=1234))
     model = model.to(dev).eval()
     sg = SpeechGenerator(ditto_model=model, device=dev)
@@ -261,7 +262,7 @@ def main():
             "metric": f"DiT denoise steps/sec ({cfg.num_layers}L, d={cfg.hidden_dim}, latent_len={N})",
             "value": value, "unit": "utterance-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "fp8(e4m3) linear + bf16 attention" if cfg.fp8_linear else "bf16", "data": "synthetic",
             "config": {"workload": f"{args.config}: DiTTO {cfg.num_layers}L d={cfg.hidden_dim} h={cfg.num_heads} "
                                    f"N={N} T={T}, {S}-step DDPM sampling loop (forward + update + noise draw), "
                                    f"B={B} utterances per GPU, text K/V cached per utterance batch",

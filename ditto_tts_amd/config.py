@@ -19,6 +19,7 @@ class DiTTOConfig:
     time_dim: int = 256
     text_dim: int = 768
     diffusion_steps: int = 1000
+    fp8_linear: bool = False   # QKV / fc1|gate / fc2 GEMMs with fp8 e4m3 operands (BASELINE config 5)
 
     def __post_init__(self):
         if self.hidden_dim % self.num_heads:
@@ -29,6 +30,8 @@ class DiTTOConfig:
             raise ValueError("text_dim must equal hidden_dim (reference cross-attn has no kdim/vdim)")
         if (self.hidden_dim // self.num_heads) % 2:
             raise ValueError("head_dim must be even (half-split RoPE)")
+        if self.fp8_linear and self.hidden_dim % 128:
+            raise ValueError("fp8_linear needs hidden_dim % 128 == 0")
 
     @property
     def head_dim(self) -> int:
@@ -55,7 +58,8 @@ PRESETS = {
     "C2": dict(cfg=DiTTOConfig(768, 12, 12, 256, 768, 50), B=32, N=1024, T=1024),
     "C3": dict(cfg=DiTTOConfig(768, 12, 12, 256, 768, 50), B=32, N=1024, T=1024),  # per GPU of 8
     "C4": dict(cfg=DiTTOConfig(768, 12, 12, 256, 768, 50), B=8, N=4096, T=1024),
-    "C5": dict(cfg=DiTTOConfig(1024, 24, 16, 256, 1024, 50), B=16, N=1024, T=1024),
+    "C5": dict(cfg=DiTTOConfig(1024, 24, 16, 256, 1024, 50, fp8_linear=True), B=16, N=1024, T=1024),
+    "C5_bf16": dict(cfg=DiTTOConfig(1024, 24, 16, 256, 1024, 50), B=16, N=1024, T=1024),
     # the shipped ConfigDiTTO of the reference (src/utils/Config.py:109-116): 5 layers, ONE head
     "shipped": dict(cfg=DiTTOConfig(768, 5, 1, 256, 768, 1000), B=1, N=64, T=64),
 }

@@ -65,6 +65,17 @@ DITTO_DEV float fast_gelu_erf(float x) {
     return 0.5f * x * (1.0f + copysignf(erf_abs, z));
 }
 
+// four fp32 -> packed OCP fp8 e4m3 in one dword (byte 0 = first), saturating at +-448 (v_cvt_pk_fp8_f32 does not
+// clamp: an overflow would become NaN in e4m3fn)
+DITTO_DEV unsigned pack_fp8x4(float a, float b, float c, float d) {
+    const float L = 448.0f;
+    a = fminf(fmaxf(a, -L), L); b = fminf(fmaxf(b, -L), L); c = fminf(fmaxf(c, -L), L); d = fminf(fmaxf(d, -L), L);
+    int pk = 0;
+    pk = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, pk, false);
+    pk = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, pk, true);
+    return (unsigned)pk;
+}
+
 // Bijective XCD-aware block remap (guide §5 "XCD swizzle must be bijective"): blocks b and b+8
 // share an XCD/L2, so give each XCD a contiguous chunk of the logical tile space.
 DITTO_DEV int xcd_remap(int orig, int nwg) {

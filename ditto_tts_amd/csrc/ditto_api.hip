@@ -46,13 +46,14 @@ inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct LayerPack {
     const void *Wqkv, *Wcq, *Wco, *W1g, *W2;
+    const float *sqkv, *s1g, *s2;   // fp8 weight scales (DITTO_CFG_FP8_LINEAR)
     const float *bqkv, *bcq, *bco, *b1g, *b2;
     const float *g1, *be1, *g2, *be2, *g3, *be3;
 };
 
 struct ArenaPlan {
     size_t total = 0;
-    struct L { size_t Wqkv, Wcq, Wco, W1g, W2, bqkv, bcq, bco, b1g, b2, g1, be1, g2, be2, g3, be3; };
+    struct L { size_t Wqkv, Wcq, Wco, W1g, W2, bqkv, bcq, bco, b1g, b2, g1, be1, g2, be2, g3, be3, sqkv, s1g, s2; };
     std::vector<L> layers;
     size_t Wkv, bkv, Wfin, bfin, ttab, wx, bx, invf;
 };
@@ -65,8 +66,10 @@ ArenaPlan plan_arena(const ditto_config& c) {
     p.layers.resize(L);
     for (size_t l = 0; l < L; ++l) {
         auto& q = p.layers[l];
-        q.Wqkv = take(3 * d * d * 2); q.Wcq = take(d * d * 2); q.Wco = take(d * d * 2);
-        q.W1g = take(8 * d * d * 2); q.W2 = take(4 * d * d * 2);
+        const size_t we = (c.flags & DITTO_CFG_FP8_LINEAR) ? 1 : 2;   // bytes per element of the fp8-able weights
+        q.Wqkv = take(3 * d * d * we); q.Wcq = take(d * d * 2); q.Wco = take(d * d * 2);
+        q.W1g = take(8 * d * d * we); q.W2 = take(4 * d * d * we);
+        q.sqkv = take(3 * d * 4); q.s1g = take(8 * d * 4); q.s2 = take(d * 4);   // fp8 per-row weight scales
         q.bqkv = take(3 * d * 4); q.bcq = take(d * 4); q.bco = take(d * 4); q.b1g = take(8 * d * 4); q.b2 = take(d * 4);
         q.g1 = take(d * 4); q.be1 = take(d * 4); q.g2 = take(d * 4); q.be2 = take(d * 4); q.g3 = take(d * 4);
         q.be3 = take(d * 4);
@@ -115,6 +118,9 @@ int check_cfg(const ditto_config* c) {
     if (c->hidden_dim > 2048) return fail(DITTO_ERR_SHAPE, "hidden_dim > 2048 not supported by the LayerNorm kernel");
     const int dh = c->hidden_dim / c->num_heads;
     if (dh % 64) return fail(DITTO_ERR_SHAPE, "head_dim (%d) must be a multiple of 64", dh);
+    if ((c->flags & DITTO_CFG_FP8_LINEAR) && c->hidden_dim % 128)
+        return fail(DITTO_ERR_SHAPE, "fp8 linear layers need hidden_dim %% 128 == 0");
+    if (c->flags & ~DITTO_CFG_FP8_LINEAR) return fail(DITTO_ERR_ARG, "unknown config flag");
     return DITTO_OK;
 }
 
@@ -169,15 +175,21 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
     const int d = c.hidden_dim, H = c.num_heads, dh = d / H, M = B * N;
     const float scale = 1.0f / sqrtf((float)dh);
     const bool fused_rope = (dh == 64);
+    const bool fp8 = (c.flags & DITTO_CFG_FP8_LINEAR) != 0;   // u / act hold fp8 bytes for the fp8 GEMMs
     const LayerPack& lp = m->layers[l];
         // ---- self-attention (src/components/DiT.py:103-139) ----
-        { ProfScope ps(m, s, DITTO_KC_LAYERNORM); HIP_TRY(launch_layernorm(h, lp.g1, lp.be1, u, d, M, d, s)); }
+        {
+            ProfScope ps(m, s, DITTO_KC_LAYERNORM);
+            if (fp8) HIP_TRY(launch_layernorm_fp8(h, lp.g1, lp.be1, u, d, M, d, s));
+            else HIP_TRY(launch_layernorm(h, lp.g1, lp.be1, u, d, M, d, s));
+        }
         {
             ProfScope ps(m, s, DITTO_KC_GEMM_QKV);
             GemmArgs g{};
             g.A = u; g.lda = d; g.W = lp.Wqkv; g.bias = lp.bqkv; g.out = qkv; g.ldo = 3 * d;
             g.M = M; g.N = 3 * d; g.K = d;
             g.rope_cos = rope_cos; g.rope_sin = rope_sin; g.rope_rows_per_batch = N; g.rope_cols = 2 * d;
+            g.fp8 = fp8; g.wscale = fp8 ? lp.sqkv : nullptr;
             HIP_TRY(launch_gemm(g, fused_rope ? EPI_QKV_ROPE : EPI_BIAS_BF16, s));
             if (!fused_rope) HIP_TRY(launch_rope_inplace(qkv, 3 * d, rope_cos, rope_sin, M, N, 2 * d, dh, s));
         }
@@ -214,19 +226,23 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
             HIP_TRY(launch_gemm(g, EPI_BIAS_RES_F32, s));
         }
         // ---- gated MLP (src/components/DiT.py:150-155) ----
-        { ProfScope ps(m, s, DITTO_KC_LAYERNORM); HIP_TRY(launch_layernorm(h, lp.g3, lp.be3, u, d, M, d, s)); }
+        {
+            ProfScope ps(m, s, DITTO_KC_LAYERNORM);
+            if (fp8) HIP_TRY(launch_layernorm_fp8(h, lp.g3, lp.be3, u, d, M, d, s));
+            else HIP_TRY(launch_layernorm(h, lp.g3, lp.be3, u, d, M, d, s));
+        }
         {
             ProfScope ps(m, s, DITTO_KC_GEMM_GATED);
             GemmArgs g{};
             g.A = u; g.lda = d; g.W = lp.W1g; g.bias = lp.b1g; g.out = act; g.ldo = 4 * d; g.M = M; g.N = 8 * d;
-            g.K = d;
-            HIP_TRY(launch_gemm(g, EPI_GATED, s));
+            g.K = d; g.fp8 = fp8; g.wscale = fp8 ? lp.s1g : nullptr;
+            HIP_TRY(launch_gemm(g, fp8 ? EPI_GATED_FP8 : EPI_GATED, s));
         }
         {
             ProfScope ps(m, s, DITTO_KC_GEMM_FC2);
             GemmArgs g{};
             g.A = act; g.lda = 4 * d; g.W = lp.W2; g.bias = lp.b2; g.residual = h; g.ldr = d; g.out = h; g.ldo = d;
-            g.M = M; g.N = d; g.K = 4 * d;
+            g.M = M; g.N = d; g.K = 4 * d; g.fp8 = fp8; g.wscale = fp8 ? lp.s2 : nullptr;
             if (xcat_or_null) { g.out2_bf16 = xcat_or_null + (size_t)d * 2; g.ldo2 = 2 * d; }  // bf16(h_L) for proj_out
             HIP_TRY(launch_gemm(g, EPI_BIAS_RES_F32, s));
         }
@@ -289,7 +305,18 @@ int ditto_model_create(const ditto_config* cfg, const ditto_weights* w, void* ar
         for (const float* p : need)
             if (!p) return fail(DITTO_ERR_ARG, "null weight pointer in layer %d", l);
         // self-attention in_proj [3d, d] (q | k | v rows), reference src/components/DiT.py:110-114
+        const bool fp8 = (cfg->flags & DITTO_CFG_FP8_LINEAR) != 0;
+        if (fp8) {
+            HIP_TRY(launch_pack_fp8(lw.attn_in_proj_weight, A + q.Wqkv, (float*)(A + q.sqkv), 3 * d, d, d, BIG, 1, 0, s));
+            HIP_TRY(launch_pack_fp8(lw.mlp_fc1_weight, A + q.W1g, (float*)(A + q.s1g), 4 * d, d, d, 16, 2, 0, s));
+            HIP_TRY(launch_pack_fp8(lw.gate_weight, A + q.W1g, (float*)(A + q.s1g), 4 * d, d, d, 16, 2, 16, s));
+            HIP_TRY(launch_pack_fp8(lw.mlp_fc2_weight, A + q.W2, (float*)(A + q.s2), d, 4 * d, 4 * d, BIG, 1, 0, s));
+        } else {
         HIP_TRY(launch_pack_bf16(lw.attn_in_proj_weight, A + q.Wqkv, 3 * d, d, d, 0, BIG, 1, 0, s));
+        HIP_TRY(launch_pack_bf16(lw.mlp_fc1_weight, A + q.W1g, 4 * d, d, d, 0, 16, 2, 0, s));
+        HIP_TRY(launch_pack_bf16(lw.gate_weight, A + q.W1g, 4 * d, d, d, 0, 16, 2, 16, s));
+        HIP_TRY(launch_pack_bf16(lw.mlp_fc2_weight, A + q.W2, d, 4 * d, 4 * d, 0, BIG, 1, 0, s));
+        }
         HIP_TRY(hipMemcpyAsync(A + q.bqkv, lw.attn_in_proj_bias, 3 * d * 4, hipMemcpyDeviceToDevice, s));
         // cross-attention: q rows [0,d) per layer; k,v rows [d,3d) go to the all-layer Wkv
         HIP_TRY(launch_pack_bf16(lw.cross_in_proj_weight, A + q.Wcq, d, d, d, 0, BIG, 1, 0, s));
@@ -301,11 +328,8 @@ int ditto_model_create(const ditto_config* cfg, const ditto_weights* w, void* ar
         HIP_TRY(launch_pack_bf16(lw.cross_out_proj_weight, A + q.Wco, d, d, d, 0, BIG, 1, 0, s));
         HIP_TRY(hipMemcpyAsync(A + q.bco, lw.cross_out_proj_bias, d * 4, hipMemcpyDeviceToDevice, s));
         // gated MLP: rows interleaved [16 x fc1 | 16 x gate] so both halves of a product meet in one lane
-        HIP_TRY(launch_pack_bf16(lw.mlp_fc1_weight, A + q.W1g, 4 * d, d, d, 0, 16, 2, 0, s));
-        HIP_TRY(launch_pack_bf16(lw.gate_weight, A + q.W1g, 4 * d, d, d, 0, 16, 2, 16, s));
         HIP_TRY(launch_pack_vec(lw.mlp_fc1_bias, (float*)(A + q.b1g), 4 * d, 16, 2, 0, s));
         HIP_TRY(launch_pack_vec(lw.gate_bias, (float*)(A + q.b1g), 4 * d, 16, 2, 16, s));
-        HIP_TRY(launch_pack_bf16(lw.mlp_fc2_weight, A + q.W2, d, 4 * d, 4 * d, 0, BIG, 1, 0, s));
         HIP_TRY(hipMemcpyAsync(A + q.b2, lw.mlp_fc2_bias, d * 4, hipMemcpyDeviceToDevice, s));
         const float* lnsrc[6] = {lw.norm1_weight, lw.norm1_bias, lw.norm2_weight, lw.norm2_bias, lw.norm3_weight,
                                  lw.norm3_bias};
@@ -316,6 +340,7 @@ int ditto_model_create(const ditto_config* cfg, const ditto_weights* w, void* ar
         lp.Wqkv = A + q.Wqkv; lp.Wcq = A + q.Wcq; lp.Wco = A + q.Wco; lp.W1g = A + q.W1g; lp.W2 = A + q.W2;
         lp.bqkv = (const float*)(A + q.bqkv); lp.bcq = (const float*)(A + q.bcq); lp.bco = (const float*)(A + q.bco);
         lp.b1g = (const float*)(A + q.b1g); lp.b2 = (const float*)(A + q.b2);
+        lp.sqkv = (const float*)(A + q.sqkv); lp.s1g = (const float*)(A + q.s1g); lp.s2 = (const float*)(A + q.s2);
         lp.g1 = (const float*)(A + q.g1); lp.be1 = (const float*)(A + q.be1); lp.g2 = (const float*)(A + q.g2);
         lp.be2 = (const float*)(A + q.be2); lp.g3 = (const float*)(A + q.g3); lp.be3 = (const float*)(A + q.be3);
     }
@@ -564,6 +589,44 @@ int ditto_attention_bf16(const void* q, int ldq, const void* k, int ldk, const v
     a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.dh = dh; a.scale = scale;
     a.workspace = workspace; a.workspace_bytes = workspace_bytes;
     HIP_TRY(launch_attention(a, (hipStream_t)stream));
+    return DITTO_OK;
+}
+
+int ditto_quantize_rows_fp8(const float* src, int rows, int cols, void* dst_fp8, float* scales, ditto_stream_t stream) {
+    if (!src || !dst_fp8 || !scales || rows <= 0 || cols <= 0) return fail(DITTO_ERR_ARG, "bad argument to ditto_quantize_rows_fp8");
+    if (cols % 4) return fail(DITTO_ERR_SHAPE, "cols must be a multiple of 4");
+    HIP_TRY(launch_pack_fp8(src, dst_fp8, scales, rows, cols, cols, 1 << 30, 1, 0, (hipStream_t)stream));
+    return DITTO_OK;
+}
+
+int ditto_layernorm_fp8(const float* x, const float* gamma, const float* beta, void* out_fp8, int M, int d,
+                        ditto_stream_t stream) {
+    if (!x || !out_fp8 || M <= 0 || d <= 0 || (gamma == nullptr) != (beta == nullptr))
+        return fail(DITTO_ERR_ARG, "bad argument to ditto_layernorm_fp8");
+    if (d % 4 || d > 2048) return fail(DITTO_ERR_SHAPE, "d must be a multiple of 4 and <= 2048");
+    HIP_TRY(launch_layernorm_fp8(x, gamma, beta, out_fp8, d, M, d, (hipStream_t)stream));
+    return DITTO_OK;
+}
+
+int ditto_gemm_fp8(const void* A, int lda, const void* W, const float* wscale, const float* bias,
+                   const float* residual, void* out, int ldo, int M, int N, int K, int epilogue,
+                   ditto_stream_t stream) {
+    if (!A || !W || !out) return fail(DITTO_ERR_ARG, "null pointer to ditto_gemm_fp8");
+    if (K % 128 || N % 16 || lda % 16) return fail(DITTO_ERR_SHAPE, "need K %% 128 == 0, N %% 16 == 0, lda %% 16 == 0");
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.W = W; g.bias = bias; g.residual = residual; g.ldr = ldo; g.out = out; g.ldo = ldo;
+    g.M = M; g.N = N; g.K = K; g.fp8 = true; g.wscale = wscale;
+    GemmEpilogue e;
+    switch (epilogue) {
+        case 0: e = EPI_BIAS_BF16; break;
+        case 1: e = EPI_BIAS_RES_F32; break;
+        case 4: e = EPI_BIAS_F32; break;
+        case 5:
+            if (!bias || N % 32) return fail(DITTO_ERR_ARG, "gated epilogue needs a bias and N %% 32 == 0");
+            e = EPI_GATED_FP8; break;
+        default: return fail(DITTO_ERR_ARG, "epilogue must be 0, 1, 4 or 5");
+    }
+    HIP_TRY(launch_gemm(g, e, (hipStream_t)stream));
     return DITTO_OK;
 }
 

@@ -132,9 +132,13 @@ hipError_t launch_t(const GemmParams& p, hipStream_t s) {
 
 hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return hipErrorInvalidValue;
-    if (a.K % BK || a.N % 16 || a.lda % 8 || (a.ldw % 8)) return hipErrorInvalidValue;
+    if (a.fp8) {
+        if (a.K % 128 || a.N % 16 || a.lda % 16 || a.ldw % 16) return hipErrorInvalidValue;
+    } else if (a.K % BK || a.N % 16 || a.lda % 8 || (a.ldw % 8)) {
+        return hipErrorInvalidValue;
+    }
     GemmParams p;
-    p.A = (const bf16*)a.A; p.lda = a.lda; p.W = (const bf16*)a.W; p.bias = a.bias;
+    p.A = (const bf16*)a.A; p.lda = a.lda; p.W = (const bf16*)a.W; p.bias = a.bias; p.wscale = a.wscale;
     p.ldw = a.ldw ? a.ldw : a.K; p.w_rows = a.w_rows ? a.w_rows : a.N;
     p.residual = a.residual; p.ldr = a.ldr; p.out = a.out; p.ldo = a.ldo;
     p.out2 = (bf16*)a.out2_bf16; p.ldo2 = a.ldo2;
@@ -146,6 +150,7 @@ hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s) {
                 return hipErrorInvalidValue;
             break;
         case EPI_GATED:
+        case EPI_GATED_FP8:
             if (a.N % 32 || !a.bias) return hipErrorInvalidValue;
             break;
         default: break;
@@ -154,6 +159,12 @@ hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s) {
     // eight-phase kernel wins once every CU gets >= 4 tiles (QKV: 145 vs 166 us, gated MLP: 307 vs 424 us);
     // at 1.5 tiles per CU (the N = 768 GEMMs) its tile quantisation loses to the 128x128 kernel (d x d 84 vs
     // 69 us, fc2 218 vs 205 us).  DITTO_GEMM=128|256 / ditto_set_option("gemm_tile") force one.
+    if (a.fp8) {
+        p.tiles_m = (a.M + 255) / 256;
+        p.tiles_n = (a.N + 255) / 256;
+        return launch_gemm256_fp8(p, epi, s);
+    }
+    if (epi == EPI_GATED_FP8) return hipErrorInvalidValue;   // fp8 output only from the fp8 GEMM
     const int forced = g_gemm_tile;
     const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
     if (forced == 256 || (forced == 0 && t256 >= 4 * 256)) {
@@ -181,6 +192,7 @@ hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s) {
         case EPI_QKV_ROPE: return launch_t<EPI_QKV_ROPE>(p, s);
         case EPI_GATED: return launch_t<EPI_GATED>(p, s);
         case EPI_BIAS_F32: return launch_t<EPI_BIAS_F32>(p, s);
+        default: break;
     }
     return hipErrorInvalidValue;
 }

@@ -32,6 +32,8 @@
 //             barriers after both groups' waits.
 //   tails     rows past M / N are clamped on load and masked on store; K-tiles past the end are neither
 //             loaded nor multiplied.
+#include <type_traits>
+
 #include "gemm_common.h"
 
 namespace ditto {
@@ -47,14 +49,17 @@ struct IC { static constexpr int value = V; };
 
 #define DITTO_BAR() asm volatile("s_barrier" ::: "memory")
 
-template <int EPI, bool WIDE>
+template <int EPI, bool WIDE, bool FP8>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 2, wn = wid & 3;
     const int ntiles = p.tiles_m * p.tiles_n;
-    const int nkt = p.K / 64;
+    // A K-tile is 128 BYTES of every row: 64 bf16 or 128 fp8 elements; the LDS image, the DMA and the swizzle are
+    // byte-identical for both, only the fragment chunks and the MFMA differ.
+    constexpr int ESZ = FP8 ? 1 : 2;
+    const int nkt = p.K / (128 / ESZ);
 
     // ---- DMA source addressing: this wave moves pieces 2*wid, 2*wid+1 (1 KiB = 8 rows) of every half-tile ----
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;   // LDS byte address of the dynamic region
@@ -64,21 +69,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     auto stage = [&](int buf, auto HALF, int kt) {
         constexpr int half = decltype(HALF)::value;
         if (kt >= nkt) return;    // wave-uniform; the waits below account for it
-        const int k0 = kt * 64;
+        const int k0b = kt * 128;             // byte offset of the K-tile inside a row
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int piece = wid * 2 + i;
             const int row = piece * 8 + srow;  // 0..127 inside the half
             const int c = scpos ^ ((row >> 1) & 7);
-            const bf16* src;
+            const char* src;
             if constexpr (half < 2) {
                 int gr = m0 + half * 128 + row;
                 gr = gr < p.M ? gr : p.M - 1;
-                src = p.A + (size_t)gr * p.lda + k0 + c * 8;
+                src = (const char*)p.A + (size_t)gr * p.lda * ESZ + k0b + c * 16;
             } else {
                 int gr = n0 + (half - 2) * 128 + row;
                 gr = gr < p.w_rows ? gr : p.w_rows - 1;
-                src = p.W + (size_t)gr * p.ldw + k0 + c * 8;
+                src = (const char*)p.W + (size_t)gr * p.ldw * ESZ + k0b + c * 16;
             }
             glds16(src, lds_base + (unsigned)(buf * KT_BYTES + half * HALF_BYTES + piece * 1024));
         }
@@ -101,40 +106,88 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     const int frow = lane & 15, fq = lane >> 4, fswz = frow >> 1;
     const int a_base = wm * HALF_BYTES + frow * 128;                                 // + (ai*64 + m*16)*128
     const int b_base = (2 + (wn >> 1)) * HALF_BYTES + ((wn & 1) * 64 + frow) * 128;  // + (bj*32 + n*16)*128
-    const int coff0 = ((0 + fq) ^ fswz) << 4, coff1 = ((4 + fq) ^ fswz) << 4;
+    // bf16: a lane's two 16-B reads are the k-chunks fq and 4+fq (two K = 32 MFMA steps); fp8: chunks 2fq, 2fq+1
+    // (one K = 128 step: 32 consecutive bytes per lane).  Operands of both products use the same chunk map, so the
+    // k order inside a step is irrelevant.
+    const int coff0 = (((FP8 ? 2 * fq : fq)) ^ fswz) << 4, coff1 = (((FP8 ? 2 * fq + 1 : 4 + fq)) ^ fswz) << 4;
 
-    bf16x8 af[8], b0f[4], b1f[4];
+    // Fragment registers.  bf16: 16-B fragments, one per (block, k-step).  fp8: the MFMA operand is 8 consecutive
+    // registers, so the fragment is allocated as ONE 8-dword vector and the two ds_read_b128 land in its halves
+    // (building it later from two 4-dword values made hipcc copy into fresh aligned tuples: 160-210 spills).
+    typedef __attribute__((ext_vector_type(8))) int i32x8;
+    typedef __attribute__((ext_vector_type(4))) int i32x4;
+    struct Frags16 { u32x4 a[8], b0[4], b1[4]; };
+    struct Frags8 { i32x8 a[4], b0[2], b1[2]; };
+    typename std::conditional<FP8, Frags8, Frags16>::type fr;
     f32x4 acc[8][4];
 
+    auto ld8 = [&](const char* ptr) {   // 32 bytes as one 8-dword operand
+        const i32x4 lo = *reinterpret_cast<const i32x4*>(ptr + coff0), hi = *reinterpret_cast<const i32x4*>(ptr + coff1);
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
     auto read_A = [&](int buf, auto AI) {
         constexpr int ai = decltype(AI)::value;
         const char* base = smem + buf * KT_BYTES + a_base + ai * 64 * 128;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            af[m * 2 + 0] = *reinterpret_cast<const bf16x8*>(base + m * 16 * 128 + coff0);
-            af[m * 2 + 1] = *reinterpret_cast<const bf16x8*>(base + m * 16 * 128 + coff1);
+            if constexpr (FP8) {
+                fr.a[m] = ld8(base + m * 16 * 128);
+            } else {
+                fr.a[m * 2 + 0] = *reinterpret_cast<const u32x4*>(base + m * 16 * 128 + coff0);
+                fr.a[m * 2 + 1] = *reinterpret_cast<const u32x4*>(base + m * 16 * 128 + coff1);
+            }
         }
     };
-    auto read_B = [&](int buf, auto BJ, bf16x8(&bf)[4]) {
+    auto read_B = [&](int buf, auto BJ) {   // B half bj -> fr.b0 (bj = 0) / fr.b1 (bj = 1)
         constexpr int bj = decltype(BJ)::value;
         const char* base = smem + buf * KT_BYTES + b_base + bj * 32 * 128;
+        auto& dst = bj == 0 ? fr.b0 : fr.b1;
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-            bf[n * 2 + 0] = *reinterpret_cast<const bf16x8*>(base + n * 16 * 128 + coff0);
-            bf[n * 2 + 1] = *reinterpret_cast<const bf16x8*>(base + n * 16 * 128 + coff1);
+            if constexpr (FP8) {
+                dst[n] = ld8(base + n * 16 * 128);
+            } else {
+                dst[n * 2 + 0] = *reinterpret_cast<const u32x4*>(base + n * 16 * 128 + coff0);
+                dst[n * 2 + 1] = *reinterpret_cast<const u32x4*>(base + n * 16 * 128 + coff1);
+            }
         }
     };
-    auto mma = [&](auto AI, auto BJ, const bf16x8(&bf)[4]) {
+    auto mma = [&](auto AI, auto BJ) {
         constexpr int ai = decltype(AI)::value, bj = decltype(BJ)::value;
+        auto& bf = bj == 0 ? fr.b0 : fr.b1;
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (FP8) {
+            // 8 x v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3 x e4m3, unit e8m0 scales): 32 cycles each, 4x the K of
+            // the bf16 instruction -> twice the FLOPs per cycle at the same bytes per K-tile.
+            // ONE asm volatile block per cluster: as builtins hipcc SINKS these (pure) calls across the
+            // memory-only asm barriers into later phases, keeping several phases' fragments live (160-260 spills,
+            // 2.6x slower than bf16); volatile asm keeps its order relative to the barrier statements.  MFMAs that
+            // accumulate into different tiles need no wait states between them; hipcc waits for the ds_reads that
+            // feed the operands before the statement (it tracks its own LDS loads).
+            const int one = 0x7F7F7F7F;   // e8m0 scale 1.0 in every byte
+            f32x4* c = &acc[ai * 4][bj * 2];   // c[m * 4 + n]  (acc rows are 4 tiles wide)
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass must not see amdgcn register constraints (it dropped the stub)
+#define DITTO_MS(ci, ai_, bi_) "v_mfma_scale_f32_16x16x128_f8f6f4 %" #ci ", %" #bi_ ", %" #ai_ ", %" #ci ", %14, %14 op_sel_hi:[0,0,0]\n\t"
+            asm volatile("s_nop 4\n\t"   // VALU-write -> MFMA-read wait states for operands hipcc may have just moved
+                         DITTO_MS(0, 8, 12) DITTO_MS(1, 8, 13) DITTO_MS(2, 9, 12) DITTO_MS(3, 9, 13)
+                         DITTO_MS(4, 10, 12) DITTO_MS(5, 10, 13) DITTO_MS(6, 11, 12) DITTO_MS(7, 11, 13)
+                         : "+v"(c[0]), "+v"(c[1]), "+v"(c[4]), "+v"(c[5]), "+v"(c[8]), "+v"(c[9]), "+v"(c[12]), "+v"(c[13])
+                         : "v"(fr.a[0]), "v"(fr.a[1]), "v"(fr.a[2]), "v"(fr.a[3]), "v"(bf[0]), "v"(bf[1]), "v"(one));
+#undef DITTO_MS
+#else
+            (void)one; (void)c; (void)bf;
+#endif
+        } else {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+            for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    acc[ai * 4 + m][bj * 2 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        bf[n * 2 + kk], af[m * 2 + kk], acc[ai * 4 + m][bj * 2 + n], 0, 0, 0);
+                    for (int n = 0; n < 2; ++n)
+                        acc[ai * 4 + m][bj * 2 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, bf[n * 2 + kk]), __builtin_bit_cast(bf16x8, fr.a[m * 2 + kk]),
+                            acc[ai * 4 + m][bj * 2 + n], 0, 0, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
     };
     // counted wait: `ahead` = the DMA this phase issued itself exists (4 loads stay in flight), else drain
@@ -147,7 +200,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     // DMA (stores; the compiler's own waits retire the loads).  vmcnt retires in order, so the tile-start wait may
     // leave these (younger) stores in flight and still guarantee the (older) prologue DMA has landed: the store
     // drain of the previous tile then overlaps the first phases instead of stalling the whole workgroup.
-    constexpr int EPI_STORES = EPI == EPI_BIAS_BF16 ? 16 : EPI == EPI_QKV_ROPE ? 16 : EPI == EPI_GATED ? 8 : 32;
+    constexpr int EPI_STORES = EPI == EPI_BIAS_BF16 ? 16 : EPI == EPI_QKV_ROPE ? 16
+                               : (EPI == EPI_GATED || EPI == EPI_GATED_FP8) ? 8 : 32;
     bool prev_interior = false;   // previous tile of this workgroup was interior (its store count is exact)
 
     const int niter = (nkt + 1) / 2;
@@ -191,15 +245,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             for (int it = 0; it < niter; ++it) {
                 const int te = 2 * it, to = te + 1;
                 const bool odd_valid = to < nkt;
-                read_B(0, IC<0>{}, b0f);
-                read_B(0, IC<1>{}, b1f);
+                read_B(0, IC<0>{});
+                read_B(0, IC<1>{});
                 read_A(0, IC<0>{});
                 stage(1, IC<0>{}, to);
                 stage(1, IC<1>{}, to);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 DITTO_BAR();
-                mma(IC<0>{}, IC<0>{}, b0f);
-                mma(IC<0>{}, IC<1>{}, b1f);
+                mma(IC<0>{}, IC<0>{});
+                mma(IC<0>{}, IC<1>{});
                 DITTO_BAR();
 
                 read_A(0, IC<1>{});
@@ -208,20 +262,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
                 wait_dma(te + 2 < nkt);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 DITTO_BAR();
-                mma(IC<1>{}, IC<1>{}, b1f);
-                mma(IC<1>{}, IC<0>{}, b0f);
+                mma(IC<1>{}, IC<1>{});
+                mma(IC<1>{}, IC<0>{});
                 DITTO_BAR();
 
-                read_B(1, IC<0>{}, b0f);
-                read_B(1, IC<1>{}, b1f);
+                read_B(1, IC<0>{});
+                read_B(1, IC<1>{});
                 read_A(1, IC<0>{});
                 stage(0, IC<0>{}, te + 2);
                 stage(0, IC<1>{}, te + 2);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 DITTO_BAR();
                 if (odd_valid) {
-                    mma(IC<0>{}, IC<0>{}, b0f);
-                    mma(IC<0>{}, IC<1>{}, b1f);
+                    mma(IC<0>{}, IC<0>{});
+                    mma(IC<0>{}, IC<1>{});
                 }
                 DITTO_BAR();
 
@@ -232,8 +286,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 DITTO_BAR();
                 if (odd_valid) {
-                    mma(IC<1>{}, IC<1>{}, b1f);
-                    mma(IC<1>{}, IC<0>{}, b0f);
+                    mma(IC<1>{}, IC<1>{});
+                    mma(IC<1>{}, IC<0>{});
                 }
                 DITTO_BAR();
             }
@@ -242,55 +296,55 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
                 const int te = 2 * it, to = te + 1;
                 const bool odd_valid = to < nkt;
                 // ---------------- K-tile te from buffer 0 ----------------
-                read_B(0, IC<0>{}, b0f);
+                read_B(0, IC<0>{});
                 read_A(0, IC<0>{});
                 stage(1, IC<0>{}, to);                    // P1: o.A_lo   (buffer 1's A halves were last read in P7)
                 DITTO_BAR();
-                mma(IC<0>{}, IC<0>{}, b0f);
+                mma(IC<0>{}, IC<0>{});
                 DITTO_BAR();
 
-                read_B(0, IC<1>{}, b1f);
+                read_B(0, IC<1>{});
                 stage(1, IC<1>{}, to);                    // P2: o.A_hi
                 DITTO_BAR();
-                mma(IC<0>{}, IC<1>{}, b1f);
+                mma(IC<0>{}, IC<1>{});
                 DITTO_BAR();
 
                 read_A(0, IC<1>{});                       // P3: no DMA
                 DITTO_BAR();
-                mma(IC<1>{}, IC<1>{}, b1f);
+                mma(IC<1>{}, IC<1>{});
                 DITTO_BAR();
 
                 stage(0, IC<2>{}, te + 2);                // P4: e.B_lo + e.B_hi (buffer 0's B halves were last read in P2)
                 stage(0, IC<3>{}, te + 2);
                 wait_dma(te + 2 < nkt);                   // buffer 1 (tile to: issued P8, P1, P2) has landed
                 DITTO_BAR();
-                mma(IC<1>{}, IC<0>{}, b0f);
+                mma(IC<1>{}, IC<0>{});
                 DITTO_BAR();
 
                 // ---------------- K-tile to from buffer 1 ----------------
-                read_B(1, IC<0>{}, b0f);
+                read_B(1, IC<0>{});
                 read_A(1, IC<0>{});
                 stage(0, IC<0>{}, te + 2);                // P5: e.A_lo   (buffer 0's A halves were last read in P3)
                 DITTO_BAR();
-                if (odd_valid) mma(IC<0>{}, IC<0>{}, b0f);
+                if (odd_valid) mma(IC<0>{}, IC<0>{});
                 DITTO_BAR();
 
-                read_B(1, IC<1>{}, b1f);
+                read_B(1, IC<1>{});
                 stage(0, IC<1>{}, te + 2);                // P6: e.A_hi
                 DITTO_BAR();
-                if (odd_valid) mma(IC<0>{}, IC<1>{}, b1f);
+                if (odd_valid) mma(IC<0>{}, IC<1>{});
                 DITTO_BAR();
 
                 read_A(1, IC<1>{});                       // P7: no DMA
                 DITTO_BAR();
-                if (odd_valid) mma(IC<1>{}, IC<1>{}, b1f);
+                if (odd_valid) mma(IC<1>{}, IC<1>{});
                 DITTO_BAR();
 
                 stage(1, IC<2>{}, to + 2);                // P8: o.B_lo + o.B_hi of the next odd tile
                 stage(1, IC<3>{}, to + 2);
                 wait_dma(to + 2 < nkt);                   // buffer 0 (tile te+2: issued P4, P5, P6) has landed
                 DITTO_BAR();
-                if (odd_valid) mma(IC<1>{}, IC<0>{}, b0f);
+                if (odd_valid) mma(IC<1>{}, IC<0>{});
                 DITTO_BAR();
             }
         }
@@ -312,6 +366,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         }
         f32x4 bias4[4];
         load_bias(p, cur_n0 + wn * 64, fq, bias4);
+        if constexpr (FP8) {   // per-output-column weight scale of the fp8 quantisation
+            f32x4 ws4[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int c = cur_n0 + wn * 64 + n * 16 + fq * 4;
+                ws4[n] = f32x4{1.f, 1.f, 1.f, 1.f};
+                if (p.wscale && c < p.N) ws4[n] = *reinterpret_cast<const f32x4*>(p.wscale + c);
+            }
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[m][n] *= ws4[n];
+        }
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             const int row = cur_m0 + wm * 128 + m * 16 + frow;
@@ -321,21 +388,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     }
 }
 
-template <int EPI, bool WIDE>
+template <int EPI, bool WIDE, bool FP8>
 hipError_t launch256_tw(const GemmParams& p, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI, WIDE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI, WIDE, FP8>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS256);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm256_kernel<EPI, WIDE>), dim3(p.tile_stride), dim3(512), LDS256, s, p);
+    hipLaunchKernelGGL((gemm256_kernel<EPI, WIDE, FP8>), dim3(p.tile_stride), dim3(512), LDS256, s, p);
     return hipGetLastError();
 }
 template <int EPI>
 hipError_t launch256_t(const GemmParams& p, hipStream_t s) {
-    return (p.flags & GF_WIDE_PHASE) ? launch256_tw<EPI, true>(p, s) : launch256_tw<EPI, false>(p, s);
+    return (p.flags & GF_WIDE_PHASE) ? launch256_tw<EPI, true, false>(p, s) : launch256_tw<EPI, false, false>(p, s);
 }
 
 }  // namespace
@@ -362,6 +429,30 @@ hipError_t launch_gemm256(const GemmParams& p_in, GemmEpilogue epi, hipStream_t 
         case EPI_QKV_ROPE: return launch256_t<EPI_QKV_ROPE>(p, s);
         case EPI_GATED: return launch256_t<EPI_GATED>(p, s);
         case EPI_BIAS_F32: return launch256_t<EPI_BIAS_F32>(p, s);
+        default: break;
+    }
+    return hipErrorInvalidValue;
+}
+
+// fp8 e4m3 operands (always the wide-phase schedule)
+hipError_t launch_gemm256_fp8(const GemmParams& p_in, GemmEpilogue epi, hipStream_t s) {
+    int dev = 0, n_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+        n_cu = 256;
+    GemmParams p = p_in;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    p.tile_stride = ntiles < n_cu ? ntiles : n_cu;
+    p.flags = g_gemm_flags;
+    p.group_n = pick_group_n(p.tiles_n, p.flags);
+    p.stagger_ticks = (int)((p.K / 128 * 1.5 + 8.0) * 100.0 / 4.0);
+    switch (epi) {
+        case EPI_BIAS_BF16: return launch256_tw<EPI_BIAS_BF16, true, true>(p, s);
+        case EPI_BIAS_RES_F32: return launch256_tw<EPI_BIAS_RES_F32, true, true>(p, s);
+        case EPI_QKV_ROPE: return launch256_tw<EPI_QKV_ROPE, true, true>(p, s);
+        case EPI_BIAS_F32: return launch256_tw<EPI_BIAS_F32, true, true>(p, s);
+        case EPI_GATED_FP8: return launch256_tw<EPI_GATED_FP8, true, true>(p, s);
+        default: break;
     }
     return hipErrorInvalidValue;
 }

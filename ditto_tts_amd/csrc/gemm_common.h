@@ -15,6 +15,7 @@ struct GemmParams {
     const bf16* A; int lda;
     const bf16* W; int ldw; int w_rows;
     const float* bias;
+    const float* wscale;   // fp8 GEMMs: per-output-column weight scale (null otherwise)
     const float* residual; int ldr;
     void* out; int ldo;
     bf16* out2; int ldo2;
@@ -137,7 +138,28 @@ template <int EPI>
 DITTO_DEV void epilogue_row(const GemmParams& p, int row, int cbase, const f32x4 (&acc)[4], const f32x4 (&bias)[4],
                             int fq) {
     const int c4 = fq * 4;
-    if constexpr (EPI == EPI_GATED) {
+    if constexpr (EPI == EPI_GATED_FP8) {
+        // as EPI_GATED with an fp8 e4m3 result: 4 values = one dword per 16-column block; the lane^16 exchange
+        // makes it 8 consecutive bytes per lane
+        unsigned pk[2];
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const f32x4 b1 = bias[2 * pr], bg = bias[2 * pr + 1];
+            const f32x4 h = acc[2 * pr], g = acc[2 * pr + 1];
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fast_gelu_erf(h[e] + b1[e]) * fast_sigmoid(g[e] + bg[e]);
+            pk[pr] = pack_fp8x4(o[0], o[1], o[2], o[3]);
+        }
+        const auto r = __builtin_amdgcn_permlane16_swap(pk[0], pk[1], false, false);
+        const int odd = fq & 1;
+        const int c = cbase / 2 + odd * 16 + 4 * (fq - odd);
+        if (c < p.N / 2) {
+            u32x2 st;
+            st[0] = r[0]; st[1] = r[1];
+            *reinterpret_cast<u32x2*>((unsigned char*)p.out + (size_t)row * p.ldo + c) = st;
+        }
+    } else if constexpr (EPI == EPI_GATED) {
         // packed columns: 16 x fc1 | 16 x gate | 16 x fc1 | 16 x gate  (reference src/components/DiT.py:153-155)
         u32x2 pk[2];
 #pragma unroll
@@ -222,6 +244,7 @@ DITTO_DEV void epilogue_row(const GemmParams& p, int row, int cbase, const f32x4
 
 // gemm256.hip
 hipError_t launch_gemm256(const GemmParams& p, GemmEpilogue epi, hipStream_t s);
+hipError_t launch_gemm256_fp8(const GemmParams& p, GemmEpilogue epi, hipStream_t s);
 // gemm_p128.hip
 hipError_t launch_gemm_p128(const GemmParams& p, GemmEpilogue epi, hipStream_t s);
 

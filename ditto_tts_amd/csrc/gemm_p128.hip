@@ -234,6 +234,7 @@ hipError_t launch_gemm_p128(const GemmParams& p_in, GemmEpilogue epi, hipStream_
         case EPI_QKV_ROPE: return launch_p128_t<EPI_QKV_ROPE>(p, s);
         case EPI_GATED: return launch_p128_t<EPI_GATED>(p, s);
         case EPI_BIAS_F32: return launch_p128_t<EPI_BIAS_F32>(p, s);
+        default: break;
     }
     return hipErrorInvalidValue;
 }

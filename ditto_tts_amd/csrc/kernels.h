@@ -11,6 +11,12 @@ namespace ditto {
 //   gamma/beta: affine (both or neither).  out_bf16 [M, ldo] bf16.
 hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, void* out_bf16, int ldo,
                             int M, int d, hipStream_t s);
+// same, output fp8 e4m3 (saturating), [M, ldo] bytes
+hipError_t launch_layernorm_fp8(const float* x, const float* gamma, const float* beta, void* out_fp8, int ldo,
+                                int M, int d, hipStream_t s);
+// per-row quantisation fp32 [rows, cols] -> fp8 e4m3 with scale[r] = amax(row)/448; row map as launch_pack_bf16
+hipError_t launch_pack_fp8(const float* src, void* dst_fp8, float* scales, int rows, int cols, int dst_ld, int blk,
+                           int mult, int row_off, hipStream_t s);
 // GlobalAdaLN apply: h = LN_noaffine(x) * (1 + ttab[t[b]][j] + tmod[b][j]) + (ttab[t[b]][d+j] + tmod[b][d+j]);
 // also writes bf16(x) (the RAW input) to raw_bf16 [M, ldraw] for the fused proj_in.
 hipError_t launch_adaln(const float* x, const float* ttab, const float* tmod, const int64_t* t, int steps,
@@ -43,7 +49,8 @@ enum GemmEpilogue {
     EPI_BIAS_RES_F32 = 1, // out fp32 [M, ldo] = acc + bias + residual (may alias out); optional bf16 copy
     EPI_QKV_ROPE = 2,     // out bf16 [M, ldo]; columns < 2*d_model get half-split RoPE (head_dim 64 only)
     EPI_GATED = 3,        // W rows interleaved [fc1 x16 | gate x16]; out bf16 [M, N/2] = gelu(a) * sigmoid(g)
-    EPI_BIAS_F32 = 4      // out fp32 [M, ldo] = acc + bias
+    EPI_BIAS_F32 = 4,     // out fp32 [M, ldo] = acc + bias
+    EPI_GATED_FP8 = 5     // as EPI_GATED, out fp8 e4m3 [M, N/2] (A operand of an fp8 fc2)
 };
 struct GemmArgs {
     const void* A; int lda;          // bf16 [M, K], row stride lda (elements)
@@ -55,6 +62,9 @@ struct GemmArgs {
     void* out2_bf16; int ldo2;       // optional bf16 copy of the fp32 result (EPI_BIAS_RES_F32)
     const float* rope_cos; const float* rope_sin; int rope_rows_per_batch; int rope_cols;  // EPI_QKV_ROPE
     int M, N, K;
+    // fp8 (OCP e4m3) operands: A and W are 1-byte elements, acc is multiplied by wscale[n] (per-output-row weight
+    // scale, fp32 [N]) before the bias.  Runs the persistent 256x256 kernel with v_mfma_scale_f32_16x16x128_f8f6f4.
+    bool fp8; const float* wscale;
 };
 hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s);
 extern int g_gemm_tile;  // 0 auto | 128 | 256

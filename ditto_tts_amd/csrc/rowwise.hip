@@ -17,6 +17,7 @@ namespace ditto {
 // wave-instruction.  Two-pass statistics on the register copy (mean, then sum (x-mean)^2).
 // MODE 0: affine (gamma/beta may be null) -> bf16.   MODE 1: AdaLN modulation -> fp32 + bf16(raw x).
 // ------------------------------------------------------------------------------------------------
+// MODE 2: as MODE 0 with fp8 e4m3 output (A operand of the fp8 QKV / fc1|gate GEMMs, config C5)
 template <int CH, int MODE>
 __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                  const float* __restrict__ beta, const float* __restrict__ ttab,
@@ -55,7 +56,23 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, co
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
 
-    if constexpr (MODE == 0) {
+    if constexpr (MODE == 2) {
+        unsigned char* orow = reinterpret_cast<unsigned char*>(out_bf16) + (size_t)row * ldo;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int i = lane + 64 * c;
+            if (i < nv) {
+                f32x4 g = {1.f, 1.f, 1.f, 1.f}, b = {0.f, 0.f, 0.f, 0.f};
+                if (gamma) {
+                    g = reinterpret_cast<const f32x4*>(gamma)[i];
+                    b = reinterpret_cast<const f32x4*>(beta)[i];
+                }
+                *reinterpret_cast<unsigned*>(orow + 4 * i) =
+                    pack_fp8x4((v[c][0] - mean) * rstd * g[0] + b[0], (v[c][1] - mean) * rstd * g[1] + b[1],
+                               (v[c][2] - mean) * rstd * g[2] + b[2], (v[c][3] - mean) * rstd * g[3] + b[3]);
+            }
+        }
+    } else if constexpr (MODE == 0) {
         bf16* orow = out_bf16 + (size_t)row * ldo;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -126,6 +143,11 @@ static hipError_t ln_dispatch(const float* x, const float* gamma, const float* b
 hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, void* out_bf16, int ldo, int M,
                             int d, hipStream_t s) {
     return ln_dispatch<0>(x, gamma, beta, nullptr, nullptr, nullptr, 0, 1, (bf16*)out_bf16, ldo, nullptr, M, d, s);
+}
+
+hipError_t launch_layernorm_fp8(const float* x, const float* gamma, const float* beta, void* out_fp8, int ldo, int M,
+                                int d, hipStream_t s) {
+    return ln_dispatch<2>(x, gamma, beta, nullptr, nullptr, nullptr, 0, 1, (bf16*)out_fp8, ldo, nullptr, M, d, s);
 }
 
 hipError_t launch_adaln(const float* x, const float* ttab, const float* tmod, const int64_t* t, int steps,
@@ -374,6 +396,30 @@ hipError_t launch_pack_bf16(const float* src, void* dst, int rows, int cols, int
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)(g ? g : 1)), dim3(256), 0, s, src, (bf16*)dst, rows, cols,
                        dst_ld, col_off, blk, mult, row_off);
+    return hipGetLastError();
+}
+// fp32 [rows, cols] -> fp8 e4m3 rows with a per-row scale (amax / 448): one wave per row.
+__global__ __launch_bounds__(256) void pack_fp8_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst,
+                                                       float* __restrict__ scales, int rows, int cols, int dst_ld,
+                                                       int blk, int mult, int row_off) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* sr = src + (size_t)r * cols;
+    float amax = 0.f;
+    for (int c = lane; c < cols; c += 64) amax = fmaxf(amax, fabsf(sr[c]));
+    amax = wave_max(amax);
+    const float scale = amax > 0.f ? amax / 448.0f : 1.0f, inv = 1.0f / scale;
+    const size_t dr = (size_t)(r / blk) * ((size_t)blk * mult) + (r % blk) + row_off;
+    if (lane == 0) scales[dr] = scale;
+    for (int c = lane * 4; c < cols; c += 256)   // cols % 4 == 0
+        *reinterpret_cast<unsigned*>(dst + dr * dst_ld + c) =
+            pack_fp8x4(sr[c] * inv, sr[c + 1] * inv, sr[c + 2] * inv, sr[c + 3] * inv);
+}
+hipError_t launch_pack_fp8(const float* src, void* dst, float* scales, int rows, int cols, int dst_ld, int blk, int mult,
+                           int row_off, hipStream_t s) {
+    if (cols % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pack_fp8_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, src, (unsigned char*)dst, scales, rows,
+                       cols, dst_ld, blk, mult, row_off);
     return hipGetLastError();
 }
 __global__ void pack_vec_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int blk, int mult,

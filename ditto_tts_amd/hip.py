@@ -12,6 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libditto_hip.so")
 
 OK, ERR_ARG, ERR_SHAPE, ERR_HIP, ERR_SIZE = range(5)
+CFG_FP8_LINEAR = 1
 
 KERNEL_CLASSES = ["layernorm", "gemm_qkv_rope", "gemm_d_x_d", "gemm_gated_mlp", "gemm_fc2", "gemm_final",
                   "attn_self", "attn_cross", "adaln", "p_sample_update"]
@@ -26,7 +27,7 @@ class DittoHipError(RuntimeError):
 
 class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                ("hidden_dim", "num_layers", "num_heads", "time_dim", "text_dim", "diffusion_steps")]
+                ("hidden_dim", "num_layers", "num_heads", "time_dim", "text_dim", "diffusion_steps", "flags")]
 
 
 _LAYER_FIELDS = ["norm1_weight", "norm1_bias", "attn_in_proj_weight", "attn_in_proj_bias",
@@ -94,6 +95,9 @@ SYMBOLS = {
     "ditto_gemm_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ditto_attention_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
     "ditto_attention_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "ditto_quantize_rows_fp8": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "ditto_layernorm_fp8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "ditto_gemm_fp8": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ditto_set_option": (_i, [C.c_char_p, _i]),
     "ditto_profile_enable": (_i, [_vp, _i]),
     "ditto_profile_read": (_i, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
@@ -115,7 +119,7 @@ def lib() -> C.CDLL:
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = res, args
-        if l.ditto_abi_version() != 1:
+        if l.ditto_abi_version() != 2:
             raise RuntimeError("libditto_hip.so ABI version mismatch")
         _lib = l
     return _lib
@@ -127,4 +131,5 @@ def check(rc: int):
 
 
 def make_config(cfg) -> Config:
-    return Config(cfg.hidden_dim, cfg.num_layers, cfg.num_heads, cfg.time_dim, cfg.text_dim, cfg.diffusion_steps)
+    return Config(cfg.hidden_dim, cfg.num_layers, cfg.num_heads, cfg.time_dim, cfg.text_dim, cfg.diffusion_steps,
+                  CFG_FP8_LINEAR if getattr(cfg, "fp8_linear", False) else 0)

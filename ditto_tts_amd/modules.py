@@ -199,9 +199,12 @@ class DiTTO(nn.Module):
     caller's own tree (`model.NeuralAudioCodec.NAC`, as the reference does, src/model/DiTTO.py:4)."""
 
     def __init__(self, hidden_dim=768, num_layers=12, num_heads=12, time_dim=256, text_dim=768,
-                 diffusion_steps=1000, lambda_factor=0.1, nac_model_path=None, nac: Optional[nn.Module] = None):
+                 diffusion_steps=1000, lambda_factor=0.1, nac_model_path=None, nac: Optional[nn.Module] = None,
+                 fp8_linear: bool = False):
         super().__init__()
-        self.cfg = DiTTOConfig(hidden_dim, num_layers, num_heads, time_dim, text_dim, diffusion_steps)
+        # fp8_linear (extra, optional): QKV / FFN GEMMs with fp8 e4m3 operands (BASELINE config 5)
+        self.cfg = DiTTOConfig(hidden_dim, num_layers, num_heads, time_dim, text_dim, diffusion_steps,
+                               fp8_linear=fp8_linear)
         if nac is not None:
             self.nac = nac
         elif nac_model_path is not None:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DITTO_ABI_VERSION 1
+#define DITTO_ABI_VERSION 2
 
 typedef enum ditto_status {
     DITTO_OK = 0,
@@ -50,7 +50,13 @@ typedef struct ditto_config {
     int32_t time_dim;          /*          (256)  */
     int32_t text_dim;          /* must equal hidden_dim: reference src/components/DiT.py:90-91 */
     int32_t diffusion_steps;   /* rows of t_embedding (1000; 50 for the benchmark loop) */
+    int32_t flags;             /* DITTO_CFG_* */
 } ditto_config;
+
+/* QKV, fc1|gate and fc2 GEMMs with OCP fp8 (e4m3) operands on the MX-scaled MFMA (BASELINE config 5): weights
+ * quantised per output row at ditto_model_create, activations by the producing LayerNorm / gated-MLP epilogue;
+ * fp32 accumulation, bf16 attention, fp32 residual stream unchanged.  Needs hidden_dim % 128 == 0. */
+#define DITTO_CFG_FP8_LINEAR 1
 
 /* fp32 device pointers, named after the reference state_dict keys.
  * `blocks.i.attn.out_proj.*` and `blocks.i.rotary.inv_freq` are intentionally absent:
@@ -193,6 +199,18 @@ size_t ditto_attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh);
  * "gemm_flags": bit mask for kernel experiments (bit 0 = relaxed tile-start wait, default on; bits 1, 2 are
  * DIAGNOSTIC timing switches that skip stores / the epilogue and produce WRONG results — tools/ only). */
 int ditto_set_option(const char* name, int value);
+
+/* fp8 building blocks, exported for unit parity tests (all e4m3, OCP):
+ * ditto_quantize_rows_fp8: fp32 [rows, cols] -> fp8 [rows, cols] + scales fp32 [rows] (amax/448 per row);
+ * ditto_layernorm_fp8: as ditto_layernorm_bf16 with a saturating fp8 result;
+ * ditto_gemm_fp8: out = (A_fp8[M,K] * W_fp8[N,K]^T) * wscale[n] + bias ..., epilogue 0 (bf16), 1 (fp32 + residual),
+ *                 4 (fp32), 5 (gated MLP, fp8 out [M, N/2], interleaved rows as epilogue 3). */
+int ditto_quantize_rows_fp8(const float* src, int rows, int cols, void* dst_fp8, float* scales, ditto_stream_t stream);
+int ditto_layernorm_fp8(const float* x, const float* gamma, const float* beta, void* out_fp8, int M, int d,
+                        ditto_stream_t stream);
+int ditto_gemm_fp8(const void* A, int lda, const void* W, const float* wscale, const float* bias,
+                   const float* residual, void* out, int ldo, int M, int N, int K, int epilogue,
+                   ditto_stream_t stream);
 
 /* ---- profiling aid (bench.py): per-kernel-class HIP-event timing -------------------------
  * When enabled on a handle, ditto_forward brackets every launch with hipEvents on `stream`

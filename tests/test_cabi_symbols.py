@@ -25,12 +25,12 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, n), f"{n} declared in ditto_hip.h but not exported by libditto_hip.so"
         assert n in hip.SYMBOLS, f"{n} has no ctypes prototype in ditto_tts_amd/hip.py"
     assert sorted(hip.SYMBOLS) == names
-    assert lib.ditto_abi_version() == 1
+    assert lib.ditto_abi_version() == 2
 
 
 def test_struct_layout_matches_header():
-    # 14 model-level pointers + layers pointer; 18 per-layer pointers; 6 int32 config fields
-    assert C.sizeof(hip.Config) == 24
+    # 14 model-level pointers + layers pointer; 18 per-layer pointers; 7 int32 config fields
+    assert C.sizeof(hip.Config) == 28
     assert C.sizeof(hip.LayerWeights) == 18 * 8
     assert C.sizeof(hip.Weights) == 15 * 8
 
@@ -45,10 +45,12 @@ def test_size_queries_and_errors():
     cond = lib.ditto_cond_bytes(C.byref(c), 32, 1024)
     assert cond >= 32 * 1024 * 12 * 2 * 768 * 2
     assert ws >= 32 * 1024 * 768 * (4 + 2 + 6 + 8 + 4 + 4)
-    bad = hip.Config(768, 12, 12, 256, 512, 50)             # text_dim != hidden_dim
+    bad = hip.Config(768, 12, 12, 256, 512, 50, 0)          # text_dim != hidden_dim
     assert lib.ditto_arena_bytes(C.byref(bad)) == 0
     assert b"text_dim" in lib.ditto_last_error()
-    bad = hip.Config(96, 1, 1, 64, 96, 10)                   # not a multiple of 64
+    bad = hip.Config(96, 1, 1, 64, 96, 10, 0)                # not a multiple of 64
+    assert lib.ditto_arena_bytes(C.byref(bad)) == 0
+    bad = hip.Config(192, 1, 3, 64, 192, 10, hip.CFG_FP8_LINEAR)   # fp8 needs hidden_dim % 128 == 0
     assert lib.ditto_arena_bytes(C.byref(bad)) == 0
     for kc, name in enumerate(hip.KERNEL_CLASSES):
         assert lib.ditto_kernel_class_name(kc).decode() == name

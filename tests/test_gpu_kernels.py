@@ -207,3 +207,92 @@ def test_component_modules_adaln_and_rope(golden):
     want = O.apply_rope(g["rotary_pos"], tq)
     got = rot.apply_rope(pos, tq.to(DEV))
     assert rel_l2(got, want) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------------------
+# fp8 (OCP e4m3) building blocks of BASELINE config 5.  torch.float8_e4m3fn is the same format, used only to
+# DEQUANTISE what the library produced.
+# ------------------------------------------------------------------------------------------------------------
+def _deq(t_u8, scales=None):
+    f = t_u8.view(torch.float8_e4m3fn).float()
+    return f if scales is None else f * scales[:, None]
+
+
+def _quant(lib, w):
+    rows, cols = w.shape
+    q = torch.empty(rows, cols, dtype=torch.uint8, device=DEV)
+    sc = torch.empty(rows, dtype=torch.float32, device=DEV)
+    hip.check(lib.ditto_quantize_rows_fp8(w.data_ptr(), rows, cols, q.data_ptr(), sc.data_ptr(), stream()))
+    return q, sc
+
+
+def test_fp8_quantize_rows(lib):
+    w = (asym((200, 384), 21) * torch.linspace(0.01, 30, 200)[:, None]).to(DEV)
+    q, sc = _quant(lib, w)
+    assert torch.allclose(sc, w.abs().amax(dim=1) / 448.0, rtol=1e-6)
+    back = _deq(q, sc)
+    assert rel_l2(back, w) < 4e-2          # e4m3: 3 mantissa bits -> ~2^-4 / sqrt(3) rms relative error
+    assert float((back.abs().amax(dim=1) - w.abs().amax(dim=1)).abs().max()) < 1e-3 * float(w.abs().max())
+
+
+def test_fp8_layernorm(lib):
+    M, d = 70, 1024
+    x = (asym((M, d), 22) * 1.7 + 0.3).to(DEV)
+    g, b = (1 + 0.1 * asym((d,), 23)).to(DEV), (0.1 * asym((d,), 24)).to(DEV)
+    out = torch.empty(M, d, dtype=torch.uint8, device=DEV)
+    hip.check(lib.ditto_layernorm_fp8(x.data_ptr(), g.data_ptr(), b.data_ptr(), out.data_ptr(), M, d, stream()))
+    want = torch.nn.functional.layer_norm(x, (d,), g, b, 1e-5)
+    assert torch.equal(_deq(out), want.to(torch.float8_e4m3fn).float())   # same RNE rounding as torch's cast
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 320, 384), (1000, 768, 1024), (64, 16, 128),
+                                   (513, 2304, 768)])
+@pytest.mark.parametrize("epi", [0, 1, 4])
+def test_fp8_gemm(lib, M, N, K, epi):
+    """exact in the operands: the reference multiplies the DEQUANTISED fp8 values in fp32."""
+    a32 = asym((M, K), 25).to(DEV)
+    w32 = (asym((N, K), 26) / math.sqrt(K)).to(DEV)
+    Aq = a32.to(torch.float8_e4m3fn).view(torch.uint8).contiguous()        # activations: scale 1
+    Wq, ws = _quant(lib, w32)
+    bias = (0.1 * asym((N,), 27)).to(DEV)
+    res = asym((M, N), 28).to(DEV)
+    want = _deq(Aq) @ _deq(Wq, ws).T + bias
+    if epi == 0:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        hip.check(lib.ditto_gemm_fp8(Aq.data_ptr(), K, Wq.data_ptr(), ws.data_ptr(), bias.data_ptr(), None,
+                                     out.data_ptr(), N, M, N, K, 0, stream()))
+        assert rel_l2(out.float(), want) < 4e-3
+    elif epi == 1:
+        out = res.clone()
+        hip.check(lib.ditto_gemm_fp8(Aq.data_ptr(), K, Wq.data_ptr(), ws.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                                     out.data_ptr(), N, M, N, K, 1, stream()))
+        assert rel_l2(out, want + res) < 5e-5
+    else:
+        out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+        hip.check(lib.ditto_gemm_fp8(Aq.data_ptr(), K, Wq.data_ptr(), ws.data_ptr(), bias.data_ptr(), None,
+                                     out.data_ptr(), N, M, N, K, 4, stream()))
+        assert rel_l2(out, want) < 5e-5   # the reference scales W before the product, the kernel scales acc after
+        assert max_abs(out, want) < 1e-3
+
+
+def test_fp8_gemm_gated(lib):
+    """fp8 gated-MLP epilogue: interleaved fc1|gate rows, fp8 output."""
+    M, d = 300, 256
+    a32 = asym((M, d), 29).to(DEV)
+    w1, wg = (asym((4 * d, d), 30) / math.sqrt(d)).to(DEV), (asym((4 * d, d), 31) / math.sqrt(d)).to(DEV)
+    b1, bg = (0.1 * asym((4 * d,), 32)).to(DEV), (0.1 * asym((4 * d,), 33)).to(DEV)
+    idx = torch.arange(4 * d, device=DEV)
+    pos1, posg = (idx // 16) * 32 + idx % 16, (idx // 16) * 32 + idx % 16 + 16   # packed row of fc1 row i / gate row i
+    wp = torch.empty(8 * d, d, device=DEV); wp[pos1], wp[posg] = w1, wg
+    bp = torch.empty(8 * d, device=DEV); bp[pos1], bp[posg] = b1, bg
+    Aq = a32.to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
+    Wq, ws = _quant(lib, wp)
+    out = torch.empty(M, 4 * d, dtype=torch.uint8, device=DEV)
+    hip.check(lib.ditto_gemm_fp8(Aq.data_ptr(), d, Wq.data_ptr(), ws.data_ptr(), bp.data_ptr(), None, out.data_ptr(),
+                                 4 * d, M, 8 * d, d, 5, stream()))
+    wdq = _deq(Wq, ws)
+    h = _deq(Aq) @ wdq[pos1].T + b1
+    g = _deq(Aq) @ wdq[posg].T + bg
+    want = torch.nn.functional.gelu(h) * torch.sigmoid(g)
+    assert rel_l2(_deq(out), want) < 4e-2      # one e4m3 rounding of the result
+    assert max_abs(_deq(out), want.clamp(-448, 448)) < 0.07 * (1 + float(want.abs().max()))

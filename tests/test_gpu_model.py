@@ -195,6 +195,32 @@ def test_long_form_c4_shape():
     close(out[:1], want)
 
 
+@torch.no_grad()
+def test_c5_fp8_linear_against_oracle():
+    """BASELINE configs[4] (d=1024, h=16, fp8 QKV/FFN GEMMs) at a size the oracle finishes in seconds.
+    STATED TOLERANCE for the fp8 path: rel-L2 <= 6e-2 against the fp32 oracle (e4m3 has 3 mantissa bits: every
+    fp8 GEMM adds ~3 % of independent noise to its output; measured value is printed)."""
+    from oracle import ditto_oracle as O
+    L = 4
+    cfg8 = DiTTOConfig(1024, L, 16, 256, 1024, 50, fp8_linear=True)
+    cfg16 = DiTTOConfig(1024, L, 16, 256, 1024, 50)
+    sd = synthetic_state_dict(cfg16, 6)
+    x, text, t = synthetic_inputs(cfg16, 2, 256, 192, seed=4)
+    want = O.ditto_forward(sd, L, 16, x, text, t)
+    outs = {}
+    for name, cfg in (("bf16", cfg16), ("fp8", cfg8)):
+        m = DiTTO(1024, L, 16, 256, 1024, 50, fp8_linear=cfg.fp8_linear)
+        m.load_state_dict(sd)
+        m = m.to(DEV).eval()
+        outs[name] = m(x.to(DEV), text.to(DEV), t.to(DEV))
+        assert torch.equal(outs[name], m(x.to(DEV), text.to(DEV).clone(), t.to(DEV)))
+    r16, r8 = rel_l2(outs["bf16"], want), rel_l2(outs["fp8"], want)
+    print(f"C5-shape {L}L: bf16 rel-L2 {r16:.3e}, fp8 rel-L2 {r8:.3e}")
+    assert r16 < RTOL
+    assert r8 < 6e-2
+    assert r8 > r16          # the fp8 path really ran
+
+
 def test_training_surface_fails_loudly():
     cfg = DiTTOConfig(128, 1, 2, 64, 128, 20)
     m = build(cfg, 1).train()
