@@ -592,6 +592,47 @@ int ditto_attention_bf16(const void* q, int ldq, const void* k, int ldk, const v
     return DITTO_OK;
 }
 
+int ditto_vq_argmin(const float* latents, const float* codebook, int64_t* idx, int R, int K, int D, float* scratch_k,
+                    ditto_stream_t stream) {
+    if (!latents || !codebook || !idx || !scratch_k || R <= 0 || K <= 0 || D <= 0)
+        return fail(DITTO_ERR_ARG, "bad argument to ditto_vq_argmin");
+    HIP_TRY(launch_vq_argmin(latents, codebook, scratch_k, idx, R, K, D, (hipStream_t)stream));
+    return DITTO_OK;
+}
+
+int ditto_embedding_gather(const float* table, const int64_t* ids, float* out, int n, int V, int d,
+                           ditto_stream_t stream) {
+    if (!table || !ids || !out || n <= 0 || V <= 0 || d <= 0) return fail(DITTO_ERR_ARG, "bad argument to ditto_embedding_gather");
+    if (d % 4) return fail(DITTO_ERR_SHAPE, "d must be a multiple of 4");
+    HIP_TRY(launch_embedding_gather(table, ids, out, n, V, d, (hipStream_t)stream));
+    return DITTO_OK;
+}
+
+int ditto_code_embed_mean(const float* table, const int64_t* codes, float* out, int B, int C, int F, int Fout, int V,
+                          int d, ditto_stream_t stream) {
+    if (!table || !codes || !out || B <= 0 || C <= 0 || F <= 0 || Fout <= 0 || Fout > F || V <= 0 || d <= 0)
+        return fail(DITTO_ERR_ARG, "bad argument to ditto_code_embed_mean");
+    if (d % 4) return fail(DITTO_ERR_SHAPE, "d must be a multiple of 4");
+    HIP_TRY(launch_code_embed_mean(table, codes, out, B, C, F, Fout, V, d, (hipStream_t)stream));
+    return DITTO_OK;
+}
+
+int ditto_linear_update(float* x, const float* eps, const float* noise, const float* a, const float* ce,
+                        const float* cz, int B, size_t elems_per_utt, ditto_stream_t stream) {
+    if (!x || !eps || !a || !ce || (noise && !cz) || B <= 0 || elems_per_utt == 0)
+        return fail(DITTO_ERR_ARG, "bad argument to ditto_linear_update");
+    if (elems_per_utt % 4) return fail(DITTO_ERR_SHAPE, "elems_per_utt must be a multiple of 4");
+    HIP_TRY(launch_linear_update(x, eps, noise, a, ce, cz, B, elems_per_utt, (hipStream_t)stream));
+    return DITTO_OK;
+}
+
+int ditto_cfg_combine(const float* eps2, float* out, float w, size_t elems_half, ditto_stream_t stream) {
+    if (!eps2 || !out || elems_half == 0) return fail(DITTO_ERR_ARG, "bad argument to ditto_cfg_combine");
+    if (elems_half % 4) return fail(DITTO_ERR_SHAPE, "elems_half must be a multiple of 4");
+    HIP_TRY(launch_cfg_combine(eps2, out, w, elems_half, (hipStream_t)stream));
+    return DITTO_OK;
+}
+
 int ditto_quantize_rows_fp8(const float* src, int rows, int cols, void* dst_fp8, float* scales, ditto_stream_t stream) {
     if (!src || !dst_fp8 || !scales || rows <= 0 || cols <= 0) return fail(DITTO_ERR_ARG, "bad argument to ditto_quantize_rows_fp8");
     if (cols % 4) return fail(DITTO_ERR_SHAPE, "cols must be a multiple of 4");

@@ -71,6 +71,17 @@ extern int g_gemm_tile;  // 0 auto | 128 | 256
 extern int g_gemm_flags; // GF_* (gemm_common.h)
 extern int g_attn_flags; // attention.hip
 
+// ---------------- around_loop.hip : steps either side of the loop ----------------
+hipError_t launch_vq_argmin(const float* x, const float* codebook, float* cc_scratch, int64_t* idx, int R, int K, int D,
+                            hipStream_t s);
+hipError_t launch_embedding_gather(const float* table, const int64_t* ids, float* out, int n, int V, int d,
+                                   hipStream_t s);
+hipError_t launch_code_embed_mean(const float* table, const int64_t* codes, float* out, int B, int C, int F, int Fout,
+                                  int V, int d, hipStream_t s);
+hipError_t launch_linear_update(float* x, const float* eps, const float* z, const float* a, const float* ce,
+                                const float* cz, int B, size_t elems_per_utt, hipStream_t s);
+hipError_t launch_cfg_combine(const float* eps2, float* out, float w, size_t elems_half, hipStream_t s);
+
 // ---------------- attention.hip ----------------
 struct AttnArgs {
     const void* q; int ldq;   // bf16, head h at columns [h*dh, (h+1)*dh)

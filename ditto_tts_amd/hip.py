@@ -95,6 +95,11 @@ SYMBOLS = {
     "ditto_gemm_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ditto_attention_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
     "ditto_attention_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "ditto_vq_argmin": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ditto_embedding_gather": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "ditto_code_embed_mean": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ditto_linear_update": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _sz, _vp]),
+    "ditto_cfg_combine": (_i, [_vp, _vp, _f, _sz, _vp]),
     "ditto_quantize_rows_fp8": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "ditto_layernorm_fp8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "ditto_gemm_fp8": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

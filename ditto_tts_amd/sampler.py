@@ -112,6 +112,58 @@ class SpeechGenerator:
                 keep[i] = x.clone()
         return x
 
+    # ---------------------------------------------------------------- strided (DDIM) loop + CFG  
+    @torch.no_grad()
+    def sample_latents_strided(self, text_emb, audio_emb, n_steps=25, eta=0.0, cfg_scale=None, null_text_emb=None,
+                               cond_by_audio=False, noises=None):
+        """The serving configuration of the paper (App. A: 25 steps, guidance 5.0), which the reference lacks: a
+        DDIM-style loop over `n_steps` evenly spaced timesteps, x' = a x + ce eps + cz z per step
+        (ditto_linear_update), with optional classifier-free guidance: the step runs ONE forward on the doubled
+        batch [x; x] x [text; null_text] and combines eps_u + w (eps_c - eps_u) (ditto_cfg_combine)."""
+        from .around import cfg_combine, linear_update_
+        m = self.ditto_model
+        T = self.diffusion_steps
+        if not 1 <= n_steps <= T:
+            raise ValueError("n_steps must be in [1, diffusion_steps]")
+        x = (torch.randn_like(audio_emb) if not cond_by_audio else audio_emb.clone()).to(self.device).float().contiguous()
+        B = x.shape[0]
+        eng = m.engine(x.device)
+        text = text_emb.to(x.device).float()
+        if cfg_scale is not None:
+            if null_text_emb is None:
+                raise ValueError("classifier-free guidance needs null_text_emb (the unconditional text embedding)")
+            text = torch.cat([text, null_text_emb.to(x.device).float().expand_as(text)], dim=0).contiguous()
+        cond = eng.prepare_text(text, x.shape[1])
+        stride = T / n_steps
+        taus = [int(round(T - 1 - i * stride)) for i in range(n_steps)]
+        ac = self.alphas_cumprod.double().cpu()
+        nb = 2 * B if cfg_scale is not None else B
+        t_tensor = torch.empty(nb, device=x.device, dtype=torch.long)
+        coef = torch.empty(3, B, device=x.device, dtype=torch.float32)
+        z = torch.empty_like(x)
+        x2 = torch.empty(nb, *x.shape[1:], device=x.device) if cfg_scale is not None else None
+        for i, t_val in enumerate(taus):
+            ab_t = ac[t_val]
+            ab_p = ac[taus[i + 1]] if i + 1 < n_steps else torch.tensor(1.0, dtype=torch.float64)
+            sigma = eta * torch.sqrt((1 - ab_p) / (1 - ab_t)) * torch.sqrt(1 - ab_t / ab_p)
+            a = torch.sqrt(ab_p / ab_t)
+            ce = torch.sqrt(torch.clamp(1 - ab_p - sigma ** 2, min=0.0)) - torch.sqrt(ab_p * (1 - ab_t) / ab_t)
+            coef[0].fill_(float(a)); coef[1].fill_(float(ce)); coef[2].fill_(float(sigma))
+            t_tensor.fill_(t_val)
+            if cfg_scale is not None:
+                x2[:B].copy_(x); x2[B:].copy_(x)
+                eps = cfg_combine(eng.forward(x2, cond, t_tensor), cfg_scale)
+            else:
+                eps = eng.forward(x, cond, t_tensor)
+            use_noise = float(sigma) != 0.0
+            if use_noise:
+                if noises is None:
+                    z.normal_()
+                else:
+                    z.copy_((noises(i) if callable(noises) else noises[i]).to(x.device))
+            linear_update_(x, eps, z if use_noise else None, coef[0], coef[1], coef[2])
+        return x
+
     # public aliases (the mangled names above are what the reference's own code reaches)
     def p_sample(self, x, t, text_emb, noise=None):
         return self.__p_sample(x, t, text_emb, noise)

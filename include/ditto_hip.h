@@ -200,6 +200,28 @@ size_t ditto_attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh);
  * DIAGNOSTIC timing switches that skip stores / the epilogue and produce WRONG results — tools/ only). */
 int ditto_set_option(const char* name, int value);
 
+/* ---- either side of the loop -------------------------------------------------------
+ * ditto_vq_argmin: VectorQuantizer.forward (src/components/VectorQuantizer.py:22-43): idx[r] = argmin_k
+ *   ||latents[r] - codebook[k]||^2 in fp32, first minimum on ties (torch.argmin); latents fp32 [R,D], codebook
+ *   fp32 [K,D], idx int64 [R], scratch fp32 [K].
+ * ditto_embedding_gather: nn.Embedding lookup out[i] = table[ids[i]] (GPT-2 wte for z_text,
+ *   src/model/SpeechGenerator.py:101-103); table fp32 [V,d], ids int64 [n]; an id outside [0,V) is clamped to the
+ *   table (nn.Embedding raises on the host; a stream-ordered kernel must not fault).
+ * ditto_code_embed_mean: EnCodec codes -> embedding_head rows, mean over the C codebooks, first Fout frames
+ *   (src/components/EnCodec.py:35-37, src/model/SpeechGenerator.py:97-98); codes int64 [B,C,F] -> fp32 [B,Fout,d].
+ * ditto_linear_update: x <- a[b]*x + ce[b]*eps + cz[b]*noise (noise may be NULL): one step of a strided-DDPM /
+ *   DDIM sampler (the paper's 25-step schedule; the reference only has stride 1).  a/ce/cz fp32 [B] (device).
+ * ditto_cfg_combine: classifier-free guidance eps = eps_u + w*(eps_c - eps_u); eps2 fp32 [2,B,...] = [cond; uncond]. */
+int ditto_vq_argmin(const float* latents, const float* codebook, int64_t* idx, int R, int K, int D, float* scratch_k,
+                    ditto_stream_t stream);
+int ditto_embedding_gather(const float* table, const int64_t* ids, float* out, int n, int V, int d,
+                           ditto_stream_t stream);
+int ditto_code_embed_mean(const float* table, const int64_t* codes, float* out, int B, int C, int F, int Fout, int V,
+                          int d, ditto_stream_t stream);
+int ditto_linear_update(float* x, const float* eps, const float* noise, const float* a, const float* ce,
+                        const float* cz, int B, size_t elems_per_utt, ditto_stream_t stream);
+int ditto_cfg_combine(const float* eps2, float* out, float w, size_t elems_half, ditto_stream_t stream);
+
 /* fp8 building blocks, exported for unit parity tests (all e4m3, OCP):
  * ditto_quantize_rows_fp8: fp32 [rows, cols] -> fp8 [rows, cols] + scales fp32 [rows] (amax/448 per row);
  * ditto_layernorm_fp8: as ditto_layernorm_bf16 with a saturating fp8 result;

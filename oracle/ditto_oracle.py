@@ -222,3 +222,60 @@ def sample_latents(sd: Mapping[str, Tensor], num_layers: int, num_heads: int, x_
         if i in keep:
             kept[i] = x.clone()
     return x, kept
+
+
+# --------------------------------------------------------------------------- #
+# either side of the loop
+# --------------------------------------------------------------------------- #
+def vq_indices(codebook: Tensor, latents: Tensor) -> Tensor:
+    """VectorQuantizer.forward, src/components/VectorQuantizer.py:22-43 (latents [B,C,F,D] -> indices [B,C,F])."""
+    Bz, C, Fr, D = latents.shape
+    flat = latents.reshape(-1, D)
+    distances = (torch.sum(flat ** 2, dim=1, keepdim=True)                    # :34-38
+                 - 2 * torch.matmul(flat, codebook.T)
+                 + torch.sum(codebook ** 2, dim=1))
+    return torch.argmin(distances, dim=-1).view(Bz, C, Fr)                    # :40-41
+
+
+def code_embed_mean(embedding_head: Tensor, codes: Tensor, max_length: int) -> Tensor:
+    """EnCodec.forward's lookup (src/components/EnCodec.py:35-37) followed by the clip + mean over the codebooks
+    of src/model/SpeechGenerator.py:97-98: codes [B,C,F] -> [B, min(F,max_length), D]."""
+    return embedding_head[codes][:, :, :max_length].mean(dim=1)
+
+
+def ddim_coefficients(alphas_cumprod: Tensor, t: int, t_prev: int, eta: float = 0.0):
+    """One step of the strided sampler the paper uses (doc/1686_DiTTo_TTS_Diffusion_Trans.pdf App. A; Song et al.
+    2021 eq. 12) written as x' = a*x + ce*eps + cz*z.  NOT in the reference: parity anchor is the
+    published formula.  t_prev < 0 means the final step (abar_prev = 1)."""
+    ab_t = alphas_cumprod[t]
+    ab_p = alphas_cumprod[t_prev] if t_prev >= 0 else torch.tensor(1.0)
+    sigma = eta * torch.sqrt((1 - ab_p) / (1 - ab_t)) * torch.sqrt(1 - ab_t / ab_p)
+    a = torch.sqrt(ab_p / ab_t)
+    ce = torch.sqrt(torch.clamp(1 - ab_p - sigma ** 2, min=0.0)) - torch.sqrt(ab_p * (1 - ab_t) / ab_t)
+    return float(a), float(ce), float(sigma)
+
+
+def sample_latents_strided(sd, num_layers, num_heads, x_init, text_emb, timesteps, n_steps, noises=None, eta=0.0,
+                           cfg_scale=None, null_text=None):
+    """DDIM-style loop over n_steps evenly spaced timesteps, optional classifier-free guidance
+    eps = eps_u + w (eps_c - eps_u)."""
+    _, _, ac = sampler_tables(timesteps)
+    taus = strided_timesteps(timesteps, n_steps)
+    x = x_init
+    for i, t_val in enumerate(taus):
+        t = torch.full((x.shape[0],), t_val, dtype=torch.long)
+        eps = ditto_forward(sd, num_layers, num_heads, x, text_emb, t)
+        if cfg_scale is not None:
+            eps_u = ditto_forward(sd, num_layers, num_heads, x, null_text, t)
+            eps = eps_u + cfg_scale * (eps - eps_u)
+        t_prev = taus[i + 1] if i + 1 < len(taus) else -1
+        a, ce, cz = ddim_coefficients(ac, t_val, t_prev, eta)
+        z = noises[i] if (noises is not None and cz != 0.0) else torch.zeros_like(x)
+        x = a * x + ce * eps + cz * z
+    return x
+
+
+def strided_timesteps(timesteps: int, n_steps: int):
+    """n_steps descending timesteps T-1 ... spaced evenly (ends at the smallest multiple of the stride)."""
+    stride = timesteps / n_steps
+    return [int(round(timesteps - 1 - i * stride)) for i in range(n_steps)]

@@ -162,5 +162,24 @@ def main():
          x_step0=kept[0], x_step1=kept[1], x_step10=kept[10], x_step49=kept[49])
 
 
+@torch.no_grad()
+def make_vq():
+    """G6: the reference's VectorQuantizer on a hashed codebook / latents (indices are the fixture)."""
+    import_reference()
+    import components.VectorQuantizer as ref_vq
+    vq = ref_vq.VectorQuantizer(1024, 768)
+    cb = hash_normal((1024, 768), "codebook", 66) * 0.05
+    vq.codebook.data.copy_(cb)
+    lat = hash_normal((2, 2, 96, 768), "vq_latents", 66) * 0.06
+    lat[0, 0, :8] = cb[:8] + 1e-3 * hash_normal((8, 768), "jit", 66)     # near exact hits on known rows
+    idx = vq(lat)
+    assert idx[0, 0, :8].tolist() == list(range(8))
+    save("G6_vq.npz", indices=idx.to(torch.int16))
+
+
 if __name__ == "__main__":
-    main()
+    if "--vq-only" in sys.argv:
+        make_vq()
+    else:
+        main()
+        make_vq()

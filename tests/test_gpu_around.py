@@ -1,0 +1,139 @@
+"""-m gpu parity of the steps either side of the denoise loop, through the C-ABI:
+VectorQuantizer indices (integer: bit-exact against the reference's golden G6 and the oracle, with a documented
+near-tie rule), embedding gathers (bit-exact), the strided/DDIM update and the classifier-free-guidance combine
+(fp32 elementwise: <= 1e-6 relative), and the strided + CFG sampler loop against the oracle (bf16 path: rel-L2 <= 2e-2)."""
+import pytest
+import torch
+
+from ditto_tts_amd.around import (VectorQuantizer, cfg_combine, code_embed_mean, embedding_gather, linear_update_)
+from ditto_tts_amd.config import DiTTOConfig
+from ditto_tts_amd.modules import DiTTO
+from ditto_tts_amd.sampler import SpeechGenerator
+from ditto_tts_amd.synth import hash_normal, hash_uniform, synthetic_state_dict
+from gpu_util import max_abs, rel_l2
+from oracle import ditto_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _assert_indices(idx, want, cb, lat):
+    """Exact, except where the two candidate codes are closer than fp32 can order: |d1-d2| <= 1e-6 * d (fp64)."""
+    idx, want = idx.cpu().flatten(), want.flatten()
+    bad = (idx != want).nonzero().flatten()
+    flat = lat.reshape(-1, lat.shape[-1]).double()
+    for r in bad.tolist():
+        d1 = float(((flat[r] - cb[idx[r]].double()) ** 2).sum())
+        d2 = float(((flat[r] - cb[want[r]].double()) ** 2).sum())
+        assert abs(d1 - d2) <= 1e-6 * max(d1, d2), f"row {r}: got {int(idx[r])} ({d1}) want {int(want[r])} ({d2})"
+    assert len(bad) <= max(1, idx.numel() // 1000)
+
+
+def test_vq_indices_golden_g6(golden):
+    g = golden("G6_vq.npz")
+    cb = hash_normal((1024, 768), "codebook", 66) * 0.05
+    lat = hash_normal((2, 2, 96, 768), "vq_latents", 66) * 0.06
+    lat[0, 0, :8] = cb[:8] + 1e-3 * hash_normal((8, 768), "jit", 66)
+    vq = VectorQuantizer(1024, 768)
+    assert list(vq.state_dict().keys()) == ["codebook"]
+    vq.codebook.data.copy_(cb)
+    vq = vq.to(DEV)
+    idx = vq(lat.to(DEV))
+    assert idx.dtype == torch.int64 and idx.shape == (2, 2, 96)
+    _assert_indices(idx, g["indices"].long(), cb, lat)
+    assert idx[0, 0, :8].tolist() == list(range(8))
+
+
+@pytest.mark.parametrize("R,K,D", [(1, 1, 8), (5, 3, 4), (64, 64, 64), (67, 130, 100), (1000, 1024, 128), (4096, 2048, 768)])
+def test_vq_indices_ragged_shapes_vs_oracle(R, K, D):
+    cb = hash_normal((K, D), "cb", R + K)
+    lat = hash_normal((1, 1, R, D), "lat", R + D)
+    vq = VectorQuantizer(K, D)
+    vq.codebook.data.copy_(cb)
+    idx = vq.to(DEV)(lat.to(DEV))
+    _assert_indices(idx, O.vq_indices(cb, lat), cb, lat)
+
+
+def test_vq_exact_ties_take_first_index():
+    """Duplicate codebook rows: torch.argmin returns the first minimum; so must the kernel."""
+    cb = hash_normal((96, 32), "cbt", 3)
+    cb[70] = cb[5]; cb[91] = cb[5]; cb[64] = cb[63]
+    lat = cb[[5, 63, 70, 64, 91]].clone().view(1, 1, 5, 32)
+    vq = VectorQuantizer(96, 32)
+    vq.codebook.data.copy_(cb)
+    idx = vq.to(DEV)(lat.to(DEV)).cpu().flatten().tolist()
+    assert idx == [5, 63, 5, 63, 5]
+    assert idx == O.vq_indices(cb, lat).flatten().tolist()
+
+
+def test_vq_rejects_cpu_input():
+    vq = VectorQuantizer(8, 4)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        vq(torch.zeros(1, 1, 2, 4))
+
+
+def test_embedding_gather_bit_exact():
+    tab = hash_normal((50257, 768), "wte", 9)[:5000].contiguous()
+    ids = (hash_uniform((3, 77), "ids", 9) * 5000).long().clamp_(0, 4999)
+    ids[0, 0], ids[0, 1] = 0, 4999
+    out = embedding_gather(tab.to(DEV), ids.to(DEV))
+    assert torch.equal(out.cpu(), tab[ids])
+
+
+def test_embedding_gather_out_of_range_ids_do_not_fault():
+    """nn.Embedding raises on the host for an id outside the table; a stream-ordered kernel cannot, so the id is
+    clamped to the table (documented in include/ditto_hip.h) instead of reading out of bounds."""
+    tab = hash_normal((10, 16), "t", 1).to(DEV)
+    ids = torch.tensor([1, 10, -3], device=DEV)
+    out = embedding_gather(tab, ids)
+    assert torch.equal(out, tab[torch.tensor([1, 9, 0], device=DEV)])
+
+
+@pytest.mark.parametrize("C,F,maxlen", [(2, 150, 1024), (8, 300, 256), (1, 7, 7)])
+def test_code_embed_mean_vs_oracle(C, F, maxlen):
+    tab = hash_normal((1024, 128), "head", C)
+    codes = (hash_uniform((3, C, F), "codes", F) * 1024).long().clamp_(0, 1023)
+    out = code_embed_mean(tab.to(DEV), codes.to(DEV), maxlen)
+    want = O.code_embed_mean(tab, codes, maxlen)
+    assert out.shape == want.shape
+    assert max_abs(out, want) < 1e-6 * (1 + float(want.abs().max())) * C
+
+
+def test_linear_update_and_cfg_combine_vs_oracle():
+    B, N, d = 3, 50, 96
+    x = hash_normal((B, N, d), "x", 1); e = hash_normal((B, N, d), "e", 2); z = hash_normal((B, N, d), "z", 3)
+    a = torch.tensor([1.01, 0.99, 1.2]); ce = torch.tensor([-0.1, -0.5, 0.02]); cz = torch.tensor([0.0, 0.3, 0.01])
+    want = a.view(-1, 1, 1) * x + ce.view(-1, 1, 1) * e + cz.view(-1, 1, 1) * z
+    xd = x.to(DEV).clone()
+    linear_update_(xd, e.to(DEV), z.to(DEV), a.to(DEV), ce.to(DEV), cz.to(DEV))
+    assert rel_l2(xd, want) < 1e-6
+    xd = x.to(DEV).clone()
+    linear_update_(xd, e.to(DEV), None, a.to(DEV), ce.to(DEV), cz.to(DEV))
+    assert rel_l2(xd, a.view(-1, 1, 1) * x + ce.view(-1, 1, 1) * e) < 1e-6
+    e2 = torch.cat([e, z], 0)
+    got = cfg_combine(e2.to(DEV), 5.0)
+    assert got.shape == e.shape and rel_l2(got, z + 5.0 * (e - z)) < 1e-6
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("cfg_scale,eta", [(None, 0.0), (3.0, 0.0), (2.0, 1.0)])
+def test_strided_sampler_vs_oracle(cfg_scale, eta):
+    """25-of-50 strided loop (the paper's serving schedule) on a 2-layer model, against the fp32 oracle loop.
+    bf16 forward inside a 25-step recurrence: rel-L2 <= 2e-2 (north_star tolerance)."""
+    cfg = DiTTOConfig(256, 2, 4, 256, 256, 50)
+    sd = synthetic_state_dict(cfg, 5)
+    m = DiTTO(256, 2, 4, 256, 256, 50)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    sg = SpeechGenerator(ditto_model=m, device=DEV)
+    B, N, T, S = 2, 64, 32, 25
+    text = hash_normal((B, T, 256), "text", 55)
+    null = torch.zeros(1, T, 256)
+    xinit = hash_normal((B, N, 256), "xT", 55)
+    noises = [hash_normal((B, N, 256), f"z{i}", 77) for i in range(S)]
+    got = sg.sample_latents_strided(text.to(DEV), xinit.to(DEV), n_steps=S, eta=eta, cfg_scale=cfg_scale,
+                                    null_text_emb=null.to(DEV), cond_by_audio=True, noises=noises)
+    want = O.sample_latents_strided(sd, 2, 4, xinit, text, 50, S, noises=noises, eta=eta, cfg_scale=cfg_scale,
+                                    null_text=null.expand(B, T, 256))
+    r = rel_l2(got, want)
+    assert r < 2e-2, f"rel-L2 {r:.3e}"

@@ -79,3 +79,34 @@ def test_g5_sampler_trajectory(golden):
     x, kept = O.sample_latents(sd, 2, 4, g["xinit"], g["text"], S, noises, keep=(0, 1, 10, 49))
     for i in (0, 1, 10, 49):
         assert rel_l2(kept[i], g[f"x_step{i}"]) < 1e-4, i   # 50 chained steps of fp32 round-off
+
+
+def _vq_inputs():
+    cb = hash_normal((1024, 768), "codebook", 66) * 0.05
+    lat = hash_normal((2, 2, 96, 768), "vq_latents", 66) * 0.06
+    lat[0, 0, :8] = cb[:8] + 1e-3 * hash_normal((8, 768), "jit", 66)
+    return cb, lat
+
+
+def test_g6_vector_quantizer_indices(golden):
+    """Integer output: bit-exact against the reference's VectorQuantizer.forward."""
+    g = golden("G6_vq.npz")
+    cb, lat = _vq_inputs()
+    idx = O.vq_indices(cb, lat)
+    assert idx.dtype == torch.int64 and idx.shape == (2, 2, 96)
+    assert torch.equal(idx, g["indices"].long())
+
+
+def test_strided_schedule_and_ddim_coefficients():
+    """Published-formula anchors (the reference has no strided sampler): stride 1 + eta=1 reproduces the
+    reference's posterior noise scale up to the beta-tilde/beta choice, eta=0 is deterministic, and the last step
+    lands on x0 = (x - sqrt(1-ab) eps)/sqrt(ab)."""
+    betas, alphas, ac = O.sampler_tables(50)
+    assert O.strided_timesteps(50, 50) == list(range(49, -1, -1))
+    taus = O.strided_timesteps(50, 25)
+    assert taus[0] == 49 and len(taus) == 25 and all(a > b for a, b in zip(taus, taus[1:])) and taus[-1] >= 0
+    a, ce, cz = O.ddim_coefficients(ac, taus[-1], -1, 0.0)
+    ab = float(ac[taus[-1]])
+    assert abs(a - ab ** -0.5) < 1e-6 and abs(ce + ((1 - ab) / ab) ** 0.5) < 1e-6 and cz == 0.0
+    a, ce, cz = O.ddim_coefficients(ac, 30, 28, 1.0)
+    assert cz > 0 and abs(cz ** 2 - (1 - float(ac[28])) / (1 - float(ac[30])) * (1 - float(ac[30] / ac[28]))) < 1e-6
