@@ -11,6 +11,13 @@ from ditto_tts_amd.modules import DiTTO
 from ditto_tts_amd.sampler import SpeechGenerator
 from ditto_tts_amd.synth import hash_normal, hash_uniform, synthetic_state_dict
 from gpu_util import max_abs, rel_l2
+
+
+def hash_ids(shape, name, seed, V):
+    """int64 ids in [0, V) from the hashed uniform in [-1, 1)"""
+    u = torch.from_numpy((hash_uniform(shape, name, seed) + 1.0) * 0.5)
+    return (u * V).long().clamp_(0, V - 1)
+
 from oracle import ditto_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -74,7 +81,7 @@ def test_vq_rejects_cpu_input():
 
 def test_embedding_gather_bit_exact():
     tab = hash_normal((50257, 768), "wte", 9)[:5000].contiguous()
-    ids = (hash_uniform((3, 77), "ids", 9) * 5000).long().clamp_(0, 4999)
+    ids = hash_ids((3, 77), "ids", 9, 5000)
     ids[0, 0], ids[0, 1] = 0, 4999
     out = embedding_gather(tab.to(DEV), ids.to(DEV))
     assert torch.equal(out.cpu(), tab[ids])
@@ -92,7 +99,7 @@ def test_embedding_gather_out_of_range_ids_do_not_fault():
 @pytest.mark.parametrize("C,F,maxlen", [(2, 150, 1024), (8, 300, 256), (1, 7, 7)])
 def test_code_embed_mean_vs_oracle(C, F, maxlen):
     tab = hash_normal((1024, 128), "head", C)
-    codes = (hash_uniform((3, C, F), "codes", F) * 1024).long().clamp_(0, 1023)
+    codes = hash_ids((3, C, F), "codes", F, 1024)
     out = code_embed_mean(tab.to(DEV), codes.to(DEV), maxlen)
     want = O.code_embed_mean(tab, codes, maxlen)
     assert out.shape == want.shape
