@@ -45,6 +45,7 @@ struct AttnParams {
     const bf16* v; int ldv;
     bf16* out; int ldo;
     float* resid; int ldr;
+    const float* resid_in;
     int B, H, Sq, Skv, nqb;
     float scale_log2;  // scale * log2(e)
 };
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void attn64_kernel(AttnParams p) {
             for (int e = 0; e < 4; ++e) o[e] = ot[db][4 * g + e] * inv;
             if constexpr (RESID) {
                 float* rp = p.resid + grow * p.ldr + col;
-                f32x4 r = *reinterpret_cast<f32x4*>(rp);
+                f32x4 r = *reinterpret_cast<const f32x4*>(p.resid_in + grow * p.ldr + col);
                 r += o;  // x = attn_out + residual (src/components/DiT.py:139)
                 *reinterpret_cast<f32x4*>(rp) = r;
             } else {
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(256, 2) void attn64x2_kernel(AttnParams p) {
                 for (int e = 0; e < 4; ++e) o[e] = ot[qi][db][4 * g + e] * inv;
                 if constexpr (RESID) {
                     float* rp = p.resid + grow * p.ldr + col;
-                    f32x4 r = *reinterpret_cast<f32x4*>(rp);
+                    f32x4 r = *reinterpret_cast<const f32x4*>(p.resid_in + grow * p.ldr + col);
                     r += o;
                     *reinterpret_cast<f32x4*>(rp) = r;
                 } else {
@@ -515,7 +516,7 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const bf16* __restri
 // in-place half-split RoPE on bf16 rows (generic head_dim): columns [0, ncols) are heads of width dh.
 __global__ __launch_bounds__(256) void rope_inplace_kernel(bf16* __restrict__ x, int ld, const float* __restrict__ cs,
                                                            const float* __restrict__ sn, int M, int rpb, int ncols,
-                                                           int dh) {
+                                                           int dh, float sin_sign) {
     const int half = dh >> 1;
     const size_t npairs = (size_t)M * (ncols >> 1);
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < npairs; i += (size_t)gridDim.x * blockDim.x) {
@@ -524,7 +525,7 @@ __global__ __launch_bounds__(256) void rope_inplace_kernel(bf16* __restrict__ x,
         const int pos = row % rpb;
         bf16* pl = x + (size_t)row * ld + head * dh + j;
         const float lo = (float)pl[0], hi = (float)pl[half];
-        const float cc = cs[(size_t)pos * half + j], ss = sn[(size_t)pos * half + j];
+        const float cc = cs[(size_t)pos * half + j], ss = sin_sign * sn[(size_t)pos * half + j];
         pl[0] = (bf16)(lo * cc - hi * ss);
         pl[half] = (bf16)(hi * cc + lo * ss);
     }
@@ -534,32 +535,36 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace
 
-size_t attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh) {
-    (void)B; (void)H;
-    if (dh == DH) return 0;
+static size_t generic_fwd_bytes(int Sq, int Skv, int dh) {
     const size_t ld = (size_t)((Skv + 63) / 64) * 64;
     return align256((size_t)Sq * ld * 4) + align256((size_t)Sq * ld * 2) + align256((size_t)dh * ld * 2);
 }
+size_t attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh) {
+    (void)B; (void)H;
+    if (dh == DH) return 0;
+    return generic_fwd_bytes(Sq, Skv, dh);
+}
 
 hipError_t launch_rope_inplace(void* x, int ld, const float* cs, const float* sn, int M, int rpb, int ncols, int dh,
-                               hipStream_t s) {
+                               hipStream_t s, float sin_sign) {
     const size_t npairs = (size_t)M * (ncols / 2);
     size_t g = (npairs + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(rope_inplace_kernel, dim3((unsigned)(g ? g : 1)), dim3(256), 0, s, (bf16*)x, ld, cs, sn, M, rpb,
-                       ncols, dh);
+                       ncols, dh, sin_sign);
     return hipGetLastError();
 }
 
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     if (a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Skv <= 0) return hipErrorInvalidValue;
     const float LOG2E = 1.4426950408889634f;
-    if (a.dh == DH) {
+    if (a.dh == DH && !a.force_generic) {
+        if (a.dropout_p > 0.f) return hipErrorInvalidValue;   // the fused kernel has no dropout: use force_generic
         if ((a.ldq | a.ldk | a.ldv) % 8) return hipErrorInvalidValue;
         AttnParams p;
         p.q = (const bf16*)a.q; p.ldq = a.ldq; p.k = (const bf16*)a.k; p.ldk = a.ldk;
         p.v = (const bf16*)a.v; p.ldv = a.ldv; p.out = (bf16*)a.out_bf16; p.ldo = a.ldo;
-        p.resid = a.resid_f32; p.ldr = a.ldr; p.B = a.B; p.H = a.H; p.Sq = a.Sq; p.Skv = a.Skv;
+        p.resid = a.resid_f32; p.ldr = a.ldr; p.resid_in = a.resid_in ? a.resid_in : a.resid_f32; p.B = a.B; p.H = a.H; p.Sq = a.Sq; p.Skv = a.Skv;
         p.nqb = (a.Sq + QBLK - 1) / QBLK;
         p.scale_log2 = a.scale * LOG2E;
         if ((g_attn_flags & 4) && a.Sq >= 2 * QBLK) {   // two query blocks per wave
@@ -590,8 +595,7 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     // ---- generic head_dim: per (batch, head)  S = Q K^T (GEMM) -> row softmax -> O = P V (GEMM on V^T) ----
     if (a.dh % 64) return hipErrorInvalidValue;
     const int ld = ((a.Skv + 63) / 64) * 64;
-    if (a.workspace_bytes < attention_workspace_bytes(a.B, a.H, a.Sq, a.Skv, a.dh) || !a.workspace)
-        return hipErrorInvalidValue;
+    if (a.workspace_bytes < generic_fwd_bytes(a.Sq, a.Skv, a.dh) || !a.workspace) return hipErrorInvalidValue;
     char* ws = (char*)a.workspace;
     float* S = (float*)ws;
     bf16* P = (bf16*)(ws + align256((size_t)a.Sq * ld * 4));
@@ -606,8 +610,14 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
             g1.M = a.Sq; g1.N = ld; g1.K = a.dh; g1.w_rows = a.Skv;
             hipError_t e = launch_gemm(g1, EPI_BIAS_F32, s);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(softmax_rows_kernel, dim3((a.Sq + 3) / 4), dim3(256), 0, s, S, P, a.Sq, a.Skv, ld,
-                               a.scale * LOG2E);
+            if (a.dropout_p > 0.f) {
+                e = launch_softmax_drop_rows(S, P, a.Sq, a.Skv, ld, a.scale,
+                                             dropout_stream_host(a.seed, a.layer, b * a.H + h), a.dropout_p, s);
+                if (e != hipSuccess) return e;
+            } else {
+                hipLaunchKernelGGL(softmax_rows_kernel, dim3((a.Sq + 3) / 4), dim3(256), 0, s, S, P, a.Sq, a.Skv, ld,
+                                   a.scale * LOG2E);
+            }
             hipLaunchKernelGGL(transpose_pad_kernel, dim3(ld / 32, (a.dh + 31) / 32), dim3(256), 0, s, v, a.ldv, Vt,
                                ld, a.Skv, a.dh);
             if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -615,7 +625,8 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
             g2.A = P; g2.lda = ld; g2.W = Vt; g2.ldw = ld; g2.M = a.Sq; g2.N = a.dh; g2.K = ld; g2.w_rows = a.dh;
             if (a.resid_f32) {
                 float* r = a.resid_f32 + (size_t)b * a.Sq * a.ldr + h * a.dh;
-                g2.residual = r; g2.ldr = a.ldr; g2.out = r; g2.ldo = a.ldr;
+                g2.residual = (a.resid_in ? a.resid_in : a.resid_f32) + (size_t)b * a.Sq * a.ldr + h * a.dh;
+                g2.ldr = a.ldr; g2.out = r; g2.ldo = a.ldr;
                 e = launch_gemm(g2, EPI_BIAS_RES_F32, s);
             } else {
                 g2.out = (bf16*)a.out_bf16 + (size_t)b * a.Sq * a.ldo + h * a.dh; g2.ldo = a.ldo;
@@ -623,6 +634,95 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
             }
             if (e != hipSuccess) return e;
         }
+    return hipSuccess;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Attention backward, GEMM-composed (any head_dim % 64 == 0), per (batch, head), probabilities recomputed:
+//   S = Q K^T,  P = dropout(softmax(S * scale)),  dV = P^T dO,  dPd = dO V^T,
+//   dS = P_nodrop * (mask * dPd / (1-p) - rowsum) * scale,  dQ = dS K,  dK = dS^T Q.
+// The "^T" operands of the forward GEMM family (K-contiguous rows) are made by transpose_bf16.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct BwdWs { size_t S, dP, P, dS, Pt, dOt, Kt, Qt, total; };
+BwdWs plan_bwd(int Sq, int Skv, int dh) {
+    BwdWs w;
+    const size_t ld = (size_t)((Skv + 63) / 64) * 64, sqp = (size_t)((Sq + 63) / 64) * 64;
+    size_t off = 0;
+    auto take = [&](size_t b) { size_t o = off; off += align256(b); return o; };
+    w.S = take((size_t)Sq * ld * 4); w.dP = take((size_t)Sq * ld * 4); w.P = take((size_t)Sq * ld * 2);
+    w.dS = take((size_t)Sq * ld * 2); w.Pt = take(ld * sqp * 2); w.dOt = take((size_t)dh * sqp * 2);
+    w.Kt = take((size_t)dh * ld * 2); w.Qt = take((size_t)dh * sqp * 2);
+    w.total = off;
+    return w;
+}
+}  // namespace
+
+size_t attention_train_workspace_bytes(int Sq, int Skv, int dh) {
+    const size_t f = generic_fwd_bytes(Sq, Skv, dh), b = plan_bwd(Sq, Skv, dh).total;
+    return f > b ? f : b;
+}
+
+hipError_t launch_attention_bwd(const AttnBwdArgs& a, hipStream_t s) {
+    if (a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Skv <= 0 || a.dh % 64) return hipErrorInvalidValue;
+    const BwdWs w = plan_bwd(a.Sq, a.Skv, a.dh);
+    if (!a.workspace || a.workspace_bytes < w.total) return hipErrorInvalidValue;
+    const int ld = ((a.Skv + 63) / 64) * 64, sqp = ((a.Sq + 63) / 64) * 64;
+    char* ws = (char*)a.workspace;
+    float* S = (float*)(ws + w.S);
+    float* dP = (float*)(ws + w.dP);
+    bf16* P = (bf16*)(ws + w.P);
+    bf16* dS = (bf16*)(ws + w.dS);
+    bf16* Pt = (bf16*)(ws + w.Pt);
+    bf16* dOt = (bf16*)(ws + w.dOt);
+    bf16* Kt = (bf16*)(ws + w.Kt);
+    bf16* Qt = (bf16*)(ws + w.Qt);
+    hipError_t e;
+#define ATRY(x) do { if ((e = (x)) != hipSuccess) return e; } while (0)
+    for (int b = 0; b < a.B; ++b)
+        for (int h = 0; h < a.H; ++h) {
+            const bf16* q = (const bf16*)a.q + (size_t)b * a.Sq * a.ldq + h * a.dh;
+            const bf16* k = (const bf16*)a.k + (size_t)b * a.Skv * a.ldk + h * a.dh;
+            const bf16* v = (const bf16*)a.v + (size_t)b * a.Skv * a.ldv + h * a.dh;
+            const bf16* dO = (const bf16*)a.dout + (size_t)b * a.Sq * a.lddo + h * a.dh;
+            bf16* dq = (bf16*)a.dq + (size_t)b * a.Sq * a.lddq + h * a.dh;
+            bf16* dk = (bf16*)a.dk + (size_t)b * a.Skv * a.lddk + h * a.dh;
+            bf16* dv = (bf16*)a.dv + (size_t)b * a.Skv * a.lddv + h * a.dh;
+            const unsigned stream = dropout_stream_host(a.seed, a.layer, b * a.H + h);
+            GemmArgs g{};
+            // S = Q K^T
+            g.A = q; g.lda = a.ldq; g.W = k; g.ldw = a.ldk; g.w_rows = a.Skv; g.out = S; g.ldo = ld;
+            g.M = a.Sq; g.N = ld; g.K = a.dh;
+            ATRY(launch_gemm(g, EPI_BIAS_F32, s));
+            ATRY(launch_softmax_drop_rows(S, P, a.Sq, a.Skv, ld, a.scale, stream, a.dropout_p, s));
+            // dV = P^T dO
+            ATRY(launch_transpose_bf16(P, ld, a.Sq, ld, Pt, sqp, s));
+            ATRY(launch_transpose_bf16(dO, a.lddo, a.Sq, a.dh, dOt, sqp, s));
+            g = GemmArgs{};
+            g.A = Pt; g.lda = sqp; g.W = dOt; g.ldw = sqp; g.w_rows = a.dh; g.out = dv; g.ldo = a.lddv;
+            g.M = a.Skv; g.N = a.dh; g.K = sqp;
+            ATRY(launch_gemm(g, EPI_BIAS_BF16, s));
+            // dPd = dO V^T
+            g = GemmArgs{};
+            g.A = dO; g.lda = a.lddo; g.W = v; g.ldw = a.ldv; g.w_rows = a.Skv; g.out = dP; g.ldo = ld;
+            g.M = a.Sq; g.N = ld; g.K = a.dh;
+            ATRY(launch_gemm(g, EPI_BIAS_F32, s));
+            ATRY(launch_softmax_bwd_rows(S, dP, dS, a.Sq, a.Skv, ld, a.scale, stream, a.dropout_p, s));
+            // dQ = dS K
+            ATRY(launch_transpose_bf16(k, a.ldk, a.Skv, a.dh, Kt, ld, s));
+            g = GemmArgs{};
+            g.A = dS; g.lda = ld; g.W = Kt; g.ldw = ld; g.w_rows = a.dh; g.out = dq; g.ldo = a.lddq;
+            g.M = a.Sq; g.N = a.dh; g.K = ld;
+            ATRY(launch_gemm(g, EPI_BIAS_BF16, s));
+            // dK = dS^T Q
+            ATRY(launch_transpose_bf16(dS, ld, a.Sq, ld, Pt, sqp, s));
+            ATRY(launch_transpose_bf16(q, a.ldq, a.Sq, a.dh, Qt, sqp, s));
+            g = GemmArgs{};
+            g.A = Pt; g.lda = sqp; g.W = Qt; g.ldw = sqp; g.w_rows = a.dh; g.out = dk; g.ldo = a.lddk;
+            g.M = a.Skv; g.N = a.dh; g.K = sqp;
+            ATRY(launch_gemm(g, EPI_BIAS_BF16, s));
+        }
+#undef ATRY
     return hipSuccess;
 }
 

@@ -20,12 +20,11 @@
 #include <new>
 #include <vector>
 
-#include "../../include/ditto_hip.h"
-#include "kernels.h"
+#include "model.h"
 
 using namespace ditto;
 
-namespace {
+namespace ditto {
 
 thread_local char g_err[512] = "";
 
@@ -36,27 +35,6 @@ int fail(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
-#define HIP_TRY(expr)                                                                                  \
-    do {                                                                                               \
-        hipError_t _e = (expr);                                                                        \
-        if (_e != hipSuccess) return fail(DITTO_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e));      \
-    } while (0)
-
-inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
-
-struct LayerPack {
-    const void *Wqkv, *Wcq, *Wco, *W1g, *W2;
-    const float *sqkv, *s1g, *s2;   // fp8 weight scales (DITTO_CFG_FP8_LINEAR)
-    const float *bqkv, *bcq, *bco, *b1g, *b2;
-    const float *g1, *be1, *g2, *be2, *g3, *be3;
-};
-
-struct ArenaPlan {
-    size_t total = 0;
-    struct L { size_t Wqkv, Wcq, Wco, W1g, W2, bqkv, bcq, bco, b1g, b2, g1, be1, g2, be2, g3, be3, sqkv, s1g, s2; };
-    std::vector<L> layers;
-    size_t Wkv, bkv, Wfin, bfin, ttab, wx, bx, invf;
-};
 
 ArenaPlan plan_arena(const ditto_config& c) {
     ArenaPlan p;
@@ -83,10 +61,8 @@ ArenaPlan plan_arena(const ditto_config& c) {
     return p;
 }
 
-struct WsPlan { size_t h, u, qkv, act, xcat, eps, attn, attn_bytes, total; };
-
 // ditto_text_precompute scratch (front of the same workspace): bf16(text) | pooled fp32
-inline size_t text_scratch_bytes(const ditto_config& c, int B, int T) {
+static inline size_t text_scratch_bytes(const ditto_config& c, int B, int T) {
     return al((size_t)B * T * c.text_dim * 2) + al((size_t)B * c.text_dim * 4);
 }
 
@@ -124,24 +100,7 @@ int check_cfg(const ditto_config* c) {
     return DITTO_OK;
 }
 
-}  // namespace
-
-struct ditto_model {
-    ditto_config cfg;
-    ArenaPlan plan;
-    char* arena;
-    std::vector<LayerPack> layers;
-    const void* Wkv; const float* bkv; const void* Wfin; const float* bfin;
-    const float* ttab; const float* wx; const float* bx; const float* invf;
-    bool blocks_only = false;    // created without the model-level weights: only ditto_block_forward works
-    // profiling
-    bool prof = false;
-    struct Rec { hipEvent_t a, b; int kc; };
-    std::vector<Rec> recs;       // pending, un-synchronised
-    std::vector<hipEvent_t> pool;
-    int32_t launches[DITTO_KC_COUNT] = {0};
-    float ms[DITTO_KC_COUNT] = {0};
-};
+}  // namespace ditto
 
 namespace {
 
@@ -252,7 +211,7 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
 extern "C" {
 
 int ditto_abi_version(void) { return DITTO_ABI_VERSION; }
-const char* ditto_last_error(void) { return g_err; }
+const char* ditto_last_error(void) { return ditto::g_err; }
 
 const char* ditto_kernel_class_name(int kc) {
     static const char* names[DITTO_KC_COUNT] = {"layernorm", "gemm_qkv_rope", "gemm_d_x_d", "gemm_gated_mlp",

@@ -1,0 +1,480 @@
+// ditto_train.hip — training entry points of libditto_hip.so (include/ditto_hip.h, "training"): the forward that
+// keeps its activations and the backward of DiTTO.forward (reference src/model/DiTTO.py:66-94 + src/components/
+// DiT.py:25-40,100-157 under autograd, as driven by src/TrainDiTTO.py:55-95).
+//
+// HBM layout.  `tape` (caller-owned, ditto_tape_bytes): kv bf16[Mt, L*2d] | tmod fp32[B,2d] | text bf16[Mt,d] |
+//   pooled fp32[B,dt] | xcat bf16[M,2d] | hs fp32[3L+1][M,d] (the residual stream after AdaLN, after every
+//   self-attention, cross-attention and MLP segment) | per layer { u1,u2,u3 bf16[M,d] (LayerNorm outputs) |
+//   qkv bf16[M,3d] (RoPE applied) | qc bf16[M,d] | oc bf16[M,d] | pre bf16[M,8d] (fc1|gate pre-activations,
+//   interleaved by 16) | act bf16[M,4d] }.   With 288 GB of HBM nothing is recomputed except the attention
+//   probabilities: C2 at B = 32 keeps 17 GB.
+// Backward data flow per segment (dh = gradient of the fp32 residual stream, updated in place):
+//   dyb = bf16(dh) -> bias grad = colsum(dh) -> wgrad GEMM (dyb^T x act^T, both transposed to K-contiguous) ->
+//   dgrad GEMM (dyb x W^T pack) -> elementwise backward -> ... -> LayerNorm backward adds into dh.
+#include <cmath>
+#include <cstring>
+
+#include "model.h"
+
+using namespace ditto;
+
+namespace {
+
+inline size_t pad64(size_t x) { return (x + 63) & ~(size_t)63; }
+
+struct TapePlan {
+    size_t kv, tmod, text, pooled, xcat, hs, hs_stride;
+    struct L { size_t u1, u2, u3, qkv, qc, oc, pre, act; };
+    std::vector<L> layers;
+    size_t total;
+};
+TapePlan plan_tape(const ditto_config& c, int B, int N, int T) {
+    TapePlan p;
+    const size_t d = c.hidden_dim, L = c.num_layers, M = (size_t)B * N, Mt = (size_t)B * T;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
+    p.kv = take(Mt * L * 2 * d * 2); p.tmod = take((size_t)B * 2 * d * 4); p.text = take(Mt * c.text_dim * 2);
+    p.pooled = take((size_t)B * c.text_dim * 4); p.xcat = take(M * 2 * d * 2);
+    p.hs_stride = al(M * d * 4);
+    p.hs = off; off += (3 * L + 1) * p.hs_stride;
+    p.layers.resize(L);
+    for (auto& q : p.layers) {
+        q.u1 = take(M * d * 2); q.u2 = take(M * d * 2); q.u3 = take(M * d * 2); q.qkv = take(M * 3 * d * 2);
+        q.qc = take(M * d * 2); q.oc = take(M * d * 2); q.pre = take(M * 8 * d * 2); q.act = take(M * 4 * d * 2);
+    }
+    p.total = off;
+    return p;
+}
+
+struct TrainArenaPlan {
+    struct L { size_t WqkvT, WcqT, WcoT, W1gT, W2T; };
+    std::vector<L> layers;
+    size_t WoutT, total;
+};
+TrainArenaPlan plan_train_arena(const ditto_config& c) {
+    TrainArenaPlan p;
+    const size_t d = c.hidden_dim;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
+    p.layers.resize(c.num_layers);
+    for (auto& q : p.layers) {
+        q.WqkvT = take(3 * d * d * 2); q.WcqT = take(d * d * 2); q.WcoT = take(d * d * 2); q.W1gT = take(8 * d * d * 2);
+        q.W2T = take(4 * d * d * 2);
+    }
+    p.WoutT = take(d * d * 2);
+    p.total = off;
+    return p;
+}
+
+struct TrainWsPlan {
+    size_t dh, du, dyb, big1, big2, dkv, tA, tB, textT, wtmp, vtmp, red, dmod, small, attn, attn_bytes, total;
+};
+TrainWsPlan plan_train_ws(const ditto_config& c, int B, int N, int T) {
+    TrainWsPlan w;
+    const size_t d = c.hidden_dim, M = (size_t)B * N, Mt = (size_t)B * T, dh = d / c.num_heads;
+    const size_t Mp = pad64(M), Mtp = pad64(Mt), Mx = Mp > Mtp ? Mp : Mtp;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
+    w.dh = take(M * d * 4); w.du = take(M * d * 4); w.dyb = take(M * d * 2);
+    w.big1 = take(M * 8 * d * 2); w.big2 = take(M * 4 * d * 2); w.dkv = take(Mt * 2 * d * 2);
+    w.tA = take(8 * d * Mx * 2); w.tB = take(4 * d * Mx * 2); w.textT = take(d * Mtp * 2);
+    w.wtmp = take(8 * d * d * 4); w.vtmp = take(8 * d * 4);
+    size_t red = (size_t)256 * 8 * d * 4;   // colsum: <= 256 row chunks x <= 8d columns
+    const size_t r2 = ln_bwd_scratch_bytes((int)M, 1, (int)d), r3 = ln_bwd_scratch_bytes(N, B, (int)d);
+    red = red > r2 ? red : r2; red = red > r3 ? red : r3;
+    w.red = take(red);
+    w.dmod = take((size_t)B * 2 * d * 4);
+    w.small = take(6 * al((size_t)B * c.time_dim * 4));
+    const size_t a1 = attention_train_workspace_bytes(N, N, (int)dh), a2 = attention_train_workspace_bytes(N, T, (int)dh);
+    w.attn_bytes = a1 > a2 ? a1 : a2;
+    w.attn = take(w.attn_bytes);
+    w.total = off;
+    return w;
+}
+
+int check_train(const ditto_model* m) {
+    if (!m) return fail(DITTO_ERR_ARG, "null model");
+    if (m->blocks_only) return fail(DITTO_ERR_ARG, "training needs a full model handle (not blocks-only)");
+    if (m->cfg.flags & DITTO_CFG_FP8_LINEAR) return fail(DITTO_ERR_SHAPE, "training with fp8 linear layers is not supported");
+    return DITTO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ditto_train_arena_bytes(const ditto_config* cfg) {
+    if (check_cfg(cfg) != DITTO_OK) return 0;
+    return plan_train_arena(*cfg).total;
+}
+size_t ditto_tape_bytes(const ditto_config* cfg, int B, int N, int T) {
+    if (check_cfg(cfg) != DITTO_OK || B <= 0 || N <= 0 || T <= 0) return 0;
+    return plan_tape(*cfg, B, N, T).total;
+}
+size_t ditto_train_workspace_bytes(const ditto_config* cfg, int B, int N, int T) {
+    if (check_cfg(cfg) != DITTO_OK || B <= 0 || N <= 0 || T <= 0) return 0;
+    return plan_train_ws(*cfg, B, N, T).total;
+}
+
+int ditto_train_attach(ditto_model_t m, const ditto_weights* w, void* train_arena, size_t train_arena_bytes,
+                       ditto_stream_t stream) {
+    if (int rc = check_train(m)) return rc;
+    if (!w || !w->layers || !train_arena) return fail(DITTO_ERR_ARG, "null argument to ditto_train_attach");
+    const ditto_config& c = m->cfg;
+    const TrainArenaPlan p = plan_train_arena(c);
+    if (train_arena_bytes < p.total) return fail(DITTO_ERR_SIZE, "train arena too small: %zu < %zu", train_arena_bytes, p.total);
+    if ((uintptr_t)train_arena % 256) return fail(DITTO_ERR_ARG, "train arena must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int d = c.hidden_dim, L = c.num_layers, BIG = 1 << 30;
+    char* A = (char*)train_arena;
+    m->layersT.resize(L);
+    for (int l = 0; l < L; ++l) {
+        const ditto_layer_weights& lw = w->layers[l];
+        const auto& q = p.layers[l];
+        // W [out, in] -> W^T [in, out]: the "weight" of the dgrad GEMM  dX[M,in] = dY[M,out] * W
+        HIP_TRY(launch_pack_bf16_t(lw.attn_in_proj_weight, A + q.WqkvT, 3 * d, d, 3 * d, BIG, 1, 0, s));
+        HIP_TRY(launch_pack_bf16_t(lw.cross_in_proj_weight, A + q.WcqT, d, d, d, BIG, 1, 0, s));
+        HIP_TRY(launch_pack_bf16_t(lw.cross_out_proj_weight, A + q.WcoT, d, d, d, BIG, 1, 0, s));
+        HIP_TRY(launch_pack_bf16_t(lw.mlp_fc1_weight, A + q.W1gT, 4 * d, d, 8 * d, 16, 2, 0, s));
+        HIP_TRY(launch_pack_bf16_t(lw.gate_weight, A + q.W1gT, 4 * d, d, 8 * d, 16, 2, 16, s));
+        HIP_TRY(launch_pack_bf16_t(lw.mlp_fc2_weight, A + q.W2T, d, 4 * d, d, BIG, 1, 0, s));
+        m->layersT[l] = LayerPackT{A + q.WqkvT, A + q.WcqT, A + q.WcoT, A + q.W1gT, A + q.W2T};
+    }
+    HIP_TRY(launch_pack_bf16_t(w->proj_out_weight, A + p.WoutT, d, d, d, BIG, 1, 0, s));
+    m->WoutT = A + p.WoutT;
+    return DITTO_OK;
+}
+
+int ditto_train_forward(ditto_model_t m, const float* x, const float* text, const int64_t* t, int B, int N, int T,
+                        const float* rope_cos, const float* rope_sin, float dropout_p, uint64_t seed, float* eps_out,
+                        void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes, ditto_stream_t stream) {
+    if (int rc = check_train(m)) return rc;
+    if (!x || !text || !t || !rope_cos || !rope_sin || !eps_out || !tape || !workspace || B <= 0 || N <= 0 || T <= 0)
+        return fail(DITTO_ERR_ARG, "bad argument to ditto_train_forward");
+    if (!(dropout_p >= 0.f && dropout_p < 1.f)) return fail(DITTO_ERR_ARG, "dropout_p must be in [0, 1)");
+    const ditto_config& c = m->cfg;
+    const TapePlan tp = plan_tape(c, B, N, T);
+    const TrainWsPlan wp = plan_train_ws(c, B, N, T);
+    if (tape_bytes < tp.total) return fail(DITTO_ERR_SIZE, "tape too small: %zu < %zu", tape_bytes, tp.total);
+    if (workspace_bytes < wp.total) return fail(DITTO_ERR_SIZE, "train workspace too small: %zu < %zu", workspace_bytes, wp.total);
+    if ((uintptr_t)tape % 256 || (uintptr_t)workspace % 256) return fail(DITTO_ERR_ARG, "tape / workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int d = c.hidden_dim, L = c.num_layers, H = c.num_heads, dh = d / H, M = B * N, Mt = B * T;
+    const float scale = 1.0f / sqrtf((float)dh);
+    const bool fused_rope = (dh == 64);
+    char* tb = (char*)tape;
+    char* ws = (char*)workspace;
+    char* kv = tb + tp.kv;
+    float* tmod = (float*)(tb + tp.tmod);
+    void* textbf = tb + tp.text;
+    float* pooled = (float*)(tb + tp.pooled);
+    char* xcat = tb + tp.xcat;
+    auto hs = [&](int i) { return (float*)(tb + tp.hs + (size_t)i * tp.hs_stride); };
+    void* attn_ws = ws + wp.attn;
+
+    // text: bf16 copy, every layer's cross-attention K/V projection, the text half of the AdaLN modulation
+    HIP_TRY(launch_cast_bf16(text, textbf, (size_t)Mt * c.text_dim, s));
+    {
+        GemmArgs g{};
+        g.A = textbf; g.lda = c.text_dim; g.W = m->Wkv; g.bias = m->bkv; g.out = kv; g.ldo = L * 2 * d;
+        g.M = Mt; g.N = L * 2 * d; g.K = d;
+        HIP_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
+    }
+    HIP_TRY(launch_text_mod(text, m->wx, m->bx, pooled, tmod, B, T, c.text_dim, d, s));
+    HIP_TRY(launch_adaln(x, m->ttab, tmod, t, c.diffusion_steps, hs(0), xcat, 2 * d, B, N, d, s));
+
+    for (int l = 0; l < L; ++l) {
+        const LayerPack& lp = m->layers[l];
+        const auto& q = tp.layers[l];
+        float *h0 = hs(3 * l), *h1 = hs(3 * l + 1), *h2 = hs(3 * l + 2), *h3 = hs(3 * l + 3);
+        char* qkv = tb + q.qkv;
+        // ---- self-attention ----
+        HIP_TRY(launch_layernorm(h0, lp.g1, lp.be1, tb + q.u1, d, M, d, s));
+        {
+            GemmArgs g{};
+            g.A = tb + q.u1; g.lda = d; g.W = lp.Wqkv; g.bias = lp.bqkv; g.out = qkv; g.ldo = 3 * d;
+            g.M = M; g.N = 3 * d; g.K = d;
+            g.rope_cos = rope_cos; g.rope_sin = rope_sin; g.rope_rows_per_batch = N; g.rope_cols = 2 * d;
+            HIP_TRY(launch_gemm(g, fused_rope ? EPI_QKV_ROPE : EPI_BIAS_BF16, s));
+            if (!fused_rope) HIP_TRY(launch_rope_inplace(qkv, 3 * d, rope_cos, rope_sin, M, N, 2 * d, dh, s));
+        }
+        {
+            AttnArgs a{};
+            a.q = qkv; a.ldq = 3 * d; a.k = qkv + (size_t)d * 2; a.ldk = 3 * d; a.v = qkv + (size_t)2 * d * 2;
+            a.ldv = 3 * d; a.resid_f32 = h1; a.resid_in = h0; a.ldr = d; a.B = B; a.H = H; a.Sq = N; a.Skv = N;
+            a.dh = dh; a.scale = scale; a.workspace = attn_ws; a.workspace_bytes = wp.attn_bytes;
+            HIP_TRY(launch_attention(a, s));
+        }
+        // ---- cross-attention (dropout on the probabilities in train mode) ----
+        HIP_TRY(launch_layernorm(h1, lp.g2, lp.be2, tb + q.u2, d, M, d, s));
+        {
+            GemmArgs g{};
+            g.A = tb + q.u2; g.lda = d; g.W = lp.Wcq; g.bias = lp.bcq; g.out = tb + q.qc; g.ldo = d;
+            g.M = M; g.N = d; g.K = d;
+            HIP_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
+        }
+        {
+            AttnArgs a{};
+            a.q = tb + q.qc; a.ldq = d; a.k = kv + (size_t)l * 2 * d * 2; a.ldk = L * 2 * d;
+            a.v = kv + ((size_t)l * 2 * d + d) * 2; a.ldv = L * 2 * d; a.out_bf16 = tb + q.oc; a.ldo = d;
+            a.B = B; a.H = H; a.Sq = N; a.Skv = T; a.dh = dh; a.scale = scale;
+            a.workspace = attn_ws; a.workspace_bytes = wp.attn_bytes;
+            a.dropout_p = dropout_p; a.seed = seed; a.layer = l; a.force_generic = dropout_p > 0.f;
+            HIP_TRY(launch_attention(a, s));
+        }
+        {
+            GemmArgs g{};
+            g.A = tb + q.oc; g.lda = d; g.W = lp.Wco; g.bias = lp.bco; g.residual = h1; g.ldr = d; g.out = h2; g.ldo = d;
+            g.M = M; g.N = d; g.K = d;
+            HIP_TRY(launch_gemm(g, EPI_BIAS_RES_F32, s));
+        }
+        // ---- gated MLP: pre-activations are kept for the backward, the product is a separate pass ----
+        HIP_TRY(launch_layernorm(h2, lp.g3, lp.be3, tb + q.u3, d, M, d, s));
+        {
+            GemmArgs g{};
+            g.A = tb + q.u3; g.lda = d; g.W = lp.W1g; g.bias = lp.b1g; g.out = tb + q.pre; g.ldo = 8 * d;
+            g.M = M; g.N = 8 * d; g.K = d;
+            HIP_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
+        }
+        HIP_TRY(launch_gated_fwd(tb + q.pre, tb + q.act, M, 4 * d, s));
+        {
+            GemmArgs g{};
+            g.A = tb + q.act; g.lda = 4 * d; g.W = lp.W2; g.bias = lp.b2; g.residual = h2; g.ldr = d; g.out = h3;
+            g.ldo = d; g.M = M; g.N = d; g.K = 4 * d;
+            if (l == L - 1) { g.out2_bf16 = xcat + (size_t)d * 2; g.ldo2 = 2 * d; }
+            HIP_TRY(launch_gemm(g, EPI_BIAS_RES_F32, s));
+        }
+    }
+    {
+        GemmArgs g{};
+        g.A = xcat; g.lda = 2 * d; g.W = m->Wfin; g.bias = m->bfin; g.out = eps_out; g.ldo = d; g.M = M; g.N = d;
+        g.K = 2 * d;
+        HIP_TRY(launch_gemm(g, EPI_BIAS_F32, s));
+    }
+    return DITTO_OK;
+}
+
+int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* grad_eps, const float* x,
+                         const int64_t* t, int B, int N, int T, const float* rope_cos, const float* rope_sin,
+                         float dropout_p, uint64_t seed, const void* tape, size_t tape_bytes, const ditto_grads* grads,
+                         void* workspace, size_t workspace_bytes, ditto_stream_t stream) {
+    if (int rc = check_train(m)) return rc;
+    if (!w || !grad_eps || !x || !t || !rope_cos || !rope_sin || !tape || !grads || !grads->layers || !workspace ||
+        B <= 0 || N <= 0 || T <= 0)
+        return fail(DITTO_ERR_ARG, "bad argument to ditto_train_backward");
+    if (m->layersT.empty() || !m->WoutT) return fail(DITTO_ERR_ARG, "ditto_train_attach was not called on this handle");
+    const ditto_config& c = m->cfg;
+    const TapePlan tp = plan_tape(c, B, N, T);
+    const TrainWsPlan wp = plan_train_ws(c, B, N, T);
+    if (tape_bytes < tp.total) return fail(DITTO_ERR_SIZE, "tape too small: %zu < %zu", tape_bytes, tp.total);
+    if (workspace_bytes < wp.total) return fail(DITTO_ERR_SIZE, "train workspace too small: %zu < %zu", workspace_bytes, wp.total);
+    hipStream_t s = (hipStream_t)stream;
+    const int d = c.hidden_dim, L = c.num_layers, H = c.num_heads, dhd = d / H, M = B * N, Mt = B * T, td = c.time_dim;
+    const int Mp = (int)pad64(M), Mtp = (int)pad64(Mt);
+    const float scale = 1.0f / sqrtf((float)dhd);
+    const char* tb = (const char*)tape;
+    char* ws = (char*)workspace;
+    const char* kv = tb + tp.kv;
+    const char* xcat = tb + tp.xcat;
+    auto hs = [&](int i) { return (const float*)(tb + tp.hs + (size_t)i * tp.hs_stride); };
+    float* dh = (float*)(ws + wp.dh);
+    float* du = (float*)(ws + wp.du);
+    char* dyb = ws + wp.dyb;
+    char* big1 = ws + wp.big1;
+    char* big2 = ws + wp.big2;
+    char* dkv = ws + wp.dkv;
+    char* tA = ws + wp.tA;
+    char* tB = ws + wp.tB;
+    char* textT = ws + wp.textT;
+    float* wtmp = (float*)(ws + wp.wtmp);
+    float* vtmp = (float*)(ws + wp.vtmp);
+    float* red = (float*)(ws + wp.red);
+    float* dmod = (float*)(ws + wp.dmod);
+    void* attn_ws = ws + wp.attn;
+
+    // dW[n1, n2] = dY[rows, n1]^T X[rows, n2]: both operands transposed to K-contiguous rows, one GEMM with K = rows
+    auto wgrad_t = [&](const void* At, int n1, const void* Bt, int n2, int kp, float* out, int ldo) -> int {
+        GemmArgs g{};
+        g.A = At; g.lda = kp; g.W = Bt; g.ldw = kp; g.w_rows = n2; g.out = out; g.ldo = ldo; g.M = n1; g.N = n2; g.K = kp;
+        HIP_TRY(launch_gemm(g, EPI_BIAS_F32, s));
+        return DITTO_OK;
+    };
+    auto wgrad = [&](const void* dY, int ld1, int n1, const void* X, int ld2, int n2, int rows, int rp, float* out) -> int {
+        HIP_TRY(launch_transpose_bf16(dY, ld1, rows, n1, tA, rp, s));
+        HIP_TRY(launch_transpose_bf16(X, ld2, rows, n2, tB, rp, s));
+        return wgrad_t(tA, n1, tB, n2, rp, out, n2);
+    };
+    // dX[M, n_in] = dY[M, n_out] * W, with Wt = W^T bf16 [n_in, n_out]
+    auto dgrad = [&](const void* dY, int n_out, const void* Wt, int n_in, void* out, bool f32) -> int {
+        GemmArgs g{};
+        g.A = dY; g.lda = n_out; g.W = Wt; g.out = out; g.ldo = n_in; g.M = M; g.N = n_in; g.K = n_out;
+        HIP_TRY(launch_gemm(g, f32 ? EPI_BIAS_F32 : EPI_BIAS_BF16, s));
+        return DITTO_OK;
+    };
+    auto ln_back = [&](const float* xin, const float* gamma, float* gw, float* gb) -> int {
+        HIP_TRY(launch_ln_bwd(du, xin, gamma, dh, vtmp, red, M, 1, d, s));
+        HIP_TRY(hipMemcpyAsync(gw, vtmp, (size_t)d * 4, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(gb, vtmp + d, (size_t)d * 4, hipMemcpyDeviceToDevice, s));
+        return DITTO_OK;
+    };
+#define TRY_RC(expr) do { if (int _rc = (expr)) return _rc; } while (0)
+
+    HIP_TRY(launch_transpose_bf16(tb + tp.text, c.text_dim, Mt, c.text_dim, textT, Mtp, s));
+
+    // ---- eps = [bf16(x) | bf16(h_L)] Wfin^T + (b_in + b_out)   (src/model/DiTTO.py:83,93-94) ----
+    HIP_TRY(launch_cast_bf16(grad_eps, dyb, (size_t)M * d, s));
+    HIP_TRY(launch_colsum_f32(grad_eps, d, M, d, grads->proj_in_bias, red, s));
+    HIP_TRY(hipMemcpyAsync(grads->proj_out_bias, grads->proj_in_bias, (size_t)d * 4, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(launch_transpose_bf16(dyb, d, M, d, tA, Mp, s));
+    HIP_TRY(launch_transpose_bf16(xcat, 2 * d, M, 2 * d, tB, Mp, s));
+    TRY_RC(wgrad_t(tA, d, tB, d, Mp, grads->proj_in_weight, d));
+    TRY_RC(wgrad_t(tA, d, tB + (size_t)d * Mp * 2, d, Mp, grads->proj_out_weight, d));
+    TRY_RC(dgrad(dyb, d, m->WoutT, d, dh, true));
+
+    for (int l = L - 1; l >= 0; --l) {
+        const LayerPack& lp = m->layers[l];
+        const LayerPackT& lt = m->layersT[l];
+        const auto& q = tp.layers[l];
+        const ditto_layer_grads& G = grads->layers[l];
+        const float *h0 = hs(3 * l), *h1 = hs(3 * l + 1), *h2 = hs(3 * l + 2);
+
+        // ---- gated MLP: h3 = h2 + act W2^T + b2,  act = gelu(a) sigmoid(g),  [a|g] = u3 W1g^T + b1g ----
+        HIP_TRY(launch_cast_bf16(dh, dyb, (size_t)M * d, s));
+        HIP_TRY(launch_colsum_f32(dh, d, M, d, G.mlp_fc2_bias, red, s));
+        TRY_RC(wgrad(dyb, d, d, tb + q.act, 4 * d, 4 * d, M, Mp, G.mlp_fc2_weight));
+        TRY_RC(dgrad(dyb, d, lt.W2T, 4 * d, big2, false));
+        HIP_TRY(launch_gated_bwd(big2, tb + q.pre, big1, M, 4 * d, s));
+        HIP_TRY(launch_colsum_bf16(big1, 8 * d, M, 8 * d, vtmp, red, s));
+        HIP_TRY(launch_unpack_vec(vtmp, G.mlp_fc1_bias, 4 * d, 16, 2, 0, s));
+        HIP_TRY(launch_unpack_vec(vtmp, G.gate_bias, 4 * d, 16, 2, 16, s));
+        TRY_RC(wgrad(big1, 8 * d, 8 * d, tb + q.u3, d, d, M, Mp, wtmp));
+        HIP_TRY(launch_unpack_rows(wtmp, G.mlp_fc1_weight, 4 * d, d, 16, 2, 0, s));
+        HIP_TRY(launch_unpack_rows(wtmp, G.gate_weight, 4 * d, d, 16, 2, 16, s));
+        TRY_RC(dgrad(big1, 8 * d, lt.W1gT, d, du, true));
+        TRY_RC(ln_back(h2, lp.g3, G.norm3_weight, G.norm3_bias));
+
+        // ---- cross-attention: h2 = h1 + oc Wo^T + bo,  oc = attn(qc, Kc, Vc),  qc = u2 Wq^T + bq ----
+        HIP_TRY(launch_cast_bf16(dh, dyb, (size_t)M * d, s));
+        HIP_TRY(launch_colsum_f32(dh, d, M, d, G.cross_out_proj_bias, red, s));
+        TRY_RC(wgrad(dyb, d, d, tb + q.oc, d, d, M, Mp, G.cross_out_proj_weight));
+        TRY_RC(dgrad(dyb, d, lt.WcoT, d, big2, false));
+        {
+            AttnBwdArgs a{};
+            a.q = tb + q.qc; a.ldq = d; a.k = kv + (size_t)l * 2 * d * 2; a.ldk = L * 2 * d;
+            a.v = kv + ((size_t)l * 2 * d + d) * 2; a.ldv = L * 2 * d; a.dout = big2; a.lddo = d;
+            a.dq = big1; a.lddq = d; a.dk = dkv; a.lddk = 2 * d; a.dv = dkv + (size_t)d * 2; a.lddv = 2 * d;
+            a.B = B; a.H = H; a.Sq = N; a.Skv = T; a.dh = dhd; a.scale = scale;
+            a.dropout_p = dropout_p; a.seed = seed; a.layer = l; a.workspace = attn_ws; a.workspace_bytes = wp.attn_bytes;
+            HIP_TRY(launch_attention_bwd(a, s));
+        }
+        HIP_TRY(launch_colsum_bf16(big1, d, M, d, G.cross_in_proj_bias, red, s));
+        HIP_TRY(launch_colsum_bf16(dkv, 2 * d, Mt, 2 * d, G.cross_in_proj_bias + d, red, s));
+        TRY_RC(wgrad(big1, d, d, tb + q.u2, d, d, M, Mp, G.cross_in_proj_weight));
+        HIP_TRY(launch_transpose_bf16(dkv, 2 * d, Mt, 2 * d, tA, Mtp, s));
+        TRY_RC(wgrad_t(tA, 2 * d, textT, d, Mtp, G.cross_in_proj_weight + (size_t)d * d, d));
+        TRY_RC(dgrad(big1, d, lt.WcqT, d, du, true));
+        TRY_RC(ln_back(h1, lp.g2, G.norm2_weight, G.norm2_bias));
+
+        // ---- self-attention: h1 = h0 + attn(rope(q), rope(k), v), NO out-proj (src/components/DiT.py:134-139) ----
+        HIP_TRY(launch_cast_bf16(dh, dyb, (size_t)M * d, s));
+        {
+            const char* qkv = tb + q.qkv;
+            AttnBwdArgs a{};
+            a.q = qkv; a.ldq = 3 * d; a.k = qkv + (size_t)d * 2; a.ldk = 3 * d; a.v = qkv + (size_t)2 * d * 2; a.ldv = 3 * d;
+            a.dout = dyb; a.lddo = d;
+            a.dq = big1; a.lddq = 3 * d; a.dk = big1 + (size_t)d * 2; a.lddk = 3 * d; a.dv = big1 + (size_t)2 * d * 2;
+            a.lddv = 3 * d; a.B = B; a.H = H; a.Sq = N; a.Skv = N; a.dh = dhd; a.scale = scale;
+            a.workspace = attn_ws; a.workspace_bytes = wp.attn_bytes;
+            HIP_TRY(launch_attention_bwd(a, s));
+        }
+        HIP_TRY(launch_rope_inplace(big1, 3 * d, rope_cos, rope_sin, M, N, 2 * d, dhd, s, -1.0f));
+        HIP_TRY(launch_colsum_bf16(big1, 3 * d, M, 3 * d, G.attn_in_proj_bias, red, s));
+        TRY_RC(wgrad(big1, 3 * d, 3 * d, tb + q.u1, d, d, M, Mp, G.attn_in_proj_weight));
+        TRY_RC(dgrad(big1, 3 * d, lt.WqkvT, d, du, true));
+        TRY_RC(ln_back(h0, lp.g1, G.norm1_weight, G.norm1_bias));
+    }
+
+    // ---- GlobalAdaLN (src/components/DiT.py:25-40): h0 = xhat (1 + s_t + s_x) + (b_t + b_x) ----
+    // dmod[b] = [sum_n dh xhat | sum_n dh]: the gradient of BOTH branches' (scale, shift) vectors
+    HIP_TRY(launch_ln_bwd(dh, x, nullptr, nullptr, dmod, red, N, B, d, s));
+    const float* pooled = (const float*)(tb + tp.pooled);
+    HIP_TRY(launch_small_linear_bwd_w(dmod, pooled, grads->ada_text_mlp_weight, grads->ada_text_mlp_bias, B,
+                                      c.text_dim, 2 * d, true, s));
+    {   // time branch: e0 = emb[t]; z1 = W0 e0 + b0; e2 = W2 silu(z1) + b2; mod_t = Wt silu(e2) + bt
+        char* sm = ws + wp.small;
+        const size_t st = al((size_t)B * td * 4);
+        float *e0 = (float*)sm, *z1 = (float*)(sm + st), *e2 = (float*)(sm + 2 * st), *de2 = (float*)(sm + 3 * st),
+              *dz1 = (float*)(sm + 4 * st), *de0 = (float*)(sm + 5 * st);
+        HIP_TRY(launch_embedding_gather(w->t_embedding_weight, t, e0, B, c.diffusion_steps, td, s));
+        HIP_TRY(launch_small_linear_fwd(e0, w->time_embed_0_weight, w->time_embed_0_bias, z1, B, td, td, false, s));
+        HIP_TRY(launch_small_linear_fwd(z1, w->time_embed_2_weight, w->time_embed_2_bias, e2, B, td, td, true, s));
+        HIP_TRY(launch_small_linear_bwd_w(dmod, e2, grads->ada_time_mlp_weight, grads->ada_time_mlp_bias, B, td, 2 * d, true, s));
+        HIP_TRY(launch_small_linear_bwd_x(dmod, w->ada_time_mlp_weight, e2, de2, B, td, 2 * d, true, s));
+        HIP_TRY(launch_small_linear_bwd_w(de2, z1, grads->time_embed_2_weight, grads->time_embed_2_bias, B, td, td, true, s));
+        HIP_TRY(launch_small_linear_bwd_x(de2, w->time_embed_2_weight, z1, dz1, B, td, td, true, s));
+        HIP_TRY(launch_small_linear_bwd_w(dz1, e0, grads->time_embed_0_weight, grads->time_embed_0_bias, B, td, td, false, s));
+        HIP_TRY(launch_small_linear_bwd_x(dz1, w->time_embed_0_weight, e0, de0, B, td, td, false, s));
+        HIP_TRY(hipMemsetAsync(grads->t_embedding_weight, 0, (size_t)c.diffusion_steps * td * 4, s));
+        HIP_TRY(launch_embedding_scatter_add(de0, t, grads->t_embedding_weight, B, c.diffusion_steps, td, s));
+    }
+#undef TRY_RC
+    return DITTO_OK;
+}
+
+size_t ditto_layernorm_bwd_scratch_bytes(int rows_per_group, int groups, int d) {
+    if (rows_per_group <= 0 || groups <= 0 || d <= 0) return 0;
+    return ln_bwd_scratch_bytes(rows_per_group, groups, d);
+}
+int ditto_layernorm_bwd(const float* dy, const float* x, const float* gamma, float* dx_accum, float* dgamma_dbeta,
+                        void* scratch, size_t scratch_bytes, int rows_per_group, int groups, int d,
+                        ditto_stream_t stream) {
+    if (!dy || !x || rows_per_group <= 0 || groups <= 0 || (!dx_accum && !dgamma_dbeta))
+        return fail(DITTO_ERR_ARG, "bad argument to ditto_layernorm_bwd");
+    if (d % 4 || d > 2048) return fail(DITTO_ERR_SHAPE, "d must be a multiple of 4 and <= 2048");
+    if (dgamma_dbeta && (!scratch || scratch_bytes < ln_bwd_scratch_bytes(rows_per_group, groups, d)))
+        return fail(DITTO_ERR_SIZE, "scratch too small for ditto_layernorm_bwd");
+    HIP_TRY(launch_ln_bwd(dy, x, gamma, dx_accum, dgamma_dbeta, (float*)scratch, rows_per_group, groups, d,
+                          (hipStream_t)stream));
+    return DITTO_OK;
+}
+
+size_t ditto_attention_bwd_workspace_bytes(int Sq, int Skv, int dh) {
+    if (Sq <= 0 || Skv <= 0 || dh <= 0) return 0;
+    return attention_train_workspace_bytes(Sq, Skv, dh);
+}
+int ditto_attention_bwd_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* dout,
+                             int lddo, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int B, int H, int Sq,
+                             int Skv, int dh, float scale, float dropout_p, uint64_t seed, int layer, void* workspace,
+                             size_t workspace_bytes, ditto_stream_t stream) {
+    if (!q || !k || !v || !dout || !dq || !dk || !dv || !workspace)
+        return fail(DITTO_ERR_ARG, "null pointer to ditto_attention_bwd_bf16");
+    if (dh % 64) return fail(DITTO_ERR_SHAPE, "head_dim must be a multiple of 64");
+    if ((ldq | ldk | ldv | lddo | lddq | lddk | lddv) % 8) return fail(DITTO_ERR_SHAPE, "row strides must be multiples of 8");
+    if (workspace_bytes < attention_train_workspace_bytes(Sq, Skv, dh))
+        return fail(DITTO_ERR_SIZE, "attention backward workspace too small");
+    AttnBwdArgs a{};
+    a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.dout = dout; a.lddo = lddo;
+    a.dq = dq; a.lddq = lddq; a.dk = dk; a.lddk = lddk; a.dv = dv; a.lddv = lddv;
+    a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.dh = dh; a.scale = scale;
+    a.dropout_p = dropout_p; a.seed = seed; a.layer = layer; a.workspace = workspace; a.workspace_bytes = workspace_bytes;
+    HIP_TRY(launch_attention_bwd(a, (hipStream_t)stream));
+    return DITTO_OK;
+}
+int ditto_attention_dropout_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out,
+                                 int ldo, int B, int H, int Sq, int Skv, int dh, float scale, float dropout_p,
+                                 uint64_t seed, int layer, void* workspace, size_t workspace_bytes,
+                                 ditto_stream_t stream) {
+    if (!q || !k || !v || !out || !workspace) return fail(DITTO_ERR_ARG, "null pointer to ditto_attention_dropout_bf16");
+    if (dh % 64) return fail(DITTO_ERR_SHAPE, "head_dim must be a multiple of 64");
+    if (workspace_bytes < attention_train_workspace_bytes(Sq, Skv, dh))
+        return fail(DITTO_ERR_SIZE, "attention workspace too small");
+    AttnArgs a{};
+    a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.out_bf16 = out; a.ldo = ldo;
+    a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.dh = dh; a.scale = scale;
+    a.workspace = workspace; a.workspace_bytes = workspace_bytes;
+    a.dropout_p = dropout_p; a.seed = seed; a.layer = layer; a.force_generic = true;
+    HIP_TRY(launch_attention(a, (hipStream_t)stream));
+    return DITTO_OK;
+}
+
+}  // extern "C"

@@ -88,15 +88,63 @@ struct AttnArgs {
     const void* k; int ldk;
     const void* v; int ldv;
     void* out_bf16; int ldo;         // used when resid_f32 == nullptr
-    float* resid_f32; int ldr;       // if set: resid[row, h*dh + c] += O   (self-attention, no out-proj)
+    float* resid_f32; int ldr;       // if set: resid[row, h*dh + c] = resid_in[...] + O   (self-attention, no out-proj)
+    const float* resid_in;           // nullptr -> resid_f32 (in place); the training forward keeps both streams
     int B, H, Sq, Skv, dh;
     float scale;                     // 1/sqrt(dh)
     void* workspace; size_t workspace_bytes;   // generic (dh != 64) path only
+    // training forward: dropout on the probabilities (nn.MultiheadAttention train mode), mask = hash(seed, layer, ...)
+    float dropout_p; uint64_t seed; int layer;
+    bool force_generic;              // run the GEMM-composed path even at dh == 64
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 size_t attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh);
-// in-place half-split RoPE on bf16 [M, ld] for `nheads` heads of width dh starting at column 0 (generic path)
+// in-place half-split RoPE on bf16 [M, ld] for `nheads` heads of width dh starting at column 0 (generic path);
+// sin_sign = -1 applies the inverse rotation (the backward of RoPE)
 hipError_t launch_rope_inplace(void* qk_bf16, int ld, const float* cosT, const float* sinT, int M,
-                               int rows_per_batch, int ncols, int dh, hipStream_t s);
+                               int rows_per_batch, int ncols, int dh, hipStream_t s, float sin_sign = 1.0f);
+
+// attention backward: dq/dk/dv bf16 (same head layout as q/k/v) from dO bf16; probabilities recomputed
+struct AttnBwdArgs {
+    const void* q; int ldq; const void* k; int ldk; const void* v; int ldv;
+    const void* dout; int lddo;
+    void* dq; int lddq; void* dk; int lddk; void* dv; int lddv;
+    int B, H, Sq, Skv, dh;
+    float scale;
+    float dropout_p; uint64_t seed; int layer;
+    void* workspace; size_t workspace_bytes;
+};
+hipError_t launch_attention_bwd(const AttnBwdArgs& a, hipStream_t s);
+size_t attention_train_workspace_bytes(int Sq, int Skv, int dh);   // generic forward + backward scratch
+
+// ---------------- train.hip : backward-pass row / elementwise kernels ----------------
+hipError_t launch_transpose_bf16(const void* src, int ld, int rows, int cols, void* dst, int ldT, hipStream_t s);
+size_t colsum_scratch_bytes(int M, int n);
+hipError_t launch_colsum_f32(const float* x, int ld, int M, int n, float* out, float* scratch, hipStream_t s);
+hipError_t launch_colsum_bf16(const void* x, int ld, int M, int n, float* out, float* scratch, hipStream_t s);
+size_t ln_bwd_scratch_bytes(int rows_per_group, int groups, int d);
+hipError_t launch_ln_bwd(const float* dy, const float* x, const float* gamma, float* dx_accum, float* dgb_out,
+                         float* scratch, int rows_per_group, int groups, int d, hipStream_t s);
+hipError_t launch_gated_fwd(const void* pre, void* act, int M, int F, hipStream_t s);
+hipError_t launch_gated_bwd(const void* dact, const void* pre, void* dpre, int M, int F, hipStream_t s);
+hipError_t launch_unpack_rows(const float* src, float* dst, int rows, int cols, int blk, int mult, int row_off,
+                              hipStream_t s);
+hipError_t launch_unpack_vec(const float* src, float* dst, int rows, int blk, int mult, int row_off, hipStream_t s);
+hipError_t launch_pack_bf16_t(const float* src, void* dst, int rows, int cols, int ldT, int blk, int mult, int row_off,
+                              hipStream_t s);
+unsigned dropout_stream_host(uint64_t seed, int layer, int bh);
+hipError_t launch_softmax_drop_rows(const float* S, void* P, int Sq, int Skv, int ld, float scale, unsigned stream,
+                                    float p_drop, hipStream_t s);
+hipError_t launch_softmax_bwd_rows(const float* S, const float* dPd, void* dS, int Sq, int Skv, int ld, float scale,
+                                   unsigned stream, float p_drop, hipStream_t s);
+hipError_t launch_small_linear_fwd(const float* x, const float* W, const float* bias, float* y, int B, int I, int O,
+                                   bool silu_in, hipStream_t s);
+hipError_t launch_small_linear_bwd_w(const float* dy, const float* x, float* dW, float* dbias, int B, int I, int O,
+                                     bool silu_in, hipStream_t s);
+hipError_t launch_small_linear_bwd_x(const float* dy, const float* W, const float* x, float* dx, int B, int I, int O,
+                                     bool silu_in, hipStream_t s);
+hipError_t launch_embedding_scatter_add(const float* drows, const int64_t* ids, float* dtable, int B, int V, int d,
+                                        hipStream_t s);
+hipError_t launch_sub_to_bf16(const float* a, const float* b, void* dst, size_t n, hipStream_t s);
 
 }  // namespace ditto

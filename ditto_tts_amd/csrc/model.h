@@ -1,0 +1,62 @@
+// model.h — internal: the model handle, arena / workspace plans and error helpers shared by ditto_api.hip
+// (inference entry points) and ditto_train.hip (training entry points).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <vector>
+
+#include "../../include/ditto_hip.h"
+#include "kernels.h"
+
+namespace ditto {
+
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) return ::ditto::fail(DITTO_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct LayerPack {
+    const void *Wqkv, *Wcq, *Wco, *W1g, *W2;
+    const float *sqkv, *s1g, *s2;   // fp8 weight scales (DITTO_CFG_FP8_LINEAR)
+    const float *bqkv, *bcq, *bco, *b1g, *b2;
+    const float *g1, *be1, *g2, *be2, *g3, *be3;
+};
+// transposed bf16 copies for the dgrad GEMMs (dX = dY W runs as the forward GEMM with weight W^T), ditto_train_attach
+struct LayerPackT { const void *WqkvT, *WcqT, *WcoT, *W1gT, *W2T; };
+
+struct ArenaPlan {
+    size_t total = 0;
+    struct L { size_t Wqkv, Wcq, Wco, W1g, W2, bqkv, bcq, bco, b1g, b2, g1, be1, g2, be2, g3, be3, sqkv, s1g, s2; };
+    std::vector<L> layers;
+    size_t Wkv, bkv, Wfin, bfin, ttab, wx, bx, invf;
+};
+ArenaPlan plan_arena(const ditto_config& c);
+
+struct WsPlan { size_t h, u, qkv, act, xcat, eps, attn, attn_bytes, total; };
+WsPlan plan_ws(const ditto_config& c, int B, int N, int T);
+int check_cfg(const ditto_config* c);
+
+}  // namespace ditto
+
+struct ditto_model {
+    ditto_config cfg;
+    ditto::ArenaPlan plan;
+    char* arena;
+    std::vector<ditto::LayerPack> layers;
+    const void* Wkv; const float* bkv; const void* Wfin; const float* bfin;
+    const float* ttab; const float* wx; const float* bx; const float* invf;
+    bool blocks_only = false;    // created without the model-level weights: only ditto_block_forward works
+    // training (ditto_train_attach)
+    std::vector<ditto::LayerPackT> layersT;
+    const void* WoutT = nullptr;
+    // profiling
+    bool prof = false;
+    struct Rec { hipEvent_t a, b; int kc; };
+    std::vector<Rec> recs;       // pending, un-synchronised
+    std::vector<hipEvent_t> pool;
+    int32_t launches[DITTO_KC_COUNT] = {0};
+    float ms[DITTO_KC_COUNT] = {0};
+};

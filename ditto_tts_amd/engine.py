@@ -78,6 +78,7 @@ class DenoiseEngine:
                                                   self.arena.numel(), _stream(), C.byref(self.handle)))
             torch.cuda.current_stream().synchronize()  # staging copies may now be freed
         self._rope.clear()
+        self._train_attached = False    # a new handle: the transposed training copies must be re-attached
 
     def repack(self, state: Mapping[str, torch.Tensor]):
         self._pack(state)
@@ -210,6 +211,110 @@ class DenoiseEngine:
                                                layer if cond_layer is None else cond_layer, B, N, cond.T,
                                                c.data_ptr(), s.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
         return h
+
+    # ------------------------------------------------------------------ training
+    def _weights_struct(self, state: Mapping[str, torch.Tensor]):
+        """ditto_weights over the CURRENT fp32 CUDA tensors of `state` (no copies when they already are fp32,
+        contiguous and on this device: the nn.Parameters themselves).  Returns (struct, keepalive)."""
+        keep = []
+
+        def dev(key):
+            t = state[key].detach().to(device=self.device, dtype=torch.float32).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        L = self.cfg.num_layers
+        layers = (hip.LayerWeights * L)()
+        for l in range(L):
+            for f, k in hip.LAYER_KEY.items():
+                setattr(layers[l], f, dev(f"blocks.{l}.{k}"))
+        w = hip.Weights()
+        for f, k in hip.GLOBAL_KEY.items():
+            setattr(w, f, dev(k))
+        w.layers = layers
+        keep.append(layers)
+        return w, keep
+
+    def train_attach(self, state: Mapping[str, torch.Tensor]):
+        """Pack the transposed weight copies the dgrad GEMMs read (after every weight change)."""
+        nb = self.lib.ditto_train_arena_bytes(C.byref(self._ccfg))
+        if getattr(self, "_train_arena", None) is None:
+            self._train_arena = torch.empty(nb, dtype=torch.uint8, device=self.device)
+            self._tapes = {}
+            self._train_ws = None
+        w, keep = self._weights_struct(state)
+        hip.check(self.lib.ditto_train_attach(self.handle, C.byref(w), self._train_arena.data_ptr(), nb, _stream()))
+        torch.cuda.current_stream().synchronize()
+        self._train_attached = True
+
+    def _train_workspace(self, B, N, T):
+        need = self.lib.ditto_train_workspace_bytes(C.byref(self._ccfg), B, N, T)
+        if need == 0:
+            raise hip.DittoHipError(hip.ERR_SHAPE, self.lib.ditto_last_error().decode())
+        if self._train_ws is None or self._train_ws.numel() < need:
+            self._train_ws = None
+            self._train_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._train_ws
+
+    def _take_tape(self, B, N, T):
+        need = self.lib.ditto_tape_bytes(C.byref(self._ccfg), B, N, T)
+        pool = self._tapes.setdefault((B, N, T), [])
+        return pool.pop() if pool else torch.empty(need, dtype=torch.uint8, device=self.device)
+
+    def release_tape(self, tape, B, N, T):
+        self._tapes.setdefault((B, N, T), []).append(tape)
+
+    def train_forward(self, x, text_emb, t, dropout_p: float, seed: int):
+        """DiTTO.forward in train mode: returns (eps fp32 [B,N,d], tape)."""
+        if not getattr(self, "_train_attached", False):
+            raise RuntimeError("train_attach() has not been called for the current weights")
+        xf, text = self._f32(x, "x"), self._f32(text_emb, "text_emb")
+        B, N, d = xf.shape
+        T = text.shape[1]
+        if d != self.cfg.hidden_dim or text.shape[0] != B or text.shape[2] != self.cfg.text_dim:
+            raise ValueError("x / text_emb shapes do not match the model")
+        tt = self._t64(t, B)
+        tape = self._take_tape(B, N, T)
+        ws = self._train_workspace(B, N, T)
+        c, s = self.rope_tables(N)
+        out = torch.empty_like(xf)
+        hip.check(self.lib.ditto_train_forward(self.handle, xf.data_ptr(), text.data_ptr(), tt.data_ptr(), B, N, T,
+                                               c.data_ptr(), s.data_ptr(), float(dropout_p), int(seed), out.data_ptr(),
+                                               tape.data_ptr(), tape.numel(), ws.data_ptr(), ws.numel(), _stream()))
+        return out, tape, xf, tt
+
+    def train_backward(self, state: Mapping[str, torch.Tensor], grad_eps, xf, tt, T: int, tape, dropout_p: float,
+                       seed: int) -> Dict[str, torch.Tensor]:
+        """Backward of train_forward: fp32 gradients keyed by the reference state_dict names (fresh tensors)."""
+        B, N, d = xf.shape
+        g = self._f32(grad_eps, "grad_output")
+        w, keep = self._weights_struct(state)
+        keys = [f"blocks.{l}.{k}" for l in range(self.cfg.num_layers) for k in hip.LAYER_KEY.values()] + \
+               [k for f, k in hip.GLOBAL_KEY.items() if f != "rotary_inv_freq"]
+        sizes = [state[k].numel() for k in keys]
+        offs, total = [], 0
+        for n in sizes:
+            offs.append(total)
+            total += (n + 63) // 64 * 64          # 256-byte aligned slices
+        flat = torch.empty(total, dtype=torch.float32, device=self.device)
+        grads = {k: flat[o:o + n].view(state[k].shape) for k, o, n in zip(keys, offs, sizes)}
+        L = self.cfg.num_layers
+        layers = (hip.LayerGrads * L)()
+        for l in range(L):
+            for f, k in hip.LAYER_KEY.items():
+                setattr(layers[l], f, grads[f"blocks.{l}.{k}"].data_ptr())
+        gs = hip.Grads()
+        for f, k in hip.GLOBAL_KEY.items():
+            if f != "rotary_inv_freq":
+                setattr(gs, f, grads[k].data_ptr())
+        gs.layers = layers
+        ws = self._train_workspace(B, N, T)
+        c, s = self.rope_tables(N)
+        hip.check(self.lib.ditto_train_backward(self.handle, C.byref(w), g.data_ptr(), xf.data_ptr(), tt.data_ptr(), B,
+                                                N, T, c.data_ptr(), s.data_ptr(), float(dropout_p), int(seed),
+                                                tape.data_ptr(), tape.numel(), C.byref(gs), ws.data_ptr(), ws.numel(),
+                                                _stream()))
+        return grads
 
     # ------------------------------------------------------------------ profiling (bench.py)
     def profile_enable(self, on: bool):

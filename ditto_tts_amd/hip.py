@@ -71,8 +71,11 @@ class Weights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in _GLOBAL_FIELDS] + [("layers", C.POINTER(LayerWeights))]
 
 
+# ditto_layer_grads / ditto_grads have the layout of the weight structs (one pointer per state_dict key)
+LayerGrads, Grads = LayerWeights, Weights
+
 # every symbol include/ditto_hip.h declares: name -> (restype, argtypes)
-_vp, _i, _sz, _f = C.c_void_p, C.c_int, C.c_size_t, C.c_float
+_vp, _i, _sz, _f, _u64 = C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.c_uint64
 SYMBOLS = {
     "ditto_abi_version": (_i, []),
     "ditto_last_error": (C.c_char_p, []),
@@ -100,6 +103,20 @@ SYMBOLS = {
     "ditto_code_embed_mean": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ditto_linear_update": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _sz, _vp]),
     "ditto_cfg_combine": (_i, [_vp, _vp, _f, _sz, _vp]),
+    "ditto_train_arena_bytes": (_sz, [C.POINTER(Config)]),
+    "ditto_tape_bytes": (_sz, [C.POINTER(Config), _i, _i, _i]),
+    "ditto_train_workspace_bytes": (_sz, [C.POINTER(Config), _i, _i, _i]),
+    "ditto_train_attach": (_i, [_vp, C.POINTER(Weights), _vp, _sz, _vp]),
+    "ditto_train_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _u64, _vp, _vp, _sz, _vp, _sz, _vp]),
+    "ditto_train_backward": (_i, [_vp, C.POINTER(Weights), _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _u64, _vp, _sz,
+                                  C.POINTER(Grads), _vp, _sz, _vp]),
+    "ditto_layernorm_bwd_scratch_bytes": (_sz, [_i, _i, _i]),
+    "ditto_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
+    "ditto_attention_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ditto_attention_bwd_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i,
+                                      _i, _i, _i, _i, _i, _f, _f, _u64, _i, _vp, _sz, _vp]),
+    "ditto_attention_dropout_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _i,
+                                          _vp, _sz, _vp]),
     "ditto_quantize_rows_fp8": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "ditto_layernorm_fp8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "ditto_gemm_fp8": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -124,7 +141,7 @@ def lib() -> C.CDLL:
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = res, args
-        if l.ditto_abi_version() != 2:
+        if l.ditto_abi_version() != 3:
             raise RuntimeError("libditto_hip.so ABI version mismatch")
         _lib = l
     return _lib

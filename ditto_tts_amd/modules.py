@@ -11,9 +11,12 @@ torch.nn modules are used only as PARAMETER CONTAINERS (so `state_dict()`, `.to(
 reference's checkpoints work unchanged); none of their forward()s is ever called.  There is no CPU or
 eager-PyTorch fallback: a non-CUDA input or a missing libditto_hip.so raises.
 
-Training: the HIP path is forward-only in this round.  Calling forward() with autograd enabled AND
-parameters that require grad raises NotImplementedError (SURVEY.md §8f row 1 — backward kernels — is the
-next row); wrap inference in torch.no_grad() (the reference's sampler does, SpeechGenerator.py:130,149).
+Training: `DiTTO.forward` under autograd runs ditto_train_forward / ditto_train_backward
+through a torch.autograd.Function, so the reference's training closure (src/TrainDiTTO.py:55-95) drives the HIP
+path unchanged: `model.train()`, `loss.backward()`, any torch optimizer over `model.parameters()`.  Gradients
+reach every live parameter; `blocks.i.attn.out_proj.*` get none (dead in the reference too), and neither do `x`
+and `text_emb` (frozen-encoder outputs in the reference) — asking for those raises.  The standalone
+`DiT` / `GlobalAdaLN` modules stay forward-only.
 """
 from __future__ import annotations
 
@@ -38,8 +41,35 @@ def _require_cuda(t: torch.Tensor, what: str):
 def _refuse_autograd(module: nn.Module):
     if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters(recurse=True)):
         raise NotImplementedError(
-            "ditto_tts_amd: the HIP DiT path is forward-only (backward kernels are SURVEY.md §8f row 1, not built "
-            "yet). Call under torch.no_grad() / torch.inference_mode().")
+            "ditto_tts_amd: the standalone DiT / GlobalAdaLN modules are forward-only (the backward pass is built for "
+            "the whole model: train through DiTTO.forward). Call under torch.no_grad() / torch.inference_mode().")
+
+
+class _DiTTOTrainFn(torch.autograd.Function):
+    """DiTTO.forward with a tape (ditto_train_forward) and its backward (ditto_train_backward)."""
+
+    @staticmethod
+    def forward(ctx, model, x, text_emb, t, dropout_p, seed, keys, *params):
+        eng = model.engine(x.device, train=True)
+        out, tape, xf, tt = eng.train_forward(x, text_emb.to(x.device), t, dropout_p, seed)
+        ctx.model, ctx.eng, ctx.tape, ctx.xf, ctx.tt = model, eng, tape, xf, tt
+        ctx.T, ctx.dropout_p, ctx.seed, ctx.keys = text_emb.shape[1], dropout_p, seed, keys
+        ctx.sig = model._watch.sig
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        model, eng = ctx.model, ctx.eng
+        if model._watch.sig != ctx.sig or model._watch.changed(model._path_tensors()):
+            raise RuntimeError("DiTTO parameters changed between forward and backward")
+        if ctx.tape is None:
+            raise RuntimeError("backward through the same DiTTO.forward twice (the activation tape was released)")
+        sd = {k: v for k, v in model.state_dict(keep_vars=True).items() if not k.startswith("nac.")}
+        grads = eng.train_backward(sd, grad_out, ctx.xf, ctx.tt, ctx.T, ctx.tape, ctx.dropout_p, ctx.seed)
+        B, N, _ = ctx.xf.shape
+        eng.release_tape(ctx.tape, B, N, ctx.T)
+        ctx.tape = None
+        return (None, None, None, None, None, None, None) + tuple(grads.get(k) for k in ctx.keys)
 
 
 class _ParamWatch:
@@ -241,8 +271,9 @@ class DiTTO(nn.Module):
     def _path_tensors(self):
         return [p for n, p in self.named_parameters() if not n.startswith("nac.")] + [self.rotary.inv_freq]
 
-    def engine(self, device=None) -> DenoiseEngine:
-        """The packed HIP model for the current parameters (rebuilt lazily after they change)."""
+    def engine(self, device=None, train: bool = False) -> DenoiseEngine:
+        """The packed HIP model for the current parameters (rebuilt lazily after they change); `train` also packs
+        the transposed copies the backward's dgrad GEMMs read."""
         device = torch.device(device) if device is not None else self.proj_in.weight.device
         if device.type != "cuda":
             raise RuntimeError("DiTTO parameters are not on a CUDA (ROCm) device: call .to('cuda') first; "
@@ -253,9 +284,14 @@ class DiTTO(nn.Module):
             self._engine = DenoiseEngine(self.cfg, sd, device)
             self._watch.changed(tensors)
             self._cond_key = None
+            self._train_packed = False
         elif self._watch.changed(tensors):
             self._engine.repack({k: v for k, v in self.state_dict().items() if not k.startswith("nac.")})
             self._cond_key = None
+            self._train_packed = False
+        if train and not getattr(self, "_train_packed", False):
+            self._engine.train_attach({k: v for k, v in self.state_dict().items() if not k.startswith("nac.")})
+            self._train_packed = True
         return self._engine
 
     def text_cond(self, text_emb: torch.Tensor, N_hint: int = 1) -> TextCond:
@@ -273,7 +309,20 @@ class DiTTO(nn.Module):
         """x [B,N,d] noisy latents, text_emb [B,T,text_dim], t [B] long -> predicted noise [B,N,d]
         (reference src/model/DiTTO.py:66-94)."""
         _require_cuda(x, "x")
-        _refuse_autograd(self)
+        if torch.is_grad_enabled() and (x.requires_grad or text_emb.requires_grad):
+            raise NotImplementedError("ditto_tts_amd: gradients with respect to x / text_emb are not produced (the "
+                                      "reference feeds frozen-encoder outputs, src/TrainDiTTO.py:66-73); detach them")
+        named = [(n, p) for n, p in self.named_parameters() if not n.startswith("nac.") and ".attn.out_proj." not in n]
+        if torch.is_grad_enabled() and any(p.requires_grad for _, p in named):
+            if self.cfg.fp8_linear:
+                raise NotImplementedError("ditto_tts_amd: training with fp8_linear=True is not supported")
+            # cross-attention dropout is active in train mode only (nn.MultiheadAttention(dropout=0.1),
+            # reference src/components/DiT.py:90-91); its mask seed comes from torch's CPU generator
+            p_drop = float(self.blocks[0].cross_attn.dropout) if self.training else 0.0
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p_drop > 0 else 0
+            keys = tuple(n for n, _ in named)
+            out = _DiTTOTrainFn.apply(self, x, text_emb, t, p_drop, seed, keys, *[p for _, p in named])
+            return out if x.dtype == torch.float32 else out.to(x.dtype)
         eng = self.engine(x.device)
         cond = self.text_cond(text_emb.to(x.device), x.shape[1])
         out = eng.forward(x, cond, t)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DITTO_ABI_VERSION 2
+#define DITTO_ABI_VERSION 3
 
 typedef enum ditto_status {
     DITTO_OK = 0,
@@ -221,6 +221,72 @@ int ditto_code_embed_mean(const float* table, const int64_t* codes, float* out, 
 int ditto_linear_update(float* x, const float* eps, const float* noise, const float* a, const float* ce,
                         const float* cz, int B, size_t elems_per_utt, ditto_stream_t stream);
 int ditto_cfg_combine(const float* eps2, float* out, float w, size_t elems_half, ditto_stream_t stream);
+
+/* ---- training: the backward of DiTTO.forward, so that the reference's training closure
+ * (src/TrainDiTTO.py:55-95: model.train(); loss = mse(model(x_t, text, t), noise); loss.backward()) runs on this
+ * library.  Gradients are fp32, in the reference's parameter layout (one pointer per state_dict key, as
+ * ditto_weights); bf16 operands / fp32 accumulation inside, deterministic (no atomics).  No gradient is produced
+ * for x, text_emb (both come from frozen encoders in the reference, TrainDiTTO.py:66-73) or for the dead
+ * blocks.i.attn.out_proj.* (never used by the forward, src/components/DiT.py:134-139).
+ *
+ * ditto_train_attach : packs the transposed bf16 weight copies the dgrad GEMMs read (dX = dY W) into a caller-owned
+ *                      arena; call after ditto_model_create, i.e. after every optimizer step.
+ * ditto_train_forward: DiTTO.forward in train mode — as ditto_forward, from raw text_emb (no cached cond), keeping the
+ *                      activations in `tape`; dropout_p is nn.MultiheadAttention's cross-attention dropout
+ *                      (src/components/DiT.py:90-91), its mask a counter-based hash of (seed, layer, b, h, i, j).
+ * ditto_train_backward: consumes the tape, writes every gradient of `grads` (overwrites, does not accumulate). */
+typedef struct ditto_layer_grads {
+    float* norm1_weight;  float* norm1_bias;
+    float* attn_in_proj_weight;  float* attn_in_proj_bias;
+    float* norm2_weight;  float* norm2_bias;
+    float* cross_in_proj_weight; float* cross_in_proj_bias;
+    float* cross_out_proj_weight; float* cross_out_proj_bias;
+    float* norm3_weight;  float* norm3_bias;
+    float* mlp_fc1_weight; float* mlp_fc1_bias;
+    float* gate_weight;    float* gate_bias;
+    float* mlp_fc2_weight; float* mlp_fc2_bias;
+} ditto_layer_grads;
+typedef struct ditto_grads {
+    float* t_embedding_weight;
+    float* time_embed_0_weight; float* time_embed_0_bias;
+    float* time_embed_2_weight; float* time_embed_2_bias;
+    float* ada_time_mlp_weight; float* ada_time_mlp_bias;
+    float* ada_text_mlp_weight; float* ada_text_mlp_bias;
+    float* proj_in_weight;  float* proj_in_bias;
+    float* proj_out_weight; float* proj_out_bias;
+    float* unused_rotary_inv_freq;                                       /* a buffer, no gradient; keeps the layout of ditto_weights */
+    const ditto_layer_grads* layers;                                     /* HOST array [num_layers] */
+} ditto_grads;
+size_t ditto_train_arena_bytes(const ditto_config* cfg);
+size_t ditto_tape_bytes(const ditto_config* cfg, int B, int N, int T);
+size_t ditto_train_workspace_bytes(const ditto_config* cfg, int B, int N, int T);
+int ditto_train_attach(ditto_model_t m, const ditto_weights* w, void* train_arena, size_t train_arena_bytes,
+                       ditto_stream_t stream);
+int ditto_train_forward(ditto_model_t m, const float* x, const float* text, const int64_t* t, int B, int N, int T,
+                        const float* rope_cos, const float* rope_sin, float dropout_p, uint64_t seed, float* eps_out,
+                        void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes, ditto_stream_t stream);
+int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* grad_eps, const float* x,
+                         const int64_t* t, int B, int N, int T, const float* rope_cos, const float* rope_sin,
+                         float dropout_p, uint64_t seed, const void* tape, size_t tape_bytes, const ditto_grads* grads,
+                         void* workspace, size_t workspace_bytes, ditto_stream_t stream);
+/* building blocks of the backward, exported for unit parity tests:
+ * ditto_layernorm_bwd: dx_accum fp32 [M,d] += LN'(dy); dgamma_dbeta fp32 [groups, 2d] (rows_per_group * groups = M;
+ *   gamma may be NULL = ones; dx_accum or dgamma_dbeta may be NULL); scratch >= ditto_layernorm_bwd_scratch_bytes.
+ * ditto_attention_bwd_bf16: dq/dk/dv bf16 from dout bf16 (layouts as ditto_attention_bf16), dropout as above. */
+size_t ditto_layernorm_bwd_scratch_bytes(int rows_per_group, int groups, int d);
+int ditto_layernorm_bwd(const float* dy, const float* x, const float* gamma, float* dx_accum, float* dgamma_dbeta,
+                        void* scratch, size_t scratch_bytes, int rows_per_group, int groups, int d,
+                        ditto_stream_t stream);
+size_t ditto_attention_bwd_workspace_bytes(int Sq, int Skv, int dh);
+int ditto_attention_bwd_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* dout,
+                             int lddo, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int B, int H, int Sq,
+                             int Skv, int dh, float scale, float dropout_p, uint64_t seed, int layer, void* workspace,
+                             size_t workspace_bytes, ditto_stream_t stream);
+/* forward twin for the tests of the dropout path: as ditto_attention_bf16 on the GEMM-composed path with dropout */
+int ditto_attention_dropout_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out,
+                                 int ldo, int B, int H, int Sq, int Skv, int dh, float scale, float dropout_p,
+                                 uint64_t seed, int layer, void* workspace, size_t workspace_bytes,
+                                 ditto_stream_t stream);
 
 /* fp8 building blocks, exported for unit parity tests (all e4m3, OCP):
  * ditto_quantize_rows_fp8: fp32 [rows, cols] -> fp8 [rows, cols] + scales fp32 [rows] (amax/448 per row);

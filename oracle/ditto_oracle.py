@@ -86,7 +86,7 @@ def global_adaln(sd: Mapping[str, Tensor], x: Tensor, time_emb: Tensor, text_emb
 # --------------------------------------------------------------------------- #
 def dit_block(sd: Mapping[str, Tensor], prefix: str, x: Tensor, text_emb: Tensor, rotary_pos: Tensor,
               num_heads: int, taps: Optional[Dict[str, Tensor]] = None,
-              dropout_p: float = 0.0) -> Tensor:
+              dropout_p: float = 0.0, drop_mask: Optional[Tensor] = None) -> Tensor:
     B, N, d = x.shape
     dh = d // num_heads
     T = text_emb.shape[1]
@@ -123,7 +123,9 @@ def dit_block(sd: Mapping[str, Tensor], prefix: str, x: Tensor, text_emb: Tensor
     vc = vc.view(B, T, num_heads, dh).permute(0, 2, 1, 3)
     qc = qc * math.sqrt(1.0 / float(dh))                 # functional.py: q_scaled = q * sqrt(1/E_head)
     ac = torch.softmax(torch.matmul(qc, kc.transpose(-2, -1)), dim=-1)   # no key-padding mask (SURVEY B-4)
-    if dropout_p > 0.0:
+    if drop_mask is not None:                            # train mode with a GIVEN keep-mask [B,H,N,T] (hash_dropout_mask)
+        ac = ac * drop_mask * (1.0 / (1.0 - dropout_p))
+    elif dropout_p > 0.0:
         ac = F.dropout(ac, p=dropout_p)                  # only in train mode (DiT.py:90-91)
     oc = torch.matmul(ac, vc).permute(0, 2, 1, 3).reshape(B, N, d)
     oc = F.linear(oc, sd[prefix + "cross_attn.out_proj.weight"], sd[prefix + "cross_attn.out_proj.bias"])
@@ -152,7 +154,10 @@ def time_embedding(sd: Mapping[str, Tensor], t: Tensor) -> Tensor:
 
 
 def ditto_forward(sd: Mapping[str, Tensor], num_layers: int, num_heads: int, x: Tensor, text_emb: Tensor,
-                  t: Tensor, taps: Optional[Dict[str, Tensor]] = None) -> Tensor:
+                  t: Tensor, taps: Optional[Dict[str, Tensor]] = None, dropout_p: float = 0.0,
+                  dropout_seed: Optional[int] = None) -> Tensor:
+    """dropout_p > 0 with dropout_seed: train-mode forward whose cross-attention keep-masks are the build's
+    counter-based hash (hash_dropout_mask) instead of torch's Philox draw, so values can be compared."""
     temb = time_embedding(sd, t)                                                      # :75-76
     rotary_pos = rotary_table(sd["rotary.inv_freq"], x.shape[1])                      # :79-80
     x_skip = F.linear(x, sd["proj_in.weight"], sd["proj_in.bias"])                    # :83 (RAW input)
@@ -160,7 +165,10 @@ def ditto_forward(sd: Mapping[str, Tensor], num_layers: int, num_heads: int, x: 
     if taps is not None:
         taps["after_adaln"] = h
     for l in range(num_layers):                                                       # :89-90
-        h = dit_block(sd, f"blocks.{l}.", h, text_emb, rotary_pos, num_heads, taps)
+        mask = None
+        if dropout_p > 0.0 and dropout_seed is not None:
+            mask = hash_dropout_mask(dropout_seed, l, x.shape[0], num_heads, x.shape[1], text_emb.shape[1], dropout_p)
+        h = dit_block(sd, f"blocks.{l}.", h, text_emb, rotary_pos, num_heads, taps, dropout_p, mask)
     return x_skip + F.linear(h, sd["proj_out.weight"], sd["proj_out.bias"])           # :93-94
 
 
@@ -279,3 +287,32 @@ def strided_timesteps(timesteps: int, n_steps: int):
     """n_steps descending timesteps T-1 ... spaced evenly (ends at the smallest multiple of the stride)."""
     stride = timesteps / n_steps
     return [int(round(timesteps - 1 - i * stride)) for i in range(n_steps)]
+
+
+# --------------------------------------------------------------------------- #
+# train-mode dropout mask of the build (NOT in the reference: torch draws its mask from Philox; the HIP path
+# draws it from this counter-based hash so the backward can regenerate it — csrc/train.hip drop_stream/drop_keep)
+# --------------------------------------------------------------------------- #
+def _lowbias32(h):
+    import numpy as np
+    h = h.astype(np.uint64)
+    h ^= h >> np.uint64(16); h = (h * np.uint64(0x7FEB352D)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(15); h = (h * np.uint64(0x846CA68B)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(16)
+    return h
+
+
+def hash_dropout_mask(seed: int, layer: int, B: int, H: int, Sq: int, Skv: int, p: float) -> Tensor:
+    """keep-mask float32 [B, H, Sq, Skv] in {0, 1}: keep iff hash(stream(seed, layer, b*H+h), i, j) >= p * 2^32."""
+    import numpy as np
+    M32 = np.uint64(0xFFFFFFFF)
+    thr = np.uint64(min(int(float(np.float32(p)) * 4294967296.0), 0xFFFFFFFF))
+    lo, hi = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    bh = np.arange(B * H, dtype=np.uint64)
+    inner = _lowbias32((hi + np.uint64(layer) * np.uint64(0x632BE5AB) + bh * np.uint64(0x9E3779B1)) & M32)
+    stream = _lowbias32(lo ^ inner)                                                   # [B*H]
+    i = np.arange(Sq, dtype=np.uint64)[:, None]
+    j = np.arange(Skv, dtype=np.uint64)[None, :]
+    ctr = (i * np.uint64(0x9E3779B1) + j * np.uint64(0x85EBCA6B)) & M32               # [Sq, Skv]
+    h = _lowbias32(stream[:, None, None] ^ ctr[None])
+    return torch.from_numpy((h >= thr).astype(np.float32)).view(B, H, Sq, Skv)

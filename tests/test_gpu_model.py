@@ -221,14 +221,13 @@ def test_c5_fp8_linear_against_oracle():
     assert r8 > r16          # the fp8 path really ran
 
 
-def test_training_surface_fails_loudly():
-    cfg = DiTTOConfig(128, 1, 2, 64, 128, 20)
-    m = build(cfg, 1).train()
-    x, text, t = synthetic_inputs(cfg, 1, 16, 8)
+def test_standalone_blocks_are_forward_only():
+    """DiTTO trains (tests/test_gpu_train.py); the standalone DiT / GlobalAdaLN modules refuse autograd loudly."""
+    from ditto_tts_amd.modules import DiT
+    blk = DiT(128, 2, 64, 128).to(DEV)
+    x = torch.zeros(1, 8, 128, device=DEV)
     with pytest.raises(NotImplementedError, match="forward-only"):
-        m(x.to(DEV), text.to(DEV), t.to(DEV))
-    with torch.no_grad():
-        m(x.to(DEV), text.to(DEV), t.to(DEV))   # no dropout on the HIP path: eval semantics
+        blk(x, x, None, torch.zeros(8, 64))
 
 
 @torch.no_grad()

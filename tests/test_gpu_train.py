@@ -1,0 +1,229 @@
+"""-m gpu parity of the BACKWARD pass through the C-ABI / the nn.Module surface.
+
+Oracle: torch autograd over the fp32 CPU restatement (oracle/ditto_oracle.py) — the reference's own modules under
+autograd are what tests/test_oracle_vs_reference.py pins that restatement to.  Tolerances (stated per test):
+fp32 row kernels 1e-5; bf16-operand attention backward 2e-2; whole-model parameter gradients rel-L2 <= 3e-2 per
+tensor (bf16 operands, fp32 accumulation, bf16-rounded activation gradients between GEMMs).
+Train-mode dropout: the HIP path draws the cross-attention keep-mask from a counter-based hash, restated in the
+oracle (hash_dropout_mask), so train-mode VALUES are compared, not only structure."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from ditto_tts_amd import hip
+from ditto_tts_amd.config import DiTTOConfig
+from ditto_tts_amd.modules import DiTTO
+from ditto_tts_amd.synth import hash_normal, synthetic_inputs, synthetic_state_dict
+from gpu_util import bf16, max_abs, rel_l2, stream
+from oracle import ditto_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+# ----------------------------------------------------------------------------------------------- row kernels
+@pytest.mark.parametrize("M,d,groups", [(37, 64, 1), (300, 768, 1), (96, 256, 4), (50, 2048, 2), (4096, 768, 8)])
+def test_layernorm_backward_vs_autograd(M, d, groups):
+    lib = hip.lib()
+    x = (hash_normal((M, d), "x", M) * 1.7 + 0.3).requires_grad_(True)
+    gamma = (1 + 0.2 * hash_normal((d,), "g", d)).requires_grad_(True)
+    beta = (0.1 * hash_normal((d,), "b", d)).requires_grad_(True)
+    dy = hash_normal((M, d), "dy", M + 1)
+    F.layer_norm(x, (d,), gamma, beta, 1e-5).backward(dy)
+    rpg = M // groups
+    xd, dyd, gd = x.detach().to(DEV), dy.to(DEV), gamma.detach().to(DEV)
+    acc0 = hash_normal((M, d), "acc", 3).to(DEV)
+    acc = acc0.clone()
+    dgb = torch.empty(groups, 2 * d, device=DEV)
+    nb = lib.ditto_layernorm_bwd_scratch_bytes(rpg, groups, d)
+    scratch = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    hip.check(lib.ditto_layernorm_bwd(dyd.data_ptr(), xd.data_ptr(), gd.data_ptr(), acc.data_ptr(), dgb.data_ptr(),
+                                      scratch.data_ptr(), nb, rpg, groups, d, stream()))
+    assert rel_l2(acc - acc0, x.grad) < 1e-5
+    assert rel_l2(dgb[:, :d].sum(0), gamma.grad) < 1e-5 and rel_l2(dgb[:, d:].sum(0), beta.grad) < 1e-5
+    if groups > 1:   # per-group partials (the GlobalAdaLN reduction): group g = rows [g*rpg, (g+1)*rpg)
+        xh = F.layer_norm(x.detach(), (d,), None, None, 1e-5)
+        want = (dy * xh).view(groups, rpg, d).sum(1)
+        assert rel_l2(dgb[:, :d], want) < 1e-5
+    # gamma = NULL (ones), dx only
+    x2 = x.detach().clone().requires_grad_(True)
+    F.layer_norm(x2, (d,), None, None, 1e-5).backward(dy)
+    acc = torch.zeros(M, d, device=DEV)
+    hip.check(lib.ditto_layernorm_bwd(dyd.data_ptr(), xd.data_ptr(), None, acc.data_ptr(), None, None, 0, rpg, groups,
+                                      d, stream()))
+    assert rel_l2(acc, x2.grad) < 1e-5
+
+
+def _attn_ref(q, k, v, scale, mask=None, p=0.0):
+    """fp32 reference on [B,H,S,dh] tensors; mask = keep-mask [B,H,Sq,Skv]"""
+    a = torch.softmax(torch.matmul(q, k.transpose(-2, -1)) * scale, dim=-1)
+    if mask is not None:
+        a = a * mask / (1.0 - p)
+    return torch.matmul(a, v)
+
+
+def _heads(t, B, S, H, dh):
+    return t.view(B, S, H, dh).permute(0, 2, 1, 3)
+
+
+@pytest.mark.parametrize("B,H,Sq,Skv,dh,p", [(1, 2, 64, 64, 64, 0.0), (2, 2, 100, 72, 64, 0.1), (1, 1, 48, 80, 256, 0.1),
+                                              (2, 3, 130, 130, 64, 0.0)])
+def test_attention_dropout_forward_and_backward_vs_autograd(B, H, Sq, Skv, dh, p):
+    """bf16 operands: compare against fp32 autograd on the SAME bf16-rounded q/k/v/dO.  Tolerance 2e-2 rel-L2
+    (P and dS are rounded to bf16 between the two products)."""
+    lib = hip.lib()
+    d = H * dh
+    seed, layer = 0x1234567890ABCDEF, 3
+    q = bf16(hash_normal((B, Sq, d), "q", 1)).float().requires_grad_(True)
+    k = bf16(hash_normal((B, Skv, d), "k", 2)).float().requires_grad_(True)
+    v = bf16(hash_normal((B, Skv, d), "v", 3)).float().requires_grad_(True)
+    do = bf16(hash_normal((B, Sq, d), "do", 4)).float()
+    scale = dh ** -0.5
+    mask = O.hash_dropout_mask(seed, layer, B, H, Sq, Skv, p) if p > 0 else None
+    out = _attn_ref(_heads(q, B, Sq, H, dh), _heads(k, B, Skv, H, dh), _heads(v, B, Skv, H, dh), scale, mask, p)
+    out = out.permute(0, 2, 1, 3).reshape(B, Sq, d)
+    out.backward(do)
+    qd, kd, vd, dod = (bf16(z.detach()).to(DEV) for z in (q, k, v, do))
+    nb = lib.ditto_attention_bwd_workspace_bytes(Sq, Skv, dh)
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    o = torch.empty(B, Sq, d, dtype=torch.bfloat16, device=DEV)
+    hip.check(lib.ditto_attention_dropout_bf16(qd.data_ptr(), d, kd.data_ptr(), d, vd.data_ptr(), d, o.data_ptr(), d,
+                                               B, H, Sq, Skv, dh, scale, p, seed, layer, ws.data_ptr(), nb, stream()))
+    assert rel_l2(o.float(), out) < 1.5e-2
+    dq = torch.empty_like(qd); dk = torch.empty_like(kd); dv = torch.empty_like(vd)
+    hip.check(lib.ditto_attention_bwd_bf16(qd.data_ptr(), d, kd.data_ptr(), d, vd.data_ptr(), d, dod.data_ptr(), d,
+                                           dq.data_ptr(), d, dk.data_ptr(), d, dv.data_ptr(), d, B, H, Sq, Skv, dh,
+                                           scale, p, seed, layer, ws.data_ptr(), nb, stream()))
+    for name, got, want in (("dq", dq, q.grad), ("dk", dk, k.grad), ("dv", dv, v.grad)):
+        r = rel_l2(got.float(), want)
+        assert r < 2e-2, f"{name}: rel-L2 {r:.3e}"
+
+
+# ----------------------------------------------------------------------------------------------- whole model
+def _build(cfg, seed):
+    m = DiTTO(cfg.hidden_dim, cfg.num_layers, cfg.num_heads, cfg.time_dim, cfg.text_dim, cfg.diffusion_steps)
+    m.load_state_dict(synthetic_state_dict(cfg, seed))
+    return m.to(DEV)
+
+
+def _oracle_grads(cfg, seed, x, text, t, target, p=0.0, drop_seed=None):
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in synthetic_state_dict(cfg, seed).items()}
+    out = O.ditto_forward(sd, cfg.num_layers, cfg.num_heads, x, text, t, dropout_p=p, dropout_seed=drop_seed)
+    loss = F.mse_loss(out, target)
+    loss.backward()
+    return out.detach(), float(loss), {k: v.grad for k, v in sd.items() if v.requires_grad}
+
+
+def _check_grads(m, want, tol):
+    worst = (0.0, "")
+    for name, p in m.named_parameters():
+        if ".attn.out_proj." in name:
+            assert p.grad is None, f"{name}: the reference never uses it, so it must get no gradient"
+            assert want[name] is None
+            continue
+        assert p.grad is not None, f"{name}: no gradient"
+        r = rel_l2(p.grad, want[name])
+        worst = max(worst, (r, name))
+        assert r < tol, f"{name}: rel-L2 {r:.3e}"
+    return worst
+
+
+@pytest.mark.parametrize("cfg,B,N,T", [
+    (DiTTOConfig(128, 2, 2, 64, 128, 20), 2, 48, 40),          # d_h = 64: fused forward attention
+    (DiTTOConfig(256, 1, 1, 64, 256, 20), 1, 40, 24),          # ONE head, d_h = 256 (the shipped config's shape class)
+    (DiTTOConfig(256, 3, 4, 256, 256, 50), 3, 100, 72),        # ragged N / T, 3 layers
+])
+def test_parameter_gradients_vs_oracle_autograd(cfg, B, N, T):
+    """eval-mode forward under autograd (no dropout): every live parameter's gradient vs fp32 autograd of the
+    oracle.  Tolerance rel-L2 <= 3e-2 per tensor."""
+    x, text, t = synthetic_inputs(cfg, B, N, T, seed=7)
+    t[0] = t[-1]                                       # duplicate timestep rows: t_embedding grads must accumulate
+    target = hash_normal((B, N, cfg.hidden_dim), "noise", 9)
+    want_out, want_loss, want = _oracle_grads(cfg, 4, x, text, t, target)
+    m = _build(cfg, 4).eval()
+    out = m(x.to(DEV), text.to(DEV), t.to(DEV))
+    assert out.requires_grad and rel_l2(out, want_out) < 2e-2
+    loss = F.mse_loss(out, target.to(DEV))
+    loss.backward()
+    assert abs(float(loss) - want_loss) < 2e-2 * want_loss
+    _check_grads(m, want, 3e-2)
+
+
+def test_train_mode_dropout_values_and_gradients_vs_oracle():
+    """model.train(): cross-attention dropout p = 0.1 with the hashed mask; forward values and gradients."""
+    cfg = DiTTOConfig(128, 2, 2, 64, 128, 20)
+    B, N, T = 2, 64, 48
+    x, text, t = synthetic_inputs(cfg, B, N, T, seed=8)
+    target = hash_normal((B, N, 128), "noise", 10)
+    torch.manual_seed(77)
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())   # what DiTTO.forward will draw
+    want_out, want_loss, want = _oracle_grads(cfg, 5, x, text, t, target, p=0.1, drop_seed=seed)
+    nodrop_out, _, _ = _oracle_grads(cfg, 5, x, text, t, target)
+    m = _build(cfg, 5).train()
+    torch.manual_seed(77)
+    out = m(x.to(DEV), text.to(DEV), t.to(DEV))
+    assert rel_l2(out, want_out) < 2e-2
+    assert rel_l2(out, nodrop_out) > 2 * rel_l2(out, want_out)        # the mask really was applied
+    F.mse_loss(out, target.to(DEV)).backward()
+    _check_grads(m, want, 3e-2)
+    # same seed -> bit-identical, another seed -> different
+    torch.manual_seed(77)
+    assert torch.equal(m(x.to(DEV), text.to(DEV), t.to(DEV)), out)
+    torch.manual_seed(78)
+    assert not torch.equal(m(x.to(DEV), text.to(DEV), t.to(DEV)), out)
+
+
+def test_training_closure_like_the_reference():
+    """The loop of reference src/TrainDiTTO.py:55-95 (q_sample -> forward -> MSE -> backward -> AdamW step) on the
+    HIP path against the same loop on the oracle: losses agree step by step and go down."""
+    cfg = DiTTOConfig(128, 2, 2, 64, 128, 20)
+    B, N, T, steps = 2, 32, 32, 4
+    m = _build(cfg, 6).eval()            # eval: no dropout, so both loops see the same function
+    opt = torch.optim.AdamW([p for n, p in m.named_parameters()], lr=2e-3)
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in synthetic_state_dict(cfg, 6).items()}
+    live = [v for k, v in sd.items() if v.requires_grad and ".attn.out_proj." not in k and k != "alphas_cumprod"]
+    opt_o = torch.optim.AdamW(live, lr=2e-3)
+    losses, losses_o = [], []
+    for i in range(steps):
+        x0 = hash_normal((B, N, 128), f"x0{i}", 1); noise = hash_normal((B, N, 128), f"nz{i}", 2)
+        text = hash_normal((B, T, 128), f"tx{i}", 3); t = torch.tensor([3 + i, 17 - i])
+        xt = m.q_sample(x0.to(DEV), t.to(DEV), noise.to(DEV))
+        loss = F.mse_loss(m(xt, text.to(DEV), t.to(DEV)), noise.to(DEV))
+        opt.zero_grad(); loss.backward(); opt.step()
+        losses.append(float(loss))
+        xt_o = O.q_sample(sd["alphas_cumprod"], x0, t, noise)
+        loss_o = F.mse_loss(O.ditto_forward(sd, 2, 2, xt_o, text, t), noise)
+        opt_o.zero_grad(); loss_o.backward(); opt_o.step()
+        losses_o.append(float(loss_o))
+    for a, b in zip(losses, losses_o):
+        assert abs(a - b) < 3e-2 * b, (losses, losses_o)
+    # the same batch again after the updates: lower loss than before them
+    with torch.no_grad():
+        again = float(F.mse_loss(m(xt, text.to(DEV), t.to(DEV)), noise.to(DEV)))
+    assert again < losses[-1]
+
+
+def test_training_surface_contract():
+    cfg = DiTTOConfig(128, 1, 2, 64, 128, 20)
+    m = _build(cfg, 1).train()
+    x, text, t = (z.to(DEV) for z in synthetic_inputs(cfg, 1, 16, 8))
+    with pytest.raises(NotImplementedError, match="x / text_emb"):
+        m(x.clone().requires_grad_(True), text, t)
+    out = m(x, text, t)
+    out.sum().backward()
+    with pytest.raises(RuntimeError):
+        out.sum().backward()                            # the tape was released
+    # frozen model: plain inference path even with grad mode on
+    for p in m.parameters():
+        p.requires_grad_(False)
+    assert not m(x, text, t).requires_grad
+    # gradient accumulation over two micro-batches == sum of the two gradients
+    m2 = _build(cfg, 1).eval()
+    a = m2(x, text, t).square().mean(); a.backward()
+    g1 = m2.proj_out.weight.grad.clone()
+    b = m2(x * 0.5, text, t).square().mean(); b.backward()
+    m3 = _build(cfg, 1).eval()
+    m3(x * 0.5, text, t).square().mean().backward()
+    assert torch.allclose(m2.proj_out.weight.grad, g1 + m3.proj_out.weight.grad, rtol=1e-5, atol=1e-7)
