@@ -48,6 +48,9 @@ struct AttnParams {
     const float* resid_in;
     int B, H, Sq, Skv, nqb;
     float scale_log2;  // scale * log2(e)
+    // training forward (TRAIN instantiations only)
+    float* lse;                    // [B, H, Sq] log2-domain log-sum-exp: m * scale_log2 + log2(l)
+    unsigned drop_thr; float keep_scale; unsigned seed_lo, seed_hi; int layer;
 };
 
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
@@ -67,7 +70,7 @@ constexpr float RESCALE_THR_LOG2 = 8.0f;
 // __launch_bounds__(256, 2): 2 waves per SIMD => a 256-register budget, so the MFMA accumulators (S^T, O^T: 64
 // registers) stay in VGPRs.  With the default budget hipcc parks them in AGPRs and moves all 64 through
 // v_accvgpr_read/write around every softmax (127 extra VALU per tile, as much as the softmax itself).
-template <bool RESID, bool DMA, bool PFV>
+template <bool RESID, bool DMA, bool PFV, bool TRAIN = false>
 __global__ __launch_bounds__(256, 2) void attn64_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KV_TILE_BYTES];  // [buf][K|V]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -148,6 +151,8 @@ __global__ __launch_bounds__(256, 2) void attn64_kernel(AttnParams p) {
     for (int i = 0; i < 16; ++i) { ot[0][i] = 0.f; ot[1][i] = 0.f; }
     float m_run = -1e30f, l_run = 0.f;
     const float c = p.scale_log2;
+    unsigned dstream = 0;
+    if constexpr (TRAIN) dstream = drop_stream(p.seed_lo, p.seed_hi, p.layer, bh);
 
     const int nkt = (p.Skv + KBLK - 1) / KBLK;
     if constexpr (DMA) {
@@ -233,6 +238,16 @@ __global__ __launch_bounds__(256, 2) void attn64_kernel(AttnParams p) {
                 e[j] = __builtin_amdgcn_exp2f(st[s2 >> 1][8 * (s2 & 1) + j] * c - mc);
                 psum += e[j];
             }
+            if constexpr (TRAIN) {   // dropout on the probabilities; the row sum l stays that of the full softmax
+                if (p.drop_thr) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int rr = 8 * (s2 & 1) + j;
+                        const int key = kt * KBLK + (s2 >> 1) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * hh;
+                        e[j] = drop_keep(dstream, qrow, key, p.drop_thr) ? e[j] * p.keep_scale : 0.f;
+                    }
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) pf[s2][j] = (bf16)e[j];
         }
@@ -272,6 +287,9 @@ __global__ __launch_bounds__(256, 2) void attn64_kernel(AttnParams p) {
     const float inv = 1.0f / l_tot;
     if (!qvalid) return;
     const size_t grow = (size_t)b * p.Sq + qrow;
+    if constexpr (TRAIN) {
+        if (p.lse && hh == 0) p.lse[(size_t)bh * p.Sq + qrow] = m_run * c + __builtin_amdgcn_logf(l_tot);
+    }
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -559,7 +577,6 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     if (a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Skv <= 0) return hipErrorInvalidValue;
     const float LOG2E = 1.4426950408889634f;
     if (a.dh == DH && !a.force_generic) {
-        if (a.dropout_p > 0.f) return hipErrorInvalidValue;   // the fused kernel has no dropout: use force_generic
         if ((a.ldq | a.ldk | a.ldv) % 8) return hipErrorInvalidValue;
         AttnParams p;
         p.q = (const bf16*)a.q; p.ldq = a.ldq; p.k = (const bf16*)a.k; p.ldk = a.ldk;
@@ -567,6 +584,15 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
         p.resid = a.resid_f32; p.ldr = a.ldr; p.resid_in = a.resid_in ? a.resid_in : a.resid_f32; p.B = a.B; p.H = a.H; p.Sq = a.Sq; p.Skv = a.Skv;
         p.nqb = (a.Sq + QBLK - 1) / QBLK;
         p.scale_log2 = a.scale * LOG2E;
+        p.lse = a.lse_out; p.drop_thr = dropout_threshold(a.dropout_p);
+        p.keep_scale = p.drop_thr ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
+        p.seed_lo = (unsigned)(a.seed & 0xFFFFFFFFu); p.seed_hi = (unsigned)(a.seed >> 32); p.layer = a.layer;
+        if (a.lse_out || p.drop_thr) {   // training forward: log-sum-exp kept for the backward, dropout
+            const dim3 gridt(p.nqb * a.H * a.B);
+            if (a.resid_f32) hipLaunchKernelGGL((attn64_kernel<true, true, true, true>), gridt, dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((attn64_kernel<false, true, true, true>), gridt, dim3(256), 0, s, p);
+            return hipGetLastError();
+        }
         if ((g_attn_flags & 4) && a.Sq >= 2 * QBLK) {   // two query blocks per wave
             p.nqb = (a.Sq + 2 * QBLK - 1) / (2 * QBLK);
             const dim3 grid2(p.nqb * a.H * a.B);
@@ -658,13 +684,23 @@ BwdWs plan_bwd(int Sq, int Skv, int dh) {
 }
 }  // namespace
 
-size_t attention_train_workspace_bytes(int Sq, int Skv, int dh) {
+size_t attention_train_workspace_bytes(int B, int H, int Sq, int Skv, int dh) {
     const size_t f = generic_fwd_bytes(Sq, Skv, dh), b = plan_bwd(Sq, Skv, dh).total;
-    return f > b ? f : b;
+    const size_t dl = align256((size_t)B * H * Sq * 4);   // fused backward: delta [B, H, Sq]
+    const size_t g = f > b ? f : b;
+    return g > dl ? g : dl;
 }
 
 hipError_t launch_attention_bwd(const AttnBwdArgs& a, hipStream_t s) {
     if (a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Skv <= 0 || a.dh % 64) return hipErrorInvalidValue;
+    if (a.dh == DH && a.lse) {   // fused: delta = rowsum(dO * O) into the workspace, then the two kernels
+        if (!a.workspace || a.workspace_bytes < (size_t)a.B * a.H * a.Sq * 4) return hipErrorInvalidValue;
+        float* delta = (float*)a.workspace;
+        hipError_t e = launch_attention_delta(a.dout, a.lddo, a.o_bf16, a.ldo, a.h_after, a.h_before, a.ldh, delta, a.B,
+                                              a.H, a.Sq, s);
+        if (e != hipSuccess) return e;
+        return launch_attention_bwd64(a, a.lse, delta, s);
+    }
     const BwdWs w = plan_bwd(a.Sq, a.Skv, a.dh);
     if (!a.workspace || a.workspace_bytes < w.total) return hipErrorInvalidValue;
     const int ld = ((a.Skv + 63) / 64) * 64, sqp = ((a.Sq + 63) / 64) * 64;

@@ -76,6 +76,18 @@ DITTO_DEV unsigned pack_fp8x4(float a, float b, float c, float d) {
     return (unsigned)pk;
 }
 
+// Counter-based dropout mask of the training path (train.hip header): keep iff hash(stream, query, key) >= thr.
+DITTO_DEV unsigned lowbias32(unsigned h) {
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return h;
+}
+DITTO_DEV unsigned drop_stream(unsigned seed_lo, unsigned seed_hi, int layer, int bh) {
+    return lowbias32(seed_lo ^ lowbias32(seed_hi + (unsigned)layer * 0x632BE5ABu + (unsigned)bh * 0x9E3779B1u));
+}
+DITTO_DEV bool drop_keep(unsigned stream, int i, int j, unsigned thr) {
+    return lowbias32(stream ^ ((unsigned)i * 0x9E3779B1u + (unsigned)j * 0x85EBCA6Bu)) >= thr;
+}
+
 // Bijective XCD-aware block remap (guide §5 "XCD swizzle must be bijective"): blocks b and b+8
 // share an XCD/L2, so give each XCD a contiguous chunk of the logical tile space.
 DITTO_DEV int xcd_remap(int orig, int nwg) {

@@ -6,7 +6,7 @@
 //   pooled fp32[B,dt] | xcat bf16[M,2d] | hs fp32[3L+1][M,d] (the residual stream after AdaLN, after every
 //   self-attention, cross-attention and MLP segment) | per layer { u1,u2,u3 bf16[M,d] (LayerNorm outputs) |
 //   qkv bf16[M,3d] (RoPE applied) | qc bf16[M,d] | oc bf16[M,d] | pre bf16[M,8d] (fc1|gate pre-activations,
-//   interleaved by 16) | act bf16[M,4d] }.   With 288 GB of HBM nothing is recomputed except the attention
+//   interleaved by 16) | act bf16[M,4d] | lse_self, lse_cross fp32[B,H,N] (head_dim 64 only) }.   With 288 GB of HBM nothing is recomputed except the attention
 //   probabilities: C2 at B = 32 keeps 17 GB.
 // Backward data flow per segment (dh = gradient of the fp32 residual stream, updated in place):
 //   dyb = bf16(dh) -> bias grad = colsum(dh) -> wgrad GEMM (dyb^T x act^T, both transposed to K-contiguous) ->
@@ -24,7 +24,7 @@ inline size_t pad64(size_t x) { return (x + 63) & ~(size_t)63; }
 
 struct TapePlan {
     size_t kv, tmod, text, pooled, xcat, hs, hs_stride;
-    struct L { size_t u1, u2, u3, qkv, qc, oc, pre, act; };
+    struct L { size_t u1, u2, u3, qkv, qc, oc, pre, act, lse_s, lse_c; };
     std::vector<L> layers;
     size_t total;
 };
@@ -41,6 +41,7 @@ TapePlan plan_tape(const ditto_config& c, int B, int N, int T) {
     for (auto& q : p.layers) {
         q.u1 = take(M * d * 2); q.u2 = take(M * d * 2); q.u3 = take(M * d * 2); q.qkv = take(M * 3 * d * 2);
         q.qc = take(M * d * 2); q.oc = take(M * d * 2); q.pre = take(M * 8 * d * 2); q.act = take(M * 4 * d * 2);
+        q.lse_s = take((size_t)B * c.num_heads * N * 4); q.lse_c = take((size_t)B * c.num_heads * N * 4);
     }
     p.total = off;
     return p;
@@ -85,7 +86,8 @@ TrainWsPlan plan_train_ws(const ditto_config& c, int B, int N, int T) {
     w.red = take(red);
     w.dmod = take((size_t)B * 2 * d * 4);
     w.small = take(6 * al((size_t)B * c.time_dim * 4));
-    const size_t a1 = attention_train_workspace_bytes(N, N, (int)dh), a2 = attention_train_workspace_bytes(N, T, (int)dh);
+    const size_t a1 = attention_train_workspace_bytes(B, c.num_heads, N, N, (int)dh);
+    const size_t a2 = attention_train_workspace_bytes(B, c.num_heads, N, T, (int)dh);
     w.attn_bytes = a1 > a2 ? a1 : a2;
     w.attn = take(w.attn_bytes);
     w.total = off;
@@ -203,6 +205,7 @@ int ditto_train_forward(ditto_model_t m, const float* x, const float* text, cons
             a.q = qkv; a.ldq = 3 * d; a.k = qkv + (size_t)d * 2; a.ldk = 3 * d; a.v = qkv + (size_t)2 * d * 2;
             a.ldv = 3 * d; a.resid_f32 = h1; a.resid_in = h0; a.ldr = d; a.B = B; a.H = H; a.Sq = N; a.Skv = N;
             a.dh = dh; a.scale = scale; a.workspace = attn_ws; a.workspace_bytes = wp.attn_bytes;
+            if (dh == 64) a.lse_out = (float*)(tb + q.lse_s);
             HIP_TRY(launch_attention(a, s));
         }
         // ---- cross-attention (dropout on the probabilities in train mode) ----
@@ -219,7 +222,8 @@ int ditto_train_forward(ditto_model_t m, const float* x, const float* text, cons
             a.v = kv + ((size_t)l * 2 * d + d) * 2; a.ldv = L * 2 * d; a.out_bf16 = tb + q.oc; a.ldo = d;
             a.B = B; a.H = H; a.Sq = N; a.Skv = T; a.dh = dh; a.scale = scale;
             a.workspace = attn_ws; a.workspace_bytes = wp.attn_bytes;
-            a.dropout_p = dropout_p; a.seed = seed; a.layer = l; a.force_generic = dropout_p > 0.f;
+            a.dropout_p = dropout_p; a.seed = seed; a.layer = l;
+            if (dh == 64) a.lse_out = (float*)(tb + q.lse_c);
             HIP_TRY(launch_attention(a, s));
         }
         {
@@ -365,6 +369,7 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
             a.dq = big1; a.lddq = d; a.dk = dkv; a.lddk = 2 * d; a.dv = dkv + (size_t)d * 2; a.lddv = 2 * d;
             a.B = B; a.H = H; a.Sq = N; a.Skv = T; a.dh = dhd; a.scale = scale;
             a.dropout_p = dropout_p; a.seed = seed; a.layer = l; a.workspace = attn_ws; a.workspace_bytes = wp.attn_bytes;
+            if (dhd == 64) { a.lse = (const float*)(tb + q.lse_c); a.o_bf16 = tb + q.oc; a.ldo = d; }
             HIP_TRY(launch_attention_bwd(a, s));
         }
         HIP_TRY(launch_colsum_bf16(big1, d, M, d, G.cross_in_proj_bias, red, s));
@@ -385,6 +390,7 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
             a.dq = big1; a.lddq = 3 * d; a.dk = big1 + (size_t)d * 2; a.lddk = 3 * d; a.dv = big1 + (size_t)2 * d * 2;
             a.lddv = 3 * d; a.B = B; a.H = H; a.Sq = N; a.Skv = N; a.dh = dhd; a.scale = scale;
             a.workspace = attn_ws; a.workspace_bytes = wp.attn_bytes;
+            if (dhd == 64) { a.lse = (const float*)(tb + q.lse_s); a.h_after = h1; a.h_before = h0; a.ldh = d; }
             HIP_TRY(launch_attention_bwd(a, s));
         }
         HIP_TRY(launch_rope_inplace(big1, 3 * d, rope_cos, rope_sin, M, N, 2 * d, dhd, s, -1.0f));
@@ -438,21 +444,23 @@ int ditto_layernorm_bwd(const float* dy, const float* x, const float* gamma, flo
     return DITTO_OK;
 }
 
-size_t ditto_attention_bwd_workspace_bytes(int Sq, int Skv, int dh) {
-    if (Sq <= 0 || Skv <= 0 || dh <= 0) return 0;
-    return attention_train_workspace_bytes(Sq, Skv, dh);
+size_t ditto_attention_bwd_workspace_bytes(int B, int H, int Sq, int Skv, int dh) {
+    if (B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0 || dh <= 0) return 0;
+    return attention_train_workspace_bytes(B, H, Sq, Skv, dh);
 }
 int ditto_attention_bwd_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* dout,
-                             int lddo, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int B, int H, int Sq,
-                             int Skv, int dh, float scale, float dropout_p, uint64_t seed, int layer, void* workspace,
-                             size_t workspace_bytes, ditto_stream_t stream) {
+                             int lddo, const void* out, int ldo, const float* lse, void* dq, int lddq, void* dk, int lddk,
+                             void* dv, int lddv, int B, int H, int Sq, int Skv, int dh, float scale, float dropout_p,
+                             uint64_t seed, int layer, void* workspace, size_t workspace_bytes, ditto_stream_t stream) {
     if (!q || !k || !v || !dout || !dq || !dk || !dv || !workspace)
         return fail(DITTO_ERR_ARG, "null pointer to ditto_attention_bwd_bf16");
     if (dh % 64) return fail(DITTO_ERR_SHAPE, "head_dim must be a multiple of 64");
     if ((ldq | ldk | ldv | lddo | lddq | lddk | lddv) % 8) return fail(DITTO_ERR_SHAPE, "row strides must be multiples of 8");
-    if (workspace_bytes < attention_train_workspace_bytes(Sq, Skv, dh))
+    if (workspace_bytes < attention_train_workspace_bytes(B, H, Sq, Skv, dh))
         return fail(DITTO_ERR_SIZE, "attention backward workspace too small");
+    if (lse && (dh != 64 || !out)) return fail(DITTO_ERR_ARG, "the fused backward (lse given) needs head_dim 64 and `out`");
     AttnBwdArgs a{};
+    a.lse = lse; a.o_bf16 = out; a.ldo = ldo;
     a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.dout = dout; a.lddo = lddo;
     a.dq = dq; a.lddq = lddq; a.dk = dk; a.lddk = lddk; a.dv = dv; a.lddv = lddv;
     a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.dh = dh; a.scale = scale;
@@ -461,18 +469,20 @@ int ditto_attention_bwd_bf16(const void* q, int ldq, const void* k, int ldk, con
     return DITTO_OK;
 }
 int ditto_attention_dropout_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out,
-                                 int ldo, int B, int H, int Sq, int Skv, int dh, float scale, float dropout_p,
-                                 uint64_t seed, int layer, void* workspace, size_t workspace_bytes,
+                                 int ldo, float* lse_out, int B, int H, int Sq, int Skv, int dh, float scale,
+                                 float dropout_p, uint64_t seed, int layer, void* workspace, size_t workspace_bytes,
                                  ditto_stream_t stream) {
     if (!q || !k || !v || !out || !workspace) return fail(DITTO_ERR_ARG, "null pointer to ditto_attention_dropout_bf16");
     if (dh % 64) return fail(DITTO_ERR_SHAPE, "head_dim must be a multiple of 64");
-    if (workspace_bytes < attention_train_workspace_bytes(Sq, Skv, dh))
+    if (workspace_bytes < attention_train_workspace_bytes(B, H, Sq, Skv, dh))
         return fail(DITTO_ERR_SIZE, "attention workspace too small");
+    if (lse_out && dh != 64) return fail(DITTO_ERR_ARG, "lse_out is produced by the fused head_dim-64 kernel only");
     AttnArgs a{};
     a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.out_bf16 = out; a.ldo = ldo;
     a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.dh = dh; a.scale = scale;
     a.workspace = workspace; a.workspace_bytes = workspace_bytes;
-    a.dropout_p = dropout_p; a.seed = seed; a.layer = layer; a.force_generic = true;
+    a.dropout_p = dropout_p; a.seed = seed; a.layer = layer; a.force_generic = lse_out == nullptr;
+    a.lse_out = lse_out;
     HIP_TRY(launch_attention(a, (hipStream_t)stream));
     return DITTO_OK;
 }

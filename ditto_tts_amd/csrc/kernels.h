@@ -96,6 +96,7 @@ struct AttnArgs {
     // training forward: dropout on the probabilities (nn.MultiheadAttention train mode), mask = hash(seed, layer, ...)
     float dropout_p; uint64_t seed; int layer;
     bool force_generic;              // run the GEMM-composed path even at dh == 64
+    float* lse_out;                  // fused (dh == 64) path: fp32 [B, H, Sq] log2-domain log-sum-exp for the backward
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 size_t attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh);
@@ -113,9 +114,17 @@ struct AttnBwdArgs {
     float scale;
     float dropout_p; uint64_t seed; int layer;
     void* workspace; size_t workspace_bytes;
+    // fused path (dh == 64): the forward's log-sum-exp (log2 domain) and the forward output O, given either as bf16
+    // (cross-attention) or as the residual stream after / before the segment (self-attention: O = after - before)
+    const float* lse;
+    const void* o_bf16; int ldo;
+    const float* h_after; const float* h_before; int ldh;
 };
 hipError_t launch_attention_bwd(const AttnBwdArgs& a, hipStream_t s);
-size_t attention_train_workspace_bytes(int Sq, int Skv, int dh);   // generic forward + backward scratch
+hipError_t launch_attention_delta(const void* dout, int lddo, const void* o_bf16, int ldo, const float* h_after,
+                                  const float* h_before, int ldh, float* delta, int B, int H, int Sq, hipStream_t s);
+hipError_t launch_attention_bwd64(const AttnBwdArgs& a, const float* lse, const float* delta, hipStream_t s);
+size_t attention_train_workspace_bytes(int B, int H, int Sq, int Skv, int dh);   // forward + backward scratch
 
 // ---------------- train.hip : backward-pass row / elementwise kernels ----------------
 hipError_t launch_transpose_bf16(const void* src, int ld, int rows, int cols, void* dst, int ldT, hipStream_t s);
@@ -133,6 +142,7 @@ hipError_t launch_unpack_vec(const float* src, float* dst, int rows, int blk, in
 hipError_t launch_pack_bf16_t(const float* src, void* dst, int rows, int cols, int ldT, int blk, int mult, int row_off,
                               hipStream_t s);
 unsigned dropout_stream_host(uint64_t seed, int layer, int bh);
+unsigned dropout_threshold(float p);
 hipError_t launch_softmax_drop_rows(const float* S, void* P, int Sq, int Skv, int ld, float scale, unsigned stream,
                                     float p_drop, hipStream_t s);
 hipError_t launch_softmax_bwd_rows(const float* S, const float* dPd, void* dS, int Sq, int Skv, int ld, float scale,

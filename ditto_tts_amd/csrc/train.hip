@@ -400,17 +400,6 @@ hipError_t launch_pack_bf16_t(const float* src, void* dst, int rows, int cols, i
 // Philox stream; this path draws it from a counter-based hash of (seed, layer, batch*head, query, key) so the
 // backward kernels regenerate it instead of storing a [B,H,N,T] mask.  tests/ restate the same hash in numpy.
 // ---------------------------------------------------------------------------------------------------------
-DITTO_DEV unsigned lowbias32(unsigned h) {
-    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
-    return h;
-}
-DITTO_DEV unsigned drop_stream(unsigned seed_lo, unsigned seed_hi, int layer, int bh) {
-    return lowbias32(seed_lo ^ lowbias32(seed_hi + (unsigned)layer * 0x632BE5ABu + (unsigned)bh * 0x9E3779B1u));
-}
-DITTO_DEV bool drop_keep(unsigned stream, int i, int j, unsigned thr) {
-    return lowbias32(stream ^ ((unsigned)i * 0x9E3779B1u + (unsigned)j * 0x85EBCA6Bu)) >= thr;
-}
-
 // P bf16 [Sq, ld] = dropout(softmax(S * scale)) (first Skv columns; padding columns zero).  One wave per row.
 __global__ __launch_bounds__(256) void softmax_drop_rows_kernel(const float* __restrict__ S, bf16* __restrict__ P, int Sq,
                                                                 int Skv, int ld, float scale_log2, unsigned stream,

@@ -112,10 +112,10 @@ SYMBOLS = {
                                   C.POINTER(Grads), _vp, _sz, _vp]),
     "ditto_layernorm_bwd_scratch_bytes": (_sz, [_i, _i, _i]),
     "ditto_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
-    "ditto_attention_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
-    "ditto_attention_bwd_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i,
+    "ditto_attention_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "ditto_attention_bwd_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i,
                                       _i, _i, _i, _i, _i, _f, _f, _u64, _i, _vp, _sz, _vp]),
-    "ditto_attention_dropout_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _u64, _i,
+    "ditto_attention_dropout_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _f, _u64, _i,
                                           _vp, _sz, _vp]),
     "ditto_quantize_rows_fp8": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "ditto_layernorm_fp8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),

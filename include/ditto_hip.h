@@ -277,15 +277,18 @@ size_t ditto_layernorm_bwd_scratch_bytes(int rows_per_group, int groups, int d);
 int ditto_layernorm_bwd(const float* dy, const float* x, const float* gamma, float* dx_accum, float* dgamma_dbeta,
                         void* scratch, size_t scratch_bytes, int rows_per_group, int groups, int d,
                         ditto_stream_t stream);
-size_t ditto_attention_bwd_workspace_bytes(int Sq, int Skv, int dh);
+size_t ditto_attention_bwd_workspace_bytes(int B, int H, int Sq, int Skv, int dh);
+/* lse == NULL: GEMM-composed backward (any head_dim % 64 == 0; `out` unused).  lse != NULL (head_dim 64): the fused
+ * two-kernel backward; lse fp32 [B,H,Sq] from ditto_attention_dropout_bf16(lse_out) and `out` that call's output. */
 int ditto_attention_bwd_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* dout,
-                             int lddo, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int B, int H, int Sq,
-                             int Skv, int dh, float scale, float dropout_p, uint64_t seed, int layer, void* workspace,
-                             size_t workspace_bytes, ditto_stream_t stream);
-/* forward twin for the tests of the dropout path: as ditto_attention_bf16 on the GEMM-composed path with dropout */
+                             int lddo, const void* out, int ldo, const float* lse, void* dq, int lddq, void* dk, int lddk,
+                             void* dv, int lddv, int B, int H, int Sq, int Skv, int dh, float scale, float dropout_p,
+                             uint64_t seed, int layer, void* workspace, size_t workspace_bytes, ditto_stream_t stream);
+/* training-forward attention: as ditto_attention_bf16 with dropout.  lse_out == NULL: the GEMM-composed path;
+ * lse_out != NULL (head_dim 64): the fused kernel, which also writes the log2-domain log-sum-exp per query row. */
 int ditto_attention_dropout_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out,
-                                 int ldo, int B, int H, int Sq, int Skv, int dh, float scale, float dropout_p,
-                                 uint64_t seed, int layer, void* workspace, size_t workspace_bytes,
+                                 int ldo, float* lse_out, int B, int H, int Sq, int Skv, int dh, float scale,
+                                 float dropout_p, uint64_t seed, int layer, void* workspace, size_t workspace_bytes,
                                  ditto_stream_t stream);
 
 /* fp8 building blocks, exported for unit parity tests (all e4m3, OCP):

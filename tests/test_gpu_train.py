@@ -68,11 +68,15 @@ def _heads(t, B, S, H, dh):
     return t.view(B, S, H, dh).permute(0, 2, 1, 3)
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("B,H,Sq,Skv,dh,p", [(1, 2, 64, 64, 64, 0.0), (2, 2, 100, 72, 64, 0.1), (1, 1, 48, 80, 256, 0.1),
-                                              (2, 3, 130, 130, 64, 0.0)])
-def test_attention_dropout_forward_and_backward_vs_autograd(B, H, Sq, Skv, dh, p):
+                                              (2, 3, 130, 130, 64, 0.0), (1, 2, 257, 321, 64, 0.1)])
+def test_attention_dropout_forward_and_backward_vs_autograd(B, H, Sq, Skv, dh, p, fused):
     """bf16 operands: compare against fp32 autograd on the SAME bf16-rounded q/k/v/dO.  Tolerance 2e-2 rel-L2
-    (P and dS are rounded to bf16 between the two products)."""
+    (P and dS are rounded to bf16 between the two products).  fused = the head_dim-64 flash kernels (forward with
+    log-sum-exp, two-kernel backward); otherwise the GEMM-composed path."""
+    if fused and dh != 64:
+        pytest.skip("the fused kernels are head_dim 64 only")
     lib = hip.lib()
     d = H * dh
     seed, layer = 0x1234567890ABCDEF, 3
@@ -82,18 +86,25 @@ def test_attention_dropout_forward_and_backward_vs_autograd(B, H, Sq, Skv, dh, p
     do = bf16(hash_normal((B, Sq, d), "do", 4)).float()
     scale = dh ** -0.5
     mask = O.hash_dropout_mask(seed, layer, B, H, Sq, Skv, p) if p > 0 else None
-    out = _attn_ref(_heads(q, B, Sq, H, dh), _heads(k, B, Skv, H, dh), _heads(v, B, Skv, H, dh), scale, mask, p)
+    qh, kh, vh = _heads(q, B, Sq, H, dh), _heads(k, B, Skv, H, dh), _heads(v, B, Skv, H, dh)
+    out = _attn_ref(qh, kh, vh, scale, mask, p)
     out = out.permute(0, 2, 1, 3).reshape(B, Sq, d)
     out.backward(do)
     qd, kd, vd, dod = (bf16(z.detach()).to(DEV) for z in (q, k, v, do))
-    nb = lib.ditto_attention_bwd_workspace_bytes(Sq, Skv, dh)
+    nb = lib.ditto_attention_bwd_workspace_bytes(B, H, Sq, Skv, dh)
     ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
     o = torch.empty(B, Sq, d, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B, H, Sq, dtype=torch.float32, device=DEV) if fused else None
     hip.check(lib.ditto_attention_dropout_bf16(qd.data_ptr(), d, kd.data_ptr(), d, vd.data_ptr(), d, o.data_ptr(), d,
-                                               B, H, Sq, Skv, dh, scale, p, seed, layer, ws.data_ptr(), nb, stream()))
-    assert rel_l2(o.float(), out) < 1.5e-2
+                                               lse.data_ptr() if fused else None, B, H, Sq, Skv, dh, scale, p, seed,
+                                               layer, ws.data_ptr(), nb, stream()))
+    assert rel_l2(o.float(), out.detach()) < 1.5e-2
+    if fused:   # log2-domain log-sum-exp of the scaled scores
+        want = torch.logsumexp(torch.matmul(qh, kh.transpose(-2, -1)).detach() * scale, dim=-1) / 0.6931471805599453
+        assert max_abs(lse, want) < 2e-3 * (1 + float(want.abs().max()))
     dq = torch.empty_like(qd); dk = torch.empty_like(kd); dv = torch.empty_like(vd)
     hip.check(lib.ditto_attention_bwd_bf16(qd.data_ptr(), d, kd.data_ptr(), d, vd.data_ptr(), d, dod.data_ptr(), d,
+                                           o.data_ptr(), d, lse.data_ptr() if fused else None,
                                            dq.data_ptr(), d, dk.data_ptr(), d, dv.data_ptr(), d, B, H, Sq, Skv, dh,
                                            scale, p, seed, layer, ws.data_ptr(), nb, stream()))
     for name, got, want in (("dq", dq, q.grad), ("dk", dk, k.grad), ("dv", dv, v.grad)):
