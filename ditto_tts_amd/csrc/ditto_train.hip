@@ -68,8 +68,16 @@ TrainArenaPlan plan_train_arena(const ditto_config& c) {
 }
 
 struct TrainWsPlan {
-    size_t dh, du, dyb, big1, big2, dkv, tA, tB, textT, wtmp, vtmp, red, dmod, small, attn, attn_bytes, total;
+    size_t dh, du, dyb, big1, big2, dkv, tA, tB, textT, wtmp, vtmp, red, dmod, small, wpart, attn, attn_bytes, total;
 };
+// split-K factor of a wgrad GEMM with `tiles` 128x128 output tiles and `kt` K-tiles of 64: aim at >= 512 workgroups
+// (2 per CU), keep >= 8 K-tiles per split
+inline int wgrad_splits(long tiles, long kt) {
+    long s = (512 + tiles - 1) / tiles;
+    if (s > kt / 8) s = kt / 8;
+    return (int)(s < 1 ? 1 : s);
+}
+constexpr size_t WPART_BYTES = (size_t)(512 + 320) * 128 * 128 * 4;   // S * tiles <= 512 + tiles, tiles <= 8d*d/128^2
 TrainWsPlan plan_train_ws(const ditto_config& c, int B, int N, int T) {
     TrainWsPlan w;
     const size_t d = c.hidden_dim, M = (size_t)B * N, Mt = (size_t)B * T, dh = d / c.num_heads;
@@ -86,6 +94,7 @@ TrainWsPlan plan_train_ws(const ditto_config& c, int B, int N, int T) {
     w.red = take(red);
     w.dmod = take((size_t)B * 2 * d * 4);
     w.small = take(6 * al((size_t)B * c.time_dim * 4));
+    w.wpart = take(WPART_BYTES);
     const size_t a1 = attention_train_workspace_bytes(B, c.num_heads, N, N, (int)dh);
     const size_t a2 = attention_train_workspace_bytes(B, c.num_heads, N, T, (int)dh);
     w.attn_bytes = a1 > a2 ? a1 : a2;
@@ -297,9 +306,19 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
     void* attn_ws = ws + wp.attn;
 
     // dW[n1, n2] = dY[rows, n1]^T X[rows, n2]: both operands transposed to K-contiguous rows, one GEMM with K = rows
+    float* wpart = (float*)(ws + wp.wpart);
     auto wgrad_t = [&](const void* At, int n1, const void* Bt, int n2, int kp, float* out, int ldo) -> int {
         GemmArgs g{};
         g.A = At; g.lda = kp; g.W = Bt; g.ldw = kp; g.w_rows = n2; g.out = out; g.ldo = ldo; g.M = n1; g.N = n2; g.K = kp;
+        const long tiles = (long)((n1 + 127) / 128) * ((n2 + 127) / 128);
+        const int S = wgrad_splits(tiles, kp / 64);
+        if (S > 1 && ldo == n2 && (size_t)S * n1 * n2 * 4 <= WPART_BYTES) {
+            // long K, few output tiles: S slices of K in parallel, fp32 partial products summed in slice order
+            g.out = wpart; g.k_splits = S; g.split_stride = (size_t)n1 * n2;
+            HIP_TRY(launch_gemm(g, EPI_BIAS_F32, s));
+            HIP_TRY(launch_reduce_partials(wpart, S, (size_t)n1 * n2, out, s));
+            return DITTO_OK;
+        }
         HIP_TRY(launch_gemm(g, EPI_BIAS_F32, s));
         return DITTO_OK;
     };

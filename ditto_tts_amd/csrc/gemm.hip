@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmParams p) {
 
     const int nwg = p.tiles_m * p.tiles_n;
     int tm, tn;
-    tile_to_mn(xcd_remap(blockIdx.x, nwg), p.tiles_m, p.tiles_n, p.group_n, tm, tn);
+    const int split = p.k_splits > 1 ? blockIdx.x / nwg : 0;
+    tile_to_mn(xcd_remap(p.k_splits > 1 ? blockIdx.x % nwg : blockIdx.x, nwg), p.tiles_m, p.tiles_n, p.group_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     f32x4 acc[4][4];
@@ -75,8 +76,15 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmParams p) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nkt = p.K / BK;
-    stage_tile(p, smem, m0, n0, 0, wid, lane);
+    int nkt = p.K / BK, kbase = 0;
+    if (p.k_splits > 1) {   // split-K: this workgroup owns K-tiles [kbase, kbase + nkt) and its own output slice
+        const int per = (nkt + p.k_splits - 1) / p.k_splits;
+        kbase = split * per;
+        nkt = nkt - kbase < per ? nkt - kbase : per;
+        if (nkt < 0) nkt = 0;
+        p.out = (float*)p.out + (size_t)split * p.split_stride;
+    }
+    if (nkt > 0) stage_tile(p, smem, m0, n0, kbase * BK, wid, lane);
     __syncthreads();  // (hipcc drains the LDS-DMA with vmcnt(0) here)
 
     // per-lane fragment addressing: row (lane&15) of a 16-row block, k-chunk (lane>>4) of a 32-wide k-step
@@ -86,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmParams p) {
 
     for (int kt = 0; kt < nkt; ++kt) {
         char* cur = smem + (kt & 1) * BUF_BYTES;
-        if (kt + 1 < nkt) stage_tile(p, smem + ((kt + 1) & 1) * BUF_BYTES, m0, n0, (kt + 1) * BK, wid, lane);
+        if (kt + 1 < nkt) stage_tile(p, smem + ((kt + 1) & 1) * BUF_BYTES, m0, n0, (kbase + kt + 1) * BK, wid, lane);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int coff = ((kk * 4 + fq) ^ fswz) << 4;
@@ -124,7 +132,8 @@ hipError_t launch_t(const GemmParams& p, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm128_kernel<EPI>), dim3(p.tiles_m * p.tiles_n), dim3(256), GEMM_LDS, s, p);
+    hipLaunchKernelGGL((gemm128_kernel<EPI>), dim3(p.tiles_m * p.tiles_n * (p.k_splits > 1 ? p.k_splits : 1)), dim3(256),
+                       GEMM_LDS, s, p);
     return hipGetLastError();
 }
 
@@ -144,6 +153,8 @@ hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s) {
     p.out2 = (bf16*)a.out2_bf16; p.ldo2 = a.ldo2;
     p.rope_cos = a.rope_cos; p.rope_sin = a.rope_sin; p.rope_rpb = a.rope_rows_per_batch; p.rope_cols = a.rope_cols;
     p.M = a.M; p.N = a.N; p.K = a.K;
+    p.k_splits = a.k_splits > 1 ? a.k_splits : 1; p.split_stride = a.split_stride;
+    if (p.k_splits > 1 && (epi != EPI_BIAS_F32 || a.bias || a.fp8)) return hipErrorInvalidValue;
     switch (epi) {
         case EPI_QKV_ROPE:
             if (a.N % 64 || a.rope_cols % 64 || !a.rope_cos || !a.rope_sin || a.rope_rows_per_batch <= 0)
@@ -165,7 +176,7 @@ hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s) {
         return launch_gemm256_fp8(p, epi, s);
     }
     if (epi == EPI_GATED_FP8) return hipErrorInvalidValue;   // fp8 output only from the fp8 GEMM
-    const int forced = g_gemm_tile;
+    const int forced = p.k_splits > 1 ? 128 : g_gemm_tile;
     const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
     if (forced == 256 || (forced == 0 && t256 >= 4 * 256)) {
         p.tiles_m = (a.M + 255) / 256;

@@ -26,6 +26,7 @@ struct GemmParams {
     int tile_stride;   // gemm256: persistent workgroups walk tiles b, b + stride, ...
     int stagger_ticks; // GF_STAGGER_START: s_memrealtime ticks (100 MHz) per quarter tile
     int flags;         // experiment switches (ditto_set_option("gemm_flags")): see GF_* below
+    int k_splits; size_t split_stride;   // gemm128 only: see GemmArgs
 };
 
 enum { GF_RELAXED_WAIT = 1,        // tile-start wait skips over the previous tile's epilogue stores

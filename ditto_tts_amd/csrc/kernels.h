@@ -65,6 +65,10 @@ struct GemmArgs {
     // fp8 (OCP e4m3) operands: A and W are 1-byte elements, acc is multiplied by wscale[n] (per-output-row weight
     // scale, fp32 [N]) before the bias.  Runs the persistent 256x256 kernel with v_mfma_scale_f32_16x16x128_f8f6f4.
     bool fp8; const float* wscale;
+    // split-K (EPI_BIAS_F32 without bias, 128x128 structure): split s of k_splits multiplies K range
+    // [s, s+1) * K / k_splits and writes its partial product to out + s * split_stride (fp32 elements); the caller
+    // sums the slices (launch_reduce_partials).  The long-K, few-tile wgrad GEMMs of the backward pass.
+    int k_splits; size_t split_stride;
 };
 hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s);
 extern int g_gemm_tile;  // 0 auto | 128 | 256
@@ -129,6 +133,7 @@ size_t attention_train_workspace_bytes(int B, int H, int Sq, int Skv, int dh);  
 // ---------------- train.hip : backward-pass row / elementwise kernels ----------------
 hipError_t launch_transpose_bf16(const void* src, int ld, int rows, int cols, void* dst, int ldT, hipStream_t s);
 size_t colsum_scratch_bytes(int M, int n);
+hipError_t launch_reduce_partials(const float* partial, int chunks, size_t n, float* out, hipStream_t s);
 hipError_t launch_colsum_f32(const float* x, int ld, int M, int n, float* out, float* scratch, hipStream_t s);
 hipError_t launch_colsum_bf16(const void* x, int ld, int M, int n, float* out, float* scratch, hipStream_t s);
 size_t ln_bwd_scratch_bytes(int rows_per_group, int groups, int d);

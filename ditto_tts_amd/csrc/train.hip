@@ -85,15 +85,26 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
         *reinterpret_cast<f32x4*>(partial + (size_t)blockIdx.y * n + col) = r;
     }
 }
-// out[g][j] = sum_c partial[g][c][j]   (groups of `chunks` partial rows)
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int chunks, int n,
+// out[g][j] = sum_c partial[g][c][j]   (groups of `chunks` partial rows).  Block = 64 columns x 4 chunk-lanes: the
+// chunk loop is split 4 ways and combined through LDS in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int chunks, size_t n,
                                                               float* __restrict__ out) {
-    const int j = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
-    if (j >= n) return;
-    const float* p = partial + (size_t)g * chunks * n + j;
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const size_t j = (size_t)blockIdx.x * 64 + tx;
+    const int g = blockIdx.y;
     float acc = 0.f;
-    for (int c = 0; c < chunks; ++c) acc += p[(size_t)c * n];
-    out[(size_t)g * n + j] = acc;
+    if (j < n) {
+        const float* p = partial + (size_t)g * chunks * n + j;
+        for (int c = ty; c < chunks; c += 4) acc += p[(size_t)c * n];
+    }
+    red[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && j < n) out[(size_t)g * n + j] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
+hipError_t launch_reduce_partials(const float* partial, int chunks, size_t n, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 63) / 64), 1), dim3(256), 0, s, partial, chunks, n, out);
+    return hipGetLastError();
 }
 static int colsum_chunks(int M, int n) {
     const int strips = (n + 255) / 256;
@@ -112,7 +123,7 @@ static hipError_t colsum_launch(const T* x, int ld, int M, int n, float* out, fl
     const int rpc = (M + chunks - 1) / chunks;
     hipLaunchKernelGGL((colsum_partial_kernel<T>), dim3((n + 255) / 256, chunks), dim3(256), 0, s, x, ld, M, n,
                        scratch, rpc);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 255) / 256, 1), dim3(256), 0, s, scratch, chunks, n, out);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 63) / 64, 1), dim3(256), 0, s, scratch, chunks, (size_t)n, out);
     return hipGetLastError();
 }
 hipError_t launch_colsum_f32(const float* x, int ld, int M, int n, float* out, float* scratch, hipStream_t s) {
@@ -261,8 +272,8 @@ hipError_t launch_ln_bwd(const float* dy, const float* x, const float* gamma, fl
     }
 #undef LNB_CASE
     if (dgb_out)
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * d + 255) / 256, groups), dim3(256), 0, s, scratch, chunks,
-                           2 * d, dgb_out);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * d + 63) / 64, groups), dim3(256), 0, s, scratch, chunks,
+                           (size_t)(2 * d), dgb_out);
     return hipGetLastError();
 }
 
