@@ -7,6 +7,10 @@ xGMI is point-to-point (7 links x ~153 GB/s per GPU), so root<->peer transfers a
 send/recv pairs (`torch.distributed.batch_isend_irecv` = grouped ncclSend/ncclRecv on RCCL): each peer's
 shard rides its own direct link instead of a ring bound by one link.
 
+Training adds ONE collective per step: the data-parallel gradient mean
+(`allreduce_gradients`), issued as reduce-scatter + all-gather over flat buckets so that on RCCL every GPU
+exchanges 1/W of a bucket with each peer over its own xGMI link (a ring would be bound by one link).
+
 Works on any backend: "nccl" (= RCCL on ROCm) on the GPU node, "gloo" in the CPU tests.
 """
 from __future__ import annotations
@@ -94,3 +98,47 @@ def sample_sharded(sample_fn: Callable[[torch.Tensor, torch.Tensor, int], torch.
     lo, _ = shard_bounds(total, world, rank)
     out = sample_fn(text, xT, lo) if text.shape[0] > 0 else xT
     return gather_batch(out, total, root, group)
+
+
+def allreduce_gradients(params, bucket_bytes: int = 256 << 20, group=None) -> int:
+    """Average `.grad` of `params` over the data-parallel group, in place; returns the number of buckets.
+
+    Gradients are packed into flat fp32 buckets of about `bucket_bytes` (large on purpose: 288 GB of HBM per GPU,
+    and per-link-bound xGMI favours few large transfers; the whole DiTTO-S gradient is 552 MB = 3 buckets), each
+    padded to a multiple of the world size.  On backends with reduce_scatter_tensor / all_gather_into_tensor
+    (nccl = RCCL) a bucket is reduced as reduce-scatter + all-gather; elsewhere (gloo) as one all_reduce.  Parameters
+    without a gradient (the dead `attn.out_proj`, frozen codec weights) are skipped — identically on every rank,
+    because which parameters get gradients is a property of the model, not of the data."""
+    world = dist.get_world_size(group)
+    plist = [p for p in params if p.grad is not None]
+    if world == 1 or not plist:
+        return 0
+    two_phase = dist.get_backend(group) == "nccl"
+    nb, i = 0, 0
+    while i < len(plist):
+        chunk, size = [], 0
+        while i < len(plist) and (not chunk or size + plist[i].grad.numel() * 4 <= bucket_bytes):
+            chunk.append(plist[i])
+            size += plist[i].grad.numel() * 4
+            i += 1
+        n = sum(p.grad.numel() for p in chunk)
+        padded = (n + world - 1) // world * world
+        flat = torch.zeros(padded, dtype=torch.float32, device=chunk[0].grad.device)
+        off = 0
+        for p in chunk:
+            flat[off:off + p.grad.numel()].copy_(p.grad.reshape(-1))
+            off += p.grad.numel()
+        if two_phase:
+            shard = torch.empty(padded // world, dtype=torch.float32, device=flat.device)
+            dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=group)
+            shard.mul_(1.0 / world)
+            dist.all_gather_into_tensor(flat, shard, group=group)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            flat.mul_(1.0 / world)
+        off = 0
+        for p in chunk:
+            p.grad.copy_(flat[off:off + p.grad.numel()].view_as(p.grad))
+            off += p.grad.numel()
+        nb += 1
+    return nb

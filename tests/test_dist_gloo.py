@@ -11,7 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from ditto_tts_amd.config import DiTTOConfig
-from ditto_tts_amd.dist import gather_batch, sample_sharded, scatter_batch, shard_bounds
+from ditto_tts_amd.dist import allreduce_gradients, gather_batch, sample_sharded, scatter_batch, shard_bounds
 from ditto_tts_amd.synth import hash_normal, synthetic_state_dict
 
 CFG = DiTTOConfig(64, 1, 1, 32, 64, 4)
@@ -79,3 +79,36 @@ def test_world2_equals_world1_bitwise():
         p.join(60)
         assert p.exitcode == 0
     assert torch.equal(got, want)
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ps = [torch.nn.Parameter(torch.zeros(s)) for s in ((7, 5), (3,), (11, 2), (4,))]
+        for i, p in enumerate(ps):
+            if i != 3:                                   # one parameter without a gradient (like attn.out_proj)
+                p.grad = hash_normal(tuple(p.shape), f"g{i}", rank)
+        nb = allreduce_gradients(ps, bucket_bytes=160)   # tiny buckets: forces several, with world-size padding
+        if rank == 0:
+            q.put((nb, [None if p.grad is None else p.grad.clone() for p in ps]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_gradient_allreduce_is_the_mean_over_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    nb, got = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert nb >= 2 and got[3] is None
+    for i, shape in enumerate(((7, 5), (3,), (11, 2))):
+        want = (hash_normal(shape, f"g{i}", 0) + hash_normal(shape, f"g{i}", 1)) * 0.5
+        assert torch.allclose(got[i], want, rtol=0, atol=1e-7)
