@@ -157,7 +157,7 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
             AttnArgs a{};
             a.q = qkv; a.ldq = 3 * d; a.k = qkv + (size_t)d * 2; a.ldk = 3 * d; a.v = qkv + (size_t)2 * d * 2;
             a.ldv = 3 * d; a.resid_f32 = h; a.ldr = d; a.B = B; a.H = H; a.Sq = N; a.Skv = N; a.dh = dh;
-            a.scale = scale; a.workspace = attn_ws; a.workspace_bytes = attn_ws_bytes;
+            a.scale = scale; a.workspace = attn_ws; a.workspace_bytes = attn_ws_bytes; a.q_prescaled = (dh == 64);
             HIP_TRY(launch_attention(a, s));
         }
         // ---- cross-attention (src/components/DiT.py:141-148), K/V from the per-utterance cache ----
@@ -174,7 +174,7 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
             a.q = qkv; a.ldq = d; a.k = kv + (size_t)kv_layer * 2 * d * 2; a.ldk = kv_ld;
             a.v = kv + ((size_t)kv_layer * 2 * d + d) * 2; a.ldv = kv_ld; a.out_bf16 = u; a.ldo = d;
             a.B = B; a.H = H; a.Sq = N; a.Skv = T; a.dh = dh; a.scale = scale;
-            a.workspace = attn_ws; a.workspace_bytes = attn_ws_bytes;
+            a.workspace = attn_ws; a.workspace_bytes = attn_ws_bytes; a.q_prescaled = (dh == 64);
             HIP_TRY(launch_attention(a, s));
         }
         {
@@ -265,21 +265,31 @@ int ditto_model_create(const ditto_config* cfg, const ditto_weights* w, void* ar
             if (!p) return fail(DITTO_ERR_ARG, "null weight pointer in layer %d", l);
         // self-attention in_proj [3d, d] (q | k | v rows), reference src/components/DiT.py:110-114
         const bool fp8 = (cfg->flags & DITTO_CFG_FP8_LINEAR) != 0;
+        // head_dim 64 (fused attention): q leaves its projection already multiplied by scale * log2(e), folded into
+        // the q rows of the packed weights / biases here, so the attention kernel's scores are in log2 units
+        const bool pre = (d / cfg->num_heads) == 64;
+        const float qs = pre ? 1.4426950408889634f / sqrtf((float)(d / cfg->num_heads)) : 1.0f;
         if (fp8) {
             HIP_TRY(launch_pack_fp8(lw.attn_in_proj_weight, A + q.Wqkv, (float*)(A + q.sqkv), 3 * d, d, d, BIG, 1, 0, s));
             HIP_TRY(launch_pack_fp8(lw.mlp_fc1_weight, A + q.W1g, (float*)(A + q.s1g), 4 * d, d, d, 16, 2, 0, s));
             HIP_TRY(launch_pack_fp8(lw.gate_weight, A + q.W1g, (float*)(A + q.s1g), 4 * d, d, d, 16, 2, 16, s));
             HIP_TRY(launch_pack_fp8(lw.mlp_fc2_weight, A + q.W2, (float*)(A + q.s2), d, 4 * d, 4 * d, BIG, 1, 0, s));
         } else {
-        HIP_TRY(launch_pack_bf16(lw.attn_in_proj_weight, A + q.Wqkv, 3 * d, d, d, 0, BIG, 1, 0, s));
+        HIP_TRY(launch_pack_bf16(lw.attn_in_proj_weight, A + q.Wqkv, d, d, d, 0, BIG, 1, 0, s, qs));
+        HIP_TRY(launch_pack_bf16(lw.attn_in_proj_weight + (size_t)d * d, A + q.Wqkv, 2 * d, d, d, 0, BIG, 1, d, s));
         HIP_TRY(launch_pack_bf16(lw.mlp_fc1_weight, A + q.W1g, 4 * d, d, d, 0, 16, 2, 0, s));
         HIP_TRY(launch_pack_bf16(lw.gate_weight, A + q.W1g, 4 * d, d, d, 0, 16, 2, 16, s));
         HIP_TRY(launch_pack_bf16(lw.mlp_fc2_weight, A + q.W2, d, 4 * d, 4 * d, 0, BIG, 1, 0, s));
         }
         HIP_TRY(hipMemcpyAsync(A + q.bqkv, lw.attn_in_proj_bias, 3 * d * 4, hipMemcpyDeviceToDevice, s));
         // cross-attention: q rows [0,d) per layer; k,v rows [d,3d) go to the all-layer Wkv
-        HIP_TRY(launch_pack_bf16(lw.cross_in_proj_weight, A + q.Wcq, d, d, d, 0, BIG, 1, 0, s));
+        HIP_TRY(launch_pack_bf16(lw.cross_in_proj_weight, A + q.Wcq, d, d, d, 0, BIG, 1, 0, s, qs));
         HIP_TRY(hipMemcpyAsync(A + q.bcq, lw.cross_in_proj_bias, d * 4, hipMemcpyDeviceToDevice, s));
+        if (pre) {
+            HIP_TRY(launch_scale_vec((float*)(A + q.bqkv), d, qs, s));
+            HIP_TRY(launch_scale_vec((float*)(A + q.bcq), d, qs, s));
+            if (fp8) HIP_TRY(launch_scale_vec((float*)(A + q.sqkv), d, qs, s));   // fp8: per-row weight scale carries it
+        }
         HIP_TRY(launch_pack_bf16(lw.cross_in_proj_weight + (size_t)d * d, A + plan.Wkv, 2 * d, d, d, 0, BIG, 1,
                                  l * 2 * d, s));
         HIP_TRY(hipMemcpyAsync(A + plan.bkv + (size_t)l * 2 * d * 4, lw.cross_in_proj_bias + d, 2 * d * 4,
@@ -547,6 +557,7 @@ int ditto_attention_bf16(const void* q, int ldq, const void* k, int ldk, const v
     a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.out_bf16 = out; a.ldo = ldo;
     a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.dh = dh; a.scale = scale;
     a.workspace = workspace; a.workspace_bytes = workspace_bytes;
+    a.q_prescaled = (g_attn_flags & 16) && dh == 64;   // unit tests of the pre-scaled-q kernel: q carries scale*log2(e)
     HIP_TRY(launch_attention(a, (hipStream_t)stream));
     return DITTO_OK;
 }

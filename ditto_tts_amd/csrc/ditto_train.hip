@@ -48,7 +48,7 @@ TapePlan plan_tape(const ditto_config& c, int B, int N, int T) {
 }
 
 struct TrainArenaPlan {
-    struct L { size_t WqkvT, WcqT, WcoT, W1gT, W2T; };
+    struct L { size_t WqkvT, WcqT, WcoT, W1gT, W2T, Wqkv_u, Wcq_u, bqkv_u, bcq_u; };
     std::vector<L> layers;
     size_t WoutT, total;
 };
@@ -61,6 +61,7 @@ TrainArenaPlan plan_train_arena(const ditto_config& c) {
     for (auto& q : p.layers) {
         q.WqkvT = take(3 * d * d * 2); q.WcqT = take(d * d * 2); q.WcoT = take(d * d * 2); q.W1gT = take(8 * d * d * 2);
         q.W2T = take(4 * d * d * 2);
+        q.Wqkv_u = take(3 * d * d * 2); q.Wcq_u = take(d * d * 2); q.bqkv_u = take(3 * d * 4); q.bcq_u = take(d * 4);
     }
     p.WoutT = take(d * d * 2);
     p.total = off;
@@ -149,7 +150,14 @@ int ditto_train_attach(ditto_model_t m, const ditto_weights* w, void* train_aren
         HIP_TRY(launch_pack_bf16_t(lw.mlp_fc1_weight, A + q.W1gT, 4 * d, d, 8 * d, 16, 2, 0, s));
         HIP_TRY(launch_pack_bf16_t(lw.gate_weight, A + q.W1gT, 4 * d, d, 8 * d, 16, 2, 16, s));
         HIP_TRY(launch_pack_bf16_t(lw.mlp_fc2_weight, A + q.W2T, d, 4 * d, d, BIG, 1, 0, s));
-        m->layersT[l] = LayerPackT{A + q.WqkvT, A + q.WcqT, A + q.WcoT, A + q.W1gT, A + q.W2T};
+        // forward copies of the q projections WITHOUT the softmax scale the inference pack folds in: the training
+        // kernels (log-sum-exp, backward) work on the reference's own q
+        HIP_TRY(launch_pack_bf16(lw.attn_in_proj_weight, A + q.Wqkv_u, 3 * d, d, d, 0, BIG, 1, 0, s));
+        HIP_TRY(launch_pack_bf16(lw.cross_in_proj_weight, A + q.Wcq_u, d, d, d, 0, BIG, 1, 0, s));
+        HIP_TRY(hipMemcpyAsync(A + q.bqkv_u, lw.attn_in_proj_bias, (size_t)3 * d * 4, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(A + q.bcq_u, lw.cross_in_proj_bias, (size_t)d * 4, hipMemcpyDeviceToDevice, s));
+        m->layersT[l] = LayerPackT{A + q.WqkvT, A + q.WcqT, A + q.WcoT, A + q.W1gT, A + q.W2T,
+                                   A + q.Wqkv_u, A + q.Wcq_u, (const float*)(A + q.bqkv_u), (const float*)(A + q.bcq_u)};
     }
     HIP_TRY(launch_pack_bf16_t(w->proj_out_weight, A + p.WoutT, d, d, d, BIG, 1, 0, s));
     m->WoutT = A + p.WoutT;
@@ -163,6 +171,7 @@ int ditto_train_forward(ditto_model_t m, const float* x, const float* text, cons
     if (!x || !text || !t || !rope_cos || !rope_sin || !eps_out || !tape || !workspace || B <= 0 || N <= 0 || T <= 0)
         return fail(DITTO_ERR_ARG, "bad argument to ditto_train_forward");
     if (!(dropout_p >= 0.f && dropout_p < 1.f)) return fail(DITTO_ERR_ARG, "dropout_p must be in [0, 1)");
+    if (m->layersT.empty()) return fail(DITTO_ERR_ARG, "ditto_train_attach was not called on this handle");
     const ditto_config& c = m->cfg;
     const TapePlan tp = plan_tape(c, B, N, T);
     const TrainWsPlan wp = plan_train_ws(c, B, N, T);
@@ -196,6 +205,7 @@ int ditto_train_forward(ditto_model_t m, const float* x, const float* text, cons
 
     for (int l = 0; l < L; ++l) {
         const LayerPack& lp = m->layers[l];
+        const LayerPackT& lt = m->layersT[l];
         const auto& q = tp.layers[l];
         float *h0 = hs(3 * l), *h1 = hs(3 * l + 1), *h2 = hs(3 * l + 2), *h3 = hs(3 * l + 3);
         char* qkv = tb + q.qkv;
@@ -203,7 +213,7 @@ int ditto_train_forward(ditto_model_t m, const float* x, const float* text, cons
         HIP_TRY(launch_layernorm(h0, lp.g1, lp.be1, tb + q.u1, d, M, d, s));
         {
             GemmArgs g{};
-            g.A = tb + q.u1; g.lda = d; g.W = lp.Wqkv; g.bias = lp.bqkv; g.out = qkv; g.ldo = 3 * d;
+            g.A = tb + q.u1; g.lda = d; g.W = lt.Wqkv_u; g.bias = lt.bqkv_u; g.out = qkv; g.ldo = 3 * d;
             g.M = M; g.N = 3 * d; g.K = d;
             g.rope_cos = rope_cos; g.rope_sin = rope_sin; g.rope_rows_per_batch = N; g.rope_cols = 2 * d;
             HIP_TRY(launch_gemm(g, fused_rope ? EPI_QKV_ROPE : EPI_BIAS_BF16, s));
@@ -221,7 +231,7 @@ int ditto_train_forward(ditto_model_t m, const float* x, const float* text, cons
         HIP_TRY(launch_layernorm(h1, lp.g2, lp.be2, tb + q.u2, d, M, d, s));
         {
             GemmArgs g{};
-            g.A = tb + q.u2; g.lda = d; g.W = lp.Wcq; g.bias = lp.bcq; g.out = tb + q.qc; g.ldo = d;
+            g.A = tb + q.u2; g.lda = d; g.W = lt.Wcq_u; g.bias = lt.bcq_u; g.out = tb + q.qc; g.ldo = d;
             g.M = M; g.N = d; g.K = d;
             HIP_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
         }

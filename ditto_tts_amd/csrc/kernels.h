@@ -38,7 +38,8 @@ hipError_t launch_apply_rope_f32(const float* pos, const float* x, float* out, i
 hipError_t launch_rope_tables(const float* inv_freq, float* cos_out, float* sin_out, int N, int half, hipStream_t s);
 // dst[(r/blk)*(blk*mult) + r%blk + row_off][col_off + c] = bf16(src[r][c])
 hipError_t launch_pack_bf16(const float* src, void* dst_bf16, int rows, int cols, int dst_ld, int col_off, int blk,
-                            int mult, int row_off, hipStream_t s);
+                            int mult, int row_off, hipStream_t s, float scale = 1.0f);
+hipError_t launch_scale_vec(float* v, int n, float f, hipStream_t s);
 // same row map for an fp32 vector (bias)
 hipError_t launch_pack_vec(const float* src, float* dst, int rows, int blk, int mult, int row_off, hipStream_t s);
 hipError_t launch_add_vec(const float* a, const float* b, float* dst, int n, hipStream_t s);
@@ -101,6 +102,7 @@ struct AttnArgs {
     float dropout_p; uint64_t seed; int layer;
     bool force_generic;              // run the GEMM-composed path even at dh == 64
     float* lse_out;                  // fused (dh == 64) path: fp32 [B, H, Sq] log2-domain log-sum-exp for the backward
+    bool q_prescaled;                // q already multiplied by scale * log2(e) (packed weights, dh == 64): `scale` unused
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 size_t attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh);

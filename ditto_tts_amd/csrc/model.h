@@ -25,7 +25,11 @@ struct LayerPack {
     const float *g1, *be1, *g2, *be2, *g3, *be3;
 };
 // transposed bf16 copies for the dgrad GEMMs (dX = dY W runs as the forward GEMM with weight W^T), ditto_train_attach
-struct LayerPackT { const void *WqkvT, *WcqT, *WcoT, *W1gT, *W2T; };
+// plus UNSCALED forward copies of the two q projections (the inference pack folds the softmax scale into them)
+struct LayerPackT {
+    const void *WqkvT, *WcqT, *WcoT, *W1gT, *W2T;
+    const void *Wqkv_u, *Wcq_u; const float *bqkv_u, *bcq_u;
+};
 
 struct ArenaPlan {
     size_t total = 0;

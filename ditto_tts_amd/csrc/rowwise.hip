@@ -381,21 +381,29 @@ hipError_t launch_apply_rope_f32(const float* pos, const float* x, float* out, i
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ src, bf16* __restrict__ dst,
                                                         int rows, int cols, int dst_ld, int col_off, int blk,
-                                                        int mult, int row_off) {
+                                                        int mult, int row_off, float scale) {
     const size_t n = (size_t)rows * cols;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / cols), c = (int)(i % cols);
         const size_t dr = (size_t)(r / blk) * ((size_t)blk * mult) + (r % blk) + row_off;
-        dst[dr * dst_ld + col_off + c] = (bf16)src[i];
+        dst[dr * dst_ld + col_off + c] = (bf16)(src[i] * scale);
     }
 }
 hipError_t launch_pack_bf16(const float* src, void* dst, int rows, int cols, int dst_ld, int col_off, int blk,
-                            int mult, int row_off, hipStream_t s) {
+                            int mult, int row_off, hipStream_t s, float scale) {
     const size_t n = (size_t)rows * cols;
     size_t g = (n + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)(g ? g : 1)), dim3(256), 0, s, src, (bf16*)dst, rows, cols,
-                       dst_ld, col_off, blk, mult, row_off);
+                       dst_ld, col_off, blk, mult, row_off, scale);
+    return hipGetLastError();
+}
+__global__ void scale_vec_kernel(float* __restrict__ v, int n, float f) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] *= f;
+}
+hipError_t launch_scale_vec(float* v, int n, float f, hipStream_t s) {
+    hipLaunchKernelGGL(scale_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, s, v, n, f);
     return hipGetLastError();
 }
 // fp32 [rows, cols] -> fp8 e4m3 rows with a per-row scale (amax / 448): one wave per row.

@@ -124,11 +124,19 @@ def _attn_ref(q, k, v, B, H, Sq, Skv, dh, scale):
                                            (2, 2, 300, 200, 64), (1, 3, 1024, 1024, 64),
                                            (1, 4, 64, 1, 64), (2, 12, 256, 320, 64), (1, 1, 40, 50, 128),
                                            (1, 2, 70, 33, 192)])
-@pytest.mark.parametrize("attn_flags", [0, 1, 3, 7])
+@pytest.mark.parametrize("attn_flags", [0, 1, 3, 7, 16, 16 + 64, 16 + 32 + 3])
 def test_attention(lib, B, H, Sq, Skv, dh, attn_flags):
     hip.check(lib.ditto_set_option(b"attn_flags", attn_flags))   # 1: K/V tiles by LDS-DMA
     d = H * dh
     q = bf16(asym((B * Sq, d), 8).to(DEV))
+    if attn_flags & 16 and dh == 64:
+        # the model path: q leaves its projection multiplied by scale * log2(e) (folded into the packed weights);
+        # 16 = the reduced-VALU kernel on such a q, 16+32 = the older kernels on it.  The reference is computed on
+        # the same (rounded) q, un-scaled in fp32.
+        qs = bf16(q.float() * (1.4426950408889634 / math.sqrt(dh)))
+        q_ref, q = qs.float() / (1.4426950408889634 / math.sqrt(dh)), qs
+    else:
+        q_ref = q
     k = bf16(asym((B * Skv, d), 9).to(DEV))
     v = bf16(asym((B * Skv, d), 10).to(DEV))
     scale = 1.0 / math.sqrt(dh)
@@ -138,13 +146,15 @@ def test_attention(lib, B, H, Sq, Skv, dh, attn_flags):
     hip.check(lib.ditto_attention_bf16(q.data_ptr(), d, k.data_ptr(), d, v.data_ptr(), d, out.data_ptr(), d, B, H, Sq,
                                        Skv, dh, scale, ws.data_ptr(), ws.numel(), stream()))
     hip.check(lib.ditto_set_option(b"attn_flags", 3))
-    want = _attn_ref(q, k, v, B, H, Sq, Skv, dh, scale)
+    want = _attn_ref(q_ref, k, v, B, H, Sq, Skv, dh, scale)
     assert rel_l2(out.float(), want) < 1.5e-2     # P is rounded to bf16 before the PV product
     assert max_abs(out.float(), want) < 6e-2
 
 
-def test_attention_forced_rescale(lib):
+@pytest.mark.parametrize("attn_flags", [3, 16, 16 + 64])
+def test_attention_forced_rescale(lib, attn_flags):
     """Rule 26: force the online-softmax rescale branch — one key in the LAST tile dominates one query row."""
+    hip.check(lib.ditto_set_option(b"attn_flags", attn_flags))
     B, H, Sq, Skv, dh = 1, 1, 64, 256, 64
     q = asym((Sq, dh), 11) * 0.5
     k = asym((Skv, dh), 12) * 0.5
@@ -153,8 +163,12 @@ def test_attention_forced_rescale(lib):
     k[70] = q[9] * 30.0               # and one in tile 1 for another row
     q, k, v = bf16(q.to(DEV)), bf16(k.to(DEV)), bf16(v.to(DEV))
     out = torch.empty(Sq, dh, dtype=torch.bfloat16, device=DEV)
-    hip.check(hip.lib().ditto_attention_bf16(q.data_ptr(), dh, k.data_ptr(), dh, v.data_ptr(), dh, out.data_ptr(), dh,
+    qk = bf16(q.float() * (1.4426950408889634 * 0.125)) if attn_flags & 16 else q
+    if attn_flags & 16:
+        q = qk.float() / (1.4426950408889634 * 0.125)           # what the kernel effectively sees, for the reference
+    hip.check(hip.lib().ditto_attention_bf16(qk.data_ptr(), dh, k.data_ptr(), dh, v.data_ptr(), dh, out.data_ptr(), dh,
                                              B, H, Sq, Skv, dh, 0.125, None, 0, stream()))
+    hip.check(lib.ditto_set_option(b"attn_flags", 3))
     want = _attn_ref(q, k, v, B, H, Sq, Skv, dh, 0.125)
     assert max_abs(out.float(), want) < 6e-2
     assert max_abs(out.float()[5], v.float()[Skv - 3]) < 6e-2   # row 5 is (almost) exactly that value row
