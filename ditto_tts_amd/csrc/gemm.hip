@@ -177,6 +177,7 @@ hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s) {
     }
     if (epi == EPI_GATED_FP8) return hipErrorInvalidValue;   // fp8 output only from the fp8 GEMM
     const int forced = p.k_splits > 1 ? 128 : g_gemm_tile;
+    if (forced == 130) return launch_gemm_o3(p, epi, s);
     const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
     if (forced == 256 || (forced == 0 && t256 >= 4 * 256)) {
         p.tiles_m = (a.M + 255) / 256;

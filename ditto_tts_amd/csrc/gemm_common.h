@@ -82,6 +82,17 @@ DITTO_DEV void glds16(const void* gsrc, unsigned lds_dst) {
                  : "memory");
 }
 
+// LDS-DMA with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset: the per-K-tile address update
+// is one scalar add on the base instead of a 64-bit vector add per load (the loads of a kernel's main loop differ only
+// by the K offset).
+DITTO_DEV void glds16_so(unsigned voff, const void* sbase, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+
 // Bias of the lane's 4 x 4 columns, loaded ONCE per wave (the same for every row of the tile): keeps the row
 // loop free of dependent global loads.
 DITTO_DEV void load_bias(const GemmParams& p, int cbase, int fq, f32x4 (&b)[4]) {
@@ -248,5 +259,7 @@ hipError_t launch_gemm256(const GemmParams& p, GemmEpilogue epi, hipStream_t s);
 hipError_t launch_gemm256_fp8(const GemmParams& p, GemmEpilogue epi, hipStream_t s);
 // gemm_p128.hip
 hipError_t launch_gemm_p128(const GemmParams& p, GemmEpilogue epi, hipStream_t s);
+// gemm_o3.hip
+hipError_t launch_gemm_o3(const GemmParams& p, GemmEpilogue epi, hipStream_t s);
 
 }  // namespace ditto
