@@ -72,8 +72,8 @@ constexpr float RESCALE_THR_LOG2 = 8.0f;
 // __launch_bounds__(256, 2): 2 waves per SIMD => a 256-register budget, so the MFMA accumulators (S^T, O^T: 64
 // registers) stay in VGPRs.  With the default budget hipcc parks them in AGPRs and moves all 64 through
 // v_accvgpr_read/write around every softmax (127 extra VALU per tile, as much as the softmax itself).
-template <bool RESID, bool DMA, bool PFV, bool TRAIN = false>
-__global__ __launch_bounds__(256, 2) void attn64_kernel(AttnParams p) {
+template <bool RESID, bool DMA, bool PFV, bool TRAIN = false, int WPS = 2>
+__global__ __launch_bounds__(256, WPS) void attn64_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KV_TILE_BYTES];  // [buf][K|V]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -786,8 +786,9 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
         p.seed_lo = (unsigned)(a.seed & 0xFFFFFFFFu); p.seed_hi = (unsigned)(a.seed >> 32); p.layer = a.layer;
         if (a.lse_out || p.drop_thr) {   // training forward: log-sum-exp kept for the backward, dropout
             const dim3 gridt(p.nqb * a.H * a.B);
-            if (a.resid_f32) hipLaunchKernelGGL((attn64_kernel<true, true, true, true>), gridt, dim3(256), 0, s, p);
-            else hipLaunchKernelGGL((attn64_kernel<false, true, true, true>), gridt, dim3(256), 0, s, p);
+            // 3 waves per SIMD without the V prefetch (the kernel is latency-bound: see attn64v2's launch comment)
+            if (a.resid_f32) hipLaunchKernelGGL((attn64_kernel<true, true, false, true, 3>), gridt, dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((attn64_kernel<false, true, false, true, 3>), gridt, dim3(256), 0, s, p);
             return hipGetLastError();
         }
         if (a.q_prescaled && !(g_attn_flags & 32)) {   // q already carries scale * log2(e): the reduced-VALU kernel

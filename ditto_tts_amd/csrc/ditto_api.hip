@@ -653,6 +653,11 @@ int ditto_set_option(const char* name, int value) {
         g_attn_flags = value;
         return DITTO_OK;
     }
+    if (!strcmp(name, "wgrad_wgs")) {
+        if (value < 1 || value > 512) return fail(DITTO_ERR_ARG, "wgrad_wgs must be in [1, 512]");
+        set_wgrad_wgs(value);
+        return DITTO_OK;
+    }
     if (!strcmp(name, "gemm_flags")) {
         g_gemm_flags = value;
         return DITTO_OK;

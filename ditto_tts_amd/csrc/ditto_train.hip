@@ -71,10 +71,11 @@ TrainArenaPlan plan_train_arena(const ditto_config& c) {
 struct TrainWsPlan {
     size_t dh, du, dyb, big1, big2, dkv, tA, tB, textT, wtmp, vtmp, red, dmod, small, wpart, attn, attn_bytes, total;
 };
-// split-K factor of a wgrad GEMM with `tiles` 128x128 output tiles and `kt` K-tiles of 64: aim at >= 512 workgroups
-// (2 per CU), keep >= 8 K-tiles per split
+// split-K factor of a wgrad GEMM with `tiles` 128x128 output tiles and `kt` K-tiles of 64: aim at >= g_wgrad_wgs
+// workgroups, keep >= 8 K-tiles per split
+int g_wgrad_wgs = 384;   // measured at C2 B=16 (tools/train_report.py --wgrad-wgs): 512 -> 47.3, 384 -> 46.3, 256 -> 46.8 ms/step
 inline int wgrad_splits(long tiles, long kt) {
-    long s = (512 + tiles - 1) / tiles;
+    long s = (g_wgrad_wgs + tiles - 1) / tiles;
     if (s > kt / 8) s = kt / 8;
     return (int)(s < 1 ? 1 : s);
 }
@@ -112,6 +113,10 @@ int check_train(const ditto_model* m) {
 }
 
 }  // namespace
+
+namespace ditto {
+void set_wgrad_wgs(int v) { g_wgrad_wgs = v; }
+}
 
 extern "C" {
 

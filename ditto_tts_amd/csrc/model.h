@@ -42,6 +42,7 @@ ArenaPlan plan_arena(const ditto_config& c);
 struct WsPlan { size_t h, u, qkv, act, xcat, eps, attn, attn_bytes, total; };
 WsPlan plan_ws(const ditto_config& c, int B, int N, int T);
 int check_cfg(const ditto_config* c);
+void set_wgrad_wgs(int v);   // ditto_train.hip: split-K target of the wgrad GEMMs (ditto_set_option("wgrad_wgs"))
 
 }  // namespace ditto
 

@@ -540,12 +540,22 @@ __global__ __launch_bounds__(256) void small_linear_bwd_w_kernel(const float* __
 __global__ __launch_bounds__(256) void small_linear_bwd_x_kernel(const float* __restrict__ dy, const float* __restrict__ W,
                                                                  const float* __restrict__ x, float* __restrict__ dx, int B,
                                                                  int I, int O, int silu_in) {
-    const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (i >= I) return;
+    // block = 64 input columns x 4 slices of the O outputs, combined through LDS in a fixed order
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + tx, b = blockIdx.y;
     float acc = 0.f;
-    for (int o = 0; o < O; ++o) acc += dy[(size_t)b * O + o] * W[(size_t)o * I + i];
-    if (silu_in) acc *= silu_grad(x[(size_t)b * I + i]);
-    dx[(size_t)b * I + i] = acc;
+    if (i < I) {
+        const int per = (O + 3) / 4, o0 = ty * per, o1 = o0 + per < O ? o0 + per : O;
+        for (int o = o0; o < o1; ++o) acc += dy[(size_t)b * O + o] * W[(size_t)o * I + i];
+    }
+    red[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && i < I) {
+        float r = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+        if (silu_in) r *= silu_grad(x[(size_t)b * I + i]);
+        dx[(size_t)b * I + i] = r;
+    }
 }
 hipError_t launch_small_linear_fwd(const float* x, const float* W, const float* bias, float* y, int B, int I, int O,
                                    bool silu_in, hipStream_t s) {
@@ -561,7 +571,7 @@ hipError_t launch_small_linear_bwd_w(const float* dy, const float* x, float* dW,
 }
 hipError_t launch_small_linear_bwd_x(const float* dy, const float* W, const float* x, float* dx, int B, int I, int O,
                                      bool silu_in, hipStream_t s) {
-    hipLaunchKernelGGL(small_linear_bwd_x_kernel, dim3((I + 255) / 256, B), dim3(256), 0, s, dy, W, x, dx, B, I, O,
+    hipLaunchKernelGGL(small_linear_bwd_x_kernel, dim3((I + 63) / 64, B), dim3(256), 0, s, dy, W, x, dx, B, I, O,
                        silu_in ? 1 : 0);
     return hipGetLastError();
 }

@@ -50,7 +50,11 @@ def main():
     ap.add_argument("--text", type=int, default=1024)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--wgrad-wgs", type=int, default=0)
     a = ap.parse_args()
+    if a.wgrad_wgs:
+        from ditto_tts_amd import hip
+        hip.check(hip.lib().ditto_set_option(b"wgrad_wgs", a.wgrad_wgs))
     if not a.no_parity:
         parity()
     cfg = PRESETS[a.config]["cfg"]
