@@ -178,6 +178,7 @@ hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s) {
     if (epi == EPI_GATED_FP8) return hipErrorInvalidValue;   // fp8 output only from the fp8 GEMM
     const int forced = p.k_splits > 1 ? 128 : g_gemm_tile;
     if (forced == 130) return launch_gemm_o3(p, epi, s);
+    if (forced == 192 && gemm192_supports(epi)) return launch_gemm192(p, epi, s);
     const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
     if (forced == 256 || (forced == 0 && t256 >= 4 * 256)) {
         p.tiles_m = (a.M + 255) / 256;
@@ -189,6 +190,14 @@ hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s) {
     // K = 1536 projection 96 vs 104 us against the 128x128 kernel, but the K = 768 d x d GEMMs 70 vs 69 us:
     // automatic only for K >= 1536.
     const long tp128 = (long)((a.M + 255) / 256) * ((a.N + 127) / 128);
+    // 256x192 tiles (gemm192.hip) where the output width is a multiple of 192 and whole rounds of them cost no more
+    // tile-work than the 256x128 ring's rounds: measured in-model at M = 32768 (tools/step_ab.py): fc2 183.6 vs 189.4 us,
+    // the final K = 1536 projection 92.1 vs 97.2 us, the K = 768 d x d GEMMs 69.2 vs 70.1 us (noise): long K only.
+    if (forced == 0 && gemm192_supports(epi) && a.N % 192 == 0 && a.K >= 1536) {
+        const long t192 = (long)((a.M + 255) / 256) * (a.N / 192);
+        const long r192 = (t192 + 255) / 256, r128 = (tp128 + 255) / 256;
+        if (t192 >= 256 && r192 * 3 <= r128 * 2) return launch_gemm192(p, epi, s);
+    }
     if (forced == 129 || (forced == 0 && tp128 >= 2 * 256 && a.K >= 1536)) {
         p.tiles_m = (a.M + 255) / 256;
         p.tiles_n = (a.N + 127) / 128;

@@ -259,6 +259,9 @@ hipError_t launch_gemm256(const GemmParams& p, GemmEpilogue epi, hipStream_t s);
 hipError_t launch_gemm256_fp8(const GemmParams& p, GemmEpilogue epi, hipStream_t s);
 // gemm_p128.hip
 hipError_t launch_gemm_p128(const GemmParams& p, GemmEpilogue epi, hipStream_t s);
+// gemm192.hip
+bool gemm192_supports(GemmEpilogue epi);
+hipError_t launch_gemm192(const GemmParams& p, GemmEpilogue epi, hipStream_t s);
 // gemm_o3.hip
 hipError_t launch_gemm_o3(const GemmParams& p, GemmEpilogue epi, hipStream_t s);
 
