@@ -1,3 +1,5 @@
+"""Report (not a test): rel-L2 of the bf16 and fp8-linear HIP paths against the fp32 oracle at 24 layers, d = 1024 (the C5
+shape).  Lives under tests/ because it uses the oracle.   python tests/fp8_depth_report.py"""
 import sys, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ditto_tts_amd.config import DiTTOConfig

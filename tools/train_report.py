@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Gradient parity report + training-step timing on one MI355X (supplementary to bench.py, which measures the
-denoise step).  Prints worst/median per-tensor rel-L2 of the HIP gradients against fp32 autograd of the oracle at
-a small shape, then times forward+backward+AdamW at the requested shape.
+"""Training-step timing on one MI355X (supplementary to bench.py, which measures the denoise step): forward +
+backward + AdamW at the requested shape.  (Gradient parity against the oracle lives in tests/test_gpu_train.py; only
+tests / smoke / bench's cpu_baseline may touch oracle/.)
 
-    python tools/train_report.py [--config C2] [--batch 8] [--seq 1024] [--steps 3] [--no-parity]
+    python tools/train_report.py [--config C2] [--batch 8] [--seq 1024] [--steps 3]
 """
 import argparse
 import os
@@ -19,29 +19,6 @@ from ditto_tts_amd.modules import DiTTO  # noqa: E402
 from ditto_tts_amd.synth import hash_normal, synthetic_inputs, synthetic_state_dict  # noqa: E402
 
 
-def parity():
-    from oracle import ditto_oracle as O
-    cfg = DiTTOConfig(256, 3, 4, 256, 256, 50)
-    B, N, T = 2, 128, 96
-    x, text, t = synthetic_inputs(cfg, B, N, T, seed=7)
-    target = hash_normal((B, N, 256), "noise", 9)
-    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in synthetic_state_dict(cfg, 4).items()}
-    F.mse_loss(O.ditto_forward(sd, 3, 4, x, text, t), target).backward()
-    m = DiTTO(256, 3, 4, 256, 256, 50)
-    m.load_state_dict(synthetic_state_dict(cfg, 4))
-    m = m.cuda().eval()
-    F.mse_loss(m(x.cuda(), text.cuda(), t.cuda()), target.cuda()).backward()
-    rows = []
-    for n, p in m.named_parameters():
-        if p.grad is None:
-            continue
-        a, b = p.grad.double().cpu().flatten(), sd[n].grad.double().flatten()
-        rows.append((float((a - b).norm() / b.norm().clamp_min(1e-30)), n))
-    rows.sort()
-    print(f"gradient parity (3L d=256 h=4, B=2 N=128 T=96): median rel-L2 {rows[len(rows) // 2][0]:.2e}, "
-          f"worst {rows[-1][0]:.2e} ({rows[-1][1]}), best {rows[0][0]:.2e}")
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="C2")
@@ -49,14 +26,12 @@ def main():
     ap.add_argument("--seq", type=int, default=1024)
     ap.add_argument("--text", type=int, default=1024)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="accepted and ignored (older command lines)")
     ap.add_argument("--wgrad-wgs", type=int, default=0)
     a = ap.parse_args()
     if a.wgrad_wgs:
         from ditto_tts_amd import hip
         hip.check(hip.lib().ditto_set_option(b"wgrad_wgs", a.wgrad_wgs))
-    if not a.no_parity:
-        parity()
     cfg = PRESETS[a.config]["cfg"]
     m = DiTTO(cfg.hidden_dim, cfg.num_layers, cfg.num_heads, cfg.time_dim, cfg.text_dim, cfg.diffusion_steps)
     m.load_state_dict(synthetic_state_dict(cfg, 2))
