@@ -644,8 +644,8 @@ int ditto_gemm_fp8(const void* A, int lda, const void* W, const float* wscale, c
 int ditto_set_option(const char* name, int value) {
     if (!name) return fail(DITTO_ERR_ARG, "null option name");
     if (!strcmp(name, "gemm_tile")) {
-        if (value != 0 && value != 128 && value != 256 && value != 129 && value != 130 && value != 192)
-            return fail(DITTO_ERR_ARG, "gemm_tile must be 0, 128, 129 (256x128 ring), 130 (128x256, 3 workgroups/CU), "
+        if (value != 0 && value != 127 && value != 128 && value != 256 && value != 129 && value != 130 && value != 192)
+            return fail(DITTO_ERR_ARG, "gemm_tile must be 0, 127 (128x128 deep prefetch), 128, 129 (256x128 ring), 130 (128x256, 3 workgroups/CU), "
                                        "192 (256x192 where the epilogue allows) or 256");
         g_gemm_tile = value;
         return DITTO_OK;

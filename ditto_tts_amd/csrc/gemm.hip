@@ -123,6 +123,122 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// gemm128_deep: the same 128x128x64 tile for SMALL grids (<= one workgroup per CU: batch-1 serving, where the
+// whole GEMM is one round and its time is the latency of one workgroup's K loop).  With one K-tile of look-ahead a
+// lone workgroup exposes the full DMA latency on every K step (measured at M = 1024: ~1.6 us per step, 20 us for
+// K = 768 whatever the grid size).  Here the LDS ring is 4 tiles deep (128 KiB, affordable at one workgroup per CU), the
+// DMA runs 3 tiles ahead behind a COUNTED vmcnt (asm LDS-DMA: in-order retire), one barrier per K step.
+// ------------------------------------------------------------------------------------------------
+constexpr int DEEP_NB = 4;
+constexpr int DEEP_LDS = DEEP_NB * BUF_BYTES;   // 128 KiB
+
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void gemm128_deep_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1;
+    const int nwg = p.tiles_m * p.tiles_n;
+    int tm, tn;
+    const int split = p.k_splits > 1 ? blockIdx.x / nwg : 0;
+    tile_to_mn(xcd_remap(p.k_splits > 1 ? blockIdx.x % nwg : blockIdx.x, nwg), p.tiles_m, p.tiles_n, p.group_n, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int nkt = p.K / BK, kbase = 0;
+    if (p.k_splits > 1) {
+        const int per = (nkt + p.k_splits - 1) / p.k_splits;
+        kbase = split * per;
+        nkt = nkt - kbase < per ? nkt - kbase : per;
+        if (nkt < 0) nkt = 0;
+        p.out = (float*)p.out + (size_t)split * p.split_stride;
+    }
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+    // per-lane source offsets of this wave's 4 A pieces and 4 W pieces (1 KiB = 8 rows x 128 B each), set once
+    unsigned aoff[4], woff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = wid * 4 + i;
+        const int row = piece * 8 + (lane >> 3), cpos = lane & 7;
+        const int c = cpos ^ ((row >> 1) & 7);
+        int ar = m0 + row; ar = ar < p.M ? ar : p.M - 1;
+        int wrow = n0 + row; wrow = wrow < p.w_rows ? wrow : p.w_rows - 1;
+        aoff[i] = (unsigned)(((size_t)ar * p.lda + c * 8) * 2);
+        woff[i] = (unsigned)(((size_t)wrow * p.ldw + c * 8) * 2);
+    }
+    auto stage = [&](int buf, int kt) {   // 8 LDS-DMA loads per wave
+        const char* ab = (const char*)p.A + (size_t)(kbase + kt) * (BK * 2);
+        const char* wb = (const char*)p.W + (size_t)(kbase + kt) * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = wid * 4 + i;
+            glds16_so(aoff[i], ab, lds_base + (unsigned)(buf * BUF_BYTES + piece * 1024));
+            glds16_so(woff[i], wb, lds_base + (unsigned)(buf * BUF_BYTES + TILE_BYTES + piece * 1024));
+        }
+    };
+#pragma unroll
+    for (int t = 0; t < DEEP_NB - 1; ++t)
+        if (t < nkt) stage(t, t);
+
+    const int frow = lane & 15, fq = lane >> 4, fswz = frow >> 1;
+    const int a_row_off = (wr * 64 + frow) * 128;
+    const int w_row_off = TILE_BYTES + (wc * 64 + frow) * 128;
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        // tile kt has landed once at most the loads of tiles kt+1, kt+2 (8 each) are still in flight
+        const int ahead = nkt - 1 - kt;
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // every wave's pieces of tile kt are visible; every wave is done with tile kt-1's buffer
+        if (kt + DEEP_NB - 1 < nkt) stage((kt + DEEP_NB - 1) % DEEP_NB, kt + DEEP_NB - 1);
+        const char* cur = smem + (kt % DEEP_NB) * BUF_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int coff = ((kk * 4 + fq) ^ fswz) << 4;
+            bf16x8 af[4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8*>(cur + a_row_off + i * 16 * 128 + coff);
+                wf[i] = *reinterpret_cast<const bf16x8*>(cur + w_row_off + i * 16 * 128 + coff);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], af[m], acc[m][n], 0, 0, 0);
+        }
+    }
+
+    f32x4 bias4[4];
+    load_bias(p, n0 + wc * 64, fq, bias4);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int row = m0 + wr * 64 + m * 16 + frow;
+        if (row < p.M) epilogue_row<EPI>(p, row, n0 + wc * 64, acc[m], bias4, fq);
+    }
+}
+
+template <int EPI>
+hipError_t launch_deep_t(const GemmParams& p, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm128_deep_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, DEEP_LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm128_deep_kernel<EPI>), dim3(p.tiles_m * p.tiles_n * (p.k_splits > 1 ? p.k_splits : 1)),
+                       dim3(256), DEEP_LDS, s, p);
+    return hipGetLastError();
+}
+
 template <int EPI>
 hipError_t launch_t(const GemmParams& p, hipStream_t s) {
     static bool attr_set = false;  // idempotent; races are benign (same value)
@@ -207,6 +323,19 @@ hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s) {
     p.tiles_n = (a.N + BN - 1) / BN;
     p.flags = g_gemm_flags & ~(GF_DIAG_NO_STORE | GF_DIAG_NO_EPILOGUE | GF_DIAG_LINEAR_STORE | GF_DIAG_SMALL_OUT);
     p.group_n = pick_group_n(p.tiles_n, p.flags);
+    // small grid (one workgroup per CU at most): the deep-prefetch variant; forced with gemm_tile = 127
+    const long wgs = (long)p.tiles_m * p.tiles_n * (p.k_splits > 1 ? p.k_splits : 1);
+    if (forced == 127 || (forced == 0 && wgs <= 256 && a.K >= 4 * BK)) {
+        switch (epi) {
+            case EPI_BIAS_BF16: return launch_deep_t<EPI_BIAS_BF16>(p, s);
+            case EPI_BIAS_RES_F32: return launch_deep_t<EPI_BIAS_RES_F32>(p, s);
+            case EPI_QKV_ROPE: return launch_deep_t<EPI_QKV_ROPE>(p, s);
+            case EPI_GATED: return launch_deep_t<EPI_GATED>(p, s);
+            case EPI_BIAS_F32: return launch_deep_t<EPI_BIAS_F32>(p, s);
+            default: break;
+        }
+        return hipErrorInvalidValue;
+    }
     switch (epi) {
         case EPI_BIAS_BF16: return launch_t<EPI_BIAS_BF16>(p, s);
         case EPI_BIAS_RES_F32: return launch_t<EPI_BIAS_RES_F32>(p, s);

@@ -55,7 +55,7 @@ def test_gemm(lib, M, N, K, epi):
         assert max_abs(out, want + res) < 1e-4
 
 
-@pytest.fixture(params=[(256, 73), (256, 73 + 256), (129, 73), (130, 73), (192, 73)])
+@pytest.fixture(params=[(256, 73), (256, 73 + 256), (129, 73), (130, 73), (192, 73), (127, 73)])
 def tile256(lib, request):
     """forces one persistent structure: 256x256 eight-phase, 256x256 wide-phase, 256x128 ring"""
     hip.check(lib.ditto_set_option(b"gemm_tile", request.param[0]))
