@@ -137,6 +137,10 @@ def lib() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} not found: the HIP extension is the only compute path of ditto_tts_amd. "
                 "Build it with `python -m ditto_tts_amd.build` (needs hipcc).")
+        # torch first: libditto_hip.so and torch must share ONE HIP runtime (both want SONAME libamdhip64.so.7; the
+        # first one loaded wins).  Loading ours first binds the process to /opt/rocm's runtime, under which torch's
+        # device initialisation and ours disagreed on a GPU box ("no ROCm-capable device is detected" at the first launch).
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol
