@@ -31,7 +31,7 @@
 namespace ditto {
 
 // bit 0: K/V tiles by LDS-DMA instead of register staging; bit 1: V fragments prefetched ahead of the softmax
-// (needs bit 0); bit 2: two query blocks per wave (attn64x2); bit 4 (16): ditto_attention_bf16's q is pre-scaled
+// (needs bit 0); bit 4 (16): ditto_attention_bf16's q is pre-scaled
 // (unit tests of attn64v2); bit 5 (32): run the kernels above on pre-scaled q instead of attn64v2 (A/B); bit 6 (64):
 // attn64v2 at 2 waves per SIMD with the V prefetch instead of 3 without.  ditto_set_option("attn_flags")
 int g_attn_flags = 3;
@@ -312,188 +312,6 @@ __global__ __launch_bounds__(256, WPS) void attn64_kernel(AttnParams p) {
                 *reinterpret_cast<u32x2*>(p.out + grow * p.ldo + col) = st2;
             }
         }
-}
-
-// ------------------------------------------------------------------------------------------------
-// attn64x2: the same algorithm with TWO 32-query blocks per wave (64 queries per wave, 256 per workgroup).
-// Each K fragment (ds_read_b128) and each transposed V fragment read from LDS now feeds two MFMAs, one per
-// query block, so LDS reads, K/V DMA and barriers per query are halved, and the two independent
-// {QK^T -> softmax -> PV} streams let one block's MFMAs run under the other block's softmax VALU inside a
-// wave.  ~230 VGPRs -> 2 waves per SIMD.  K/V by asm LDS-DMA, V fragments prefetched ahead of the softmax.
-// ------------------------------------------------------------------------------------------------
-template <bool RESID>
-__global__ __launch_bounds__(256, 2) void attn64x2_kernel(AttnParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KV_TILE_BYTES];  // [buf][K|V]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nwg = p.nqb * p.H * p.B;
-    const int id = xcd_remap(blockIdx.x, nwg);
-    const int qb = id % p.nqb, bh = id / p.nqb;
-    const int h = bh % p.H, b = bh / p.H;
-    const int ql = lane & 31, hh = lane >> 5;
-    const int q0 = qb * (2 * QBLK) + wid * 64;
-
-    int qrow[2];
-    bool qvalid[2];
-    bf16x8 qf[2][4];
-#pragma unroll
-    for (int qi = 0; qi < 2; ++qi) {
-        qrow[qi] = q0 + qi * 32 + ql;
-        qvalid[qi] = qrow[qi] < p.Sq;
-        qrow[qi] = qvalid[qi] ? qrow[qi] : p.Sq - 1;
-        const bf16* qp = p.q + ((size_t)b * p.Sq + qrow[qi]) * p.ldq + h * DH + 8 * hh;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[qi][ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
-    }
-
-    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
-    auto dma_kv = [&](int kt, int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int piece = wid * 2 + i;
-            const int row = piece * 8 + (lane >> 3), cpos = lane & 7;
-            int key = kt * KBLK + row;
-            key = key < p.Skv ? key : p.Skv - 1;
-            const int ck = cpos ^ ((row >> 1) & 7), cv = cpos ^ (((row >> 1) & 1) << 2);
-            glds16(p.k + ((size_t)b * p.Skv + key) * p.ldk + h * DH + ck * 8,
-                   lds_base + (unsigned)(buf * 2 * KV_TILE_BYTES + piece * 1024));
-            glds16(p.v + ((size_t)b * p.Skv + key) * p.ldv + h * DH + cv * 8,
-                   lds_base + (unsigned)(buf * 2 * KV_TILE_BYTES + KV_TILE_BYTES + piece * 1024));
-        }
-    };
-
-    const int k_row_off = ql * 128, k_swz = (ql >> 1) & 7;
-    const int tr_q = (lane & 15) >> 2, tr_p = lane & 3;
-    const int tr_colbyte = (16 * ((lane >> 4) & 1) + 4 * tr_p) * 2;
-    const int tr_row0 = 4 * hh + tr_q;
-    const int tr_swz = ((tr_q >> 1) & 1) << 6;
-
-    f32x16 ot[2][2];
-#pragma unroll
-    for (int qi = 0; qi < 2; ++qi)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { ot[qi][0][i] = 0.f; ot[qi][1][i] = 0.f; }
-    float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
-    const float c = p.scale_log2;
-
-    const int nkt = (p.Skv + KBLK - 1) / KBLK;
-    dma_kv(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    auto tile_body = [&](int kt, auto MASKED) {
-        const char* kb = smem + (kt & 1) * 2 * KV_TILE_BYTES;
-        const char* vb = kb + KV_TILE_BYTES;
-        if (kt + 1 < nkt) dma_kv(kt + 1, (kt + 1) & 1);
-
-        f32x16 st[2][2];
-#pragma unroll
-        for (int qi = 0; qi < 2; ++qi)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { st[qi][0][i] = 0.f; st[qi][1][i] = 0.f; }
-#pragma unroll
-        for (int kb2 = 0; kb2 < 2; ++kb2)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + kb2 * 32 * 128 + k_row_off +
-                                                                   (((2 * ks + hh) ^ k_swz) << 4));
-                st[0][kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][ks], st[0][kb2], 0, 0, 0);
-                st[1][kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][ks], st[1][kb2], 0, 0, 0);
-            }
-        if constexpr (decltype(MASKED)::value) {
-            const int kbase_idx = kt * KBLK + 4 * hh;
-#pragma unroll
-            for (int kb2 = 0; kb2 < 2; ++kb2)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kbase_idx + kb2 * 32 + (r & 3) + 8 * (r >> 2);
-                    if (key >= p.Skv) { st[0][kb2][r] = -1e30f; st[1][kb2][r] = -1e30f; }
-                }
-        }
-
-        bf16x8 vf[8];
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2)
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                const int colb = (tr_colbyte + 64 * db) ^ tr_swz;
-                const char* a0 = vb + (16 * s2 + tr_row0) * 128 + colb;
-                vf[s2 * 2 + db] = cat4(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0)),
-                                       __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0 + 8 * 128)));
-            }
-
-#pragma unroll
-        for (int qi = 0; qi < 2; ++qi) {
-            float mloc = fmaxf(st[qi][0][0], st[qi][1][0]);
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, fmaxf(st[qi][0][r], st[qi][1][r]));
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-            if (!__all((mloc - m_run[qi]) * c <= RESCALE_THR_LOG2)) {
-                const float m_new = fmaxf(m_run[qi], mloc);
-                const float alpha = __builtin_amdgcn_exp2f((m_run[qi] - m_new) * c);
-                m_run[qi] = m_new;
-                l_run[qi] *= alpha;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { ot[qi][0][i] *= alpha; ot[qi][1][i] *= alpha; }
-            }
-            const float mc = m_run[qi] * c;
-            float psum = 0.f;
-            bf16x8 pf[4];
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) {
-                float e[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    e[j] = __builtin_amdgcn_exp2f(st[qi][s2 >> 1][8 * (s2 & 1) + j] * c - mc);
-                    psum += e[j];
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pf[s2][j] = (bf16)e[j];
-            }
-            l_run[qi] += psum;
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2)
-#pragma unroll
-                for (int db = 0; db < 2; ++db)
-                    ot[qi][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s2 * 2 + db], pf[s2], ot[qi][db], 0, 0, 0);
-        }
-
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    };
-
-    const bool ragged = (p.Skv & (KBLK - 1)) != 0;
-    const int nfull = ragged ? nkt - 1 : nkt;
-    for (int kt = 0; kt < nfull; ++kt) tile_body(kt, std::false_type{});
-    if (ragged) tile_body(nkt - 1, std::true_type{});
-
-#pragma unroll
-    for (int qi = 0; qi < 2; ++qi) {
-        const float l_tot = l_run[qi] + __shfl_xor(l_run[qi], 32, 64);
-        const float inv = 1.0f / l_tot;
-        if (!qvalid[qi]) continue;
-        const size_t grow = (size_t)b * p.Sq + qrow[qi];
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col = h * DH + 32 * db + 8 * g + 4 * hh;
-                f32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = ot[qi][db][4 * g + e] * inv;
-                if constexpr (RESID) {
-                    float* rp = p.resid + grow * p.ldr + col;
-                    f32x4 r = *reinterpret_cast<const f32x4*>(p.resid_in + grow * p.ldr + col);
-                    r += o;
-                    *reinterpret_cast<f32x4*>(rp) = r;
-                } else {
-                    u32x2 st2;
-                    st2[0] = pack_bf16x2(o[0], o[1]);
-                    st2[1] = pack_bf16x2(o[2], o[3]);
-                    *reinterpret_cast<u32x2*>(p.out + grow * p.ldo + col) = st2;
-                }
-            }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -807,13 +625,6 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
             return hipGetLastError();
         }
         if (a.q_prescaled) p.scale_log2 = 1.0f;   // attn_flags & 32: the older kernels on pre-scaled q (A/B)
-        if ((g_attn_flags & 4) && a.Sq >= 2 * QBLK) {   // two query blocks per wave
-            p.nqb = (a.Sq + 2 * QBLK - 1) / (2 * QBLK);
-            const dim3 grid2(p.nqb * a.H * a.B);
-            if (a.resid_f32) hipLaunchKernelGGL((attn64x2_kernel<true>), grid2, dim3(256), 0, s, p);
-            else hipLaunchKernelGGL((attn64x2_kernel<false>), grid2, dim3(256), 0, s, p);
-            return hipGetLastError();
-        }
         const dim3 grid(p.nqb * a.H * a.B), block(256);
         const bool r = a.resid_f32 != nullptr;
         switch (g_attn_flags & 3) {
