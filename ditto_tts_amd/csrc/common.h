@@ -65,6 +65,36 @@ DITTO_DEV float fast_gelu_erf(float x) {
     return 0.5f * x * (1.0f + copysignf(erf_abs, z));
 }
 
+// Two (fc1, gate) pairs at once on 2-element vectors: the multiplies / FMAs of the polynomial compile to v_pk_*_f32
+// (two fp32 results per instruction; the gated-MLP epilogue is VALU-bound: 4.6 us of a 24 us tile, measured in-model
+// with the no-epilogue diagnostic), the four transcendentals per pair stay scalar.  Same formulas as the scalar forms.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+DITTO_DEV f32x2 fast_gelu_sigmoid2(f32x2 x, f32x2 g) {
+    const f32x2 z = x * 0.70710678118654752440f;
+    const f32x2 az = __builtin_elementwise_abs(z);
+    const f32x2 d1 = az * 0.3275911f + 1.0f;
+    f32x2 t;
+    t[0] = fast_rcp(d1[0]); t[1] = fast_rcp(d1[1]);
+    f32x2 poly = t * 1.061405429f + (-1.453152027f);
+    poly = poly * t + 1.421413741f;
+    poly = poly * t + (-0.284496736f);
+    poly = poly * t + 0.254829592f;
+    poly = poly * t;
+    const f32x2 ea = az * az * (-1.4426950408889634f);
+    f32x2 e;
+    e[0] = __builtin_amdgcn_exp2f(ea[0]); e[1] = __builtin_amdgcn_exp2f(ea[1]);
+    const f32x2 erf_abs = 1.0f - poly * e;
+    f32x2 erf_s;
+    erf_s[0] = copysignf(erf_abs[0], z[0]); erf_s[1] = copysignf(erf_abs[1], z[1]);
+    const f32x2 gelu = x * 0.5f * (erf_s + 1.0f);
+    const f32x2 eg = g * (-1.4426950408889634f);
+    f32x2 den;
+    den[0] = 1.0f + __builtin_amdgcn_exp2f(eg[0]); den[1] = 1.0f + __builtin_amdgcn_exp2f(eg[1]);
+    f32x2 sg;
+    sg[0] = fast_rcp(den[0]); sg[1] = fast_rcp(den[1]);
+    return gelu * sg;
+}
+
 // four fp32 -> packed OCP fp8 e4m3 in one dword (byte 0 = first), saturating at +-448 (v_cvt_pk_fp8_f32 does not
 // clamp: an overflow would become NaN in e4m3fn)
 DITTO_DEV unsigned pack_fp8x4(float a, float b, float c, float d) {

@@ -57,6 +57,7 @@ ArenaPlan plan_arena(const ditto_config& c) {
     p.ttab = take((size_t)c.diffusion_steps * 2 * d * 4);
     p.wx = take(2 * d * (size_t)c.text_dim * 4); p.bx = take(2 * d * 4);
     p.invf = take((d / c.num_heads / 2) * 4);
+    p.invf_rev = take((d / c.num_heads / 2) * 4);
     p.total = off;
     return p;
 }
@@ -148,6 +149,7 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
             g.A = u; g.lda = d; g.W = lp.Wqkv; g.bias = lp.bqkv; g.out = qkv; g.ldo = 3 * d;
             g.M = M; g.N = 3 * d; g.K = d;
             g.rope_cos = rope_cos; g.rope_sin = rope_sin; g.rope_rows_per_batch = N; g.rope_cols = 2 * d;
+            if (fused_rope && !(g_gemm_flags & 1024)) g.rope_freq_rev = m->invf_rev;   // flag 1024: A/B, table loads
             g.fp8 = fp8; g.wscale = fp8 ? lp.sqkv : nullptr;
             HIP_TRY(launch_gemm(g, fused_rope ? EPI_QKV_ROPE : EPI_BIAS_BF16, s));
             if (!fused_rope) HIP_TRY(launch_rope_inplace(qkv, 3 * d, rope_cos, rope_sin, M, N, 2 * d, dh, s));
@@ -342,6 +344,10 @@ int ditto_model_create(const ditto_config* cfg, const ditto_weights* w, void* ar
     m->Wkv = A + plan.Wkv; m->bkv = (const float*)(A + plan.bkv); m->Wfin = A + plan.Wfin;
     m->bfin = (const float*)(A + plan.bfin); m->ttab = (const float*)(A + plan.ttab);
     m->wx = (const float*)(A + plan.wx); m->bx = (const float*)(A + plan.bx); m->invf = (const float*)(A + plan.invf);
+    HIP_TRY(hipMemcpyAsync(A + plan.invf_rev, w->rotary_inv_freq, (size_t)(d / cfg->num_heads / 2) * 4,
+                           hipMemcpyDeviceToDevice, s));
+    HIP_TRY(launch_scale_vec((float*)(A + plan.invf_rev), d / cfg->num_heads / 2, 0.15915494309189535f, s));
+    m->invf_rev = (const float*)(A + plan.invf_rev);
     *out = guard.release();
     return DITTO_OK;
 }

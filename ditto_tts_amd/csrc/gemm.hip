@@ -268,6 +268,7 @@ hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s) {
     p.residual = a.residual; p.ldr = a.ldr; p.out = a.out; p.ldo = a.ldo;
     p.out2 = (bf16*)a.out2_bf16; p.ldo2 = a.ldo2;
     p.rope_cos = a.rope_cos; p.rope_sin = a.rope_sin; p.rope_rpb = a.rope_rows_per_batch; p.rope_cols = a.rope_cols;
+    p.rope_freq_rev = a.rope_freq_rev;
     p.M = a.M; p.N = a.N; p.K = a.K;
     p.k_splits = a.k_splits > 1 ? a.k_splits : 1; p.split_stride = a.split_stride;
     if (p.k_splits > 1 && (epi != EPI_BIAS_F32 || a.bias || a.fp8)) return hipErrorInvalidValue;

@@ -20,6 +20,7 @@ struct GemmParams {
     void* out; int ldo;
     bf16* out2; int ldo2;
     const float* rope_cos; const float* rope_sin; int rope_rpb; int rope_cols;
+    const float* rope_freq_rev;   // inv_freq / (2 pi) [32]: angles computed in the epilogue (v_sin / v_cos) instead of tables
     int M, N, K;
     int tiles_m, tiles_n;
     int group_n;       // super-column width in column tiles (tile order, see tile_to_mn)
@@ -156,12 +157,10 @@ DITTO_DEV void epilogue_row(const GemmParams& p, int row, int cbase, const f32x4
         unsigned pk[2];
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
-            const f32x4 b1 = bias[2 * pr], bg = bias[2 * pr + 1];
-            const f32x4 h = acc[2 * pr], g = acc[2 * pr + 1];
-            float o[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = fast_gelu_erf(h[e] + b1[e]) * fast_sigmoid(g[e] + bg[e]);
-            pk[pr] = pack_fp8x4(o[0], o[1], o[2], o[3]);
+            const f32x4 h = acc[2 * pr] + bias[2 * pr], g = acc[2 * pr + 1] + bias[2 * pr + 1];
+            const f32x2 o01 = fast_gelu_sigmoid2(f32x2{h[0], h[1]}, f32x2{g[0], g[1]});
+            const f32x2 o23 = fast_gelu_sigmoid2(f32x2{h[2], h[3]}, f32x2{g[2], g[3]});
+            pk[pr] = pack_fp8x4(o01[0], o01[1], o23[0], o23[1]);
         }
         const auto r = __builtin_amdgcn_permlane16_swap(pk[0], pk[1], false, false);
         const int odd = fq & 1;
@@ -176,13 +175,11 @@ DITTO_DEV void epilogue_row(const GemmParams& p, int row, int cbase, const f32x4
         u32x2 pk[2];
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
-            const f32x4 b1 = bias[2 * pr], bg = bias[2 * pr + 1];
-            const f32x4 h = acc[2 * pr], g = acc[2 * pr + 1];
-            float o[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = fast_gelu_erf(h[e] + b1[e]) * fast_sigmoid(g[e] + bg[e]);
-            pk[pr][0] = pack_bf16x2(o[0], o[1]);
-            pk[pr][1] = pack_bf16x2(o[2], o[3]);
+            const f32x4 h = acc[2 * pr] + bias[2 * pr], g = acc[2 * pr + 1] + bias[2 * pr + 1];
+            const f32x2 o01 = fast_gelu_sigmoid2(f32x2{h[0], h[1]}, f32x2{g[0], g[1]});
+            const f32x2 o23 = fast_gelu_sigmoid2(f32x2{h[2], h[3]}, f32x2{g[2], g[3]});
+            pk[pr][0] = pack_bf16x2(o01[0], o01[1]);
+            pk[pr][1] = pack_bf16x2(o23[0], o23[1]);
         }
         store_bf16_pair((bf16*)p.out + (size_t)row * p.ldo, cbase / 2, pk[0], pk[1], fq, p.N / 2, p.flags, p.ldo);
     } else if constexpr (EPI == EPI_QKV_ROPE) {
@@ -197,8 +194,24 @@ DITTO_DEV void epilogue_row(const GemmParams& p, int row, int cbase, const f32x4
             float r[4][4];
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                const f32x4 cs = *reinterpret_cast<const f32x4*>(p.rope_cos + (size_t)pos * 32 + n * 16 + c4);
-                const f32x4 sn = *reinterpret_cast<const f32x4*>(p.rope_sin + (size_t)pos * 32 + n * 16 + c4);
+                f32x4 cs, sn;
+                if (p.rope_freq_rev) {
+                    // cos / sin of pos * inv_freq[j] right here: v_fract + v_sin + v_cos on the angle in revolutions
+                    // (the table loads were 8 dependent row-indexed f32x4 loads per row block in a serial epilogue: 27 us of
+                    // the 129 us QKV GEMM, measured with the no-epilogue diagnostic).  fp32 fract at <= 4096 positions keeps
+                    // 14 fraction bits: 2e-4 rad, 20x below the bf16 rounding of q and k.
+                    const f32x4 fr = *reinterpret_cast<const f32x4*>(p.rope_freq_rev + n * 16 + c4);
+                    const float posf = (float)pos;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float rev = __builtin_amdgcn_fractf(posf * fr[e]);
+                        cs[e] = __builtin_amdgcn_cosf(rev);
+                        sn[e] = __builtin_amdgcn_sinf(rev);
+                    }
+                } else {
+                    cs = *reinterpret_cast<const f32x4*>(p.rope_cos + (size_t)pos * 32 + n * 16 + c4);
+                    sn = *reinterpret_cast<const f32x4*>(p.rope_sin + (size_t)pos * 32 + n * 16 + c4);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float lo = v[n][e], hi = v[n + 2][e];

@@ -62,6 +62,7 @@ struct GemmArgs {
     void* out; int ldo;              // bf16 or fp32
     void* out2_bf16; int ldo2;       // optional bf16 copy of the fp32 result (EPI_BIAS_RES_F32)
     const float* rope_cos; const float* rope_sin; int rope_rows_per_batch; int rope_cols;  // EPI_QKV_ROPE
+    const float* rope_freq_rev;      // optional, fp32 [32] = inv_freq / (2 pi): angles computed in the epilogue, tables unused
     int M, N, K;
     // fp8 (OCP e4m3) operands: A and W are 1-byte elements, acc is multiplied by wscale[n] (per-output-row weight
     // scale, fp32 [N]) before the bias.  Runs the persistent 256x256 kernel with v_mfma_scale_f32_16x16x128_f8f6f4.

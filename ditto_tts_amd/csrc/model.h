@@ -35,7 +35,7 @@ struct ArenaPlan {
     size_t total = 0;
     struct L { size_t Wqkv, Wcq, Wco, W1g, W2, bqkv, bcq, bco, b1g, b2, g1, be1, g2, be2, g3, be3, sqkv, s1g, s2; };
     std::vector<L> layers;
-    size_t Wkv, bkv, Wfin, bfin, ttab, wx, bx, invf;
+    size_t Wkv, bkv, Wfin, bfin, ttab, wx, bx, invf, invf_rev;
 };
 ArenaPlan plan_arena(const ditto_config& c);
 
@@ -53,6 +53,7 @@ struct ditto_model {
     std::vector<ditto::LayerPack> layers;
     const void* Wkv; const float* bkv; const void* Wfin; const float* bfin;
     const float* ttab; const float* wx; const float* bx; const float* invf;
+    const float* invf_rev = nullptr;   // inv_freq / (2 pi) for the in-epilogue RoPE angles (head_dim 64)
     bool blocks_only = false;    // created without the model-level weights: only ditto_block_forward works
     // training (ditto_train_attach)
     std::vector<ditto::LayerPackT> layersT;
