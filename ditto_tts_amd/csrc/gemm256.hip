@@ -379,11 +379,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 #pragma unroll
                 for (int n = 0; n < 4; ++n) acc[m][n] *= ws4[n];
         }
+        if (cur_m0 + 256 <= p.M && !(p.flags & GF_DIAG_SMALL_OUT)) {
+            // interior in M: no per-row guard, so the 8 row blocks are ONE basic block and hipcc interleaves their
+            // (independent) epilogue arithmetic instead of running 8 short dependent chains one after the other
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int row = cur_m0 + wm * 128 + m * 16 + frow;
-            if (row < p.M)
-                epilogue_row<EPI>(p, (p.flags & GF_DIAG_SMALL_OUT) ? (row & 255) : row, cur_n0 + wn * 64, acc[m], bias4, fq);
+            for (int m = 0; m < 8; ++m)
+                epilogue_row<EPI>(p, cur_m0 + wm * 128 + m * 16 + frow, cur_n0 + wn * 64, acc[m], bias4, fq);
+        } else {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int row = cur_m0 + wm * 128 + m * 16 + frow;
+                if (row < p.M)
+                    epilogue_row<EPI>(p, (p.flags & GF_DIAG_SMALL_OUT) ? (row & 255) : row, cur_n0 + wn * 64, acc[m], bias4, fq);
+            }
         }
     }
 }
