@@ -530,11 +530,18 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
         pr[j] = j < Skv ? (bf16)(__builtin_amdgcn_exp2f((s[j] - m) * scale_log2) * inv) : (bf16)0.f;
 }
 // Vt[dh, ldT] = V[Skv, dh]^T (zero padded to ldT columns); 32x32 LDS tile transpose.
+// blockIdx.z = (batch, head) inside the chunk: V += zb * vs_b + zh * vs_h, Vt += z * dh * ldT
 __global__ __launch_bounds__(256) void transpose_pad_kernel(const bf16* __restrict__ V, int ldv, bf16* __restrict__ Vt,
-                                                            int ldT, int Skv, int dh) {
+                                                            int ldT, int Skv, int dh, int H, int bh0, long long vs_b,
+                                                            long long vs_h) {
     __shared__ bf16 tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     const int k0 = blockIdx.x * 32, d0 = blockIdx.y * 32;
+    {
+        const int bh = bh0 + blockIdx.z;
+        V += (long long)(bh / H) * vs_b + (long long)(bh % H) * vs_h;
+        Vt += (size_t)blockIdx.z * dh * ldT;
+    }
     for (int i = ty; i < 32; i += 8) {
         const int key = k0 + i, dd = d0 + tx;
         tile[i][tx] = (key < Skv && dd < dh) ? V[(size_t)key * ldv + dd] : (bf16)0.f;
@@ -568,14 +575,21 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace
 
-static size_t generic_fwd_bytes(int Sq, int Skv, int dh) {
+static size_t generic_fwd_bytes(int Sq, int Skv, int dh) {   // one (batch, head)
     const size_t ld = (size_t)((Skv + 63) / 64) * 64;
     return align256((size_t)Sq * ld * 4) + align256((size_t)Sq * ld * 2) + align256((size_t)dh * ld * 2);
 }
+// the generic path multiplies a CHUNK of (batch, head) pairs per launch (batched GEMMs): as many as fit 2 GiB
+static int generic_chunk(int B, int H, int Sq, int Skv, int dh) {
+    const size_t one = generic_fwd_bytes(Sq, Skv, dh);
+    size_t n = ((size_t)2 << 30) / one;
+    if (n < 1) n = 1;
+    if (n > (size_t)B * H) n = (size_t)B * H;
+    return (int)n;
+}
 size_t attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh) {
-    (void)B; (void)H;
     if (dh == DH) return 0;
-    return generic_fwd_bytes(Sq, Skv, dh);
+    return (size_t)generic_chunk(B, H, Sq, Skv, dh) * generic_fwd_bytes(Sq, Skv, dh);
 }
 
 hipError_t launch_rope_inplace(void* x, int ld, const float* cs, const float* sn, int M, int rpb, int ncols, int dh,
@@ -643,48 +657,68 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
         }
         return hipGetLastError();
     }
-    // ---- generic head_dim: per (batch, head)  S = Q K^T (GEMM) -> row softmax -> O = P V (GEMM on V^T) ----
+    // ---- generic head_dim: S = Q K^T (GEMM) -> row softmax -> O = P V (GEMM on V^T), a chunk of (batch, head) pairs per
+    //      launch (batched GEMMs); with dropout the per-pair hash stream keeps it one pair per launch ----
     if (a.dh % 64) return hipErrorInvalidValue;
     const int ld = ((a.Skv + 63) / 64) * 64;
-    if (a.workspace_bytes < generic_fwd_bytes(a.Sq, a.Skv, a.dh) || !a.workspace) return hipErrorInvalidValue;
+    const int BH = a.B * a.H;
+    const size_t one = generic_fwd_bytes(a.Sq, a.Skv, a.dh);
+    if (!a.workspace || a.workspace_bytes < one) return hipErrorInvalidValue;
+    int chunk = (int)(a.workspace_bytes / one);
+    if (chunk > BH) chunk = BH;
+    if (a.dropout_p > 0.f) chunk = 1;
+    // only batch chunks that are whole runs of heads / batches: either all H heads of some batches, or heads of one batch
+    if (chunk >= a.H) chunk = (chunk / a.H) * a.H;
+    else while (a.H % chunk) --chunk;
     char* ws = (char*)a.workspace;
+    const size_t sS = (size_t)a.Sq * ld, sV = (size_t)a.dh * ld;
     float* S = (float*)ws;
-    bf16* P = (bf16*)(ws + align256((size_t)a.Sq * ld * 4));
-    bf16* Vt = (bf16*)((char*)P + align256((size_t)a.Sq * ld * 2));
-    for (int b = 0; b < a.B; ++b)
-        for (int h = 0; h < a.H; ++h) {
-            const bf16* q = (const bf16*)a.q + (size_t)b * a.Sq * a.ldq + h * a.dh;
-            const bf16* k = (const bf16*)a.k + (size_t)b * a.Skv * a.ldk + h * a.dh;
-            const bf16* v = (const bf16*)a.v + (size_t)b * a.Skv * a.ldv + h * a.dh;
-            GemmArgs g1{};
-            g1.A = q; g1.lda = a.ldq; g1.W = k; g1.ldw = a.ldk; g1.out = S; g1.ldo = ld;
-            g1.M = a.Sq; g1.N = ld; g1.K = a.dh; g1.w_rows = a.Skv;
-            hipError_t e = launch_gemm(g1, EPI_BIAS_F32, s);
+    bf16* P = (bf16*)(ws + align256((size_t)chunk * sS * 4));
+    bf16* Vt = (bf16*)((char*)P + align256((size_t)chunk * sS * 2));
+    for (int bh0 = 0; bh0 < BH; bh0 += chunk) {
+        const int nb = chunk < BH - bh0 ? chunk : BH - bh0;
+        const int b0 = bh0 / a.H, h0 = bh0 % a.H;
+        const int nz_o = nb >= a.H ? nb / a.H : 1, nz_i = nb >= a.H ? a.H : nb;
+        const bf16* q = (const bf16*)a.q + (size_t)b0 * a.Sq * a.ldq + h0 * a.dh;
+        const bf16* k = (const bf16*)a.k + (size_t)b0 * a.Skv * a.ldk + h0 * a.dh;
+        const bf16* v = (const bf16*)a.v + (size_t)b0 * a.Skv * a.ldv + h0 * a.dh;
+        GemmArgs g1{};
+        g1.A = q; g1.lda = a.ldq; g1.W = k; g1.ldw = a.ldk; g1.out = S; g1.ldo = ld;
+        g1.M = a.Sq; g1.N = ld; g1.K = a.dh; g1.w_rows = a.Skv;
+        g1.batch_outer = nz_o; g1.batch_inner = nz_i;
+        g1.sA[0] = (long long)a.Sq * a.ldq; g1.sA[1] = a.dh; g1.sW[0] = (long long)a.Skv * a.ldk; g1.sW[1] = a.dh;
+        g1.sO[0] = (long long)nz_i * sS; g1.sO[1] = (long long)sS;
+        hipError_t e = launch_gemm(g1, EPI_BIAS_F32, s);
+        if (e != hipSuccess) return e;
+        if (a.dropout_p > 0.f) {
+            e = launch_softmax_drop_rows(S, P, a.Sq, a.Skv, ld, a.scale, dropout_stream_host(a.seed, a.layer, bh0),
+                                         a.dropout_p, s);
             if (e != hipSuccess) return e;
-            if (a.dropout_p > 0.f) {
-                e = launch_softmax_drop_rows(S, P, a.Sq, a.Skv, ld, a.scale,
-                                             dropout_stream_host(a.seed, a.layer, b * a.H + h), a.dropout_p, s);
-                if (e != hipSuccess) return e;
-            } else {
-                hipLaunchKernelGGL(softmax_rows_kernel, dim3((a.Sq + 3) / 4), dim3(256), 0, s, S, P, a.Sq, a.Skv, ld,
-                                   a.scale * LOG2E);
-            }
-            hipLaunchKernelGGL(transpose_pad_kernel, dim3(ld / 32, (a.dh + 31) / 32), dim3(256), 0, s, v, a.ldv, Vt,
-                               ld, a.Skv, a.dh);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
-            GemmArgs g2{};
-            g2.A = P; g2.lda = ld; g2.W = Vt; g2.ldw = ld; g2.M = a.Sq; g2.N = a.dh; g2.K = ld; g2.w_rows = a.dh;
-            if (a.resid_f32) {
-                float* r = a.resid_f32 + (size_t)b * a.Sq * a.ldr + h * a.dh;
-                g2.residual = (a.resid_in ? a.resid_in : a.resid_f32) + (size_t)b * a.Sq * a.ldr + h * a.dh;
-                g2.ldr = a.ldr; g2.out = r; g2.ldo = a.ldr;
-                e = launch_gemm(g2, EPI_BIAS_RES_F32, s);
-            } else {
-                g2.out = (bf16*)a.out_bf16 + (size_t)b * a.Sq * a.ldo + h * a.dh; g2.ldo = a.ldo;
-                e = launch_gemm(g2, EPI_BIAS_BF16, s);
-            }
-            if (e != hipSuccess) return e;
+        } else {
+            hipLaunchKernelGGL(softmax_rows_kernel, dim3((nb * a.Sq + 3) / 4), dim3(256), 0, s, S, P, nb * a.Sq, a.Skv, ld,
+                               a.scale * LOG2E);
         }
+        hipLaunchKernelGGL(transpose_pad_kernel, dim3(ld / 32, (a.dh + 31) / 32, nb), dim3(256), 0, s, (const bf16*)a.v,
+                           a.ldv, Vt, ld, a.Skv, a.dh, a.H, bh0, (long long)a.Skv * a.ldv, (long long)a.dh);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        (void)v;
+        GemmArgs g2{};
+        g2.A = P; g2.lda = ld; g2.W = Vt; g2.ldw = ld; g2.M = a.Sq; g2.N = a.dh; g2.K = ld; g2.w_rows = a.dh;
+        g2.batch_outer = nz_o; g2.batch_inner = nz_i;
+        g2.sA[0] = (long long)nz_i * sS; g2.sA[1] = (long long)sS; g2.sW[0] = (long long)nz_i * sV; g2.sW[1] = (long long)sV;
+        if (a.resid_f32) {
+            float* r = a.resid_f32 + (size_t)b0 * a.Sq * a.ldr + h0 * a.dh;
+            g2.residual = (a.resid_in ? a.resid_in : a.resid_f32) + (size_t)b0 * a.Sq * a.ldr + h0 * a.dh;
+            g2.ldr = a.ldr; g2.out = r; g2.ldo = a.ldr;
+            g2.sO[0] = (long long)a.Sq * a.ldr; g2.sO[1] = a.dh; g2.sR[0] = g2.sO[0]; g2.sR[1] = g2.sO[1];
+            e = launch_gemm(g2, EPI_BIAS_RES_F32, s);
+        } else {
+            g2.out = (bf16*)a.out_bf16 + (size_t)b0 * a.Sq * a.ldo + h0 * a.dh; g2.ldo = a.ldo;
+            g2.sO[0] = (long long)a.Sq * a.ldo; g2.sO[1] = a.dh;
+            e = launch_gemm(g2, EPI_BIAS_BF16, s);
+        }
+        if (e != hipSuccess) return e;
+    }
     return hipSuccess;
 }
 

@@ -35,6 +35,7 @@ int g_gemm_tile = [] { const char* e = getenv("DITTO_GEMM"); return e ? atoi(e) 
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
+thread_local int g_batch_y = 1;   // grid.y of the launch being built (launch_gemm sets it; the launchers are templates)
 constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile
 constexpr int BUF_BYTES = 2 * TILE_BYTES;        // A + W
 constexpr int GEMM_LDS = 2 * BUF_BYTES;          // double buffered: 64 KiB
@@ -64,6 +65,13 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmParams p) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 1, wc = wid & 1;
 
+    if (gridDim.y > 1) {   // batched: this workgroup's matrices
+        const long long zo = blockIdx.y / p.batch_inner, zi = blockIdx.y % p.batch_inner;
+        p.A += zo * p.sA[0] + zi * p.sA[1];
+        p.W += zo * p.sW[0] + zi * p.sW[1];
+        p.out = (char*)p.out + (zo * p.sO[0] + zi * p.sO[1]) * p.out_esz;
+        if (p.residual) p.residual += zo * p.sR[0] + zi * p.sR[1];
+    }
     const int nwg = p.tiles_m * p.tiles_n;
     int tm, tn;
     const int split = p.k_splits > 1 ? blockIdx.x / nwg : 0;
@@ -139,6 +147,13 @@ __global__ __launch_bounds__(256, 1) void gemm128_deep_kernel(GemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 1, wc = wid & 1;
+    if (gridDim.y > 1) {   // batched: this workgroup's matrices
+        const long long zo = blockIdx.y / p.batch_inner, zi = blockIdx.y % p.batch_inner;
+        p.A += zo * p.sA[0] + zi * p.sA[1];
+        p.W += zo * p.sW[0] + zi * p.sW[1];
+        p.out = (char*)p.out + (zo * p.sO[0] + zi * p.sO[1]) * p.out_esz;
+        if (p.residual) p.residual += zo * p.sR[0] + zi * p.sR[1];
+    }
     const int nwg = p.tiles_m * p.tiles_n;
     int tm, tn;
     const int split = p.k_splits > 1 ? blockIdx.x / nwg : 0;
@@ -234,7 +249,8 @@ hipError_t launch_deep_t(const GemmParams& p, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm128_deep_kernel<EPI>), dim3(p.tiles_m * p.tiles_n * (p.k_splits > 1 ? p.k_splits : 1)),
+    hipLaunchKernelGGL((gemm128_deep_kernel<EPI>),
+                       dim3(p.tiles_m * p.tiles_n * (p.k_splits > 1 ? p.k_splits : 1), g_batch_y),
                        dim3(256), DEEP_LDS, s, p);
     return hipGetLastError();
 }
@@ -248,8 +264,8 @@ hipError_t launch_t(const GemmParams& p, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm128_kernel<EPI>), dim3(p.tiles_m * p.tiles_n * (p.k_splits > 1 ? p.k_splits : 1)), dim3(256),
-                       GEMM_LDS, s, p);
+    hipLaunchKernelGGL((gemm128_kernel<EPI>), dim3(p.tiles_m * p.tiles_n * (p.k_splits > 1 ? p.k_splits : 1), g_batch_y),
+                       dim3(256), GEMM_LDS, s, p);
     return hipGetLastError();
 }
 
@@ -271,6 +287,12 @@ hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s) {
     p.rope_freq_rev = a.rope_freq_rev;
     p.M = a.M; p.N = a.N; p.K = a.K;
     p.k_splits = a.k_splits > 1 ? a.k_splits : 1; p.split_stride = a.split_stride;
+    const int nbatch = (a.batch_outer > 1 ? a.batch_outer : 1) * (a.batch_inner > 1 ? a.batch_inner : 1);
+    p.batch_inner = a.batch_inner > 1 ? a.batch_inner : 1;
+    for (int i = 0; i < 2; ++i) { p.sA[i] = a.sA[i]; p.sW[i] = a.sW[i]; p.sO[i] = a.sO[i]; p.sR[i] = a.sR[i]; }
+    p.out_esz = (epi == EPI_BIAS_RES_F32 || epi == EPI_BIAS_F32) ? 4 : 2;
+    if (nbatch > 1 && (a.fp8 || p.k_splits > 1 || nbatch > 65535)) return hipErrorInvalidValue;
+    g_batch_y = nbatch;
     if (p.k_splits > 1 && (epi != EPI_BIAS_F32 || a.bias || a.fp8)) return hipErrorInvalidValue;
     switch (epi) {
         case EPI_QKV_ROPE:
@@ -293,7 +315,8 @@ hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s) {
         return launch_gemm256_fp8(p, epi, s);
     }
     if (epi == EPI_GATED_FP8) return hipErrorInvalidValue;   // fp8 output only from the fp8 GEMM
-    const int forced = p.k_splits > 1 ? 128 : g_gemm_tile;
+    // split-K and batched launches exist on the 128x128 structures only
+    const int forced = p.k_splits > 1 ? 128 : (nbatch > 1 ? 128 : g_gemm_tile);
     if (forced == 130) return launch_gemm_o3(p, epi, s);
     if (forced == 192 && gemm192_supports(epi)) return launch_gemm192(p, epi, s);
     const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);

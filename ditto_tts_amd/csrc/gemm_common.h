@@ -28,6 +28,9 @@ struct GemmParams {
     int stagger_ticks; // GF_STAGGER_START: s_memrealtime ticks (100 MHz) per quarter tile
     int flags;         // experiment switches (ditto_set_option("gemm_flags")): see GF_* below
     int k_splits; size_t split_stride;   // gemm128 only: see GemmArgs
+    int batch_inner;                      // gemm128 only: blockIdx.y = zo * batch_inner + zi
+    long long sA[2], sW[2], sO[2], sR[2];
+    int out_esz;                          // bytes per output element (batch offset of `out`)
 };
 
 enum { GF_RELAXED_WAIT = 1,        // tile-start wait skips over the previous tile's epilogue stores

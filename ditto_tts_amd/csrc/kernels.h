@@ -71,6 +71,11 @@ struct GemmArgs {
     // [s, s+1) * K / k_splits and writes its partial product to out + s * split_stride (fp32 elements); the caller
     // sums the slices (launch_reduce_partials).  The long-K, few-tile wgrad GEMMs of the backward pass.
     int k_splits; size_t split_stride;
+    // batched (128x128 structures only): grid.y = batch_outer * batch_inner; batch z = (zo, zi) offsets A / W / out /
+    // residual by zo * s?[0] + zi * s?[1] ELEMENTS of their own type.  (Per-(batch, head) attention products of the
+    // generic-head_dim path in one launch.)
+    int batch_outer, batch_inner;
+    long long sA[2], sW[2], sO[2], sR[2];
 };
 hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s);
 extern int g_gemm_tile;  // 0 auto | 128 | 256
