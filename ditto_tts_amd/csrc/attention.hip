@@ -658,7 +658,7 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
         return hipGetLastError();
     }
     // ---- generic head_dim: S = Q K^T (GEMM) -> row softmax -> O = P V (GEMM on V^T), a chunk of (batch, head) pairs per
-    //      launch (batched GEMMs); with dropout the per-pair hash stream keeps it one pair per launch ----
+    //      launch (batched GEMMs; the dropout kernels derive the pair's hash stream from the row index) ----
     if (a.dh % 64) return hipErrorInvalidValue;
     const int ld = ((a.Skv + 63) / 64) * 64;
     const int BH = a.B * a.H;
@@ -666,7 +666,6 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     if (!a.workspace || a.workspace_bytes < one) return hipErrorInvalidValue;
     int chunk = (int)(a.workspace_bytes / one);
     if (chunk > BH) chunk = BH;
-    if (a.dropout_p > 0.f) chunk = 1;
     // only batch chunks that are whole runs of heads / batches: either all H heads of some batches, or heads of one batch
     if (chunk >= a.H) chunk = (chunk / a.H) * a.H;
     else while (a.H % chunk) --chunk;
@@ -691,8 +690,7 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
         hipError_t e = launch_gemm(g1, EPI_BIAS_F32, s);
         if (e != hipSuccess) return e;
         if (a.dropout_p > 0.f) {
-            e = launch_softmax_drop_rows(S, P, a.Sq, a.Skv, ld, a.scale, dropout_stream_host(a.seed, a.layer, bh0),
-                                         a.dropout_p, s);
+            e = launch_softmax_drop_rows(S, P, nb * a.Sq, a.Sq, a.Skv, ld, a.scale, a.seed, a.layer, bh0, a.dropout_p, s);
             if (e != hipSuccess) return e;
         } else {
             hipLaunchKernelGGL(softmax_rows_kernel, dim3((nb * a.Sq + 3) / 4), dim3(256), 0, s, S, P, nb * a.Sq, a.Skv, ld,
@@ -729,22 +727,36 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
 // The "^T" operands of the forward GEMM family (K-contiguous rows) are made by transpose_bf16.
 // ------------------------------------------------------------------------------------------------
 namespace {
-struct BwdWs { size_t S, dP, P, dS, Pt, dOt, Kt, Qt, total; };
-BwdWs plan_bwd(int Sq, int Skv, int dh) {
+struct BwdWs { size_t S, dP, P, dS, Pt, dOt, Kt, Qt, total; };   // offsets of the per-chunk arrays
+BwdWs plan_bwd(int Sq, int Skv, int dh, int chunk) {
     BwdWs w;
-    const size_t ld = (size_t)((Skv + 63) / 64) * 64, sqp = (size_t)((Sq + 63) / 64) * 64;
+    const size_t ld = (size_t)((Skv + 63) / 64) * 64, sqp = (size_t)((Sq + 63) / 64) * 64, n = (size_t)chunk;
     size_t off = 0;
     auto take = [&](size_t b) { size_t o = off; off += align256(b); return o; };
-    w.S = take((size_t)Sq * ld * 4); w.dP = take((size_t)Sq * ld * 4); w.P = take((size_t)Sq * ld * 2);
-    w.dS = take((size_t)Sq * ld * 2); w.Pt = take(ld * sqp * 2); w.dOt = take((size_t)dh * sqp * 2);
-    w.Kt = take((size_t)dh * ld * 2); w.Qt = take((size_t)dh * sqp * 2);
+    w.S = take(n * Sq * ld * 4); w.dP = take(n * Sq * ld * 4); w.P = take(n * Sq * ld * 2);
+    w.dS = take(n * Sq * ld * 2); w.Pt = take(n * ld * sqp * 2); w.dOt = take(n * dh * sqp * 2);
+    w.Kt = take(n * dh * ld * 2); w.Qt = take(n * dh * sqp * 2);
     w.total = off;
     return w;
+}
+int bwd_chunk(int B, int H, int Sq, int Skv, int dh, size_t budget) {
+    const size_t one = plan_bwd(Sq, Skv, dh, 1).total + 8 * 256;
+    size_t n = budget / one;
+    if (n < 1) n = 1;
+    if (n > (size_t)B * H) n = (size_t)B * H;
+    int chunk = (int)n;
+    if (chunk >= H) chunk = (chunk / H) * H;   // whole batches, or a divisor of H inside one batch
+    else while (H % chunk) --chunk;
+    return chunk;
 }
 }  // namespace
 
 size_t attention_train_workspace_bytes(int B, int H, int Sq, int Skv, int dh) {
-    const size_t f = generic_fwd_bytes(Sq, Skv, dh), b = plan_bwd(Sq, Skv, dh).total;
+    // generic forward / backward: a chunk of (batch, head) pairs per launch, as many as fit 2 GiB
+    const int cf = generic_chunk(B, H, Sq, Skv, dh);
+    const size_t f = (size_t)cf * generic_fwd_bytes(Sq, Skv, dh);
+    const int cb = bwd_chunk(B, H, Sq, Skv, dh, (size_t)2 << 30);
+    const size_t b = plan_bwd(Sq, Skv, dh, cb).total;
     const size_t dl = align256((size_t)B * H * Sq * 4);   // fused backward: delta [B, H, Sq]
     const size_t g = f > b ? f : b;
     return g > dl ? g : dl;
@@ -760,8 +772,10 @@ hipError_t launch_attention_bwd(const AttnBwdArgs& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         return launch_attention_bwd64(a, a.lse, delta, s);
     }
-    const BwdWs w = plan_bwd(a.Sq, a.Skv, a.dh);
-    if (!a.workspace || a.workspace_bytes < w.total) return hipErrorInvalidValue;
+    if (!a.workspace || a.workspace_bytes < plan_bwd(a.Sq, a.Skv, a.dh, 1).total) return hipErrorInvalidValue;
+    const int BH = a.B * a.H;
+    const int chunk = bwd_chunk(a.B, a.H, a.Sq, a.Skv, a.dh, a.workspace_bytes);
+    const BwdWs w = plan_bwd(a.Sq, a.Skv, a.dh, chunk);
     const int ld = ((a.Skv + 63) / 64) * 64, sqp = ((a.Sq + 63) / 64) * 64;
     char* ws = (char*)a.workspace;
     float* S = (float*)(ws + w.S);
@@ -772,51 +786,61 @@ hipError_t launch_attention_bwd(const AttnBwdArgs& a, hipStream_t s) {
     bf16* dOt = (bf16*)(ws + w.dOt);
     bf16* Kt = (bf16*)(ws + w.Kt);
     bf16* Qt = (bf16*)(ws + w.Qt);
+    const long long sS = (long long)a.Sq * ld, sPt = (long long)ld * sqp, sDt = (long long)a.dh * sqp, sKt = (long long)a.dh * ld;
     hipError_t e;
 #define ATRY(x) do { if ((e = (x)) != hipSuccess) return e; } while (0)
-    for (int b = 0; b < a.B; ++b)
-        for (int h = 0; h < a.H; ++h) {
-            const bf16* q = (const bf16*)a.q + (size_t)b * a.Sq * a.ldq + h * a.dh;
-            const bf16* k = (const bf16*)a.k + (size_t)b * a.Skv * a.ldk + h * a.dh;
-            const bf16* v = (const bf16*)a.v + (size_t)b * a.Skv * a.ldv + h * a.dh;
-            const bf16* dO = (const bf16*)a.dout + (size_t)b * a.Sq * a.lddo + h * a.dh;
-            bf16* dq = (bf16*)a.dq + (size_t)b * a.Sq * a.lddq + h * a.dh;
-            bf16* dk = (bf16*)a.dk + (size_t)b * a.Skv * a.lddk + h * a.dh;
-            bf16* dv = (bf16*)a.dv + (size_t)b * a.Skv * a.lddv + h * a.dh;
-            const unsigned stream = dropout_stream_host(a.seed, a.layer, b * a.H + h);
-            GemmArgs g{};
-            // S = Q K^T
-            g.A = q; g.lda = a.ldq; g.W = k; g.ldw = a.ldk; g.w_rows = a.Skv; g.out = S; g.ldo = ld;
-            g.M = a.Sq; g.N = ld; g.K = a.dh;
-            ATRY(launch_gemm(g, EPI_BIAS_F32, s));
-            ATRY(launch_softmax_drop_rows(S, P, a.Sq, a.Skv, ld, a.scale, stream, a.dropout_p, s));
-            // dV = P^T dO
-            ATRY(launch_transpose_bf16(P, ld, a.Sq, ld, Pt, sqp, s));
-            ATRY(launch_transpose_bf16(dO, a.lddo, a.Sq, a.dh, dOt, sqp, s));
-            g = GemmArgs{};
-            g.A = Pt; g.lda = sqp; g.W = dOt; g.ldw = sqp; g.w_rows = a.dh; g.out = dv; g.ldo = a.lddv;
-            g.M = a.Skv; g.N = a.dh; g.K = sqp;
-            ATRY(launch_gemm(g, EPI_BIAS_BF16, s));
-            // dPd = dO V^T
-            g = GemmArgs{};
-            g.A = dO; g.lda = a.lddo; g.W = v; g.ldw = a.ldv; g.w_rows = a.Skv; g.out = dP; g.ldo = ld;
-            g.M = a.Sq; g.N = ld; g.K = a.dh;
-            ATRY(launch_gemm(g, EPI_BIAS_F32, s));
-            ATRY(launch_softmax_bwd_rows(S, dP, dS, a.Sq, a.Skv, ld, a.scale, stream, a.dropout_p, s));
-            // dQ = dS K
-            ATRY(launch_transpose_bf16(k, a.ldk, a.Skv, a.dh, Kt, ld, s));
-            g = GemmArgs{};
-            g.A = dS; g.lda = ld; g.W = Kt; g.ldw = ld; g.w_rows = a.dh; g.out = dq; g.ldo = a.lddq;
-            g.M = a.Sq; g.N = a.dh; g.K = ld;
-            ATRY(launch_gemm(g, EPI_BIAS_BF16, s));
-            // dK = dS^T Q
-            ATRY(launch_transpose_bf16(dS, ld, a.Sq, ld, Pt, sqp, s));
-            ATRY(launch_transpose_bf16(q, a.ldq, a.Sq, a.dh, Qt, sqp, s));
-            g = GemmArgs{};
-            g.A = Pt; g.lda = sqp; g.W = Qt; g.ldw = sqp; g.w_rows = a.dh; g.out = dk; g.ldo = a.lddk;
-            g.M = a.Skv; g.N = a.dh; g.K = sqp;
-            ATRY(launch_gemm(g, EPI_BIAS_BF16, s));
-        }
+    for (int bh0 = 0; bh0 < BH; bh0 += chunk) {
+        const int nb = chunk < BH - bh0 ? chunk : BH - bh0;
+        const int b0 = bh0 / a.H, h0 = bh0 % a.H;
+        const int zo = nb >= a.H ? nb / a.H : 1, zi = nb >= a.H ? a.H : nb;
+        const bf16* q = (const bf16*)a.q + (size_t)b0 * a.Sq * a.ldq + h0 * a.dh;
+        const bf16* k = (const bf16*)a.k + (size_t)b0 * a.Skv * a.ldk + h0 * a.dh;
+        const bf16* v = (const bf16*)a.v + (size_t)b0 * a.Skv * a.ldv + h0 * a.dh;
+        const bf16* dO = (const bf16*)a.dout + (size_t)b0 * a.Sq * a.lddo + h0 * a.dh;
+        bf16* dq = (bf16*)a.dq + (size_t)b0 * a.Sq * a.lddq + h0 * a.dh;
+        bf16* dk = (bf16*)a.dk + (size_t)b0 * a.Skv * a.lddk + h0 * a.dh;
+        bf16* dv = (bf16*)a.dv + (size_t)b0 * a.Skv * a.lddv + h0 * a.dh;
+        auto batched = [&](GemmArgs& g) { g.batch_outer = zo; g.batch_inner = zi; };
+        auto stacked = [&](long long (&st)[2], long long per) { st[0] = (long long)zi * per; st[1] = per; };   // [z] arrays
+        auto strided = [&](long long (&st)[2], long long rows, int ldx) { st[0] = rows * ldx; st[1] = a.dh; };  // (b, h) views
+        GemmArgs g{};
+        // S = Q K^T
+        g.A = q; g.lda = a.ldq; g.W = k; g.ldw = a.ldk; g.w_rows = a.Skv; g.out = S; g.ldo = ld;
+        g.M = a.Sq; g.N = ld; g.K = a.dh;
+        batched(g); strided(g.sA, a.Sq, a.ldq); strided(g.sW, a.Skv, a.ldk); stacked(g.sO, sS);
+        ATRY(launch_gemm(g, EPI_BIAS_F32, s));
+        ATRY(launch_softmax_drop_rows(S, P, nb * a.Sq, a.Sq, a.Skv, ld, a.scale, a.seed, a.layer, bh0, a.dropout_p, s));
+        // dV = P^T dO
+        ATRY(launch_transpose_bf16(P, ld, a.Sq, ld, Pt, sqp, s, nb, 1, sS, 0, sPt));
+        ATRY(launch_transpose_bf16(dO, a.lddo, a.Sq, a.dh, dOt, sqp, s, zo, zi, (long long)a.Sq * a.lddo, a.dh, sDt));
+        g = GemmArgs{};
+        g.A = Pt; g.lda = sqp; g.W = dOt; g.ldw = sqp; g.w_rows = a.dh; g.out = dv; g.ldo = a.lddv;
+        g.M = a.Skv; g.N = a.dh; g.K = sqp;
+        batched(g); stacked(g.sA, sPt); stacked(g.sW, sDt); strided(g.sO, a.Skv, a.lddv);
+        ATRY(launch_gemm(g, EPI_BIAS_BF16, s));
+        // dPd = dO V^T
+        g = GemmArgs{};
+        g.A = dO; g.lda = a.lddo; g.W = v; g.ldw = a.ldv; g.w_rows = a.Skv; g.out = dP; g.ldo = ld;
+        g.M = a.Sq; g.N = ld; g.K = a.dh;
+        batched(g); strided(g.sA, a.Sq, a.lddo); strided(g.sW, a.Skv, a.ldv); stacked(g.sO, sS);
+        ATRY(launch_gemm(g, EPI_BIAS_F32, s));
+        ATRY(launch_softmax_bwd_rows(S, dP, dS, nb * a.Sq, a.Sq, a.Skv, ld, a.scale, a.seed, a.layer, bh0, a.dropout_p, s));
+        // dQ = dS K
+        ATRY(launch_transpose_bf16(k, a.ldk, a.Skv, a.dh, Kt, ld, s, zo, zi, (long long)a.Skv * a.ldk, a.dh, sKt));
+        g = GemmArgs{};
+        g.A = dS; g.lda = ld; g.W = Kt; g.ldw = ld; g.w_rows = a.dh; g.out = dq; g.ldo = a.lddq;
+        g.M = a.Sq; g.N = a.dh; g.K = ld;
+        batched(g); stacked(g.sA, sS); stacked(g.sW, sKt); strided(g.sO, a.Sq, a.lddq);
+        ATRY(launch_gemm(g, EPI_BIAS_BF16, s));
+        // dK = dS^T Q
+        ATRY(launch_transpose_bf16(dS, ld, a.Sq, ld, Pt, sqp, s, nb, 1, sS, 0, sPt));
+        ATRY(launch_transpose_bf16(q, a.ldq, a.Sq, a.dh, Qt, sqp, s, zo, zi, (long long)a.Sq * a.ldq, a.dh, sDt));
+        g = GemmArgs{};
+        g.A = Pt; g.lda = sqp; g.W = Qt; g.ldw = sqp; g.w_rows = a.dh; g.out = dk; g.ldo = a.lddk;
+        g.M = a.Skv; g.N = a.dh; g.K = sqp;
+        batched(g); stacked(g.sA, sPt); stacked(g.sW, sDt); strided(g.sO, a.Skv, a.lddk);
+        ATRY(launch_gemm(g, EPI_BIAS_BF16, s));
+    }
 #undef ATRY
     return hipSuccess;
 }

@@ -139,7 +139,9 @@ hipError_t launch_attention_bwd64(const AttnBwdArgs& a, const float* lse, const 
 size_t attention_train_workspace_bytes(int B, int H, int Sq, int Skv, int dh);   // forward + backward scratch
 
 // ---------------- train.hip : backward-pass row / elementwise kernels ----------------
-hipError_t launch_transpose_bf16(const void* src, int ld, int rows, int cols, void* dst, int ldT, hipStream_t s);
+// optionally batched: nz_o * nz_i matrices, src of matrix (zo, zi) at + zo * s_o + zi * s_i, dst at + z * d_z (elements)
+hipError_t launch_transpose_bf16(const void* src, int ld, int rows, int cols, void* dst, int ldT, hipStream_t s,
+                                 int nz_o = 1, int nz_i = 1, long long s_o = 0, long long s_i = 0, long long d_z = 0);
 size_t colsum_scratch_bytes(int M, int n);
 hipError_t launch_reduce_partials(const float* partial, int chunks, size_t n, float* out, hipStream_t s);
 hipError_t launch_colsum_f32(const float* x, int ld, int M, int n, float* out, float* scratch, hipStream_t s);
@@ -156,10 +158,10 @@ hipError_t launch_pack_bf16_t(const float* src, void* dst, int rows, int cols, i
                               hipStream_t s);
 unsigned dropout_stream_host(uint64_t seed, int layer, int bh);
 unsigned dropout_threshold(float p);
-hipError_t launch_softmax_drop_rows(const float* S, void* P, int Sq, int Skv, int ld, float scale, unsigned stream,
-                                    float p_drop, hipStream_t s);
-hipError_t launch_softmax_bwd_rows(const float* S, const float* dPd, void* dS, int Sq, int Skv, int ld, float scale,
-                                   unsigned stream, float p_drop, hipStream_t s);
+hipError_t launch_softmax_drop_rows(const float* S, void* P, int nrows, int rows_per_bh, int Skv, int ld, float scale,
+                                    uint64_t seed, int layer, int bh0, float p_drop, hipStream_t s);
+hipError_t launch_softmax_bwd_rows(const float* S, const float* dPd, void* dS, int nrows, int rows_per_bh, int Skv, int ld,
+                                   float scale, uint64_t seed, int layer, int bh0, float p_drop, hipStream_t s);
 hipError_t launch_small_linear_fwd(const float* x, const float* W, const float* bias, float* y, int B, int I, int O,
                                    bool silu_in, hipStream_t s);
 hipError_t launch_small_linear_bwd_w(const float* dy, const float* x, float* dW, float* dbias, int B, int I, int O,

@@ -22,11 +22,15 @@ namespace ditto {
 // dst[c][r] = src[r][c]; dst is [cols, ldT] bf16 with ldT >= rows, columns rows..ldT-1 written as zero.
 // 64x64 tile through LDS (row pitch 66 elements = 33 words: the column gather below is conflict-free).
 // ---------------------------------------------------------------------------------------------------------
+// blockIdx.z = z (batched): src += (z / zi) * s_o + (z % zi) * s_i, dst += z * d_z  (elements)
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16* __restrict__ src, int ld, int rows, int cols,
-                                                             bf16* __restrict__ dst, int ldT) {
+                                                             bf16* __restrict__ dst, int ldT, int zi, long long s_o,
+                                                             long long s_i, long long d_z) {
     __shared__ bf16 tile[64][66];
     const int tid = threadIdx.x;
     const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    src += (long long)(blockIdx.z / zi) * s_o + (long long)(blockIdx.z % zi) * s_i;
+    dst += (long long)blockIdx.z * d_z;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int idx = tid + 256 * i;          // 512 chunks of 8
@@ -48,10 +52,12 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16* __restr
         *reinterpret_cast<bf16x8*>(dst + (size_t)(c0 + c) * ldT + r0 + ch * 8) = o;
     }
 }
-hipError_t launch_transpose_bf16(const void* src, int ld, int rows, int cols, void* dst, int ldT, hipStream_t s) {
-    if (ld % 8 || cols % 8 || ldT % 64 || ldT < rows) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(transpose_bf16_kernel, dim3(ldT / 64, (cols + 63) / 64), dim3(256), 0, s, (const bf16*)src, ld,
-                       rows, cols, (bf16*)dst, ldT);
+hipError_t launch_transpose_bf16(const void* src, int ld, int rows, int cols, void* dst, int ldT, hipStream_t s, int nz_o,
+                                 int nz_i, long long s_o, long long s_i, long long d_z) {
+    if (ld % 8 || cols % 8 || ldT % 64 || ldT < rows || nz_o < 1 || nz_i < 1 || nz_o * nz_i > 65535) return hipErrorInvalidValue;
+    if ((s_o | s_i | d_z) % 8) return hipErrorInvalidValue;   // 16-byte accesses
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3(ldT / 64, (cols + 63) / 64, nz_o * nz_i), dim3(256), 0, s,
+                       (const bf16*)src, ld, rows, cols, (bf16*)dst, ldT, nz_i, s_o, s_i, d_z);
     return hipGetLastError();
 }
 
@@ -412,11 +418,15 @@ hipError_t launch_pack_bf16_t(const float* src, void* dst, int rows, int cols, i
 // backward kernels regenerate it instead of storing a [B,H,N,T] mask.  tests/ restate the same hash in numpy.
 // ---------------------------------------------------------------------------------------------------------
 // P bf16 [Sq, ld] = dropout(softmax(S * scale)) (first Skv columns; padding columns zero).  One wave per row.
+// rows = a stack of (batch, head) score matrices, rows_per_bh each: row -> pair bh0 + row / rows_per_bh, query row % ..
 __global__ __launch_bounds__(256) void softmax_drop_rows_kernel(const float* __restrict__ S, bf16* __restrict__ P, int Sq,
-                                                                int Skv, int ld, float scale_log2, unsigned stream,
+                                                                int Skv, int ld, float scale_log2, unsigned seed_lo,
+                                                                unsigned seed_hi, int layer, int bh0, int rows_per_bh,
                                                                 unsigned thr, float keep_scale) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= Sq) return;
+    const unsigned stream = thr ? drop_stream(seed_lo, seed_hi, layer, bh0 + row / rows_per_bh) : 0u;
+    const int qi = row % rows_per_bh;
     const float* s = S + (size_t)row * ld;
     float m = -1e30f;
     for (int j = lane; j < Skv; j += 64) m = fmaxf(m, s[j]);
@@ -429,7 +439,7 @@ __global__ __launch_bounds__(256) void softmax_drop_rows_kernel(const float* __r
         float p = 0.f;
         if (j < Skv) {
             p = __builtin_amdgcn_exp2f((s[j] - m) * scale_log2) * inv;
-            if (thr) p = drop_keep(stream, row, j, thr) ? p * keep_scale : 0.f;
+            if (thr) p = drop_keep(stream, qi, j, thr) ? p * keep_scale : 0.f;
         }
         pr[j] = (bf16)p;
     }
@@ -438,10 +448,13 @@ __global__ __launch_bounds__(256) void softmax_drop_rows_kernel(const float* __r
 // dP = dPd * mask * keep_scale (dPd fp32 [Sq, ld] = dO V^T).  Padding columns zero.
 __global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __restrict__ S, const float* __restrict__ dPd,
                                                                bf16* __restrict__ dS, int Sq, int Skv, int ld,
-                                                               float scale, float scale_log2, unsigned stream,
+                                                               float scale, float scale_log2, unsigned seed_lo,
+                                                               unsigned seed_hi, int layer, int bh0, int rows_per_bh,
                                                                unsigned thr, float keep_scale) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= Sq) return;
+    const unsigned stream = thr ? drop_stream(seed_lo, seed_hi, layer, bh0 + row / rows_per_bh) : 0u;
+    const int qi = row % rows_per_bh;
     const float* s = S + (size_t)row * ld;
     const float* dp = dPd + (size_t)row * ld;
     float m = -1e30f;
@@ -454,7 +467,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __re
     for (int j = lane; j < Skv; j += 64) {
         const float p = __builtin_amdgcn_exp2f((s[j] - m) * scale_log2) * inv;
         float g = dp[j];
-        if (thr) g = drop_keep(stream, row, j, thr) ? g * keep_scale : 0.f;
+        if (thr) g = drop_keep(stream, qi, j, thr) ? g * keep_scale : 0.f;
         dsum += p * g;
     }
     dsum = wave_sum(dsum);
@@ -464,7 +477,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __re
         if (j < Skv) {
             const float p = __builtin_amdgcn_exp2f((s[j] - m) * scale_log2) * inv;
             float g = dp[j];
-            if (thr) g = drop_keep(stream, row, j, thr) ? g * keep_scale : 0.f;
+            if (thr) g = drop_keep(stream, qi, j, thr) ? g * keep_scale : 0.f;
             v = p * (g - dsum) * scale;
         }
         out[j] = (bf16)v;
@@ -480,18 +493,21 @@ unsigned dropout_stream_host(uint64_t seed, int layer, int bh) {
     const unsigned lo = (unsigned)(seed & 0xFFFFFFFFu), hi = (unsigned)(seed >> 32);
     return lb(lo ^ lb(hi + (unsigned)layer * 0x632BE5ABu + (unsigned)bh * 0x9E3779B1u));
 }
-hipError_t launch_softmax_drop_rows(const float* S, void* P, int Sq, int Skv, int ld, float scale, unsigned stream,
-                                    float p_drop, hipStream_t s) {
+// nrows = rows_per_bh * (number of stacked (batch, head) pairs starting at pair bh0)
+hipError_t launch_softmax_drop_rows(const float* S, void* P, int nrows, int rows_per_bh, int Skv, int ld, float scale,
+                                    uint64_t seed, int layer, int bh0, float p_drop, hipStream_t s) {
     const unsigned thr = dropout_threshold(p_drop);
-    hipLaunchKernelGGL(softmax_drop_rows_kernel, dim3((Sq + 3) / 4), dim3(256), 0, s, S, (bf16*)P, Sq, Skv, ld,
-                       scale * 1.4426950408889634f, stream, thr, thr ? 1.0f / (1.0f - p_drop) : 1.0f);
+    hipLaunchKernelGGL(softmax_drop_rows_kernel, dim3((nrows + 3) / 4), dim3(256), 0, s, S, (bf16*)P, nrows, Skv, ld,
+                       scale * 1.4426950408889634f, (unsigned)(seed & 0xFFFFFFFFu), (unsigned)(seed >> 32), layer, bh0,
+                       rows_per_bh, thr, thr ? 1.0f / (1.0f - p_drop) : 1.0f);
     return hipGetLastError();
 }
-hipError_t launch_softmax_bwd_rows(const float* S, const float* dPd, void* dS, int Sq, int Skv, int ld, float scale,
-                                   unsigned stream, float p_drop, hipStream_t s) {
+hipError_t launch_softmax_bwd_rows(const float* S, const float* dPd, void* dS, int nrows, int rows_per_bh, int Skv, int ld,
+                                   float scale, uint64_t seed, int layer, int bh0, float p_drop, hipStream_t s) {
     const unsigned thr = dropout_threshold(p_drop);
-    hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((Sq + 3) / 4), dim3(256), 0, s, S, dPd, (bf16*)dS, Sq, Skv, ld,
-                       scale, scale * 1.4426950408889634f, stream, thr, thr ? 1.0f / (1.0f - p_drop) : 1.0f);
+    hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((nrows + 3) / 4), dim3(256), 0, s, S, dPd, (bf16*)dS, nrows, Skv, ld,
+                       scale, scale * 1.4426950408889634f, (unsigned)(seed & 0xFFFFFFFFu), (unsigned)(seed >> 32), layer,
+                       bh0, rows_per_bh, thr, thr ? 1.0f / (1.0f - p_drop) : 1.0f);
     return hipGetLastError();
 }
 
