@@ -514,6 +514,24 @@ int ditto_p_sample(ditto_model_t m, float* x, const void* cond, const int64_t* t
                                  (size_t)N * m->cfg.hidden_dim, stream);
 }
 
+int ditto_denoise_steps(ditto_model_t m, float* x, const void* cond, int t_begin, int t_end, const float* noise,
+                        const float* betas, const float* alphas, const float* alphas_cumprod, int B, int N, int T,
+                        const float* rope_cos, const float* rope_sin, int64_t* t_scratch, void* workspace,
+                        size_t workspace_bytes, ditto_stream_t stream) {
+    if (!m || !x || !t_scratch) return fail(DITTO_ERR_ARG, "bad argument to ditto_denoise_steps");
+    if (t_end < 0 || t_begin < t_end || t_begin >= m->cfg.diffusion_steps)
+        return fail(DITTO_ERR_ARG, "need 0 <= t_end <= t_begin < diffusion_steps");
+    if (!noise && t_begin > 0) return fail(DITTO_ERR_ARG, "noise may be NULL only for the single step t = 0");
+    const size_t per_step = (size_t)B * N * m->cfg.hidden_dim;
+    for (int tv = t_begin, i = 0; tv >= t_end; --tv, ++i) {
+        HIP_TRY(launch_fill_i64(t_scratch, B, tv, (hipStream_t)stream));
+        if (int rc = ditto_p_sample(m, x, cond, t_scratch, noise ? noise + (size_t)i * per_step : nullptr, betas, alphas,
+                                    alphas_cumprod, B, N, T, rope_cos, rope_sin, workspace, workspace_bytes, stream))
+            return rc;
+    }
+    return DITTO_OK;
+}
+
 int ditto_q_sample(const float* x_start, const float* noise, const int64_t* t, const float* buffer, float* out, int B,
                    size_t elems_per_utt, ditto_stream_t stream) {
     if (!x_start || !noise || !t || !buffer || !out || B <= 0) return fail(DITTO_ERR_ARG, "bad argument to ditto_q_sample");

@@ -43,6 +43,7 @@ hipError_t launch_scale_vec(float* v, int n, float f, hipStream_t s);
 // same row map for an fp32 vector (bias)
 hipError_t launch_pack_vec(const float* src, float* dst, int rows, int blk, int mult, int row_off, hipStream_t s);
 hipError_t launch_add_vec(const float* a, const float* b, float* dst, int n, hipStream_t s);
+hipError_t launch_fill_i64(int64_t* dst, int n, int64_t value, hipStream_t s);
 
 // ---------------- gemm.hip : bf16 MFMA GEMM family  out = A[M,K] * W[N,K]^T + bias ... ----------------
 enum GemmEpilogue {

@@ -444,6 +444,14 @@ __global__ void add_vec_kernel(const float* __restrict__ a, const float* __restr
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = a[i] + b[i];
 }
+__global__ void fill_i64_kernel(int64_t* __restrict__ dst, int n, int64_t value) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = value;
+}
+hipError_t launch_fill_i64(int64_t* dst, int n, int64_t value, hipStream_t s) {
+    hipLaunchKernelGGL(fill_i64_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dst, n, value);
+    return hipGetLastError();
+}
 hipError_t launch_add_vec(const float* a, const float* b, float* dst, int n, hipStream_t s) {
     hipLaunchKernelGGL(add_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, dst, n);
     return hipGetLastError();

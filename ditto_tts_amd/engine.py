@@ -177,6 +177,27 @@ class DenoiseEngine:
                                           c.data_ptr(), s.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
         return x
 
+    def denoise_steps_(self, x: torch.Tensor, cond: TextCond, t_begin: int, t_end: int, noises: Optional[torch.Tensor],
+                       betas: torch.Tensor, alphas: torch.Tensor, alphas_cumprod: torch.Tensor):
+        """The sampling loop t_begin .. t_end (inclusive, descending) as ONE library call, in place on x;
+        noises fp32 [t_begin - t_end + 1, B, N, d] in execution order."""
+        if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()):
+            raise ValueError("denoise_steps_ needs a contiguous fp32 CUDA state tensor (it is updated in place)")
+        B, N, _ = x.shape
+        nsteps = t_begin - t_end + 1
+        if noises is not None:
+            noises = self._f32(noises, "noises")
+            if noises.shape != (nsteps, *x.shape):
+                raise ValueError(f"noises must have shape {(nsteps, *x.shape)}")
+        ws = self.workspace(B, N, cond.T)
+        c, s = self.rope_tables(N)
+        tt = torch.empty(B, dtype=torch.int64, device=self.device)
+        hip.check(self.lib.ditto_denoise_steps(self.handle, x.data_ptr(), cond.buf.data_ptr(), int(t_begin), int(t_end),
+                                               _ptr(noises), betas.data_ptr(), alphas.data_ptr(),
+                                               alphas_cumprod.data_ptr(), B, N, cond.T, c.data_ptr(), s.data_ptr(),
+                                               tt.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+        return x
+
     def capture_p_sample(self, x: torch.Tensor, cond: TextCond, t: torch.Tensor, noise: torch.Tensor,
                          betas: torch.Tensor, alphas: torch.Tensor, alphas_cumprod: torch.Tensor):
         """Capture ONE reverse-diffusion step (the ~122 stream-ordered launches of ditto_p_sample) into a HIP

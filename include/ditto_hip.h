@@ -166,6 +166,16 @@ int ditto_p_sample(ditto_model_t m, float* x, const void* cond, const int64_t* t
                    int B, int N, int T, const float* rope_cos, const float* rope_sin,
                    void* workspace, size_t workspace_bytes, ditto_stream_t stream);
 
+/* The sampling loop, SpeechGenerator.__sample_latents (src/model/SpeechGenerator.py:149-164), as ONE stream-ordered
+ * enqueue: for t_val = t_begin, t_begin-1, ..., t_end:  x <- p_sample(x, full(B, t_val), cond).  `noise` holds the
+ * N(0,1) draws of the steps in execution order, fp32 [t_begin - t_end + 1, B, N, d] (the caller's RNG: the library has
+ * none; it may be NULL only when t_begin == t_end == 0).  t_scratch: int64 [B] device scratch the loop fills.
+ * A caller that wants the whole loop in a hipGraph captures this single call. */
+int ditto_denoise_steps(ditto_model_t m, float* x, const void* cond, int t_begin, int t_end, const float* noise,
+                        const float* betas, const float* alphas, const float* alphas_cumprod, int B, int N, int T,
+                        const float* rope_cos, const float* rope_sin, int64_t* t_scratch, void* workspace,
+                        size_t workspace_bytes, ditto_stream_t stream);
+
 /* DiTTO.q_sample (src/model/DiTTO.py:106-126), bug-for-bug: `buffer` is the module's
  * `alphas_cumprod` buffer, which holds clipped betas.  out may alias x_start. */
 int ditto_q_sample(const float* x_start, const float* noise, const int64_t* t, const float* buffer,

@@ -127,6 +127,24 @@ def test_g5_sampler_trajectory(golden):
 
 
 @torch.no_grad()
+def test_denoise_steps_entry_equals_the_step_loop(golden):
+    """ditto_denoise_steps (the whole loop as one library call) == the per-step loop, bit for bit, and the golden."""
+    g = golden("G5_sampler_50.npz")
+    cfg = DiTTOConfig(256, 2, 4, 256, 256, 50)
+    m = build(cfg, 5)
+    sg = SpeechGenerator(ditto_model=m, device=DEV)
+    noises = torch.stack([hash_normal((2, 64, 256), f"z{i}", 55) for i in range(50)]).to(DEV)
+    eng = m.engine()
+    cond = eng.prepare_text(g["text"].to(DEV), 64)
+    x = g["xinit"].to(DEV).clone()
+    eng.denoise_steps_(x, cond, 49, 0, noises, sg.betas, sg.alphas, sg.alphas_cumprod)
+    y = sg._SpeechGenerator__sample_latents(g["text"].to(DEV), g["xinit"].to(DEV), cond_by_audio=True,
+                                            noises=lambda i: noises[i])
+    assert torch.equal(x, y)
+    assert rel_l2(x, g["x_step49"]) < RTOL
+
+
+@torch.no_grad()
 def test_graph_replay_equals_eager(golden):
     """The HIP-graph sampling loop (one captured step replayed 50 times) is bit-identical to eager launches."""
     g = golden("G5_sampler_50.npz")
