@@ -33,7 +33,8 @@ namespace ditto {
 // bit 0: K/V tiles by LDS-DMA instead of register staging; bit 1: V fragments prefetched ahead of the softmax
 // (needs bit 0); bit 4 (16): ditto_attention_bf16's q is pre-scaled
 // (unit tests of attn64v2); bit 5 (32): run the kernels above on pre-scaled q instead of attn64v2 (A/B); bit 6 (64):
-// attn64v2 at 2 waves per SIMD with the V prefetch instead of 3 without.  ditto_set_option("attn_flags")
+// attn64v2 at 2 waves per SIMD with the V prefetch instead of 3 without; bit 7 (128): no deep-prefetch instantiation
+// on small grids.  ditto_set_option("attn_flags")
 int g_attn_flags = 3;
 
 namespace {
@@ -326,10 +327,14 @@ __global__ __launch_bounds__(256, WPS) void attn64_kernel(AttnParams p) {
 //   * K/V DMA source addresses are base + tile * stride (the per-tile clamp only exists on a ragged last tile).
 // Deferred raise of the maximum as in attn64: P <= 2^8.
 // ------------------------------------------------------------------------------------------------
-template <bool RESID, int WPS = 2>
+// NBUF = 2: K/V one tile ahead, waited with vmcnt(0) at the end of a tile (grids of many workgroups per CU: the other
+// workgroups cover the DMA latency).  NBUF = 4 (64 KiB): K/V THREE tiles ahead behind a counted vmcnt, for small grids
+// (batch-1 serving: 96 workgroups on 256 CUs, where the kernel's time is one workgroup's serial tile loop and a single
+// tile of look-ahead exposes the full DMA latency on every tile: 1.3 us per 64-key tile measured).
+template <bool RESID, int WPS = 2, int NBUF = 2>
 __global__ __launch_bounds__(256, WPS) void attn64v2_kernel(AttnParams p) {
     constexpr bool PFV = WPS <= 2;   // V fragments prefetched ahead of the softmax only when 256 registers are available
-    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KV_TILE_BYTES];  // [buf][K|V]
+    __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * KV_TILE_BYTES];  // [buf][K|V]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nwg = p.nqb * p.H * p.B;
@@ -397,14 +402,30 @@ __global__ __launch_bounds__(256, WPS) void attn64v2_kernel(AttnParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { ot[0][i] = 0.f; ot[1][i] = 0.f; lsum[i] = 0.f; cneg[i] = 0.f; }
 
-    dma_kv(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if constexpr (NBUF == 2) {
+        dma_kv(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int t0 = 0; t0 < NBUF - 1; ++t0)
+            if (t0 < nkt) dma_kv(t0, t0);
+    }
 
     auto tile_body = [&](int kt, auto MASKED) {
-        const char* kb = smem + (kt & 1) * 2 * KV_TILE_BYTES;
+        const char* kb = smem + (kt % NBUF) * 2 * KV_TILE_BYTES;
         const char* vb = kb + KV_TILE_BYTES;
-        if (kt + 1 < nkt) dma_kv(kt + 1, (kt + 1) & 1);
+        if constexpr (NBUF == 2) {
+            if (kt + 1 < nkt) dma_kv(kt + 1, (kt + 1) & 1);
+        } else {
+            // tile kt has landed once at most the loads of the tiles behind it (4 per wave each) are in flight
+            const int ahead = nkt - 1 - kt;
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();   // every wave's pieces of tile kt are visible; every wave is done with tile kt-1's buffer
+            if (kt + NBUF - 1 < nkt) dma_kv(kt + NBUF - 1, (kt + NBUF - 1) % NBUF);
+        }
 
         // ---- S'^T[key][query] = K Q'^T - m  (log2 units) ----
         f32x16 st[2];
@@ -477,8 +498,10 @@ __global__ __launch_bounds__(256, WPS) void attn64v2_kernel(AttnParams p) {
             }
             lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[s2], lsum, 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if constexpr (NBUF == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
     };
     const int nfull = ragged ? nkt - 1 : nkt;
     for (int kt = 0; kt < nfull; ++kt) tile_body(kt, std::false_type{});
@@ -630,6 +653,12 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
             // prefetch, and 150 / 140 us for attn64 — the kernel is latency-bound (SQ counters: VALU issue 53 %,
             // MFMA 28 %, both idle 34 % of the time at 2 waves), so occupancy pays more than the prefetch.
             if (!(g_attn_flags & 64)) {
+                // small grid (at most ~1 workgroup per CU): the deep-prefetch instantiation (attn_flags 128 disables)
+                if ((int)gridv.x <= 320 && !(g_attn_flags & 128)) {
+                    if (a.resid_f32) hipLaunchKernelGGL((attn64v2_kernel<true, 2, 4>), gridv, dim3(256), 0, s, p);
+                    else hipLaunchKernelGGL((attn64v2_kernel<false, 2, 4>), gridv, dim3(256), 0, s, p);
+                    return hipGetLastError();
+                }
                 if (a.resid_f32) hipLaunchKernelGGL((attn64v2_kernel<true, 3>), gridv, dim3(256), 0, s, p);
                 else hipLaunchKernelGGL((attn64v2_kernel<false, 3>), gridv, dim3(256), 0, s, p);
                 return hipGetLastError();

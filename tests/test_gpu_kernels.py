@@ -124,7 +124,7 @@ def _attn_ref(q, k, v, B, H, Sq, Skv, dh, scale):
                                            (2, 2, 300, 200, 64), (1, 3, 1024, 1024, 64),
                                            (1, 4, 64, 1, 64), (2, 12, 256, 320, 64), (1, 1, 40, 50, 128),
                                            (1, 2, 70, 33, 192)])
-@pytest.mark.parametrize("attn_flags", [0, 1, 3, 16, 16 + 64, 16 + 32 + 3])
+@pytest.mark.parametrize("attn_flags", [0, 1, 3, 16, 16 + 64, 16 + 128, 16 + 32 + 3])
 def test_attention(lib, B, H, Sq, Skv, dh, attn_flags):
     hip.check(lib.ditto_set_option(b"attn_flags", attn_flags))   # 1: K/V tiles by LDS-DMA
     d = H * dh
@@ -151,7 +151,7 @@ def test_attention(lib, B, H, Sq, Skv, dh, attn_flags):
     assert max_abs(out.float(), want) < 6e-2
 
 
-@pytest.mark.parametrize("attn_flags", [3, 16, 16 + 64])
+@pytest.mark.parametrize("attn_flags", [3, 16, 16 + 64, 16 + 128])
 def test_attention_forced_rescale(lib, attn_flags):
     """Rule 26: force the online-softmax rescale branch — one key in the LAST tile dominates one query row."""
     hip.check(lib.ditto_set_option(b"attn_flags", attn_flags))
