@@ -161,6 +161,40 @@ def test_graph_replay_equals_eager(golden):
 
 
 @torch.no_grad()
+def test_caller_tensor_forms_are_accepted_like_the_reference():
+    """What a reference caller may hand in: half-precision / non-contiguous x, t on the CPU or as int32, a checkpoint
+    dict with the codec's `nac.*` keys — same answer as the plain fp32 call (up to the input rounding), dtype kept."""
+    from oracle import ditto_oracle as O
+    cfg = DiTTOConfig(128, 2, 2, 64, 128, 20)
+    sd = synthetic_state_dict(cfg, 7)
+    m = build(cfg, 7)
+    x, text, t = synthetic_inputs(cfg, 2, 96, 40, seed=5)
+    base = m(x.to(DEV), text.to(DEV), t.to(DEV))
+    close(base, O.ditto_forward(sd, 2, 2, x, text, t))
+    # non-contiguous views, CPU / int32 timesteps
+    xt = x.to(DEV).transpose(1, 2).contiguous().transpose(1, 2)
+    assert not xt.is_contiguous()
+    assert torch.equal(m(xt, text.to(DEV), t), base)
+    assert torch.equal(m(x.to(DEV), text.to(DEV), t.to(DEV).int()), base)
+    # half-precision inputs: computed from the rounded values, returned in the caller's dtype
+    for dt in (torch.bfloat16, torch.float16):
+        out = m(x.to(DEV).to(dt), text.to(DEV).to(dt), t.to(DEV))
+        assert out.dtype == dt
+        close(out.float(), O.ditto_forward(sd, 2, 2, x.to(dt).float(), text.to(dt).float(), t))
+    # a reference checkpoint also carries the codec sub-tree: ignored by the denoise path
+    sd2 = dict(sd)
+    sd2["nac.language_model.transformer.wte.weight"] = torch.zeros(4, 4)
+    m2 = DiTTO(128, 2, 2, 64, 128, 20)
+    missing, unexpected = m2.load_state_dict(sd2, strict=False)
+    assert unexpected == ["nac.language_model.transformer.wte.weight"] and not missing
+    assert torch.equal(m2.to(DEV).eval()(x.to(DEV), text.to(DEV), t.to(DEV)), base)
+    # one engine, changing shapes (workspace regrowth, rope tables per N)
+    for (B, N, T) in [(1, 8, 8), (4, 200, 64), (2, 96, 40)]:
+        xx, tx, tt = synthetic_inputs(cfg, B, N, T, seed=B + N)
+        close(m(xx.to(DEV), tx.to(DEV), tt.to(DEV)), O.ditto_forward(sd, 2, 2, xx, tx, tt))
+
+
+@torch.no_grad()
 def test_ragged_lengths_against_oracle():
     """N and T that are multiples of nothing (row clamps, key masking, partial tiles)."""
     from oracle import ditto_oracle as O
