@@ -107,7 +107,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(cfg, N, T, steps=3):
+def cpu_baseline(cfg, N, T, steps=12):
     """fp32 oracle on the host cores: B = 1, `steps` timed steps after 1 warm-up (bounded sample)."""
     from ditto_tts_amd.synth import hash_normal, synthetic_inputs, synthetic_state_dict
     from oracle import ditto_oracle as O
