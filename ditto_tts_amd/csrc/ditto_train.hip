@@ -69,7 +69,7 @@ TrainArenaPlan plan_train_arena(const ditto_config& c) {
 }
 
 struct TrainWsPlan {
-    size_t dh, du, dyb, big1, big2, dkv, tA, tB, textT, wtmp, vtmp, red, dmod, small, wpart, attn, attn_bytes, total;
+    size_t dh, du, dyb, big1, big2, dkv, zero, wtmp, vtmp, red, dmod, small, wpart, attn, attn_bytes, total;
 };
 // split-K factor of a wgrad GEMM with `tiles` 128x128 output tiles and `kt` K-tiles of 64: aim at >= g_wgrad_wgs
 // workgroups, keep >= 8 K-tiles per split
@@ -83,12 +83,11 @@ constexpr size_t WPART_BYTES = (size_t)(512 + 320) * 128 * 128 * 4;   // S * til
 TrainWsPlan plan_train_ws(const ditto_config& c, int B, int N, int T) {
     TrainWsPlan w;
     const size_t d = c.hidden_dim, M = (size_t)B * N, Mt = (size_t)B * T, dh = d / c.num_heads;
-    const size_t Mp = pad64(M), Mtp = pad64(Mt), Mx = Mp > Mtp ? Mp : Mtp;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
     w.dh = take(M * d * 4); w.du = take(M * d * 4); w.dyb = take(M * d * 2);
     w.big1 = take(M * 8 * d * 2); w.big2 = take(M * 4 * d * 2); w.dkv = take(Mt * 2 * d * 2);
-    w.tA = take(8 * d * Mx * 2); w.tB = take(4 * d * Mx * 2); w.textT = take(d * Mtp * 2);
+    w.zero = take(256);
     w.wtmp = take(8 * d * d * 4); w.vtmp = take(8 * d * 4);
     size_t red = (size_t)256 * 8 * d * 4;   // colsum: <= 256 row chunks x <= 8d columns
     const size_t r2 = ln_bwd_scratch_bytes((int)M, 1, (int)d), r3 = ln_bwd_scratch_bytes(N, B, (int)d);
@@ -298,7 +297,6 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
     if (workspace_bytes < wp.total) return fail(DITTO_ERR_SIZE, "train workspace too small: %zu < %zu", workspace_bytes, wp.total);
     hipStream_t s = (hipStream_t)stream;
     const int d = c.hidden_dim, L = c.num_layers, H = c.num_heads, dhd = d / H, M = B * N, Mt = B * T, td = c.time_dim;
-    const int Mp = (int)pad64(M), Mtp = (int)pad64(Mt);
     const float scale = 1.0f / sqrtf((float)dhd);
     const char* tb = (const char*)tape;
     char* ws = (char*)workspace;
@@ -311,36 +309,27 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
     char* big1 = ws + wp.big1;
     char* big2 = ws + wp.big2;
     char* dkv = ws + wp.dkv;
-    char* tA = ws + wp.tA;
-    char* tB = ws + wp.tB;
-    char* textT = ws + wp.textT;
+    const void* zero256 = ws + wp.zero;
     float* wtmp = (float*)(ws + wp.wtmp);
     float* vtmp = (float*)(ws + wp.vtmp);
     float* red = (float*)(ws + wp.red);
     float* dmod = (float*)(ws + wp.dmod);
     void* attn_ws = ws + wp.attn;
-
-    // dW[n1, n2] = dY[rows, n1]^T X[rows, n2]: both operands transposed to K-contiguous rows, one GEMM with K = rows
     float* wpart = (float*)(ws + wp.wpart);
-    auto wgrad_t = [&](const void* At, int n1, const void* Bt, int n2, int kp, float* out, int ldo) -> int {
-        GemmArgs g{};
-        g.A = At; g.lda = kp; g.W = Bt; g.ldw = kp; g.w_rows = n2; g.out = out; g.ldo = ldo; g.M = n1; g.N = n2; g.K = kp;
+    HIP_TRY(hipMemsetAsync(ws + wp.zero, 0, 256, s));
+
+    // dW[n1, n2] = dY[rows, n1]^T X[rows, n2]: the K-major GEMM (gemm_tn.hip: operands read transposed out of LDS, no
+    // transpose passes), split along K when the output has few tiles, partial tiles summed in slice order
+    auto wgrad = [&](const void* dY, int ld1, int n1, const void* X, int ld2, int n2, int rows, float* out) -> int {
         const long tiles = (long)((n1 + 127) / 128) * ((n2 + 127) / 128);
-        const int S = wgrad_splits(tiles, kp / 64);
-        if (S > 1 && ldo == n2 && (size_t)S * n1 * n2 * 4 <= WPART_BYTES) {
-            // long K, few output tiles: S slices of K in parallel, fp32 partial products summed in slice order
-            g.out = wpart; g.k_splits = S; g.split_stride = (size_t)n1 * n2;
-            HIP_TRY(launch_gemm(g, EPI_BIAS_F32, s));
+        const int S = wgrad_splits(tiles, (rows + 63) / 64);
+        if (S > 1 && (size_t)S * n1 * n2 * 4 <= WPART_BYTES) {
+            HIP_TRY(launch_gemm_tn(dY, ld1, X, ld2, zero256, wpart, n2, n1, n2, rows, S, (size_t)n1 * n2, s));
             HIP_TRY(launch_reduce_partials(wpart, S, (size_t)n1 * n2, out, s));
             return DITTO_OK;
         }
-        HIP_TRY(launch_gemm(g, EPI_BIAS_F32, s));
+        HIP_TRY(launch_gemm_tn(dY, ld1, X, ld2, zero256, out, n2, n1, n2, rows, 1, 0, s));
         return DITTO_OK;
-    };
-    auto wgrad = [&](const void* dY, int ld1, int n1, const void* X, int ld2, int n2, int rows, int rp, float* out) -> int {
-        HIP_TRY(launch_transpose_bf16(dY, ld1, rows, n1, tA, rp, s));
-        HIP_TRY(launch_transpose_bf16(X, ld2, rows, n2, tB, rp, s));
-        return wgrad_t(tA, n1, tB, n2, rp, out, n2);
     };
     // dX[M, n_in] = dY[M, n_out] * W, with Wt = W^T bf16 [n_in, n_out]
     auto dgrad = [&](const void* dY, int n_out, const void* Wt, int n_in, void* out, bool f32) -> int {
@@ -357,16 +346,12 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
     };
 #define TRY_RC(expr) do { if (int _rc = (expr)) return _rc; } while (0)
 
-    HIP_TRY(launch_transpose_bf16(tb + tp.text, c.text_dim, Mt, c.text_dim, textT, Mtp, s));
-
     // ---- eps = [bf16(x) | bf16(h_L)] Wfin^T + (b_in + b_out)   (src/model/DiTTO.py:83,93-94) ----
     HIP_TRY(launch_cast_bf16(grad_eps, dyb, (size_t)M * d, s));
     HIP_TRY(launch_colsum_f32(grad_eps, d, M, d, grads->proj_in_bias, red, s));
     HIP_TRY(hipMemcpyAsync(grads->proj_out_bias, grads->proj_in_bias, (size_t)d * 4, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(launch_transpose_bf16(dyb, d, M, d, tA, Mp, s));
-    HIP_TRY(launch_transpose_bf16(xcat, 2 * d, M, 2 * d, tB, Mp, s));
-    TRY_RC(wgrad_t(tA, d, tB, d, Mp, grads->proj_in_weight, d));
-    TRY_RC(wgrad_t(tA, d, tB + (size_t)d * Mp * 2, d, Mp, grads->proj_out_weight, d));
+    TRY_RC(wgrad(dyb, d, d, xcat, 2 * d, d, M, grads->proj_in_weight));
+    TRY_RC(wgrad(dyb, d, d, xcat + (size_t)d * 2, 2 * d, d, M, grads->proj_out_weight));
     TRY_RC(dgrad(dyb, d, m->WoutT, d, dh, true));
 
     for (int l = L - 1; l >= 0; --l) {
@@ -379,13 +364,13 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
         // ---- gated MLP: h3 = h2 + act W2^T + b2,  act = gelu(a) sigmoid(g),  [a|g] = u3 W1g^T + b1g ----
         HIP_TRY(launch_cast_bf16(dh, dyb, (size_t)M * d, s));
         HIP_TRY(launch_colsum_f32(dh, d, M, d, G.mlp_fc2_bias, red, s));
-        TRY_RC(wgrad(dyb, d, d, tb + q.act, 4 * d, 4 * d, M, Mp, G.mlp_fc2_weight));
+        TRY_RC(wgrad(dyb, d, d, tb + q.act, 4 * d, 4 * d, M, G.mlp_fc2_weight));
         TRY_RC(dgrad(dyb, d, lt.W2T, 4 * d, big2, false));
         HIP_TRY(launch_gated_bwd(big2, tb + q.pre, big1, M, 4 * d, s));
         HIP_TRY(launch_colsum_bf16(big1, 8 * d, M, 8 * d, vtmp, red, s));
         HIP_TRY(launch_unpack_vec(vtmp, G.mlp_fc1_bias, 4 * d, 16, 2, 0, s));
         HIP_TRY(launch_unpack_vec(vtmp, G.gate_bias, 4 * d, 16, 2, 16, s));
-        TRY_RC(wgrad(big1, 8 * d, 8 * d, tb + q.u3, d, d, M, Mp, wtmp));
+        TRY_RC(wgrad(big1, 8 * d, 8 * d, tb + q.u3, d, d, M, wtmp));
         HIP_TRY(launch_unpack_rows(wtmp, G.mlp_fc1_weight, 4 * d, d, 16, 2, 0, s));
         HIP_TRY(launch_unpack_rows(wtmp, G.gate_weight, 4 * d, d, 16, 2, 16, s));
         TRY_RC(dgrad(big1, 8 * d, lt.W1gT, d, du, true));
@@ -394,7 +379,7 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
         // ---- cross-attention: h2 = h1 + oc Wo^T + bo,  oc = attn(qc, Kc, Vc),  qc = u2 Wq^T + bq ----
         HIP_TRY(launch_cast_bf16(dh, dyb, (size_t)M * d, s));
         HIP_TRY(launch_colsum_f32(dh, d, M, d, G.cross_out_proj_bias, red, s));
-        TRY_RC(wgrad(dyb, d, d, tb + q.oc, d, d, M, Mp, G.cross_out_proj_weight));
+        TRY_RC(wgrad(dyb, d, d, tb + q.oc, d, d, M, G.cross_out_proj_weight));
         TRY_RC(dgrad(dyb, d, lt.WcoT, d, big2, false));
         {
             AttnBwdArgs a{};
@@ -408,9 +393,8 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
         }
         HIP_TRY(launch_colsum_bf16(big1, d, M, d, G.cross_in_proj_bias, red, s));
         HIP_TRY(launch_colsum_bf16(dkv, 2 * d, Mt, 2 * d, G.cross_in_proj_bias + d, red, s));
-        TRY_RC(wgrad(big1, d, d, tb + q.u2, d, d, M, Mp, G.cross_in_proj_weight));
-        HIP_TRY(launch_transpose_bf16(dkv, 2 * d, Mt, 2 * d, tA, Mtp, s));
-        TRY_RC(wgrad_t(tA, 2 * d, textT, d, Mtp, G.cross_in_proj_weight + (size_t)d * d, d));
+        TRY_RC(wgrad(big1, d, d, tb + q.u2, d, d, M, G.cross_in_proj_weight));
+        TRY_RC(wgrad(dkv, 2 * d, 2 * d, tb + tp.text, c.text_dim, d, Mt, G.cross_in_proj_weight + (size_t)d * d));
         TRY_RC(dgrad(big1, d, lt.WcqT, d, du, true));
         TRY_RC(ln_back(h1, lp.g2, G.norm2_weight, G.norm2_bias));
 
@@ -429,7 +413,7 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
         }
         HIP_TRY(launch_rope_inplace(big1, 3 * d, rope_cos, rope_sin, M, N, 2 * d, dhd, s, -1.0f));
         HIP_TRY(launch_colsum_bf16(big1, 3 * d, M, 3 * d, G.attn_in_proj_bias, red, s));
-        TRY_RC(wgrad(big1, 3 * d, 3 * d, tb + q.u1, d, d, M, Mp, G.attn_in_proj_weight));
+        TRY_RC(wgrad(big1, 3 * d, 3 * d, tb + q.u1, d, d, M, G.attn_in_proj_weight));
         TRY_RC(dgrad(big1, 3 * d, lt.WqkvT, d, du, true));
         TRY_RC(ln_back(h0, lp.g1, G.norm1_weight, G.norm1_bias));
     }

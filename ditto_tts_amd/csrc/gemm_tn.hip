@@ -1,0 +1,165 @@
+// gemm_tn.hip — C[m, n] = sum_k X[k, m] * Y[k, n]  (both operands K-MAJOR: rows are the contraction index) for gfx950.
+//
+// The weight-gradient GEMMs of the backward pass, dW = dY^T X with K = B*N rows of activations (ditto_train.hip): the
+// forward GEMM family wants K-contiguous operand rows, which cost a bf16 transpose pass per operand (6 % of the
+// training step).  Here both tiles stay in their natural [k][column] layout in LDS and the MFMA operands are read with
+// ds_read_b64_tr_b16 (the hardware transpose that feeds V^T in attention.hip), so nothing is transposed in memory.
+//
+//   tile      128 (m) x 128 (n) x 64 (k); 256 threads = 4 waves in 2 x 2, each wave 64 x 64 as 2 x 2 accumulators of
+//             v_mfma_f32_32x32x16_bf16 (64 fp32 registers); 2 workgroups per CU (2 x 32 KiB LDS).
+//   LDS       a tile is 64 k-rows of 256 B; the 16-B chunk c of row r sits at c ^ ((r & 3) << 2): the 4 rows a
+//             transposed-read block touches land in 4 different 64-B bank quarters.  Lane-linear image (LDS-DMA),
+//             swizzle on the source address; rows past K read a zero row (the caller's 256-B zero buffer).
+//   split-K   blockIdx.y = split: K-tile range per split, partial tiles to out + split * split_stride (fp32), summed in
+//             order by launch_reduce_partials — deterministic.
+#include "gemm_common.h"
+
+namespace ditto {
+
+namespace {
+
+constexpr int TM = 128, TN = 128, TK = 64;
+constexpr int T_TILE = TK * TM * 2;   // 16 KiB per operand tile
+constexpr int T_BUF = 2 * T_TILE;     // X | Y
+constexpr int T_LDS = 2 * T_BUF;      // double buffered: 64 KiB
+typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+
+struct TnParams {
+    const bf16* X; int ldx;   // [K, >= m0 + 128] bf16
+    const bf16* Y; int ldy;
+    const bf16* zero;         // 256 B of zeros (device)
+    float* out; int ldo;
+    int Mo, No, K;            // output rows (columns of X), output columns (columns of Y), contraction length
+    int tiles_m, tiles_n, k_splits;
+    size_t split_stride;
+};
+
+DITTO_DEV bf16x8 cat4t(bf16x4 a, bf16x4 b) {
+    bf16x8 r;
+    r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+    r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+    return r;
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1;
+    const int tm = blockIdx.x / p.tiles_n, tn = blockIdx.x % p.tiles_n;
+    const int m0 = tm * TM, n0 = tn * TN;
+    const int split = blockIdx.y;
+
+    int nkt = (p.K + TK - 1) / TK, kbase = 0;
+    if (p.k_splits > 1) {
+        const int per = (nkt + p.k_splits - 1) / p.k_splits;
+        kbase = split * per;
+        nkt = nkt - kbase < per ? nkt - kbase : per;
+        if (nkt < 0) nkt = 0;
+    }
+    float* out = p.out + (size_t)split * p.split_stride;
+
+    // DMA: a tile = 16 pieces of 1 KiB (4 k-rows x 256 B); this wave moves pieces 4*wid .. 4*wid+3 of X and of Y
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+    const int prow = lane >> 4, cpos = lane & 15;          // row inside the piece, 16-B chunk position
+    auto stage = [&](int buf, int kt) {
+        const int k0 = (kbase + kt) * TK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = wid * 4 + i;
+            const int r = piece * 4 + prow;                 // k-row inside the tile
+            const int c = cpos ^ ((r & 3) << 2);            // source chunk for this LDS position
+            const int k = k0 + r;
+            // columns past the matrix are clamped (their products land in rows / columns that are never stored)
+            int cx = m0 + c * 8; cx = cx + 8 <= p.Mo ? cx : (p.Mo >= 8 ? p.Mo - 8 : 0);
+            int cy = n0 + c * 8; cy = cy + 8 <= p.No ? cy : (p.No >= 8 ? p.No - 8 : 0);
+            const bf16* sx = k < p.K ? p.X + (size_t)k * p.ldx + cx : p.zero + c * 8;
+            const bf16* sy = k < p.K ? p.Y + (size_t)k * p.ldy + cy : p.zero + c * 8;
+            glds16(sx, lds_base + (unsigned)(buf * T_BUF + piece * 1024));
+            glds16(sy, lds_base + (unsigned)(buf * T_BUF + T_TILE + piece * 1024));
+        }
+    };
+
+    // transposed-read addressing (attention.hip: V^T fragments): lane -> row 4*hh + tr_q (+8), 8 B at column byte
+    // 32*((lane>>4)&1) + 8*tr_p of a 32-column block; the row swizzle is a lane constant (rows differ by multiples of 4)
+    const int hh = lane >> 5;
+    const int tr_q = (lane & 15) >> 2, tr_p = lane & 3;
+    const int tr_row0 = 4 * hh + tr_q;
+    const int tr_colbyte = 32 * ((lane >> 4) & 1) + 8 * tr_p;
+    const int tr_swz = (tr_q & 3) << 6;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc[0][0][i] = 0.f; acc[0][1][i] = 0.f; acc[1][0][i] = 0.f; acc[1][1][i] = 0.f; }
+
+    if (nkt > 0) stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const char* xb = smem + (kt & 1) * T_BUF;
+        const char* yb = xb + T_TILE;
+        if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {   // 16 k-rows per step
+            bf16x8 fx[2], fy[2];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const int colx = ((wr * 2 + blk) * 64 + tr_colbyte) ^ tr_swz;
+                const int coly = ((wc * 2 + blk) * 64 + tr_colbyte) ^ tr_swz;
+                const char* ax = xb + (16 * s4 + tr_row0) * 256 + colx;
+                const char* ay = yb + (16 * s4 + tr_row0) * 256 + coly;
+                fx[blk] = cat4t(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(ax)),
+                                __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(ax + 8 * 256)));
+                fy[blk] = cat4t(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(ay)),
+                                __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(ay + 8 * 256)));
+            }
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx[mb], fy[nb], acc[mb][nb], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // accumulator layout of v_mfma_f32_32x32x16: lane holds column n = lane & 31, rows m = (r & 3) + 8 * (r >> 2) + 4 * hh
+    const int ncol = lane & 31;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int col = n0 + (wc * 2 + nb) * 32 + ncol;
+            if (col >= p.No) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + (wr * 2 + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (row < p.Mo) out[(size_t)row * p.ldo + col] = acc[mb][nb][r];
+            }
+        }
+}
+
+}  // namespace
+
+// out fp32 [Mo, No] (ld = ldo) = X[K, Mo]^T Y[K, No]; k_splits > 1: partial sums to out + s * split_stride
+hipError_t launch_gemm_tn(const void* X, int ldx, const void* Y, int ldy, const void* zero256, float* out, int ldo,
+                          int Mo, int No, int K, int k_splits, size_t split_stride, hipStream_t s) {
+    if (!X || !Y || !zero256 || !out || Mo < 8 || No < 8 || K <= 0 || (ldx | ldy) % 8 || (Mo | No) % 8)
+        return hipErrorInvalidValue;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    TnParams p;
+    p.X = (const bf16*)X; p.ldx = ldx; p.Y = (const bf16*)Y; p.ldy = ldy; p.zero = (const bf16*)zero256;
+    p.out = out; p.ldo = ldo; p.Mo = Mo; p.No = No; p.K = K;
+    p.tiles_m = (Mo + TM - 1) / TM; p.tiles_n = (No + TN - 1) / TN;
+    p.k_splits = k_splits > 1 ? k_splits : 1; p.split_stride = split_stride;
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tiles_m * p.tiles_n, p.k_splits), dim3(256), T_LDS, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace ditto

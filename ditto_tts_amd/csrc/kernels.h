@@ -139,6 +139,10 @@ hipError_t launch_attention_delta(const void* dout, int lddo, const void* o_bf16
 hipError_t launch_attention_bwd64(const AttnBwdArgs& a, const float* lse, const float* delta, hipStream_t s);
 size_t attention_train_workspace_bytes(int B, int H, int Sq, int Skv, int dh);   // forward + backward scratch
 
+// ---------------- gemm_tn.hip : out fp32 [Mo, No] = X[K, Mo]^T Y[K, No], both operands K-major (wgrad) ----------------
+hipError_t launch_gemm_tn(const void* X, int ldx, const void* Y, int ldy, const void* zero256, float* out, int ldo,
+                          int Mo, int No, int K, int k_splits, size_t split_stride, hipStream_t s);
+
 // ---------------- train.hip : backward-pass row / elementwise kernels ----------------
 // optionally batched: nz_o * nz_i matrices, src of matrix (zo, zi) at + zo * s_o + zi * s_i, dst at + z * d_z (elements)
 hipError_t launch_transpose_bf16(const void* src, int ld, int rows, int cols, void* dst, int ldT, hipStream_t s,
