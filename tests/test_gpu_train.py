@@ -216,6 +216,23 @@ def test_training_closure_like_the_reference():
     assert again < losses[-1]
 
 
+def test_gradients_are_bit_reproducible():
+    """No atomics anywhere in the backward (split-K partials and column sums are reduced in a fixed order): the same
+    step twice gives bitwise-identical gradients, at a shape that exercises split-K wgrad and the fused attention."""
+    cfg = DiTTOConfig(256, 2, 4, 256, 256, 50)
+    x, text, t = (z.to(DEV) for z in synthetic_inputs(cfg, 4, 512, 256, seed=3))
+    target = hash_normal((4, 512, 256), "noise", 4).to(DEV)
+    grads = []
+    for _ in range(2):
+        m = _build(cfg, 9).train()
+        torch.manual_seed(123)
+        F.mse_loss(m(x, text, t), target).backward()
+        grads.append({n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 40
+    for n in grads[0]:
+        assert torch.equal(grads[0][n], grads[1][n]), n
+
+
 def test_training_surface_contract():
     cfg = DiTTOConfig(128, 1, 2, 64, 128, 20)
     m = _build(cfg, 1).train()
