@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Turn the two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE; one --pmc pass each, no trace flags) over
+`bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 0` into profiles/<round>_pmc_traffic.json: per
+kernel class, average KB per launch and traffic_bytes = 2*FETCH*1024 + WRITE*1024 (gfx950: FETCH_SIZE counts a wide
+streaming read at half its bytes, MI355X_MICROARCH.md §HBM).
+    python tools/pmc_traffic.py <fetch_csv> <write_csv> <out_json>"""
+import collections
+import csv
+import json
+import sys
+
+CLASSES = [("gemm_gated_mlp", "gemm256_kernel<3"), ("gemm_qkv_rope", "gemm256_kernel<2"), ("gemm_fc2", "gemm192_kernel<1"),
+           ("gemm_d_x_d_q", "gemm128_kernel<0"), ("gemm_d_x_d_out", "gemm128_kernel<1"), ("attn_self", "attn64v2_kernel<true"),
+           ("attn_cross", "attn64v2_kernel<false"), ("layernorm", "ln_kernel<3, 0>")]
+
+
+def avg(path, counter):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            acc[r["Kernel_Name"].replace("(anonymous namespace)::", "")].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+fetch, write = avg(sys.argv[1], "FETCH_SIZE"), avg(sys.argv[2], "WRITE_SIZE")
+out = {"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, bench.py --steps 2 --warmup 1, C2 B=32). "
+                "Units KB per launch. gfx950 correction: hbm_bytes = 2*FETCH*1024 + WRITE*1024; FETCH counts L2 misses "
+                "served by the Infinity Cache too."}
+for cls, pat in CLASSES:
+    ks = [k for k in fetch if pat in k]
+    if not ks:
+        continue
+    k = ks[0]
+    f, w = fetch[k], write.get(k, 0.0)
+    out[cls] = {"kernel": k[:90], "fetch_kb": round(f, 1), "write_kb": round(w, 1), "traffic_bytes": int(2 * f * 1024 + w * 1024)}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(out, indent=1))
