@@ -255,15 +255,15 @@ int ditto_train_forward(ditto_model_t m, const float* x, const float* text, cons
             g.M = M; g.N = d; g.K = d;
             HIP_TRY(launch_gemm(g, EPI_BIAS_RES_F32, s));
         }
-        // ---- gated MLP: pre-activations are kept for the backward, the product is a separate pass ----
+        // ---- gated MLP: product and pre-activations (for the backward) from one epilogue ----
         HIP_TRY(launch_layernorm(h2, lp.g3, lp.be3, tb + q.u3, d, M, d, s));
         {
             GemmArgs g{};
-            g.A = tb + q.u3; g.lda = d; g.W = lp.W1g; g.bias = lp.b1g; g.out = tb + q.pre; g.ldo = 8 * d;
+            g.A = tb + q.u3; g.lda = d; g.W = lp.W1g; g.bias = lp.b1g; g.out = tb + q.act; g.ldo = 4 * d;
+            g.out2_bf16 = tb + q.pre; g.ldo2 = 8 * d;   // the gated epilogue also keeps the pre-activations
             g.M = M; g.N = 8 * d; g.K = d;
-            HIP_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
+            HIP_TRY(launch_gemm(g, EPI_GATED, s));
         }
-        HIP_TRY(launch_gated_fwd(tb + q.pre, tb + q.act, M, 4 * d, s));
         {
             GemmArgs g{};
             g.A = tb + q.act; g.lda = 4 * d; g.W = lp.W2; g.bias = lp.b2; g.residual = h2; g.ldr = d; g.out = h3;

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         if (next < ntiles) prologue(next);
 
         // ---------------- epilogue ----------------
-        prev_interior = (cur_m0 + 256 <= p.M) && (cur_n0 + 256 <= p.N) && !(EPI == EPI_BIAS_RES_F32 && p.out2) &&
+        prev_interior = (cur_m0 + 256 <= p.M) && (cur_n0 + 256 <= p.N) && !p.out2 &&
                         !(p.flags & (GF_DIAG_NO_STORE | GF_DIAG_NO_EPILOGUE));
         if (p.flags & GF_DIAG_NO_EPILOGUE) {
 #pragma unroll

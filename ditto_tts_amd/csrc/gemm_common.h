@@ -185,6 +185,18 @@ DITTO_DEV void epilogue_row(const GemmParams& p, int row, int cbase, const f32x4
             pk[pr][1] = pack_bf16x2(o23[0], o23[1]);
         }
         store_bf16_pair((bf16*)p.out + (size_t)row * p.ldo, cbase / 2, pk[0], pk[1], fq, p.N / 2, p.flags, p.ldo);
+        if (p.out2) {   // training forward: the pre-activations (bias added, interleaved packed order) for the backward
+            u32x2 pr[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const f32x4 v = acc[n] + bias[n];
+                pr[n][0] = pack_bf16x2(v[0], v[1]);
+                pr[n][1] = pack_bf16x2(v[2], v[3]);
+            }
+            bf16* rowp = p.out2 + (size_t)row * p.ldo2;
+            store_bf16_pair(rowp, cbase, pr[0], pr[1], fq, p.N, p.flags & ~GF_DIAG_LINEAR_STORE, p.ldo2);
+            store_bf16_pair(rowp, cbase + 32, pr[2], pr[3], fq, p.N, p.flags & ~GF_DIAG_LINEAR_STORE, p.ldo2);
+        }
     } else if constexpr (EPI == EPI_QKV_ROPE) {
         float v[4][4];
 #pragma unroll

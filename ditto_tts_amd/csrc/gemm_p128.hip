@@ -180,7 +180,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p128_kernel(GemmParams p) {
         const int next = tile + p.tile_stride;
         if (next < ntiles) prologue(next);
 
-        prev_interior = (cur_m0 + 256 <= p.M) && (cur_n0 + 128 <= p.N) && !(EPI == EPI_BIAS_RES_F32 && p.out2) &&
+        prev_interior = (cur_m0 + 256 <= p.M) && (cur_n0 + 128 <= p.N) && !p.out2 &&
                         !(p.flags & (GF_DIAG_NO_STORE | GF_DIAG_NO_EPILOGUE)) && nkt > 1;
         if (p.flags & GF_DIAG_NO_EPILOGUE) {
 #pragma unroll
