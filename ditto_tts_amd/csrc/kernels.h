@@ -154,7 +154,6 @@ hipError_t launch_colsum_bf16(const void* x, int ld, int M, int n, float* out, f
 size_t ln_bwd_scratch_bytes(int rows_per_group, int groups, int d);
 hipError_t launch_ln_bwd(const float* dy, const float* x, const float* gamma, float* dx_accum, float* dgb_out,
                          float* scratch, int rows_per_group, int groups, int d, hipStream_t s);
-hipError_t launch_gated_fwd(const void* pre, void* act, int M, int F, hipStream_t s);
 hipError_t launch_gated_bwd(const void* dact, const void* pre, void* dpre, int M, int F, hipStream_t s);
 hipError_t launch_unpack_rows(const float* src, float* dst, int rows, int cols, int blk, int mult, int row_off,
                               hipStream_t s);

@@ -9,7 +9,7 @@
 //   colsum_*            bias gradients: column sums over the M rows of dY
 //   ln_bwd              LayerNorm backward (reference nn.LayerNorm, src/components/DiT.py:84,89,94) and the
 //                       scale/shift reductions of GlobalAdaLN's backward (src/components/DiT.py:34-39)
-//   gated_fwd / bwd     gelu(a) * sigmoid(g) and its derivative (src/components/DiT.py:152-154)
+//   gated_bwd           derivative of gelu(a) * sigmoid(g) (src/components/DiT.py:152-154; the forward is a GEMM epilogue)
 //   softmax_drop_rows / softmax_bwd_rows   generic-head_dim attention with the train-mode dropout of
 //                       nn.MultiheadAttention (src/components/DiT.py:90-91) from a counter-based hash
 //   small_linear_*      the [B, .] x [., .] affine maps of the time / text modulation vectors, fp32
@@ -300,22 +300,6 @@ DITTO_DEV u32x4 pack8(const float* f) {
     for (int i = 0; i < 4; ++i) o[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
     return o;
 }
-__global__ __launch_bounds__(256) void gated_fwd_kernel(const bf16* __restrict__ pre, bf16* __restrict__ act, int M,
-                                                        int F) {
-    const int per_row = F / 8;
-    const size_t n = (size_t)M * per_row;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int m = (int)(i / per_row), j = (int)(i % per_row);   // j: 8-group inside the row of F
-        const int q = j >> 1, e = j & 1;
-        const bf16* pr = pre + (size_t)m * 2 * F + 32 * q + 8 * e;
-        float a[8], g[8], o[8];
-        unpack8(*reinterpret_cast<const u32x4*>(pr), a);
-        unpack8(*reinterpret_cast<const u32x4*>(pr + 16), g);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) o[k] = gelu_erf_f(a[k]) * sigmoid_f(g[k]);
-        *reinterpret_cast<u32x4*>(act + (size_t)m * F + 8 * j) = pack8(o);
-    }
-}
 __global__ __launch_bounds__(256) void gated_bwd_kernel(const bf16* __restrict__ dact, const bf16* __restrict__ pre,
                                                         bf16* __restrict__ dpre, int M, int F) {
     const int per_row = F / 8;
@@ -343,12 +327,6 @@ __global__ __launch_bounds__(256) void gated_bwd_kernel(const bf16* __restrict__
 static int ew_grid(size_t n) {
     size_t g = (n + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
-}
-hipError_t launch_gated_fwd(const void* pre, void* act, int M, int F, hipStream_t s) {
-    if (F % 16) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(gated_fwd_kernel, dim3(ew_grid((size_t)M * F / 8)), dim3(256), 0, s, (const bf16*)pre,
-                       (bf16*)act, M, F);
-    return hipGetLastError();
 }
 hipError_t launch_gated_bwd(const void* dact, const void* pre, void* dpre, int M, int F, hipStream_t s) {
     if (F % 16) return hipErrorInvalidValue;
