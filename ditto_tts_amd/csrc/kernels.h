@@ -147,7 +147,6 @@ hipError_t launch_gemm_tn(const void* X, int ldx, const void* Y, int ldy, const 
 // optionally batched: nz_o * nz_i matrices, src of matrix (zo, zi) at + zo * s_o + zi * s_i, dst at + z * d_z (elements)
 hipError_t launch_transpose_bf16(const void* src, int ld, int rows, int cols, void* dst, int ldT, hipStream_t s,
                                  int nz_o = 1, int nz_i = 1, long long s_o = 0, long long s_i = 0, long long d_z = 0);
-size_t colsum_scratch_bytes(int M, int n);
 hipError_t launch_reduce_partials(const float* partial, int chunks, size_t n, float* out, hipStream_t s);
 hipError_t launch_colsum_f32(const float* x, int ld, int M, int n, float* out, float* scratch, hipStream_t s);
 hipError_t launch_colsum_bf16(const void* x, int ld, int M, int n, float* out, float* scratch, hipStream_t s);
@@ -160,7 +159,6 @@ hipError_t launch_unpack_rows(const float* src, float* dst, int rows, int cols, 
 hipError_t launch_unpack_vec(const float* src, float* dst, int rows, int blk, int mult, int row_off, hipStream_t s);
 hipError_t launch_pack_bf16_t(const float* src, void* dst, int rows, int cols, int ldT, int blk, int mult, int row_off,
                               hipStream_t s);
-unsigned dropout_stream_host(uint64_t seed, int layer, int bh);
 unsigned dropout_threshold(float p);
 hipError_t launch_softmax_drop_rows(const float* S, void* P, int nrows, int rows_per_bh, int Skv, int ld, float scale,
                                     uint64_t seed, int layer, int bh0, float p_drop, hipStream_t s);
@@ -174,6 +172,5 @@ hipError_t launch_small_linear_bwd_x(const float* dy, const float* W, const floa
                                      bool silu_in, hipStream_t s);
 hipError_t launch_embedding_scatter_add(const float* drows, const int64_t* ids, float* dtable, int B, int V, int d,
                                         hipStream_t s);
-hipError_t launch_sub_to_bf16(const float* a, const float* b, void* dst, size_t n, hipStream_t s);
 
 }  // namespace ditto

@@ -121,7 +121,6 @@ static int colsum_chunks(int M, int n) {
     if (chunks > maxc) chunks = maxc;
     return chunks < 1 ? 1 : chunks;
 }
-size_t colsum_scratch_bytes(int M, int n) { return (size_t)colsum_chunks(M, n) * n * 4; }
 template <typename T>
 static hipError_t colsum_launch(const T* x, int ld, int M, int n, float* out, float* scratch, hipStream_t s) {
     if (n % 4 || ld % 4) return hipErrorInvalidValue;
@@ -466,11 +465,6 @@ unsigned dropout_threshold(float p) {
     const double t = (double)p * 4294967296.0;
     return t >= 4294967295.0 ? 4294967295u : (unsigned)t;
 }
-unsigned dropout_stream_host(uint64_t seed, int layer, int bh) {
-    auto lb = [](unsigned h) { h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16; return h; };
-    const unsigned lo = (unsigned)(seed & 0xFFFFFFFFu), hi = (unsigned)(seed >> 32);
-    return lb(lo ^ lb(hi + (unsigned)layer * 0x632BE5ABu + (unsigned)bh * 0x9E3779B1u));
-}
 // nrows = rows_per_bh * (number of stacked (batch, head) pairs starting at pair bh0)
 hipError_t launch_softmax_drop_rows(const float* S, void* P, int nrows, int rows_per_bh, int Skv, int ld, float scale,
                                     uint64_t seed, int layer, int bh0, float p_drop, hipStream_t s) {
@@ -585,28 +579,6 @@ __global__ __launch_bounds__(256) void embedding_scatter_add_kernel(const float*
 hipError_t launch_embedding_scatter_add(const float* drows, const int64_t* ids, float* dtable, int B, int V, int d,
                                         hipStream_t s) {
     hipLaunchKernelGGL(embedding_scatter_add_kernel, dim3(1), dim3(256), 0, s, drows, ids, dtable, B, V, d);
-    return hipGetLastError();
-}
-
-// [dscale | dshift] of the two modulation branches are the same vector (scale = 1 + s_t + s_x, shift = b_t + b_x:
-// src/components/DiT.py:34-35), nothing to do; residual-stream helpers:
-// dst fp32 = a fp32 - b fp32 (attention output O = h_after - h_before for the softmax-backward row term)
-__global__ __launch_bounds__(256) void sub_f32_to_bf16_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                              bf16* __restrict__ dst, size_t n8) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
-        const f32x4 a0 = reinterpret_cast<const f32x4*>(a)[2 * i], a1 = reinterpret_cast<const f32x4*>(a)[2 * i + 1];
-        const f32x4 b0 = reinterpret_cast<const f32x4*>(b)[2 * i], b1 = reinterpret_cast<const f32x4*>(b)[2 * i + 1];
-        u32x4 o;
-        o[0] = pack_bf16x2(a0[0] - b0[0], a0[1] - b0[1]);
-        o[1] = pack_bf16x2(a0[2] - b0[2], a0[3] - b0[3]);
-        o[2] = pack_bf16x2(a1[0] - b1[0], a1[1] - b1[1]);
-        o[3] = pack_bf16x2(a1[2] - b1[2], a1[3] - b1[3]);
-        reinterpret_cast<u32x4*>(dst)[i] = o;
-    }
-}
-hipError_t launch_sub_to_bf16(const float* a, const float* b, void* dst, size_t n, hipStream_t s) {
-    if (n % 8) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(sub_f32_to_bf16_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, s, a, b, (bf16*)dst, n / 8);
     return hipGetLastError();
 }
 
