@@ -26,3 +26,18 @@ class ConfigDiTTO(BaseConfig):
     BATCH_SIZE = 8
     MAX_TOKEN_LENGTH = 1024
     NB_SAMPLES = 10000
+
+
+class ConfigSLP(BaseConfig):
+    """The attributes `SpeechGenerator` reads to build the length predictor (reference src/utils/Config.py:69-82,
+    src/model/SpeechGenerator.py:54-58): ONE layer, ONE head over byt5-small's 1472-wide embeddings."""
+    MODEL_NAME = "SLP"
+    EMBEDDING_DIM = 1472
+    NUM_LAYERS = 1
+    NUM_HEADS = 1
+    NB_CLASSES = int(BaseConfig.MAX_AUDIO_DURATION - BaseConfig.MIN_AUDIO_DURATION + 1)
+    EPOCHS = 20
+    LEARNING_RATE = 1e-4
+    BATCH_SIZE = 8
+    NB_SAMPLES = 10000
+    MAX_TOKEN_LENGTH = 128

@@ -537,20 +537,29 @@ __global__ __launch_bounds__(256, WPS) void attn64v2_kernel(AttnParams p) {
 // scores fp32 [Sq, ldS] -> P bf16 [Sq, ldS] = softmax(scores * scale) over the first Skv columns,
 // zeros in the padding columns.  One wave per row.
 // ------------------------------------------------------------------------------------------------
+// causal_rows > 0: rows are queries of sequences of causal_rows positions and query i sees keys j <= i + causal_off
+// (the boolean tgt_mask of src/model/SpeechLP.py:57-61: masked scores are -inf, their probabilities exactly 0).
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, bf16* __restrict__ P, int Sq,
-                                                           int Skv, int ld, float scale_log2) {
+                                                           int Skv, int ld, float scale_log2, int causal_rows,
+                                                           int causal_off) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= Sq) return;
+    int vis = Skv;   // number of visible keys
+    if (causal_rows > 0) {
+        vis = row % causal_rows + causal_off + 1;
+        vis = vis < 0 ? 0 : (vis > Skv ? Skv : vis);
+    }
     const float* s = S + (size_t)row * ld;
     float m = -1e30f;
-    for (int j = lane; j < Skv; j += 64) m = fmaxf(m, s[j]);
+    for (int j = lane; j < vis; j += 64) m = fmaxf(m, s[j]);
     m = wave_max(m);
     float sum = 0.f;
-    for (int j = lane; j < Skv; j += 64) sum += __builtin_amdgcn_exp2f((s[j] - m) * scale_log2);
-    const float inv = 1.0f / wave_sum(sum);
+    for (int j = lane; j < vis; j += 64) sum += __builtin_amdgcn_exp2f((s[j] - m) * scale_log2);
+    sum = wave_sum(sum);
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
     bf16* pr = P + (size_t)row * ld;
     for (int j = lane; j < ld; j += 64)
-        pr[j] = j < Skv ? (bf16)(__builtin_amdgcn_exp2f((s[j] - m) * scale_log2) * inv) : (bf16)0.f;
+        pr[j] = j < vis ? (bf16)(__builtin_amdgcn_exp2f((s[j] - m) * scale_log2) * inv) : (bf16)0.f;
 }
 // Vt[dh, ldT] = V[Skv, dh]^T (zero padded to ldT columns); 32x32 LDS tile transpose.
 // blockIdx.z = (batch, head) inside the chunk: V += zb * vs_b + zh * vs_h, Vt += z * dh * ldT
@@ -610,9 +619,11 @@ static int generic_chunk(int B, int H, int Sq, int Skv, int dh) {
     if (n > (size_t)B * H) n = (size_t)B * H;
     return (int)n;
 }
-size_t attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh) {
-    if (dh == DH) return 0;
+size_t attention_generic_workspace_bytes(int B, int H, int Sq, int Skv, int dh) {
     return (size_t)generic_chunk(B, H, Sq, Skv, dh) * generic_fwd_bytes(Sq, Skv, dh);
+}
+size_t attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh) {
+    return dh == DH ? 0 : attention_generic_workspace_bytes(B, H, Sq, Skv, dh);
 }
 
 hipError_t launch_rope_inplace(void* x, int ld, const float* cs, const float* sn, int M, int rpb, int ncols, int dh,
@@ -628,7 +639,8 @@ hipError_t launch_rope_inplace(void* x, int ld, const float* cs, const float* sn
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     if (a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Skv <= 0) return hipErrorInvalidValue;
     const float LOG2E = 1.4426950408889634f;
-    if (a.dh == DH && !a.force_generic) {
+    if (a.causal && a.dropout_p > 0.f) return hipErrorInvalidValue;   // no caller: the decoder stack runs in eval mode
+    if (a.dh == DH && !a.force_generic && !a.causal) {
         if ((a.ldq | a.ldk | a.ldv) % 8) return hipErrorInvalidValue;
         AttnParams p;
         p.q = (const bf16*)a.q; p.ldq = a.ldq; p.k = (const bf16*)a.k; p.ldk = a.ldk;
@@ -723,7 +735,7 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
             if (e != hipSuccess) return e;
         } else {
             hipLaunchKernelGGL(softmax_rows_kernel, dim3((nb * a.Sq + 3) / 4), dim3(256), 0, s, S, P, nb * a.Sq, a.Skv, ld,
-                               a.scale * LOG2E);
+                               a.scale * LOG2E, a.causal ? a.Sq : 0, a.Skv - a.Sq);
         }
         hipLaunchKernelGGL(transpose_pad_kernel, dim3(ld / 32, (a.dh + 31) / 32, nb), dim3(256), 0, s, (const bf16*)a.v,
                            a.ldv, Vt, ld, a.Skv, a.dh, a.H, bh0, (long long)a.Skv * a.ldv, (long long)a.dh);

@@ -564,7 +564,8 @@ int ditto_gemm_bf16(const void* A, int lda, const void* W, const float* bias, co
             if (!bias || N % 32) return fail(DITTO_ERR_ARG, "gated epilogue needs a bias and N %% 32 == 0");
             e = EPI_GATED; break;
         case 4: e = EPI_BIAS_F32; break;
-        default: return fail(DITTO_ERR_ARG, "epilogue must be 0, 1, 3 or 4");
+        case 6: e = EPI_BIAS_RELU_BF16; break;
+        default: return fail(DITTO_ERR_ARG, "epilogue must be 0, 1, 3, 4 or 6");
     }
     HIP_TRY(launch_gemm(g, e, (hipStream_t)stream));
     return DITTO_OK;

@@ -316,7 +316,10 @@ hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s) {
     }
     if (epi == EPI_GATED_FP8) return hipErrorInvalidValue;   // fp8 output only from the fp8 GEMM
     // split-K and batched launches exist on the 128x128 structures only
-    const int forced = p.k_splits > 1 ? 128 : (nbatch > 1 ? 128 : g_gemm_tile);
+    int forced = p.k_splits > 1 ? 128 : (nbatch > 1 ? 128 : g_gemm_tile);
+    // the ReLU epilogue is built for the 128x128 and 256x256 structures only
+    if (epi == EPI_BIAS_RELU_BF16 && forced != 128 && forced != 127 && forced != 256)
+        forced = (long)((a.M + 255) / 256) * ((a.N + 255) / 256) >= 4 * 256 ? 256 : 128;
     if (forced == 130) return launch_gemm_o3(p, epi, s);
     if (forced == 192 && gemm192_supports(epi)) return launch_gemm192(p, epi, s);
     const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
@@ -356,6 +359,7 @@ hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s) {
             case EPI_QKV_ROPE: return launch_deep_t<EPI_QKV_ROPE>(p, s);
             case EPI_GATED: return launch_deep_t<EPI_GATED>(p, s);
             case EPI_BIAS_F32: return launch_deep_t<EPI_BIAS_F32>(p, s);
+            case EPI_BIAS_RELU_BF16: return launch_deep_t<EPI_BIAS_RELU_BF16>(p, s);
             default: break;
         }
         return hipErrorInvalidValue;
@@ -366,6 +370,7 @@ hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s) {
         case EPI_QKV_ROPE: return launch_t<EPI_QKV_ROPE>(p, s);
         case EPI_GATED: return launch_t<EPI_GATED>(p, s);
         case EPI_BIAS_F32: return launch_t<EPI_BIAS_F32>(p, s);
+        case EPI_BIAS_RELU_BF16: return launch_t<EPI_BIAS_RELU_BF16>(p, s);
         default: break;
     }
     return hipErrorInvalidValue;

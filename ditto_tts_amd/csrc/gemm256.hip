@@ -200,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     // DMA (stores; the compiler's own waits retire the loads).  vmcnt retires in order, so the tile-start wait may
     // leave these (younger) stores in flight and still guarantee the (older) prologue DMA has landed: the store
     // drain of the previous tile then overlaps the first phases instead of stalling the whole workgroup.
-    constexpr int EPI_STORES = EPI == EPI_BIAS_BF16 ? 16 : EPI == EPI_QKV_ROPE ? 16
+    constexpr int EPI_STORES = (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_RELU_BF16) ? 16 : EPI == EPI_QKV_ROPE ? 16
                                : (EPI == EPI_GATED || EPI == EPI_GATED_FP8) ? 8 : 32;
     bool prev_interior = false;   // previous tile of this workgroup was interior (its store count is exact)
 
@@ -437,6 +437,7 @@ hipError_t launch_gemm256(const GemmParams& p_in, GemmEpilogue epi, hipStream_t 
         case EPI_QKV_ROPE: return launch256_t<EPI_QKV_ROPE>(p, s);
         case EPI_GATED: return launch256_t<EPI_GATED>(p, s);
         case EPI_BIAS_F32: return launch256_t<EPI_BIAS_F32>(p, s);
+        case EPI_BIAS_RELU_BF16: return launch256_t<EPI_BIAS_RELU_BF16>(p, s);
         default: break;
     }
     return hipErrorInvalidValue;

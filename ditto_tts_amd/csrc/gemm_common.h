@@ -248,11 +248,15 @@ DITTO_DEV void epilogue_row(const GemmParams& p, int row, int cbase, const f32x4
         bf16* rowp = (bf16*)p.out + (size_t)row * p.ldo;
         store_bf16_pair(rowp, cbase, pk[0], pk[1], fq, p.N, p.flags, p.ldo);
         store_bf16_pair(rowp, cbase + 32, pk[2], pk[3], fq, p.N, p.flags, p.ldo);
-    } else if constexpr (EPI == EPI_BIAS_BF16) {
+    } else if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_RELU_BF16) {
         u32x2 pk[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-            const f32x4 v = acc[n] + bias[n];
+            f32x4 v = acc[n] + bias[n];
+            if constexpr (EPI == EPI_BIAS_RELU_BF16) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+            }
             pk[n][0] = pack_bf16x2(v[0], v[1]);
             pk[n][1] = pack_bf16x2(v[2], v[3]);
         }

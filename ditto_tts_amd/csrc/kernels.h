@@ -52,7 +52,8 @@ enum GemmEpilogue {
     EPI_QKV_ROPE = 2,     // out bf16 [M, ldo]; columns < 2*d_model get half-split RoPE (head_dim 64 only)
     EPI_GATED = 3,        // W rows interleaved [fc1 x16 | gate x16]; out bf16 [M, N/2] = gelu(a) * sigmoid(g)
     EPI_BIAS_F32 = 4,     // out fp32 [M, ldo] = acc + bias
-    EPI_GATED_FP8 = 5     // as EPI_GATED, out fp8 e4m3 [M, N/2] (A operand of an fp8 fc2)
+    EPI_GATED_FP8 = 5,    // as EPI_GATED, out fp8 e4m3 [M, N/2] (A operand of an fp8 fc2)
+    EPI_BIAS_RELU_BF16 = 6 // out bf16 [M, ldo] = max(acc + bias, 0)  (nn.TransformerDecoderLayer linear1, slp.hip)
 };
 struct GemmArgs {
     const void* A; int lda;          // bf16 [M, K], row stride lda (elements)
@@ -110,9 +111,15 @@ struct AttnArgs {
     bool force_generic;              // run the GEMM-composed path even at dh == 64
     float* lse_out;                  // fused (dh == 64) path: fp32 [B, H, Sq] log2-domain log-sum-exp for the backward
     bool q_prescaled;                // q already multiplied by scale * log2(e) (packed weights, dh == 64): `scale` unused
+    bool causal;                     // key j visible to query i only if j <= i + (Skv - Sq); GEMM-composed path only
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 size_t attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh);
+// the GEMM-composed path's scratch at any head_dim (force_generic / causal)
+size_t attention_generic_workspace_bytes(int B, int H, int Sq, int Skv, int dh);
+// slp.hip: y = LN(x) * gamma + beta as fp32 and / or bf16 (either may be null)
+hipError_t launch_layernorm_dual(const float* x, const float* gamma, const float* beta, float* y_f32, void* y_bf16,
+                                 int M, int d, hipStream_t s);
 // in-place half-split RoPE on bf16 [M, ld] for `nheads` heads of width dh starting at column 0 (generic path);
 // sin_sign = -1 applies the inverse rotation (the backward of RoPE)
 hipError_t launch_rope_inplace(void* qk_bf16, int ld, const float* cosT, const float* sinT, int M,

@@ -71,6 +71,32 @@ class Weights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in _GLOBAL_FIELDS] + [("layers", C.POINTER(LayerWeights))]
 
 
+# the speech-length predictor's decoder stack: struct field -> state_dict key relative to "transformer.layers.{i}."
+SLP_LAYER_KEY = {
+    "self_in_proj_weight": "self_attn.in_proj_weight", "self_in_proj_bias": "self_attn.in_proj_bias",
+    "self_out_proj_weight": "self_attn.out_proj.weight", "self_out_proj_bias": "self_attn.out_proj.bias",
+    "cross_in_proj_weight": "multihead_attn.in_proj_weight", "cross_in_proj_bias": "multihead_attn.in_proj_bias",
+    "cross_out_proj_weight": "multihead_attn.out_proj.weight", "cross_out_proj_bias": "multihead_attn.out_proj.bias",
+    "linear1_weight": "linear1.weight", "linear1_bias": "linear1.bias",
+    "linear2_weight": "linear2.weight", "linear2_bias": "linear2.bias",
+    "norm1_weight": "norm1.weight", "norm1_bias": "norm1.bias", "norm2_weight": "norm2.weight",
+    "norm2_bias": "norm2.bias", "norm3_weight": "norm3.weight", "norm3_bias": "norm3.bias",
+}
+
+
+class SlpConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("d_model", "nhead", "num_layers", "dim_feedforward", "num_classes")]
+
+
+class SlpLayerWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in SLP_LAYER_KEY]
+
+
+class SlpWeights(C.Structure):
+    _fields_ = [("layers", C.POINTER(SlpLayerWeights)), ("length_predictor_weight", C.c_void_p),
+                ("length_predictor_bias", C.c_void_p)]
+
+
 # ditto_layer_grads / ditto_grads have the layout of the weight structs (one pointer per state_dict key)
 LayerGrads, Grads = LayerWeights, Weights
 
@@ -121,6 +147,14 @@ SYMBOLS = {
     "ditto_quantize_rows_fp8": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "ditto_layernorm_fp8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "ditto_gemm_fp8": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ditto_slp_arena_bytes": (_sz, [C.POINTER(SlpConfig)]),
+    "ditto_slp_workspace_bytes": (_sz, [C.POINTER(SlpConfig), _i, _i, _i]),
+    "ditto_slp_create": (_i, [C.POINTER(SlpConfig), C.POINTER(SlpWeights), _vp, _sz, _vp, C.POINTER(_vp)]),
+    "ditto_slp_destroy": (None, [_vp]),
+    "ditto_slp_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "ditto_attention_causal_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "ditto_attention_causal_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
+    "ditto_layernorm_dual": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "ditto_set_option": (_i, [C.c_char_p, _i]),
     "ditto_profile_enable": (_i, [_vp, _i]),
     "ditto_profile_read": (_i, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
@@ -146,7 +180,7 @@ def lib() -> C.CDLL:
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = res, args
-        if l.ditto_abi_version() != 3:
+        if l.ditto_abi_version() != 4:
             raise RuntimeError("libditto_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -147,3 +147,40 @@ def synthetic_inputs(cfg: DiTTOConfig, B: int, N: int, T: int, seed: int = 7):
     S = cfg.diffusion_steps
     t = torch.tensor([(S - 1 - (b * 7919) % S) % S for b in range(B)], dtype=torch.int64)
     return x, text, t
+
+
+def slp_state_shapes(d: int, nhead: int, num_layers: int, num_classes: int) -> "OrderedDict[str, tuple]":
+    """state_dict keys of the reference SLP's decoder stack + head (src/model/SpeechLP.py:22-34:
+    nn.TransformerDecoderLayer(d, nhead, dim_feedforward = d * nhead), nn.Linear(d, num_classes))."""
+    ff = d * nhead
+    shp = OrderedDict()
+    for l in range(num_layers):
+        p = f"transformer.layers.{l}."
+        for a in ("self_attn", "multihead_attn"):
+            shp[p + a + ".in_proj_weight"] = (3 * d, d)
+            shp[p + a + ".in_proj_bias"] = (3 * d,)
+            shp[p + a + ".out_proj.weight"] = (d, d)
+            shp[p + a + ".out_proj.bias"] = (d,)
+        shp[p + "linear1.weight"] = (ff, d)
+        shp[p + "linear1.bias"] = (ff,)
+        shp[p + "linear2.weight"] = (d, ff)
+        shp[p + "linear2.bias"] = (d,)
+        for n in ("norm1", "norm2", "norm3"):
+            shp[p + n + ".weight"] = (d,)
+            shp[p + n + ".bias"] = (d,)
+    shp["length_predictor.weight"] = (num_classes, d)
+    shp["length_predictor.bias"] = (num_classes,)
+    return shp
+
+
+def synthetic_slp_state_dict(d: int, nhead: int, num_layers: int, num_classes: int, seed: int = 0):
+    """Closed-form fp32 weights for the SLP decoder stack (same recipe as synthetic_state_dict)."""
+    sd = OrderedDict()
+    for k, shp in slp_state_shapes(d, nhead, num_layers, num_classes).items():
+        if ".norm" in k and k.endswith(".weight"):
+            sd[k] = 1.0 + _uniform_std(shp, "slp." + k, seed, 0.1)
+        elif k.endswith("bias"):
+            sd[k] = _uniform_std(shp, "slp." + k, seed, 0.05)
+        else:
+            sd[k] = _uniform_std(shp, "slp." + k, seed, 1.0 / np.sqrt(shp[-1]))
+    return sd

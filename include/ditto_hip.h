@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DITTO_ABI_VERSION 3
+#define DITTO_ABI_VERSION 4
 
 typedef enum ditto_status {
     DITTO_OK = 0,
@@ -190,6 +190,7 @@ int ditto_layernorm_bf16(const float* x, const float* gamma, const float* beta, 
 /* out[M,N] = A[M,K](bf16, row stride lda) * W[N,K]^T(bf16) + bias[N](fp32) — F.linear.
  * epilogue: 0 = bf16 out; 1 = fp32 out = acc + bias + residual (residual may alias out; may be NULL);
  *           4 = fp32 out = acc + bias;
+ *           6 = bf16 out = relu(acc + bias)  (linear1 of nn.TransformerDecoderLayer, src/model/SpeechLP.py:23-28);
  *           3 = gated MLP (src/components/DiT.py:153-155): W/bias rows interleaved in blocks of 16
  *               [16 x mlp_fc1 | 16 x gate | ...], out bf16 [M, N/2] = gelu_erf(a) * sigmoid(g), ldo = N/2 or more. */
 int ditto_gemm_bf16(const void* A, int lda, const void* W, const float* bias, const float* residual,
@@ -312,6 +313,54 @@ int ditto_layernorm_fp8(const float* x, const float* gamma, const float* beta, v
 int ditto_gemm_fp8(const void* A, int lda, const void* W, const float* wscale, const float* bias,
                    const float* residual, void* out, int ldo, int M, int N, int K, int epilogue,
                    ditto_stream_t stream);
+
+/* ---- the speech-length predictor's decoder stack ------------------------------------------
+ * Second user of the GEMM / attention family: the nn.TransformerDecoder the reference builds at
+ * src/model/SpeechLP.py:22-32 (post-norm layers, ReLU feed-forward, batch_first, no final norm) run as
+ * src/model/SpeechLP.py:47-55 does in eval mode — causal boolean tgt_mask on the self-attention (:50,57-61), unmasked
+ * cross-attention to the text memory (:52), then length_predictor on the LAST position (:54).  The pretrained encoders
+ * in front of it (ByT5, EnCodec; :17-19,47-49) are out of scope: the entry point takes their outputs.
+ * Weights: one pointer per state_dict key of `transformer.layers.{i}.*` / `length_predictor.*`, device fp32, row-major
+ * as PyTorch stores them ([out, in]).  d_model and dim_feedforward must be multiples of 64; the head width
+ * d_model / nhead is arbitrary (packed zero-padded to a multiple of 64, which changes no result). */
+typedef struct ditto_slp_config {
+    int32_t d_model, nhead, num_layers, dim_feedforward, num_classes;
+} ditto_slp_config;
+typedef struct ditto_slp_layer_weights {
+    const float *self_in_proj_weight, *self_in_proj_bias;      /* self_attn.in_proj_weight [3d,d], .in_proj_bias [3d] */
+    const float *self_out_proj_weight, *self_out_proj_bias;    /* self_attn.out_proj.weight [d,d], .bias [d] */
+    const float *cross_in_proj_weight, *cross_in_proj_bias;    /* multihead_attn.in_proj_* */
+    const float *cross_out_proj_weight, *cross_out_proj_bias;  /* multihead_attn.out_proj.* */
+    const float *linear1_weight, *linear1_bias;                /* [dff,d], [dff] */
+    const float *linear2_weight, *linear2_bias;                /* [d,dff], [d] */
+    const float *norm1_weight, *norm1_bias, *norm2_weight, *norm2_bias, *norm3_weight, *norm3_bias;
+} ditto_slp_layer_weights;
+typedef struct ditto_slp_weights {
+    const ditto_slp_layer_weights* layers;                     /* [num_layers] (host array of device pointers) */
+    const float *length_predictor_weight, *length_predictor_bias;   /* [num_classes,d], [num_classes] */
+} ditto_slp_weights;
+typedef struct ditto_slp* ditto_slp_t;
+
+size_t ditto_slp_arena_bytes(const ditto_slp_config* cfg);                       /* 0 + last_error on a bad config */
+size_t ditto_slp_workspace_bytes(const ditto_slp_config* cfg, int B, int S, int T);
+/* packs the weights (bf16, heads padded) into the caller's 256-byte aligned device arena */
+int ditto_slp_create(const ditto_slp_config* cfg, const ditto_slp_weights* w, void* arena, size_t arena_bytes,
+                     ditto_stream_t stream, ditto_slp_t* out);
+void ditto_slp_destroy(ditto_slp_t m);
+/* z_audio fp32 [B,S,d] (tgt), z_text fp32 [B,T,d] (memory) -> logits fp32 [B,num_classes];
+ * decoded (optional, may be NULL): fp32 [B,S,d], the decoder output for every position (z_audio_decoded, :52). */
+int ditto_slp_forward(ditto_slp_t m, const float* z_audio, const float* z_text, int B, int S, int T, float* logits,
+                      float* decoded, void* workspace, size_t workspace_bytes, ditto_stream_t stream);
+/* the masked attention of that stack on its own (unit parity tests): as ditto_attention_bf16 with the causal mask
+ * key j <= query i + (Skv - Sq); always the GEMM-composed path (any head_dim % 64 == 0, workspace required). */
+size_t ditto_attention_causal_workspace_bytes(int B, int H, int Sq, int Skv, int dh);
+int ditto_attention_causal_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
+                                void* out, int ldo, int B, int H, int Sq, int Skv, int dh, float scale,
+                                void* workspace, size_t workspace_bytes, ditto_stream_t stream);
+/* y = LayerNorm(x) * gamma + beta (eps 1e-5) as fp32 AND bf16 (post-norm residual stream + next GEMM operand);
+ * either output may be NULL; y_f32 may alias x. */
+int ditto_layernorm_dual(const float* x, const float* gamma, const float* beta, float* y_f32, void* y_bf16, int M,
+                         int d, ditto_stream_t stream);
 
 /* ---- profiling aid (bench.py): per-kernel-class HIP-event timing -------------------------
  * When enabled on a handle, ditto_forward brackets every launch with hipEvents on `stream`

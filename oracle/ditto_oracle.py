@@ -316,3 +316,49 @@ def hash_dropout_mask(seed: int, layer: int, B: int, H: int, Sq: int, Skv: int, 
     ctr = (i * np.uint64(0x9E3779B1) + j * np.uint64(0x85EBCA6B)) & M32               # [Sq, Skv]
     h = _lowbias32(stream[:, None, None] ^ ctr[None])
     return torch.from_numpy((h >= thr).astype(np.float32)).view(B, H, Sq, Skv)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Speech-length predictor: the decoder stack after the two pretrained encoders.
+# Reference: src/model/SpeechLP.py:22-32 (construction: nn.TransformerDecoderLayer defaults = post-norm, ReLU,
+# LayerNorm eps 1e-5, no final norm, dim_feedforward = d_model * nhead) and :47-55 (forward).  The layer math is
+# torch's (third-party dependency, torch/nn/modules/transformer.py TransformerDecoderLayer.forward with
+# norm_first=False; attention = F.multi_head_attention_forward) restated with plain ops.  Pinned by
+# tests/golden/G7_slp*.npz, captured from the reference's own SLP.forward with the pretrained encoders replaced by
+# pass-through stand-ins (tests/golden/make_golden.py make_slp), and against nn.TransformerDecoder live.
+# ---------------------------------------------------------------------------------------------------------------
+def _mha(sd: Mapping[str, Tensor], prefix: str, q_in: Tensor, kv_in: Tensor, nhead: int, causal: bool) -> Tensor:
+    """nn.MultiheadAttention(batch_first=True) in eval mode; `causal` = the boolean triu(diagonal=1) tgt_mask of
+    src/model/SpeechLP.py:57-61 (True = not allowed -> -inf before the softmax)."""
+    d = q_in.shape[-1]
+    W, b = sd[prefix + "in_proj_weight"].float(), sd[prefix + "in_proj_bias"].float()
+    q = F.linear(q_in, W[:d], b[:d])
+    k = F.linear(kv_in, W[d:2 * d], b[d:2 * d])
+    v = F.linear(kv_in, W[2 * d:], b[2 * d:])
+    B, S, _ = q.shape
+    T = k.shape[1]
+    dh = d // nhead
+    q = q.view(B, S, nhead, dh).transpose(1, 2) * math.sqrt(1.0 / dh)
+    k = k.view(B, T, nhead, dh).transpose(1, 2)
+    v = v.view(B, T, nhead, dh).transpose(1, 2)
+    s = q @ k.transpose(-1, -2)
+    if causal:
+        mask = torch.triu(torch.ones(S, T), diagonal=1).bool()
+        s = s.masked_fill(mask, float("-inf"))
+    o = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, S, d)
+    return F.linear(o, sd[prefix + "out_proj.weight"].float(), sd[prefix + "out_proj.bias"].float())
+
+
+def slp_decode(sd: Mapping[str, Tensor], num_layers: int, nhead: int, z_text: Tensor, z_audio: Tensor):
+    """src/model/SpeechLP.py:50-54: (z_text [B,T,d], z_audio [B,S,d]) -> (length logits [B,C], decoded [B,S,d])."""
+    x, mem = z_audio.float(), z_text.float()
+    d = x.shape[-1]
+    for l in range(num_layers):
+        p = f"transformer.layers.{l}."
+        ln = lambda t, n: F.layer_norm(t, (d,), sd[p + n + ".weight"].float(), sd[p + n + ".bias"].float(), LN_EPS)  # noqa: E731
+        x = ln(x + _mha(sd, p + "self_attn.", x, x, nhead, True), "norm1")
+        x = ln(x + _mha(sd, p + "multihead_attn.", x, mem, nhead, False), "norm2")
+        h = F.relu(F.linear(x, sd[p + "linear1.weight"].float(), sd[p + "linear1.bias"].float()))
+        x = ln(x + F.linear(h, sd[p + "linear2.weight"].float(), sd[p + "linear2.bias"].float()), "norm3")
+    logits = F.linear(x[:, -1, :], sd["length_predictor.weight"].float(), sd["length_predictor.bias"].float())
+    return logits, x

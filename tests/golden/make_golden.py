@@ -177,9 +177,61 @@ def make_vq():
     save("G6_vq.npz", indices=idx.to(torch.int16))
 
 
+SLP_CASES = {   # name: (d_model, nhead, num_layers, classes, B, codebooks x frames, T)
+    "G7_slp_4head": (128, 4, 2, 11, 2, (2, 20), 24),      # head width 32: packed zero-padded to 64
+    "G7_slp_1head": (192, 1, 1, 11, 3, (2, 9), 16),       # ConfigSLP's shape class: one layer, one head
+}
+
+
+@torch.no_grad()
+def make_slp():
+    """G7: the reference's own SLP.forward (src/model/SpeechLP.py:36-55) with its two pretrained encoders replaced by
+    pass-through stand-ins (ByT5 / EnCodec need the HF hub), so the view(), the causal mask, the TransformerDecoder
+    and the last-position head that run are the reference's.  The fixture holds the logits and the decoder output
+    (z_audio_decoded, tapped with a forward hook); inputs and weights are
+    closed-form (ditto_tts_amd.synth)."""
+    import types
+
+    import torch.nn as nn
+    import_reference()
+    import model.SpeechLP as ref_slp
+    from ditto_tts_amd.synth import synthetic_slp_state_dict
+
+    for name, (d, nhead, nl, ncls, B, (ncb, nfr), T) in SLP_CASES.items():
+        class TextStandIn(nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.model = types.SimpleNamespace(config=types.SimpleNamespace(d_model=d))
+
+            def forward(self, X):
+                return X
+
+        class AudioStandIn(nn.Module):
+            def __init__(self, hidden_size):
+                super().__init__()
+
+            def forward(self, X):
+                return X, None
+
+        ref_slp.ByT5, ref_slp.EnCodec = TextStandIn, AudioStandIn
+        slp = ref_slp.SLP(ncls, nhead, nl).eval()
+        missing = slp.load_state_dict(synthetic_slp_state_dict(d, nhead, nl, ncls, 5), strict=True)
+        assert not missing.missing_keys and not missing.unexpected_keys
+        z_text = hash_normal((B, T, d), "slp_text", 5)
+        z_audio = hash_normal((B, ncb, nfr, d), "slp_audio", 5)       # EnCodec wrapper's [B, codebooks, frames, d]
+        tap = {}
+        slp.transformer.register_forward_hook(lambda mod, args, out: tap.__setitem__("decoded", out))
+        logits = slp(z_text, z_audio)
+        assert logits.shape == (B, ncls) and tap["decoded"].shape == (B, ncb * nfr, d)
+        save(name + ".npz", logits=logits, decoded=tap["decoded"])
+
+
 if __name__ == "__main__":
     if "--vq-only" in sys.argv:
         make_vq()
+    elif "--slp-only" in sys.argv:
+        make_slp()
     else:
         main()
         make_vq()
+        make_slp()

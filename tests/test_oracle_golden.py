@@ -1,6 +1,7 @@
 """Oracle (oracle/ditto_oracle.py) == golden vectors captured from the reference's own code
 (tests/golden/make_golden.py).  Runs everywhere, including the GPU box (no /root/reference needed).
 Tolerance: fp32 restatement vs reference rel-L2 <= 1e-5, max-abs <= 1e-4 at unit scale."""
+import pytest
 import torch
 
 from conftest import max_abs, rel_l2
@@ -110,3 +111,38 @@ def test_strided_schedule_and_ddim_coefficients():
     assert abs(a - ab ** -0.5) < 1e-6 and abs(ce + ((1 - ab) / ab) ** 0.5) < 1e-6 and cz == 0.0
     a, ce, cz = O.ddim_coefficients(ac, 30, 28, 1.0)
     assert cz > 0 and abs(cz ** 2 - (1 - float(ac[28])) / (1 - float(ac[30])) * (1 - float(ac[30] / ac[28]))) < 1e-6
+
+
+# ------------------------------------------------------------------ G7: speech-length predictor decoder stack
+SLP_CASES = {"G7_slp_4head": (128, 4, 2, 11, 2, (2, 20), 24), "G7_slp_1head": (192, 1, 1, 11, 3, (2, 9), 16)}
+
+
+@pytest.mark.parametrize("name", sorted(SLP_CASES))
+def test_g7_slp_decoder_oracle_matches_reference_forward(name, golden):
+    """oracle.slp_decode vs the reference's SLP.forward outputs (tests/golden/make_golden.py make_slp)."""
+    from ditto_tts_amd.synth import synthetic_slp_state_dict
+    d, nhead, nl, ncls, B, (ncb, nfr), T = SLP_CASES[name]
+    g = golden(name + ".npz")
+    sd = synthetic_slp_state_dict(d, nhead, nl, ncls, 5)
+    z_text = hash_normal((B, T, d), "slp_text", 5)
+    z_audio = hash_normal((B, ncb, nfr, d), "slp_audio", 5).view(B, -1, d)    # src/model/SpeechLP.py:49
+    logits, decoded = O.slp_decode(sd, nl, nhead, z_text, z_audio)
+    assert rel_l2(decoded, g["decoded"]) < RTOL
+    assert rel_l2(logits, g["logits"]) < RTOL
+
+
+def test_slp_oracle_matches_torch_transformer_decoder_live():
+    """The restated layer math against nn.TransformerDecoder itself (what src/model/SpeechLP.py:22-32 instantiates),
+    byt5-small's head geometry in miniature: d = 4 * 92 (head width not a multiple of 64 or 8)."""
+    import torch.nn as nn
+    from ditto_tts_amd.synth import synthetic_slp_state_dict
+    d, nhead, nl, ncls, B, S, T = 368, 4, 2, 7, 2, 19, 11
+    sd = synthetic_slp_state_dict(d, nhead, nl, ncls, 9)
+    dec = nn.TransformerDecoder(nn.TransformerDecoderLayer(d_model=d, nhead=nhead, dim_feedforward=d * nhead,
+                                                           batch_first=True), num_layers=nl).eval()
+    dec.load_state_dict({k[len("transformer."):]: v for k, v in sd.items() if k.startswith("transformer.")})
+    z_text, z_audio = hash_normal((B, T, d), "t", 9), hash_normal((B, S, d), "a", 9)
+    with torch.no_grad():
+        want = dec(z_audio, z_text, tgt_mask=torch.triu(torch.ones(S, S), diagonal=1).bool())
+    _, decoded = O.slp_decode(sd, nl, nhead, z_text, z_audio)
+    assert rel_l2(decoded, want) < RTOL
