@@ -5,7 +5,8 @@ Mirrors the sampling surface of the reference's `SpeechGenerator`
 `alphas`, `alphas_cumprod`, `device` `:70-72`, and the two (name-mangled) methods the notebooks reach,
 `_SpeechGenerator__p_sample` `:130-147` and `_SpeechGenerator__sample_latents` `:149-164`.
 
-Out of scope: the EnCodec / GPT-2 / BigVGAN / SLP pieces around the loop.  They are taken from
+Out of scope: the EnCodec / GPT-2 / BigVGAN pieces around the loop and the SLP's encoders (its decoder
+stack is ditto_tts_amd/slp.py).  They are taken from
 `ditto_model.nac` and from injected `vocoder` / `text_tokenizer` / `audio_processor` objects when present and
 raise a clear error otherwise; nothing here re-implements them.
 
