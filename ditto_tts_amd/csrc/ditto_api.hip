@@ -67,6 +67,26 @@ static inline size_t text_scratch_bytes(const ditto_config& c, int B, int T) {
     return al((size_t)B * T * c.text_dim * 2) + al((size_t)B * c.text_dim * 4);
 }
 
+// Small batches leave the long-K GEMMs of the step on a few dozen workgroups, each walking all of K alone (B = 1:
+// fc2 is 48 tiles x 48 K-tiles = 41 us for 4.8 GFLOP).  Those run split-K: `splits` workgroups per output tile write
+// fp32 partials, launch_splitk_finish adds them in order together with bias and residual.  Target: g_splitk_wgs
+// workgroups in flight, at least 4 K-tiles per split.  Measured in-model (tools/step_ab.py, C2): B = 1 fc2 40.6 ->
+// 24.2 us, step 1.87 -> 1.68 ms at 256; B = 2 2.12 -> 2.06 ms; B >= 4 never splits.
+// OFF by default (ditto_set_option("splitk_wgs", 256) / DITTO_SPLITK_WGS=256 turn it on): the K-partition depends on
+// the batch size, so with it an utterance's result is no longer bit-identical across batch compositions — the
+// property tests/test_gpu_model.py::test_full_size_c2_properties holds the default path to.
+static int g_splitk_wgs = [] { const char* e = getenv("DITTO_SPLITK_WGS"); return e ? atoi(e) : 0; }();
+int small_batch_k_splits(int M, int N, int K) {
+    if (g_splitk_wgs <= 0) return 1;
+    const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+    const int ktiles = K / 64;
+    if (tiles > 256 || ktiles < 16) return 1;
+    long ns = g_splitk_wgs / tiles;
+    if (ns > ktiles / 4) ns = ktiles / 4;
+    if (ns > 8) ns = 8;
+    return ns < 2 ? 1 : (int)ns;
+}
+
 WsPlan plan_ws(const ditto_config& c, int B, int N, int T) {
     WsPlan w;
     const size_t d = c.hidden_dim, M = (size_t)B * N, dh = d / c.num_heads;
@@ -78,6 +98,9 @@ WsPlan plan_ws(const ditto_config& c, int B, int N, int T) {
     const size_t a2 = attention_workspace_bytes(B, c.num_heads, N, T, (int)dh);
     w.attn_bytes = a1 > a2 ? a1 : a2;
     w.attn = take(w.attn_bytes);
+    // split-K partials of fc2 / the final projection at small batch: sized for the most splits the option allows
+    w.splitk_bytes = (long)((M + 127) / 128) * ((d + 127) / 128) <= 256 ? 8 * M * d * 4 : 0;
+    w.splitk = take(w.splitk_bytes);
     const size_t tneed = text_scratch_bytes(c, B, T);
     w.total = off > tneed ? off : tneed;
     return w;
@@ -129,7 +152,7 @@ struct ProfScope {
 
 // One DiT block (reference src/components/DiT.py:100-157) on the fp32 residual stream `h`, in place.
 static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* act, char* xcat_or_null,
-                     void* attn_ws, size_t attn_ws_bytes, const char* kv, int kv_layer, int kv_ld,
+                     void* attn_ws, size_t attn_ws_bytes, float* splitk_ws, size_t splitk_bytes, const char* kv, int kv_layer, int kv_ld,
                      const float* rope_cos, const float* rope_sin, int B, int N, int T, hipStream_t s) {
     const ditto_config& c = m->cfg;
     const int d = c.hidden_dim, H = c.num_heads, dh = d / H, M = B * N;
@@ -204,8 +227,17 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
             GemmArgs g{};
             g.A = act; g.lda = 4 * d; g.W = lp.W2; g.bias = lp.b2; g.residual = h; g.ldr = d; g.out = h; g.ldo = d;
             g.M = M; g.N = d; g.K = 4 * d; g.fp8 = fp8; g.wscale = fp8 ? lp.s2 : nullptr;
-            if (xcat_or_null) { g.out2_bf16 = xcat_or_null + (size_t)d * 2; g.ldo2 = 2 * d; }  // bf16(h_L) for proj_out
-            HIP_TRY(launch_gemm(g, EPI_BIAS_RES_F32, s));
+            void* out2 = xcat_or_null ? xcat_or_null + (size_t)d * 2 : nullptr;   // bf16(h_L) for proj_out
+            const int ns = fp8 ? 1 : small_batch_k_splits(M, d, 4 * d);
+            if (ns > 1 && splitk_ws && splitk_bytes >= (size_t)ns * M * d * 4) {
+                g.bias = nullptr; g.residual = nullptr; g.out = splitk_ws; g.k_splits = ns;
+                g.split_stride = (size_t)M * d;
+                HIP_TRY(launch_gemm(g, EPI_BIAS_F32, s));
+                HIP_TRY(launch_splitk_finish(splitk_ws, ns, (size_t)M * d, lp.b2, h, h, out2, 2 * d, M, d, s));
+            } else {
+                if (out2) { g.out2_bf16 = out2; g.ldo2 = 2 * d; }
+                HIP_TRY(launch_gemm(g, EPI_BIAS_RES_F32, s));
+            }
         }
     return DITTO_OK;
 }
@@ -421,7 +453,8 @@ int ditto_forward(ditto_model_t m, const float* x, const void* cond, const int64
         HIP_TRY(launch_adaln(x, m->ttab, tmod, t, c.diffusion_steps, h, xcat, 2 * d, B, N, d, s));
     }
     for (int l = 0; l < L; ++l)
-        if (int rc = run_block(m, l, h, u, qkv, act, l == L - 1 ? xcat : nullptr, attn_ws, w.attn_bytes, kv, l,
+        if (int rc = run_block(m, l, h, u, qkv, act, l == L - 1 ? xcat : nullptr, attn_ws, w.attn_bytes,
+                               (float*)(ws + w.splitk), w.splitk_bytes, kv, l,
                                L * 2 * d, rope_cos, rope_sin, B, N, T, s))
             return rc;
     {   // eps = proj_in(x_raw) + proj_out(h_L)  (src/model/DiTTO.py:83,93-94), one K = 2d GEMM
@@ -429,7 +462,15 @@ int ditto_forward(ditto_model_t m, const float* x, const void* cond, const int64
         GemmArgs g{};
         g.A = xcat; g.lda = 2 * d; g.W = m->Wfin; g.bias = m->bfin; g.out = eps_out; g.ldo = d; g.M = M; g.N = d;
         g.K = 2 * d;
-        HIP_TRY(launch_gemm(g, EPI_BIAS_F32, s));
+        const int ns = small_batch_k_splits(M, d, 2 * d);
+        if (ns > 1 && w.splitk_bytes >= (size_t)ns * M * d * 4) {
+            float* part = (float*)(ws + w.splitk);
+            g.bias = nullptr; g.out = part; g.k_splits = ns; g.split_stride = (size_t)M * d;
+            HIP_TRY(launch_gemm(g, EPI_BIAS_F32, s));
+            HIP_TRY(launch_splitk_finish(part, ns, (size_t)M * d, m->bfin, nullptr, eps_out, nullptr, 0, M, d, s));
+        } else {
+            HIP_TRY(launch_gemm(g, EPI_BIAS_F32, s));
+        }
     }
     return DITTO_OK;
 }
@@ -447,7 +488,7 @@ int ditto_block_forward(ditto_model_t m, int layer, float* h, const void* cond, 
     if (workspace_bytes < w.total) return fail(DITTO_ERR_SIZE, "workspace too small: %zu < %zu", workspace_bytes, w.total);
     char* ws = (char*)workspace;
     return run_block(m, layer, h, ws + w.u, ws + w.qkv, ws + w.act, nullptr, ws + w.attn, w.attn_bytes,
-                     (const char*)cond, cond_layer, c.num_layers * 2 * c.hidden_dim, rope_cos, rope_sin, B, N, T,
+                     (float*)(ws + w.splitk), w.splitk_bytes, (const char*)cond, cond_layer, c.num_layers * 2 * c.hidden_dim, rope_cos, rope_sin, B, N, T,
                      (hipStream_t)stream);
 }
 
@@ -686,6 +727,11 @@ int ditto_set_option(const char* name, int value) {
     }
     if (!strcmp(name, "gemm_flags")) {
         g_gemm_flags = value;
+        return DITTO_OK;
+    }
+    if (!strcmp(name, "splitk_wgs")) {
+        if (value < 0 || value > 2048) return fail(DITTO_ERR_ARG, "splitk_wgs must be in [0, 2048]");
+        g_splitk_wgs = value;
         return DITTO_OK;
     }
     return fail(DITTO_ERR_ARG, "unknown option '%s'", name);

@@ -22,6 +22,10 @@ hipError_t launch_pack_fp8(const float* src, void* dst_fp8, float* scales, int r
 hipError_t launch_adaln(const float* x, const float* ttab, const float* tmod, const int64_t* t, int steps,
                         float* h_out, void* raw_bf16, int ldraw, int B, int N, int d, hipStream_t s);
 hipError_t launch_cast_bf16(const float* src, void* dst_bf16, size_t n, hipStream_t s);
+// out = residual + bias + sum of `nsplit` fp32 partial products (contiguous [M, N], `stride` elements apart), in order
+hipError_t launch_splitk_finish(const float* partial, int nsplit, size_t stride, const float* bias,
+                                const float* residual, float* out, void* out2_bf16, int ldo2, int M, int N,
+                                hipStream_t s);
 hipError_t launch_p_sample_update(float* x, const float* eps, const float* noise, const int64_t* t,
                                   const float* betas, const float* alphas, const float* acp, int B,
                                   size_t elems_per_utt, hipStream_t s);

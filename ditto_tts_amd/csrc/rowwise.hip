@@ -180,6 +180,42 @@ hipError_t launch_cast_bf16(const float* src, void* dst, size_t n, hipStream_t s
 }
 
 // ------------------------------------------------------------------------------------------------
+// Split-K finish (small batches: the K = 4d fc2 GEMM on a handful of workgroups, ditto_api.hip run_block):
+// out[r, c] = residual[r, c] + bias[c] + sum_s partial[s][r, c], splits added in index order (deterministic);
+// optional bf16 copy to out2 (row stride ldo2).  All fp32 arrays are contiguous [M, N]; out may alias residual.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ partial, int nsplit, size_t stride,
+                                                            const float* __restrict__ bias, const float* residual,
+                                                            float* out, bf16* __restrict__ out2, int ldo2, int N,
+                                                            size_t n4) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int nv = N >> 2;
+    const size_t row = i / nv;
+    const int cv = (int)(i % nv);
+    f32x4 acc = reinterpret_cast<const f32x4*>(partial)[i];
+    for (int sp = 1; sp < nsplit; ++sp) acc += reinterpret_cast<const f32x4*>(partial + (size_t)sp * stride)[i];
+    if (bias) acc += reinterpret_cast<const f32x4*>(bias)[cv];
+    if (residual) acc += reinterpret_cast<const f32x4*>(residual)[i];
+    reinterpret_cast<f32x4*>(out)[i] = acc;
+    if (out2) {
+        u32x2 pk;
+        pk[0] = pack_bf16x2(acc[0], acc[1]);
+        pk[1] = pack_bf16x2(acc[2], acc[3]);
+        *reinterpret_cast<u32x2*>(out2 + row * ldo2 + cv * 4) = pk;
+    }
+}
+hipError_t launch_splitk_finish(const float* partial, int nsplit, size_t stride, const float* bias,
+                                const float* residual, float* out, void* out2_bf16, int ldo2, int M, int N,
+                                hipStream_t s) {
+    if (!partial || !out || nsplit < 1 || M <= 0 || N <= 0 || N % 4 || (out2_bf16 && ldo2 % 4)) return hipErrorInvalidValue;
+    const size_t n4 = (size_t)M * (N / 4);
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, partial, nsplit, stride,
+                       bias, residual, out, (bf16*)out2_bf16, ldo2, N, n4);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // DDPM ancestral update, in place.  Reference: src/model/SpeechGenerator.py:137-145.
 // Same operation order as the torch expression; __f*_rn keep hipcc from contracting to FMA so the
 // fp32 result is the IEEE sequence torch's CPU kernels produce.

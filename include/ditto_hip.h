@@ -208,7 +208,10 @@ size_t ditto_attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh);
 /* Process-wide tuning switches (tests / experiments).  "gemm_tile": 0 = automatic choice between the three GEMM
  * tile structures, 128 (128x128) / 129 (persistent 256x128 ring) / 256 (persistent 256x256) = force one.  Results are identical up to fp32 summation order.
  * "gemm_flags": bit mask for kernel experiments (bit 0 = relaxed tile-start wait, default on; bits 1, 2 are
- * DIAGNOSTIC timing switches that skip stores / the epilogue and produce WRONG results — tools/ only). */
+ * DIAGNOSTIC timing switches that skip stores / the epilogue and produce WRONG results — tools/ only).
+ * "splitk_wgs": low-latency mode for batches of 1-2 utterances: workgroups the long-K GEMMs (fc2, final projection)
+ * are split over (K-splits with an ordered fp32 reduce; 256 is the measured choice: -10 % step time at B = 1).
+ * Default 0 = never split, which keeps an utterance's result bit-identical whatever else is in its batch. */
 int ditto_set_option(const char* name, int value);
 
 /* ---- either side of the loop -------------------------------------------------------

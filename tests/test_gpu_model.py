@@ -291,3 +291,41 @@ def test_weights_update_is_seen():
     m.proj_out.bias.add_(1.0)
     b = m(x, text, t)
     assert torch.allclose(b - a, torch.ones_like(a), atol=1e-5)
+
+
+@torch.no_grad()
+def test_low_latency_split_k_mode():
+    """ditto_set_option("splitk_wgs", 256): fc2 and the final projection of a 1-2 utterance batch run split-K with an
+    ordered fp32 reduce.  Same math in a different summation order: parity with the oracle at the usual tolerance,
+    agreement with the default path to fp32-accumulation noise, run-to-run bit-reproducible; B = 4 does not split
+    (so is bit-identical to the default); the default (0) is restored afterwards."""
+    from ditto_tts_amd import hip
+    from oracle import ditto_oracle as O
+    lib = hip.lib()
+    cfg = DiTTOConfig(256, 3, 4, 256, 256, 50)       # K = 4d = 1024 (16 K-tiles) -> 4 splits; final K = 512: none
+    sd = synthetic_state_dict(cfg, 4)
+    m = build(cfg, 4)
+    x, text, t = synthetic_inputs(cfg, 4, 96, 40, seed=6)
+    xd, td, tt = x.to(DEV), text.to(DEV), t.to(DEV)
+    base1, base4 = m(xd[:1], td[:1], tt[:1]), m(xd, td, tt)
+    big = PRESETS["C2"]["cfg"]
+    mb = build(big, 2)
+    xb, tb, ttb = synthetic_inputs(big, 1, 1024, 1024, seed=5)
+    base_big = mb(xb.to(DEV), tb.to(DEV), ttb.to(DEV))
+    hip.check(lib.ditto_set_option(b"splitk_wgs", 256))
+    try:
+        got1 = m(xd[:1], td[:1], tt[:1])
+        assert not torch.equal(got1, base1), "split-K path did not run"
+        assert rel_l2(got1, base1) < 1e-4
+        close(got1, O.ditto_forward(sd, 3, 4, x[:1], text[:1], t[:1]))
+        assert torch.equal(m(xd[:1], td[:1], tt[:1]), got1)
+        # the C2 shape at B = 1: fc2 in 5 splits, the final K = 1536 projection in 5 as well
+        got_big = mb(xb.to(DEV), tb.to(DEV), ttb.to(DEV))
+        # 12 layers deep a different fp32 summation order flips bf16 roundings downstream: the two paths differ by
+        # bf16-path noise (measured 1.5e-3), each within the stated tolerance of the oracle
+        assert not torch.equal(got_big, base_big) and rel_l2(got_big, base_big) < 5e-3
+        close(got_big, O.ditto_forward(synthetic_state_dict(big, 2), 12, 12, xb, tb, ttb))
+    finally:
+        hip.check(lib.ditto_set_option(b"splitk_wgs", 0))
+    assert torch.equal(m(xd, td, tt), base4) and torch.equal(m(xd[:1], td[:1], tt[:1]), base1)
+    assert lib.ditto_set_option(b"splitk_wgs", -1) == hip.ERR_ARG
