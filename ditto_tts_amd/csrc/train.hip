@@ -108,7 +108,24 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     __syncthreads();
     if (ty == 0 && j < n) out[(size_t)g * n + j] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
 }
+// the same sum for LARGE n (split-K weight-gradient partials: a few slices of megabytes each): 16 B per lane, the
+// slices added in index order — HBM-bound, every byte read once in 1-KiB wave rows
+__global__ __launch_bounds__(256) void reduce_slices_kernel(const float* __restrict__ partial, int chunks, size_t n4,
+                                                            float* __restrict__ out) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4* p = reinterpret_cast<const f32x4*>(partial) + i;
+    f32x4 acc = p[0];
+    for (int c = 1; c < chunks; ++c) acc += p[(size_t)c * n4];
+    reinterpret_cast<f32x4*>(out)[i] = acc;
+}
 hipError_t launch_reduce_partials(const float* partial, int chunks, size_t n, float* out, hipStream_t s) {
+    if (n >= 65536 && n % 4 == 0 && chunks <= 32) {
+        const size_t n4 = n / 4;
+        hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, partial, chunks, n4,
+                           out);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 63) / 64), 1), dim3(256), 0, s, partial, chunks, n, out);
     return hipGetLastError();
 }
