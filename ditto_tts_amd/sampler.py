@@ -44,6 +44,19 @@ class SpeechGenerator:
                 info = torch.load(ditto_model_path, map_location="cpu")
                 ditto_model.load_state_dict(info["model_state_dict"], strict=ditto_model.nac is not None)
         self.ditto_model = ditto_model.to(self.device).eval()
+        if slp is None and slp_path is not None:
+            # reference :54-62: SLP(ConfigSLP.NB_CLASSES, NUM_HEADS, NUM_LAYERS) + its checkpoint.  Only the decoder
+            # stack and the head are built here (ditto_tts_amd/slp.py); the checkpoint's text_encoder.* /
+            # audio_encoder.* entries belong to the pretrained encoders and are skipped.
+            from .compat.utils.Config import ConfigSLP
+            from .slp import SLP
+            slp = SLP(ConfigSLP.NB_CLASSES, ConfigSLP.NUM_HEADS, ConfigSLP.NUM_LAYERS,
+                      hidden_size=ConfigSLP.EMBEDDING_DIM)
+            info = torch.load(slp_path, map_location="cpu")
+            res = slp.load_state_dict(info["model_state_dict"], strict=False)
+            if res.missing_keys:
+                raise KeyError(f"SLP checkpoint {slp_path} lacks {res.missing_keys[:3]}...")
+            slp = slp.to(self.device).eval()
         self.sample_rate = sample_rate
         self.vocoder, self.mel_fn, self.slp = vocoder, mel_fn, slp
         self.text_tokenizer, self.audio_processor = text_tokenizer, audio_processor
@@ -81,8 +94,9 @@ class SpeechGenerator:
         `use_graph`: replay the step from a HIP graph (default off: measured no gain even at B = 1, the step is
         bound by per-kernel latency, not by its 122 launches; bit-identical to eager either way)."""
         if is_slp:
-            raise NotImplementedError("the speech-length-predictor branch is broken in the reference "
-                                      "(SURVEY.md App. B-6) and out of scope")
+            raise NotImplementedError("the is_slp branch is broken in the reference (it passes the predictor's logits "
+                                      "as a tensor shape, SURVEY.md App. B-6); length logits are available from "
+                                      "self.slp.decode(z_text, z_audio)")
         m = self.ditto_model
         x = torch.randn_like(audio_emb) if not cond_by_audio else audio_emb.clone()
         x = x.to(self.device).float().contiguous()

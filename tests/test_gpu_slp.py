@@ -202,3 +202,31 @@ def test_slp_surface_and_errors(lib):
     assert lib.ditto_slp_workspace_bytes(C.byref(ok), 0, 4, 4) == 0
     handle = C.c_void_p()
     assert lib.ditto_slp_create(C.byref(ok), None, None, 0, stream(), C.byref(handle)) == hip.ERR_ARG
+
+
+def test_speech_generator_builds_slp_from_checkpoint(tmp_path):
+    """SpeechGenerator(slp_path=...) (reference src/model/SpeechGenerator.py:54-62): ConfigSLP geometry, checkpoint dict
+    with "model_state_dict", encoder entries of the reference checkpoint skipped."""
+    from ditto_tts_amd.compat.utils.Config import ConfigSLP
+    from ditto_tts_amd.config import DiTTOConfig
+    from ditto_tts_amd.modules import DiTTO
+    from ditto_tts_amd.sampler import SpeechGenerator
+    from ditto_tts_amd.synth import synthetic_state_dict
+    d, nh, nl, ncls = ConfigSLP.EMBEDDING_DIM, ConfigSLP.NUM_HEADS, ConfigSLP.NUM_LAYERS, ConfigSLP.NB_CLASSES
+    sd = synthetic_slp_state_dict(d, nh, nl, ncls, 8)
+    ckpt = dict(sd)
+    ckpt["text_encoder.model.shared.weight"] = torch.zeros(4, 4)          # what a reference checkpoint also holds
+    ckpt["audio_encoder.embedding_head.weight"] = torch.zeros(4, 4)
+    path = tmp_path / "SLP_epoch_20.pth"
+    torch.save({"epoch": 20, "model_state_dict": ckpt}, path)
+    cfg = DiTTOConfig(128, 1, 2, 64, 128, 6)
+    dm = DiTTO(128, 1, 2, 64, 128, 6)
+    dm.load_state_dict(synthetic_state_dict(cfg, 3))
+    sg = SpeechGenerator(ditto_model=dm, slp_path=str(path), device=DEV)
+    assert sg.slp is not None and not sg.slp.training and sg.slp.num_classes == ncls
+    zt, za = hash_normal((2, 24, d), "t", 8), hash_normal((2, 50, d), "a", 8)
+    want, _ = O.slp_decode(sd, nl, nh, zt, za)
+    assert rel_l2(sg.slp.decode(zt.to(DEV), za.to(DEV)), want) < TOL
+    torch.save({"model_state_dict": {k: v for k, v in sd.items() if "norm3" not in k}}, path)
+    with pytest.raises(KeyError, match="lacks"):
+        SpeechGenerator(ditto_model=dm, slp_path=str(path), device=DEV)

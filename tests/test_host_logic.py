@@ -108,3 +108,35 @@ def test_shard_bounds_cover_exactly():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_slp_surface_matches_torch_decoder_keys_and_has_no_cpu_path():
+    """The SLP mirror (src/model/SpeechLP.py): same parameter keys / shapes as the nn.TransformerDecoder + Linear the
+    reference builds, reference import name, loud failure off-GPU and without the pretrained encoders."""
+    import torch.nn as nn
+    from ditto_tts_amd.compat.model.SpeechLP import SLP as SLPcompat
+    from ditto_tts_amd.compat.utils.Config import ConfigSLP
+    from ditto_tts_amd.slp import SLP
+    from ditto_tts_amd.synth import slp_state_shapes
+    assert SLPcompat is SLP
+    d, nhead, nl, ncls = 128, 4, 2, ConfigSLP.NB_CLASSES
+    m = SLP(ncls, nhead, nl, hidden_size=d)
+    ref = nn.ModuleDict({
+        "transformer": nn.TransformerDecoder(nn.TransformerDecoderLayer(d_model=d, nhead=nhead, dim_feedforward=d * nhead,
+                                                                       batch_first=True), num_layers=nl),
+        "length_predictor": nn.Linear(d, ncls)})
+    want = {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == want
+    assert dict(slp_state_shapes(d, nhead, nl, ncls)) == want
+    assert ConfigSLP.NB_CLASSES == 11 and ConfigSLP.EMBEDDING_DIM == 1472          # src/utils/Config.py:74,77
+    m.eval()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m.decode(torch.zeros(1, 4, d), torch.zeros(1, 6, d))
+    with pytest.raises(RuntimeError, match="pretrained encoders"):
+        m("text", torch.zeros(1, 100))
+    # hidden size taken from the injected text encoder, as the reference does (:18)
+    class Enc(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.model = type("M", (), {"config": type("C", (), {"d_model": 192})()})()
+    assert SLP(5, 1, 1, text_encoder=Enc()).hidden_size == 192
