@@ -1,5 +1,6 @@
 """Parity figures and timing of the speech-length predictor's decoder stack (ditto_slp_forward) on one MI355X.
-    python tools/slp_report.py            # -> one JSON line per shape
+Lives under tests/ because it imports oracle/ (the checker), which only tests / smoke / bench's cpu_baseline may do.
+    python tests/slp_report.py            # -> one JSON line per shape
 Parity is against oracle.slp_decode at sizes the CPU finishes in seconds; timing uses HIP events on the current stream."""
 import json
 import os
