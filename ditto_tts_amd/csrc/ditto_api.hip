@@ -721,7 +721,7 @@ int ditto_set_option(const char* name, int value) {
         return DITTO_OK;
     }
     if (!strcmp(name, "wgrad_wgs")) {
-        if (value < 1 || value > 512) return fail(DITTO_ERR_ARG, "wgrad_wgs must be in [1, 512]");
+        if (value < 0 || value > 2048) return fail(DITTO_ERR_ARG, "wgrad_wgs must be in [0, 2048] (0 = cost model)");
         set_wgrad_wgs(value);
         return DITTO_OK;
     }

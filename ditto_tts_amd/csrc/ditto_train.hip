@@ -71,15 +71,33 @@ TrainArenaPlan plan_train_arena(const ditto_config& c) {
 struct TrainWsPlan {
     size_t dh, du, dyb, big1, big2, dkv, zero, wtmp, vtmp, red, dmod, small, wpart, attn, attn_bytes, total;
 };
-// split-K factor of a wgrad GEMM with `tiles` 128x128 output tiles and `kt` K-tiles of 64: aim at >= g_wgrad_wgs
-// workgroups, keep >= 8 K-tiles per split
-int g_wgrad_wgs = 384;   // measured at C2 B=16 (tools/train_report.py --wgrad-wgs): 512 -> 47.3, 384 -> 46.3, 256 -> 46.8 ms/step
+// split-K factor of a wgrad GEMM with `tiles` 128x128 output tiles and `kt` K-tiles of 64.  Cost model, in units of
+// one K-tile of one resident workgroup (~1 us; 2 workgroups per CU = 512 slots): rounds(S) * ceil(kt / S) for the
+// GEMM + the bytes the ordered reduce moves ((S + 1) tile images at ~3 TB/s) + its launch.  Measured shapes at C2,
+// B = 16 (rocprofv3, per launch): d x d 36 tiles S=11 43.8 us; QKV 108 tiles S=4 90.5 us; fc2 144 tiles S=3 104.6 us;
+// fc1|gate 288 tiles: S=2 (576 workgroups = 1.1 rounds of 512) 253.9 us -> the model picks S=3 (864 = 1.7 rounds of 86
+// K-tiles).  g_wgrad_wgs > 0 (ditto_set_option("wgrad_wgs")) forces the old rule "at least that many workgroups".
+int g_wgrad_wgs = 0;
 inline int wgrad_splits(long tiles, long kt) {
-    long s = (g_wgrad_wgs + tiles - 1) / tiles;
-    if (s > kt / 8) s = kt / 8;
-    return (int)(s < 1 ? 1 : s);
+    const long smax = kt / 8 < 32 ? kt / 8 : 32;
+    if (smax <= 1) return 1;
+    if (g_wgrad_wgs > 0) {
+        long s = (g_wgrad_wgs + tiles - 1) / tiles;
+        if (s > smax) s = smax;
+        return (int)(s < 1 ? 1 : s);
+    }
+    const double slots = 512.0, tile_us = 128.0 * 128.0 * 4.0 / 3.0e6;   // one fp32 tile image at 3 TB/s, in us
+    long best = 1;
+    double best_cost = 1e30;
+    for (long s = 1; s <= smax; ++s) {
+        const double rounds = (double)((tiles * s + (long)slots - 1) / (long)slots);
+        double cost = rounds * (double)((kt + s - 1) / s);
+        if (s > 1) cost += 5.0 + (double)(s + 1) * (double)tiles * tile_us;
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
+    }
+    return (int)best;
 }
-constexpr size_t WPART_BYTES = (size_t)(512 + 320) * 128 * 128 * 4;   // S * tiles <= 512 + tiles, tiles <= 8d*d/128^2
+constexpr size_t WPART_BYTES = (size_t)(2048 + 320) * 128 * 128 * 4;   // S * tiles: up to ~4 rounds of 512 workgroups
 TrainWsPlan plan_train_ws(const ditto_config& c, int B, int N, int T) {
     TrainWsPlan w;
     const size_t d = c.hidden_dim, M = (size_t)B * N, Mt = (size_t)B * T, dh = d / c.num_heads;

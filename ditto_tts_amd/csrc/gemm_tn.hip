@@ -10,6 +10,13 @@
 //   LDS       a tile is 64 k-rows of 256 B; the 16-B chunk c of row r sits at c ^ ((r & 3) << 2): the 4 rows a
 //             transposed-read block touches land in 4 different 64-B bank quarters.  Lane-linear image (LDS-DMA),
 //             swizzle on the source address; rows past K read a zero row (the caller's 256-B zero buffer).
+//   ring      gemm_tn_ring_kernel (default): K-tiles of 32 rows in a 4-stage LDS ring (4 x 16 KiB, still 2 workgroups
+//             per CU) behind counted s_waitcnt vmcnt, fragments software-pipelined across the tile boundary (reads of
+//             the next 16 k-rows in flight under the 4 MFMAs of the current ones).  [measured] the same speed as the
+//             first version (K-tile 64, two buffers, vmcnt(0) + read -> wait -> multiply; gemm_flags bit 2048 selects
+//             it): 27.6-28.2 ms of backward either way at C2 B = 16 — with two workgroups per CU neither the
+//             global->LDS nor the LDS->register latency is what holds the kernel at ~860 TFLOP/s; the tile's 64 FLOP per
+//             byte staged (13 TB/s of L2->LDS traffic at that rate) is the suspect, i.e. a 256-wide tile the next step.
 //   split-K   blockIdx.y = split: K-tile range per split, partial tiles to out + split * split_stride (fp32), summed in
 //             order by launch_reduce_partials — deterministic.
 #include "gemm_common.h"
@@ -139,6 +146,146 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
         }
 }
 
+constexpr int RK = 32;                     // K-tile of the ring kernel
+constexpr int R_TILE = RK * TM * 2;        // 8 KiB per operand tile
+constexpr int R_STAGE = 2 * R_TILE;        // X | Y
+constexpr int R_NST = 4;
+constexpr int R_LDS = R_NST * R_STAGE;     // 64 KiB
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_ring_kernel(TnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1;
+    const int tm = blockIdx.x / p.tiles_n, tn = blockIdx.x % p.tiles_n;
+    const int m0 = tm * TM, n0 = tn * TN;
+    const int split = blockIdx.y;
+
+    int nkt = (p.K + RK - 1) / RK, kbase = 0;
+    if (p.k_splits > 1) {
+        const int per = (nkt + p.k_splits - 1) / p.k_splits;
+        kbase = split * per;
+        nkt = nkt - kbase < per ? nkt - kbase : per;
+        if (nkt < 0) nkt = 0;
+    }
+    float* out = p.out + (size_t)split * p.split_stride;
+
+    // DMA: a tile = 8 pieces of 1 KiB (4 k-rows x 256 B) per operand; this wave moves pieces 2*wid, 2*wid+1 of X and Y:
+    // 4 loads per wave per tile (the unit the counted waits below are written in)
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+    const int prow = lane >> 4, cpos = lane & 15;
+    int cx, cy;
+    {
+        const int c = cpos ^ (prow << 2);                  // piece rows are 4*piece + prow: (r & 3) == prow
+        cx = m0 + c * 8; cx = cx + 8 <= p.Mo ? cx : (p.Mo >= 8 ? p.Mo - 8 : 0);
+        cy = n0 + c * 8; cy = cy + 8 <= p.No ? cy : (p.No >= 8 ? p.No - 8 : 0);
+    }
+    const int czero = (cpos ^ (prow << 2)) * 8;
+    auto stage = [&](int kt) {
+        const int st = kt & (R_NST - 1);
+        const int k0 = (kbase + kt) * RK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int piece = wid * 2 + i;
+            const int k = k0 + piece * 4 + prow;
+            const bf16* sx = k < p.K ? p.X + (size_t)k * p.ldx + cx : p.zero + czero;
+            const bf16* sy = k < p.K ? p.Y + (size_t)k * p.ldy + cy : p.zero + czero;
+            glds16(sx, lds_base + (unsigned)(st * R_STAGE + piece * 1024));
+            glds16(sy, lds_base + (unsigned)(st * R_STAGE + R_TILE + piece * 1024));
+        }
+    };
+
+    const int hh = lane >> 5;
+    const int tr_q = (lane & 15) >> 2, tr_p = lane & 3;
+    const int tr_row0 = 4 * hh + tr_q;
+    const int tr_colbyte = 32 * ((lane >> 4) & 1) + 8 * tr_p;
+    const int tr_swz = (tr_q & 3) << 6;
+    int colx[2], coly[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        colx[blk] = ((wr * 2 + blk) * 64 + tr_colbyte) ^ tr_swz;
+        coly[blk] = ((wc * 2 + blk) * 64 + tr_colbyte) ^ tr_swz;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc[0][0][i] = 0.f; acc[0][1][i] = 0.f; acc[1][0][i] = 0.f; acc[1][1][i] = 0.f; }
+
+    // Software-pipelined over the tile boundary: the fragments of the next 16 k-rows are always in flight while the
+    // 4 MFMAs of the current ones issue:
+    //   iteration kt:  read F1 <- tile kt rows 16..31 | MFMA(F0) | wait tile kt+1, barrier, DMA tile kt+3,
+    //                  read F0 <- tile kt+1 rows 0..15 | MFMA(F1)
+    auto read_frags = [&](const char* xb, int s2, bf16x8 (&fx)[2], bf16x8 (&fy)[2]) {
+        const char* yb = xb + R_TILE;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const char* ax = xb + (16 * s2 + tr_row0) * 256 + colx[blk];
+            const char* ay = yb + (16 * s2 + tr_row0) * 256 + coly[blk];
+            fx[blk] = cat4t(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(ax)),
+                            __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(ax + 8 * 256)));
+            fy[blk] = cat4t(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(ay)),
+                            __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(ay + 8 * 256)));
+        }
+    };
+    auto mma = [&](const bf16x8 (&fx)[2], const bf16x8 (&fy)[2]) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx[mb], fy[nb], acc[mb][nb], 0, 0, 0);
+    };
+    // a tile has landed once at most the loads of the tiles issued after it are outstanding (4 per tile per wave)
+    auto wait_behind = [&](int later) {
+        if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
+    // plain s_barrier (no fence): visibility of the DMA'd tile is what the counted vmcnt waits establish, and the stage
+    // a DMA overwrites was last read two MFMA groups earlier — a fence here would drain the F1 reads just issued
+    bf16x8 f0x[2], f0y[2], f1x[2], f1y[2];
+    if (nkt > 0) {
+        for (int t = 0; t < R_NST - 1 && t < nkt; ++t) stage(t);           // tiles 0, 1, 2
+        wait_behind(nkt - 1 < R_NST - 2 ? nkt - 1 : R_NST - 2);
+        asm volatile("s_barrier" ::: "memory");
+        read_frags(smem, 0, f0x, f0y);
+        for (int kt = 0; kt + 1 < nkt; ++kt) {                             // the last tile is peeled: one path per body
+            read_frags(smem + (kt & (R_NST - 1)) * R_STAGE, 1, f1x, f1y);
+            __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMAs (the scheduler sinks them to save registers)
+            mma(f0x, f0y);
+            __builtin_amdgcn_sched_barrier(0);
+            // issued so far: tiles <= kt + 2 (iteration j issues tile j + 3 after its barrier)
+            wait_behind(kt + 2 < nkt ? 1 : 0);
+            asm volatile("s_barrier" ::: "memory");
+            // into the stage of tile kt - 1: its last reads fed MFMA(F1) of the previous iteration.  (NOT the stage of
+            // tile kt: this iteration's F1 reads are issued but may still be in the LDS pipeline.)
+            if (kt + R_NST - 1 < nkt) stage(kt + R_NST - 1);
+            read_frags(smem + ((kt + 1) & (R_NST - 1)) * R_STAGE, 0, f0x, f0y);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(f1x, f1y);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        read_frags(smem + ((nkt - 1) & (R_NST - 1)) * R_STAGE, 1, f1x, f1y);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(f0x, f0y);
+        mma(f1x, f1y);
+    }
+
+    const int ncol = lane & 31;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int col = n0 + (wc * 2 + nb) * 32 + ncol;
+            if (col >= p.No) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + (wr * 2 + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (row < p.Mo) out[(size_t)row * p.ldo + col] = acc[mb][nb][r];
+            }
+        }
+}
+
 }  // namespace
 
 // out fp32 [Mo, No] (ld = ldo) = X[K, Mo]^T Y[K, No]; k_splits > 1: partial sums to out + s * split_stride
@@ -151,6 +298,9 @@ hipError_t launch_gemm_tn(const void* X, int ldx, const void* Y, int ldy, const 
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
         if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_ring_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS);
+        if (e != hipSuccess) return e;
         attr_set = true;
     }
     TnParams p;
@@ -158,7 +308,10 @@ hipError_t launch_gemm_tn(const void* X, int ldx, const void* Y, int ldy, const 
     p.out = out; p.ldo = ldo; p.Mo = Mo; p.No = No; p.K = K;
     p.tiles_m = (Mo + TM - 1) / TM; p.tiles_n = (No + TN - 1) / TN;
     p.k_splits = k_splits > 1 ? k_splits : 1; p.split_stride = split_stride;
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tiles_m * p.tiles_n, p.k_splits), dim3(256), T_LDS, s, p);
+    if (g_gemm_flags & 2048)
+        hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tiles_m * p.tiles_n, p.k_splits), dim3(256), T_LDS, s, p);
+    else
+        hipLaunchKernelGGL(gemm_tn_ring_kernel, dim3(p.tiles_m * p.tiles_n, p.k_splits), dim3(256), R_LDS, s, p);
     return hipGetLastError();
 }
 

@@ -91,22 +91,34 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
         *reinterpret_cast<f32x4*>(partial + (size_t)blockIdx.y * n + col) = r;
     }
 }
-// out[g][j] = sum_c partial[g][c][j]   (groups of `chunks` partial rows).  Block = 64 columns x 4 chunk-lanes: the
-// chunk loop is split 4 ways and combined through LDS in a fixed order (deterministic).
+// out[g][j] = sum_c partial[g][c][j]   (groups of `chunks` partial rows).  Latency-bound (n is a few thousand columns,
+// chunks up to 256): block = 16 columns x 16 chunk-lanes, each lane keeps 4 independent running sums so that 4 loads
+// are in flight, lanes combined through LDS in a fixed order (deterministic).  The first version (64 columns x 4
+// chunk-lanes, one dependent chain of 64 loads on a 12-block grid) took 19 us per call, 110 calls per training step.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int chunks, size_t n,
                                                               float* __restrict__ out) {
-    __shared__ float red[4][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const size_t j = (size_t)blockIdx.x * 64 + tx;
+    __shared__ float red[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const size_t j = (size_t)blockIdx.x * 16 + tx;
     const int g = blockIdx.y;
-    float acc = 0.f;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (j < n) {
         const float* p = partial + (size_t)g * chunks * n + j;
-        for (int c = ty; c < chunks; c += 4) acc += p[(size_t)c * n];
+        int c = ty;
+        for (; c + 48 < chunks; c += 64) {
+            a0 += p[(size_t)c * n]; a1 += p[(size_t)(c + 16) * n]; a2 += p[(size_t)(c + 32) * n];
+            a3 += p[(size_t)(c + 48) * n];
+        }
+        for (; c < chunks; c += 16) a0 += p[(size_t)c * n];
     }
-    red[ty][tx] = acc;
+    red[ty][tx] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (ty == 0 && j < n) out[(size_t)g * n + j] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    if (ty == 0 && j < n) {
+        float r = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) r += red[i][tx];
+        out[(size_t)g * n + j] = r;
+    }
 }
 // the same sum for LARGE n (split-K weight-gradient partials: a few slices of megabytes each): 16 B per lane, the
 // slices added in index order — HBM-bound, every byte read once in 1-KiB wave rows
@@ -126,7 +138,7 @@ hipError_t launch_reduce_partials(const float* partial, int chunks, size_t n, fl
                            out);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 63) / 64), 1), dim3(256), 0, s, partial, chunks, n, out);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 15) / 16), 1), dim3(256), 0, s, partial, chunks, n, out);
     return hipGetLastError();
 }
 static int colsum_chunks(int M, int n) {
@@ -145,7 +157,7 @@ static hipError_t colsum_launch(const T* x, int ld, int M, int n, float* out, fl
     const int rpc = (M + chunks - 1) / chunks;
     hipLaunchKernelGGL((colsum_partial_kernel<T>), dim3((n + 255) / 256, chunks), dim3(256), 0, s, x, ld, M, n,
                        scratch, rpc);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 63) / 64, 1), dim3(256), 0, s, scratch, chunks, (size_t)n, out);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 15) / 16, 1), dim3(256), 0, s, scratch, chunks, (size_t)n, out);
     return hipGetLastError();
 }
 hipError_t launch_colsum_f32(const float* x, int ld, int M, int n, float* out, float* scratch, hipStream_t s) {
@@ -294,7 +306,7 @@ hipError_t launch_ln_bwd(const float* dy, const float* x, const float* gamma, fl
     }
 #undef LNB_CASE
     if (dgb_out)
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * d + 63) / 64, groups), dim3(256), 0, s, scratch, chunks,
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * d + 15) / 16, groups), dim3(256), 0, s, scratch, chunks,
                            (size_t)(2 * d), dgb_out);
     return hipGetLastError();
 }
