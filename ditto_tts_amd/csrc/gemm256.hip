@@ -69,6 +69,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     auto stage = [&](int buf, auto HALF, int kt) {
         constexpr int half = decltype(HALF)::value;
         if (kt >= nkt) return;    // wave-uniform; the waits below account for it
+#ifdef DITTO_DIAG_NODMA
+        if (kt > 0) return;       // timing experiment: the main loop without its global->LDS traffic (WRONG results)
+#endif
         const int k0b = kt * 128;             // byte offset of the K-tile inside a row
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
