@@ -69,7 +69,35 @@ DITTO_DEV float fast_gelu_erf(float x) {
 // (two fp32 results per instruction; the gated-MLP epilogue is VALU-bound: 4.6 us of a 24 us tile, measured in-model
 // with the no-epilogue diagnostic), the four transcendentals per pair stay scalar.  Same formulas as the scalar forms.
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+// The same formulas with the scalings folded and the sign handled by |x| source modifiers (23 VALU per pair instead of
+// 29; the gated epilogue is issue-bound at 1 750 instructions per wave per tile):
+//     gelu(x) sigmoid(g) = (x + |x| erf(|x|/sqrt2)) * 1 / (2 + 2 e^-g)
+//     erf(|z|) = 1 - poly(t) e^(-x^2/2),   t = 1 / (1 + (p/sqrt2) |x|)          (A&S 7.1.26, as fast_gelu_erf)
 DITTO_DEV f32x2 fast_gelu_sigmoid2(f32x2 x, f32x2 g) {
+    f32x2 t;
+    t[0] = fast_rcp(fmaf(fabsf(x[0]), 0.3275911f * 0.70710678118654752440f, 1.0f));
+    t[1] = fast_rcp(fmaf(fabsf(x[1]), 0.3275911f * 0.70710678118654752440f, 1.0f));
+    f32x2 poly = t * 1.061405429f + (-1.453152027f);
+    poly = poly * t + 1.421413741f;
+    poly = poly * t + (-0.284496736f);
+    poly = poly * t + 0.254829592f;
+    poly = poly * t;
+    const f32x2 ea = x * x * (-0.5f * 1.4426950408889634f);
+    f32x2 e;
+    e[0] = __builtin_amdgcn_exp2f(ea[0]); e[1] = __builtin_amdgcn_exp2f(ea[1]);
+    const f32x2 erf_abs = 1.0f - poly * e;
+    f32x2 num;                                               // x + |x| erf(|z|) = 2 gelu(x)
+    num[0] = fmaf(fabsf(x[0]), erf_abs[0], x[0]); num[1] = fmaf(fabsf(x[1]), erf_abs[1], x[1]);
+    const f32x2 eg = g * (-1.4426950408889634f);
+    f32x2 eg2;
+    eg2[0] = __builtin_amdgcn_exp2f(eg[0]); eg2[1] = __builtin_amdgcn_exp2f(eg[1]);
+    const f32x2 den2 = eg2 * 2.0f + 2.0f;
+    f32x2 sg;                                                // sigmoid(g) / 2
+    sg[0] = fast_rcp(den2[0]); sg[1] = fast_rcp(den2[1]);
+    return num * sg;
+}
+// first packed form (kept for reference / A/B): separate scaling multiplies, sign by v_bfi
+DITTO_DEV f32x2 fast_gelu_sigmoid2_v1(f32x2 x, f32x2 g) {
     const f32x2 z = x * 0.70710678118654752440f;
     const f32x2 az = __builtin_elementwise_abs(z);
     const f32x2 d1 = az * 0.3275911f + 1.0f;

@@ -149,6 +149,10 @@ DITTO_DEV void store_bf16_pair(bf16* rowp, int col0 /* column of block nb */, u3
     }
 }
 
+#ifdef DITTO_GATED_V1   // A/B build of the first packed form of the gated-MLP math (tools/README.md)
+#define fast_gelu_sigmoid2 fast_gelu_sigmoid2_v1
+#endif
+
 // One output row x the wave's 64-column span.  `row` < M is checked by the caller.
 template <int EPI>
 DITTO_DEV void epilogue_row(const GemmParams& p, int row, int cbase, const f32x4 (&acc)[4], const f32x4 (&bias)[4],
