@@ -11,8 +11,11 @@
 //   tile      128 (M) x 256 (N) x 32 (K); 256 threads = 4 waves in 2 x 2, each wave 64 x 128:
 //             4 x 8 accumulators of v_mfma_f32_16x16x32_bf16 = 128 fp32 registers (same LDS-read : MFMA ratio as the
 //             256^2 kernel's 128 x 64 wave tile: 12 ds_read_b128 per 32 MFMAs).
-//   LDS       rows of 64 B (32 bf16); 16-B chunk c of row r sits at c ^ ((r>>2)&3): the 16 rows a ds_read_b128 lane
-//             group touches fall in 16 distinct 16-B slots of the 256-B bank row.  Lane-linear image, swizzle on the
+//   LDS       rows of 64 B (32 bf16); 16-B chunk c of row r sits at c ^ (-(r>>2)&3): the 16 lanes of a ds_read_b128 lane
+//             group fall in 16 distinct 16-B slots of the 256-B bank row (the hardware serves
+//             ds_read_b128 in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...: with lane = 16 fq + frow, a
+//             group holds for every residue frow & 3 the row quads q = 0, 3 at k-chunk fq and q = 1, 2 at fq ^ 1, and
+//             q -> -q & 3 sends those four to four different slots; the first version used (r>>2)&3: 2-way conflicts).  Lane-linear image, swizzle on the
 //             DMA's source address.  Two buffers, tile kt+1 in flight while kt is multiplied, two barriers per K-tile.
 //   fragments A (4 x 16 B) per K-tile up front, W one 16-column block at a time (8 x 16 B, just in time) to stay
 //             under 168 registers.
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(256, 3) void gemm_o3_kernel(GemmParams p) {
         for (int i = 0; i < 6; ++i) {
             const int piece = wid * 6 + i;   // wave-uniform: pieces of one wave are all A or all W except wave 1 (6..11)
             const int row = (piece < 8 ? piece : piece - 8) * 16 + prow;
-            const int c = cpos ^ ((row >> 2) & 3);
+            const int c = cpos ^ ((0 - (row >> 2)) & 3);
             if (piece < 8) {
                 int ar = m0 + row; ar = ar < p.M ? ar : p.M - 1;
                 voff[i] = (unsigned)(((size_t)ar * p.lda + c * 8) * 2);
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(256, 3) void gemm_o3_kernel(GemmParams p) {
 
     // fragment addressing: lane reads row (lane&15) of a 16-row block, k-chunk (lane>>4) of the 32-wide K-tile
     const int frow = lane & 15, fq = lane >> 4;
-    const int coff = (fq ^ ((frow >> 2) & 3)) << 4;    // (16*blk + frow)>>2 & 3 == (frow>>2)&3
+    const int coff = (fq ^ ((0 - (frow >> 2)) & 3)) << 4;    // (16*blk + frow)>>2 & 3 == (frow>>2)&3
     const int a_off = (wr * 64 + frow) * 64 + coff;
     const int w_off = O_A_BYTES + (wc * 128 + frow) * 64 + coff;
 
