@@ -29,7 +29,10 @@
 namespace ditto {
 
 // 0 = automatic, 128 / 256 = force that tile structure (ditto_set_option("gemm_tile", v); env DITTO_GEMM seeds it)
-int g_gemm_flags = GF_RELAXED_WAIT | GF_STAGGER_START | GF_STORE_NT | GF_WIDE_PHASE;
+// GF_STAGGER_START (8) is no longer on by default: after the gated epilogue got shorter the staggered start costs more
+// than the store bursts it spreads — same-process A/B at C2 B = 32 (tools/step_ab.py, 8 rounds x 25 steps): gated GEMM
+// 291.7 -> 279.1 us per launch, step 13.06 -> 12.99 ms.
+int g_gemm_flags = GF_RELAXED_WAIT | GF_STORE_NT | GF_WIDE_PHASE;
 int g_gemm_tile = [] { const char* e = getenv("DITTO_GEMM"); return e ? atoi(e) : 0; }();
 
 namespace {

@@ -36,7 +36,7 @@ struct GemmParams {
 enum { GF_RELAXED_WAIT = 1,        // tile-start wait skips over the previous tile's epilogue stores
        GF_DIAG_NO_STORE = 2,       // DIAGNOSTIC (wrong results): epilogue computes but does not store
        GF_DIAG_NO_EPILOGUE = 4,    // DIAGNOSTIC (wrong results): no epilogue at all
-       GF_STAGGER_START = 8,       // de-synchronise the persistent workgroups: group g of 4 starts g/4 tile late
+       GF_STAGGER_START = 8,       // de-synchronise the persistent workgroups: group g of 4 starts g/4 tile late (off by default)
        GF_DIAG_LINEAR_STORE = 16,  // DIAGNOSTIC (wrong results): bf16 stores go to lane-linear addresses
        GF_STORE_SC1 = 32,          // output stores write-through, line dropped from L2 (sc1)
        GF_STORE_NT = 64,           // fp32 output stores non-temporal (nt)

@@ -62,7 +62,7 @@ def tile256(lib, request):
     hip.check(lib.ditto_set_option(b"gemm_flags", request.param[1]))
     yield
     hip.check(lib.ditto_set_option(b"gemm_tile", 0))
-    hip.check(lib.ditto_set_option(b"gemm_flags", 329))
+    hip.check(lib.ditto_set_option(b"gemm_flags", 321))
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 320, 64), (1000, 768, 768), (513, 2304, 192),

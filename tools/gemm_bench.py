@@ -58,7 +58,7 @@ tiles = a.tiles.split(",")
 def select(v):
     t, _, f = v.partition("/")
     hip.check(lib.ditto_set_option(b"gemm_tile", int(t)))
-    hip.check(lib.ditto_set_option(b"gemm_flags", int(f) if f else 329))
+    hip.check(lib.ditto_set_option(b"gemm_flags", int(f) if f else 321))
 res = {(n, t): [] for n in bufs for t in tiles}
 for n in bufs:
     for t in tiles:

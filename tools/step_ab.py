@@ -50,7 +50,7 @@ def select(v):
     hip.check(lib.ditto_set_option(b"attn_flags", int(af) if af else 0))
     tile, _, fl = v.partition("/")
     hip.check(lib.ditto_set_option(b"gemm_tile", int(tile)))
-    hip.check(lib.ditto_set_option(b"gemm_flags", int(fl) if fl else 329))
+    hip.check(lib.ditto_set_option(b"gemm_flags", int(fl) if fl else 321))
 
 
 with torch.no_grad():

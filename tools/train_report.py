@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--no-parity", action="store_true", help="accepted and ignored (older command lines)")
     ap.add_argument("--wgrad-wgs", type=int, default=0)
-    ap.add_argument("--gemm-flags", type=int, default=None, help="ditto_set_option('gemm_flags'): 329 default; "
+    ap.add_argument("--gemm-flags", type=int, default=None, help="ditto_set_option('gemm_flags'): 321 default; "
                     "+2048 = the two-buffer weight-gradient kernel (A/B)")
     a = ap.parse_args()
     if a.gemm_flags is not None:
