@@ -326,7 +326,12 @@ hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s) {
     if (forced == 130) return launch_gemm_o3(p, epi, s);
     if (forced == 192 && gemm192_supports(epi)) return launch_gemm192(p, epi, s);
     const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-    if (forced == 256 || (forced == 0 && t256 >= 4 * 256)) {
+    // Wide outputs (N >= 2048: QKV, fc1|gate) take the 256x256 structure from 144 tiles on — re-measured at the end of
+    // round 1 (tools/step_ab.py --batch 4 / 8 / 16, per launch): QKV 35.2 -> 31.0 us at B = 4 (144 tiles), 87.1 -> 79.1 at
+    // B = 16; gated 51.5 -> 48.3 (B = 4), 99.0 -> 78.3 (B = 8).  Narrow outputs (N = d) keep the 4-round rule: at B = 4
+    // the d x d GEMMs take 33 us on it against 18.
+    const bool wide256 = a.N >= 2048 && t256 >= 144;
+    if (forced == 256 || (forced == 0 && (t256 >= 4 * 256 || wide256))) {
         p.tiles_m = (a.M + 255) / 256;
         p.tiles_n = (a.N + 255) / 256;
         return launch_gemm256(p, epi, s);
@@ -339,7 +344,9 @@ hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s) {
     // 256x192 tiles (gemm192.hip) where the output width is a multiple of 192 and whole rounds of them cost no more
     // tile-work than the 256x128 ring's rounds: measured in-model at M = 32768 (tools/step_ab.py): fc2 183.6 vs 189.4 us,
     // the final K = 1536 projection 92.1 vs 97.2 us, the K = 768 d x d GEMMs 69.2 vs 70.1 us (noise): long K only.
-    if (forced == 0 && gemm192_supports(epi) && a.N % 192 == 0 && a.K >= 1536) {
+    // (K >= 768 since the end of round 1: at M = 16384 the K = 768 d x d GEMMs are exactly one round of 256 such tiles,
+    // 32.8 us against 41.2 on the 128x128 kernel; at M = 32768 the two are equal, 69.9 / 71.7.)
+    if (forced == 0 && gemm192_supports(epi) && a.N % 192 == 0 && a.K >= 768) {
         const long t192 = (long)((a.M + 255) / 256) * (a.N / 192);
         const long r192 = (t192 + 255) / 256, r128 = (tp128 + 255) / 256;
         if (t192 >= 256 && r192 * 3 <= r128 * 2) return launch_gemm192(p, epi, s);
