@@ -191,6 +191,17 @@ def check(rc: int):
         raise DittoHipError(rc, lib().ditto_last_error().decode(errors="replace"))
 
 
+def set_option(name: str, value: int):
+    """ditto_set_option: process-wide tuning switches of libditto_hip.so (include/ditto_hip.h)."""
+    check(lib().ditto_set_option(name.encode(), int(value)))
+
+
+def set_low_latency(on: bool = True):
+    """Single-utterance serving mode: the long-K GEMMs of batches of 1-2 utterances run split-K (step 1.87 -> 1.68 ms
+    at C2, B = 1).  Off by default: with it an utterance's bits depend on the size of the batch it is in."""
+    set_option("splitk_wgs", 256 if on else 0)
+
+
 def make_config(cfg) -> Config:
     return Config(cfg.hidden_dim, cfg.num_layers, cfg.num_heads, cfg.time_dim, cfg.text_dim, cfg.diffusion_steps,
                   CFG_FP8_LINEAR if getattr(cfg, "fp8_linear", False) else 0)

@@ -312,7 +312,7 @@ def test_low_latency_split_k_mode():
     mb = build(big, 2)
     xb, tb, ttb = synthetic_inputs(big, 1, 1024, 1024, seed=5)
     base_big = mb(xb.to(DEV), tb.to(DEV), ttb.to(DEV))
-    hip.check(lib.ditto_set_option(b"splitk_wgs", 256))
+    hip.set_low_latency(True)
     try:
         got1 = m(xd[:1], td[:1], tt[:1])
         assert not torch.equal(got1, base1), "split-K path did not run"
@@ -326,6 +326,6 @@ def test_low_latency_split_k_mode():
         assert not torch.equal(got_big, base_big) and rel_l2(got_big, base_big) < 5e-3
         close(got_big, O.ditto_forward(synthetic_state_dict(big, 2), 12, 12, xb, tb, ttb))
     finally:
-        hip.check(lib.ditto_set_option(b"splitk_wgs", 0))
+        hip.set_low_latency(False)
     assert torch.equal(m(xd, td, tt), base4) and torch.equal(m(xd[:1], td[:1], tt[:1]), base1)
     assert lib.ditto_set_option(b"splitk_wgs", -1) == hip.ERR_ARG
