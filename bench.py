@@ -75,13 +75,13 @@ def kernel_bytes(cfg, B, N, T):
 
 
 def pmc_traffic(kernel_class, B, N, T, cfg):
-    """HBM bytes per launch of `kernel_class` from the committed rocprofv3 PMC passes (profiles/r01_v5_pmc_traffic.json, tools/pmc_traffic.py:
+    """HBM bytes per launch of `kernel_class` from the committed rocprofv3 PMC passes (profiles/r01_v8_pmc_traffic.json, tools/pmc_traffic.py:
     separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 x2 correction on the read side).
     bench.py cannot run under the counter collector itself, so the figure is the offline one; it is only reported
     when the workload is the one those passes measured (C2, B=32), else null."""
     if not (B == 32 and N == 1024 and T == 1024 and cfg.hidden_dim == 768 and cfg.num_layers == 12):
         return None
-    for name in ("r01_v5_pmc_traffic.json", "r01_pmc_traffic.json"):   # newest counter passes first
+    for name in ("r01_v8_pmc_traffic.json", "r01_v5_pmc_traffic.json", "r01_pmc_traffic.json"):   # newest counter passes first
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             return d[kernel_class]["traffic_bytes"]
