@@ -729,6 +729,11 @@ int ditto_set_option(const char* name, int value) {
         g_gemm_flags = value;
         return DITTO_OK;
     }
+    if (!strcmp(name, "gemm_group")) {
+        if (value < 0 || value > 64) return fail(DITTO_ERR_ARG, "gemm_group must be in [0, 64]");
+        g_gemm_group = value;
+        return DITTO_OK;
+    }
     if (!strcmp(name, "splitk_wgs")) {
         if (value < 0 || value > 2048) return fail(DITTO_ERR_ARG, "splitk_wgs must be in [0, 2048]");
         g_splitk_wgs = value;

@@ -33,6 +33,7 @@ namespace ditto {
 // than the store bursts it spreads — same-process A/B at C2 B = 32 (tools/step_ab.py, 8 rounds x 25 steps): gated GEMM
 // 291.7 -> 279.1 us per launch, step 13.06 -> 12.99 ms.
 int g_gemm_flags = GF_RELAXED_WAIT | GF_STORE_NT | GF_WIDE_PHASE;
+int g_gemm_group = 0;
 int g_gemm_tile = [] { const char* e = getenv("DITTO_GEMM"); return e ? atoi(e) : 0; }();
 
 namespace {

@@ -60,6 +60,7 @@ DITTO_DEV void tile_to_mn(int t, int tiles_m, int tiles_n, int G, int& tm, int& 
 }
 // host side: split tiles_n into ceil(tiles_n / 8) super-columns of (nearly) equal width
 inline int pick_group_n(int tiles_n, int flags) {
+    if (g_gemm_group > 0) return g_gemm_group < tiles_n ? g_gemm_group : tiles_n;   // ditto_set_option("gemm_group"): A/B
     // measured in-model: with <= 12 column tiles the weights fit the 4 MiB L2 and row-major is ~5 % faster (QKV)
     if ((flags & GF_ROWMAJOR_TILES) || tiles_n <= 12) return tiles_n;
     const int nsc = (tiles_n + 7) / 8;

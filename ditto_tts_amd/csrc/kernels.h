@@ -86,6 +86,7 @@ struct GemmArgs {
 hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s);
 extern int g_gemm_tile;  // 0 auto | 128 | 256
 extern int g_gemm_flags; // GF_* (gemm_common.h)
+extern int g_gemm_group; // > 0: forced super-column width of the tile order (A/B); 0 = pick_group_n's rule
 extern int g_attn_flags; // attention.hip
 
 // ---------------- around_loop.hip : steps either side of the loop ----------------

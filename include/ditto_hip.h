@@ -209,6 +209,8 @@ size_t ditto_attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh);
  * tile structures, 128 (128x128) / 129 (persistent 256x128 ring) / 256 (persistent 256x256) = force one.  Results are identical up to fp32 summation order.
  * "gemm_flags": bit mask for kernel experiments (bit 0 = relaxed tile-start wait, default on; bits 1, 2 are
  * DIAGNOSTIC timing switches that skip stores / the epilogue and produce WRONG results — tools/ only).
+ * "gemm_group": forced super-column width of the GEMM tile order (A/B tool; 0 = the built-in rule, which a sweep of
+ * 3 / 4 / 6 / 12 / 24 at C2 B = 32 did not beat).
  * "splitk_wgs": low-latency mode for batches of 1-2 utterances: workgroups the long-K GEMMs (fc2, final projection)
  * are split over (K-splits with an ordered fp32 reduce; 256 is the measured choice: -10 % step time at B = 1).
  * Default 0 = never split, which keeps an utterance's result bit-identical whatever else is in its batch. */
