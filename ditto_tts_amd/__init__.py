@@ -1,7 +1,9 @@
 """ditto_tts_amd — MI355X-native DiT denoise path for DiTTo-TTS.
 
-`compat/` exposes the classes under the reference's import names: put `ditto_tts_amd/compat` ahead of the
-reference's `src/` on sys.path and `from model.DiTTO import DiTTO` resolves here."""
+`compat/` exposes the classes under the reference's import names as namespace-package portions: with
+`ditto_tts_amd/compat` ahead of the reference's `src/` on sys.path (`compat.install()` / `python -m
+ditto_tts_amd.run_reference script.py`) `from model.DiTTO import DiTTO` resolves here while `utils.*`,
+`model.NeuralAudioCodec`, ... stay the reference's."""
 from .config import DiTTOConfig, PRESETS  # noqa: F401
 
 __all__ = ["DiTTOConfig", "PRESETS", "DiTTO", "DiT", "GlobalAdaLN", "RotaryEmbedding", "SpeechGenerator",

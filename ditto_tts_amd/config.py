@@ -3,8 +3,8 @@
 The reference has no config object for the model: `DiTTO.__init__` takes keyword
 arguments (reference src/model/DiTTO.py:10-19) and the scripts read a static
 class `ConfigDiTTO` (reference src/utils/Config.py:102-121).  This dataclass is
-the shape tuple the HIP library needs; `compat/utils/Config.py` exposes the
-reference's attribute bag on top of it.
+the shape tuple the HIP library needs; `shipped_config.py` holds the reference's
+shipped attribute values for stand-alone use (the caller's own `utils.Config` is never shadowed).
 """
 from __future__ import annotations
 

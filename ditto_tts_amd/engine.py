@@ -30,6 +30,23 @@ class TextCond:
         self.buf, self.B, self.T = buf, B, T
 
 
+class StepGraph:
+    """One captured reverse-diffusion step.  The HIP graph holds raw device addresses; this object owns a reference
+    to every buffer behind them (state, conditioning, t, noise, schedule tables, the engine's workspace and RoPE
+    tables AT CAPTURE TIME), so the engine growing its workspace or dropping its RoPE cache later cannot hand that
+    memory to someone else while the graph can still be replayed.  A repack of the weights (new model handle, arena
+    rewritten) invalidates the graph: replay() then raises instead of running on a half-updated arena."""
+
+    def __init__(self, engine, graph, keep):
+        self._engine, self._graph, self._keep = engine, graph, keep
+        self._generation = engine._generation
+
+    def replay(self):
+        if self._generation != self._engine._generation:
+            raise RuntimeError("this step graph was captured before the engine's weights were repacked; capture again")
+        self._graph.replay()
+
+
 class DenoiseEngine:
     def __init__(self, cfg: DiTTOConfig, state: Mapping[str, torch.Tensor], device: Optional[torch.device] = None):
         """`state`: reference state_dict keys -> tensors; fp32 CUDA copies are made as needed.
@@ -48,6 +65,7 @@ class DenoiseEngine:
         self.handle = C.c_void_p()
         self._ws: Optional[torch.Tensor] = None
         self._rope: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._generation = 0            # bumped by every (re)pack: outstanding StepGraphs check it
         self._pack(state)
 
     # ------------------------------------------------------------------ weights
@@ -78,6 +96,7 @@ class DenoiseEngine:
                                                   self.arena.numel(), _stream(), C.byref(self.handle)))
             torch.cuda.current_stream().synchronize()  # staging copies may now be freed
         self._rope.clear()
+        self._generation += 1
         self._train_attached = False    # a new handle: the transposed training copies must be re-attached
 
     def repack(self, state: Mapping[str, torch.Tensor]):
@@ -201,7 +220,8 @@ class DenoiseEngine:
     def capture_p_sample(self, x: torch.Tensor, cond: TextCond, t: torch.Tensor, noise: torch.Tensor,
                          betas: torch.Tensor, alphas: torch.Tensor, alphas_cumprod: torch.Tensor):
         """Capture ONE reverse-diffusion step (the ~122 stream-ordered launches of ditto_p_sample) into a HIP
-        graph bound to these exact tensors; returns the graph.  Replaying it advances `x` in place using whatever
+        graph bound to these exact tensors; returns a StepGraph (which keeps them, the workspace and the
+        RoPE tables alive).  Replaying it advances `x` in place using whatever
         `t` and `noise` hold at replay time, so a sampling loop is: fill t, draw noise, graph.replay().
         Worth it when the step is launch-bound (small batches); the library calls neither allocate nor
         synchronise, so they are capturable as they are."""
@@ -211,14 +231,14 @@ class DenoiseEngine:
         if t.dtype != torch.int64 or not t.is_cuda:
             raise ValueError("t must be an int64 CUDA tensor")
         B, N, _ = x.shape
-        self.workspace(B, N, cond.T)      # allocate outside the capture
-        self.rope_tables(N)
+        ws = self.workspace(B, N, cond.T)      # allocate outside the capture
+        rope = self.rope_tables(N)
         self.p_sample_(x, cond, t, noise, betas, alphas, alphas_cumprod)   # warm-up (lazy kernel attributes)
         torch.cuda.current_stream().synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self.p_sample_(x, cond, t, noise, betas, alphas, alphas_cumprod)
-        return g
+        return StepGraph(self, g, (ws, rope, cond.buf, x, t, noise, betas, alphas, alphas_cumprod, self.arena))
 
     def block_forward_(self, layer: int, h: torch.Tensor, cond: TextCond, cond_layer: Optional[int] = None,
                        rope: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):

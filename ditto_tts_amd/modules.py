@@ -217,6 +217,8 @@ class _BlocksOnlyEngine(DenoiseEngine):
             hip.check(self.lib.ditto_model_create(C.byref(self._ccfg), C.byref(w), self.arena.data_ptr(),
                                                   self.arena.numel(), _stream(), C.byref(self.handle)))
             torch.cuda.current_stream().synchronize()
+        self._rope.clear()
+        self._generation += 1
 
 
 class DiTTO(nn.Module):
@@ -266,6 +268,7 @@ class DiTTO(nn.Module):
         self._watch = _ParamWatch()
         self._cond_key = None
         self._cond: Optional[TextCond] = None
+        self._cond_src: Optional[torch.Tensor] = None
 
     # ------------------------------------------------------------------ engine plumbing
     def _path_tensors(self):
@@ -298,11 +301,24 @@ class DiTTO(nn.Module):
         """Step-invariant text work, cached while the caller keeps passing the same text_emb tensor (the
         sampler does for all its steps, reference src/model/SpeechGenerator.py:161-163)."""
         eng = self.engine()
-        key = (text_emb.data_ptr(), text_emb._version, tuple(text_emb.shape), text_emb.dtype)
+        key = (text_emb.data_ptr(), text_emb._version, tuple(text_emb.shape), text_emb.dtype, text_emb.device)
         if key != self._cond_key or self._cond is None:
             self._cond = eng.prepare_text(text_emb, N_hint)
             self._cond_key = key
+            # the entry is keyed by ADDRESS: keep the keyed tensor alive for as long as the entry is, or the caching
+            # allocator hands the same address (version 0, same shape) to the next utterance's temporary
+            # (`text.to(device)` of a CPU tensor, a function-local `wte(tokens)`) and the stale K/V would hit
+            self._cond_src = text_emb
         return self._cond
+
+    def invalidate(self):
+        """Force a repack of the weights and drop the cached text conditioning on the next call.  Needed only after
+        updates the version counters cannot see: in-place writes through `.data` (`p.data.copy_(ema)`,
+        some legacy optimizers) do not bump `Tensor._version`."""
+        self._watch.sig = None
+        self._cond_key = None
+        self._cond = None
+        self._cond_src = None
 
     # ------------------------------------------------------------------ reference surface
     def forward(self, x, text_emb, t):

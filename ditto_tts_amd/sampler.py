@@ -11,8 +11,9 @@ stack is ditto_tts_amd/slp.py).  They are taken from
 raise a clear error otherwise; nothing here re-implements them.
 
 Differences from the reference, both deliberate and documented in SURVEY.md App. B:
-  * B-8: the loop length comes from this object's own tables (`len(self.betas)`), not from a mutable global
-    read at call time;
+  * B-8: the loop length is the caller's `utils.Config.ConfigDiTTO.DIFFUSION_STEPS` read at call time, as in the
+    reference, when that module is imported (bounds-checked against the frozen tables instead of overrunning them);
+    with `diffusion_steps=` or stand-alone it is this object's own table length;
   * B-9: RoPE tables and the cross-attention K/V of the unchanging text are computed once per call to
     `__sample_latents`, not once per step.
 RNG: `torch.randn_like` on the state's device, in the reference's call order (one draw for x_T unless
@@ -35,7 +36,10 @@ class SpeechGenerator:
         self.device = device
         if ditto_model is None:
             if config is None:
-                from .compat.utils.Config import ConfigDiTTO as config  # the reference's shipped values
+                # the CALLER's utils.Config.ConfigDiTTO when its tree is importable (so a notebook's mutation of the
+                # class attributes is what gets read, reference src/Experiments.ipynb cell 6), else the shipped values
+                from .shipped_config import config_classes
+                config = config_classes()[0]
             ditto_model = DiTTO(hidden_dim=config.HIDDEN_DIM, num_layers=config.NUM_LAYERS,
                                 num_heads=config.NUM_HEADS, time_dim=config.TIME_DIM,
                                 text_dim=config.TEXT_EMBED_DIM, diffusion_steps=config.DIFFUSION_STEPS,
@@ -48,7 +52,8 @@ class SpeechGenerator:
             # reference :54-62: SLP(ConfigSLP.NB_CLASSES, NUM_HEADS, NUM_LAYERS) + its checkpoint.  Only the decoder
             # stack and the head are built here (ditto_tts_amd/slp.py); the checkpoint's text_encoder.* /
             # audio_encoder.* entries belong to the pretrained encoders and are skipped.
-            from .compat.utils.Config import ConfigSLP
+            from .shipped_config import config_classes
+            ConfigSLP = config_classes()[1]
             from .slp import SLP
             slp = SLP(ConfigSLP.NB_CLASSES, ConfigSLP.NUM_HEADS, ConfigSLP.NUM_LAYERS,
                       hidden_size=ConfigSLP.EMBEDDING_DIM)
@@ -60,6 +65,11 @@ class SpeechGenerator:
         self.sample_rate = sample_rate
         self.vocoder, self.mel_fn, self.slp = vocoder, mel_fn, slp
         self.text_tokenizer, self.audio_processor = text_tokenizer, audio_processor
+        # `diffusion_steps=` (an extension) pins the loop length; without it the reference's rule applies: the tables
+        # are frozen here from the model's step count (reference :70 reads ConfigDiTTO.DIFFUSION_STEPS, which is also
+        # what the model was built from, :32-36) and the LOOP length is read from the caller's mutable
+        # ConfigDiTTO.DIFFUSION_STEPS at call time (reference :161), see `_loop_steps`.
+        self._pinned_steps = diffusion_steps is not None
         steps = diffusion_steps if diffusion_steps is not None else self.ditto_model.cfg.diffusion_steps
         if steps > self.ditto_model.cfg.diffusion_steps:
             raise ValueError("diffusion_steps exceeds the rows of the model's t_embedding")
@@ -71,6 +81,24 @@ class SpeechGenerator:
     @property
     def diffusion_steps(self) -> int:
         return int(self.betas.shape[0])
+
+    def _loop_steps(self) -> int:
+        """Number of reverse steps of one call to __sample_latents.  Reference src/model/SpeechGenerator.py:161 reads
+        the global `ConfigDiTTO.DIFFUSION_STEPS` at CALL time while the tables were frozen at construction (SURVEY
+        App. B-8).  When the caller's `utils.Config` module is imported and this object was not pinned with
+        `diffusion_steps=`, that read is reproduced (a shorter count starts the loop at that t, as the reference does;
+        a longer one would index past the tables there — here it raises with a message).  Otherwise the loop length is
+        the table length."""
+        if not self._pinned_steps:
+            from .shipped_config import caller_config
+            mod = caller_config(import_it=False)
+            if mod is not None:
+                n = int(mod.ConfigDiTTO.DIFFUSION_STEPS)
+                if n > self.diffusion_steps:
+                    raise IndexError(f"ConfigDiTTO.DIFFUSION_STEPS = {n} exceeds the {self.diffusion_steps}-entry "
+                                     "schedule tables frozen when this SpeechGenerator was built")
+                return n
+        return self.diffusion_steps
 
     # ---------------------------------------------------------------- the hot loop
     @torch.no_grad()
@@ -107,13 +135,14 @@ class SpeechGenerator:
         use_graph = bool(use_graph)
         z = torch.empty_like(x)
         graph = None
+        n_loop = self._loop_steps()
         if use_graph:
-            t_tensor.fill_(self.diffusion_steps - 1)
+            t_tensor.fill_(n_loop - 1)
             keep_x = x.clone()                      # capture runs one warm-up step on x: restore it afterwards
             z.zero_()
             graph = eng.capture_p_sample(x, cond, t_tensor, z, self.betas, self.alphas, self.alphas_cumprod)
             x.copy_(keep_x)
-        for i, t_val in enumerate(reversed(range(self.diffusion_steps))):
+        for i, t_val in enumerate(reversed(range(n_loop))):
             t_tensor.fill_(t_val)
             if noises is None:
                 z.normal_()                          # same generator stream as randn_like(x)
@@ -208,7 +237,7 @@ class SpeechGenerator:
             text_tokens = text_prompt
         text_tokens = text_tokens[:, :max_length]
         text_embeddings = nac.language_model.transformer.wte(text_tokens)
-        t = torch.full((audio_latents.size(0),), self.diffusion_steps - 1, device=self.device, dtype=torch.long)
+        t = torch.full((audio_latents.size(0),), self._loop_steps() - 1, device=self.device, dtype=torch.long)  # :105
         audio_latents = self.ditto_model.q_sample(audio_latents, t)
         refined = self.__sample_latents(text_embeddings, audio_latents, text_tokens, audio_tensor, is_slp, cond_by_audio)
         return self.__generate_speech_from_latents(refined, audio_scales, padding_mask_audio)

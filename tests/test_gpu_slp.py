@@ -207,7 +207,7 @@ def test_slp_surface_and_errors(lib):
 def test_speech_generator_builds_slp_from_checkpoint(tmp_path):
     """SpeechGenerator(slp_path=...) (reference src/model/SpeechGenerator.py:54-62): ConfigSLP geometry, checkpoint dict
     with "model_state_dict", encoder entries of the reference checkpoint skipped."""
-    from ditto_tts_amd.compat.utils.Config import ConfigSLP
+    from ditto_tts_amd.shipped_config import ConfigSLP
     from ditto_tts_amd.config import DiTTOConfig
     from ditto_tts_amd.modules import DiTTO
     from ditto_tts_amd.sampler import SpeechGenerator

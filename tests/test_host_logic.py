@@ -115,7 +115,7 @@ def test_slp_surface_matches_torch_decoder_keys_and_has_no_cpu_path():
     reference builds, reference import name, loud failure off-GPU and without the pretrained encoders."""
     import torch.nn as nn
     from ditto_tts_amd.compat.model.SpeechLP import SLP as SLPcompat
-    from ditto_tts_amd.compat.utils.Config import ConfigSLP
+    from ditto_tts_amd.shipped_config import ConfigSLP
     from ditto_tts_amd.slp import SLP
     from ditto_tts_amd.synth import slp_state_shapes
     assert SLPcompat is SLP
