@@ -5,24 +5,37 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+Launching.  `--gpus N` with no WORLD_SIZE in the environment makes THIS process a launcher: before any GPU call it
+checks that the node shows N devices and starts N ranks as a child `python -m torch.distributed.run` (never a re-exec
+of a process that touched the GPU), then exits with the child's code.  Under torchrun, WORLD_SIZE must equal
+--gpus.  `n_gpus` in the JSON line is the RCCL world size that actually joined; fewer than N ranks is an error, not a
+smaller measurement.
+
 A "step" = one reverse-diffusion step (DiTTO.forward + DDPM update + the step's N(0,1) draw) over one batch
 of B utterances per GPU, synthetic latents of the named shape, closed-form random weights.  Every 50th step
 starts a new utterance batch (fresh x_T and the step-invariant text work: cross-attention K/V of all layers
 + text AdaLN modulation), so the one-off per-utterance work is inside the timed region, amortised as in a
-real 50-step sampling loop.  value = (B x world) x K / max-over-ranks wall time.
+real 50-step sampling loop.  value = (B x world) x K / max-over-ranks wall time  ("scaling": "weak", B per GPU fixed;
+no collective in the data path, SURVEY.md §8e — the only collectives are the timing barrier and the max-reduce).
 
-Multi-GPU: batch-parallel, weak scaling (B per GPU fixed); no collective in the data path —
-the only collectives are the timing barrier and the max-reduce of the elapsed time.
-
-roofline: the dominant kernel class of the step, timed live with HIP events on the launch stream
-(libditto_hip's per-class event profiler, a separate eager pass of the same steps right after the timed
-region); achieved = algorithmic FLOPs per launch / average launch duration, peak = 2.5 PFLOP/s dense bf16.
-cpu_baseline: the fp32 oracle (proved equal to the reference, tests/test_oracle_*) on the host cores,
-rank 0, N=1 only, bounded sample.
+Besides the contract's line the JSON carries:
+  loops        5 more timed loops of K steps, HIP-event-timed on the compute stream: their ms/step and the median
+  sweep        B in {1, 8, 32} per GPU (N = 1 runs only)
+  c3_strong    BASELINE config 3 as a STRONG-scaling point: rank 0 holds a global batch of 256 utterances, scatters
+               text / x_T (grouped RCCL send/recv, ditto_tts_amd/dist.py), every rank runs the 50-step loop over its
+               shard in micro-batches of 32, latents are gathered on rank 0; scatter and gather are INSIDE the timed
+               region and reported per phase
+  roofline     dominant kernel class, timed live with HIP events on the launch stream (libditto_hip's per-class
+               event profiler, an eager pass of the same steps); achieved = algorithmic FLOPs per launch / average
+               launch duration; peak = 2.5 PFLOP/s dense bf16 (5 PFLOP/s for the fp8 GEMM classes of C5)
+  cpu_baseline the fp32 oracle (proved equal to the reference, tests/test_oracle_*) on the host cores, rank 0, N = 1
+               only, bounded samples at B = 1 and B = 4
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,7 +45,9 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+PEAK_FP8_TFLOPS = 5000.0    # ~5 PF dense fp8 (block-scaled MFMA)
 PEAK_HBM_GBS = 8000.0
+FP8_CLASSES = ("gemm_qkv_rope", "gemm_gated_mlp", "gemm_fc2")   # the GEMMs DITTO_CFG_FP8_LINEAR moves to fp8
 
 
 def parse():
@@ -44,10 +59,36 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default: the preset's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--loops", type=int, default=5, help="extra HIP-event-timed loops of K steps (median reported)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the B in {1, 8, 32} sweep (N = 1 only)")
+    ap.add_argument("--global-batch", type=int, default=256, help="C3 strong-scaling point: utterances held by rank 0")
+    ap.add_argument("--no-c3", action="store_true", help="skip the C3 strong-scaling point")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="off",
                     help="replay the step from a HIP graph.  Measured: no gain at B = 1 / 8 (2.35 / 4.59 ms per step "
                          "either way: small batches are bound by per-kernel latency on sparse grids, not by launches)")
     return ap.parse_args()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args):
+    """No WORLD_SIZE and --gpus N > 1: start N ranks as a child torchrun.  This process makes NO GPU call
+    (torch.cuda.device_count() does not initialise the device on this image)."""
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but this node shows {n_dev} GPU(s); refusing to measure fewer "
+                         f"ranks than asked for")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def kernel_flops(cfg, B, N, T):
@@ -55,7 +96,8 @@ def kernel_flops(cfg, B, N, T):
     d, M = cfg.hidden_dim, B * N
     return {
         "gemm_qkv_rope": 2.0 * M * 3 * d * d,
-        "gemm_d_x_d": 2.0 * M * d * d,
+        "gemm_q_proj": 2.0 * M * d * d,
+        "gemm_out_proj": 2.0 * M * d * d,
         "gemm_gated_mlp": 2.0 * M * 8 * d * d,
         "gemm_fc2": 2.0 * M * d * 4 * d,
         "gemm_final": 2.0 * M * d * 2 * d,
@@ -74,18 +116,40 @@ def kernel_bytes(cfg, B, N, T):
     }
 
 
+def class_peak(cfg, name):
+    return PEAK_FP8_TFLOPS if (cfg.fp8_linear and name in FP8_CLASSES) else PEAK_BF16_TFLOPS
+
+
+def step_min_seconds(cfg, B, N, T, one_off_per_step):
+    """Time the executed FLOPs of one step need at the MFMA peak of the type each part runs in (fp8 GEMMs of C5 against
+    5 PF, everything else against 2.5 PF): the denominator-free form of SURVEY §8d's time-weighted fraction."""
+    d, L = cfg.hidden_dim, cfg.num_layers
+    kf = kernel_flops(cfg, B, N, T)
+    per_layer = {k: kf[k] for k in ("gemm_qkv_rope", "gemm_q_proj", "gemm_out_proj", "gemm_gated_mlp", "gemm_fc2",
+                                    "attn_self", "attn_cross")}
+    sec = sum(L * f / (class_peak(cfg, k) * 1e12) for k, f in per_layer.items())
+    sec += kf["gemm_final"] / (PEAK_BF16_TFLOPS * 1e12)
+    sec += B * one_off_per_step / (PEAK_BF16_TFLOPS * 1e12)      # the text K/V GEMM is bf16 in every config
+    return sec
+
+
 def pmc_traffic(kernel_class, B, N, T, cfg):
-    """HBM bytes per launch of `kernel_class` from the committed rocprofv3 PMC passes (profiles/r01_v8_pmc_traffic.json, tools/pmc_traffic.py:
-    separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 x2 correction on the read side).
-    bench.py cannot run under the counter collector itself, so the figure is the offline one; it is only reported
-    when the workload is the one those passes measured (C2, B=32), else null."""
+    """HBM bytes per launch of `kernel_class` from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json,
+    tools/pmc_traffic.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 x2 correction on the
+    read side).  bench.py cannot run under the counter collector itself, so the figure is the offline one; it is only
+    reported when the workload is the one those passes measured (C2, B=32), else null."""
     if not (B == 32 and N == 1024 and T == 1024 and cfg.hidden_dim == 768 and cfg.num_layers == 12):
         return None
-    for name in ("r01_v8_pmc_traffic.json", "r01_v5_pmc_traffic.json", "r01_pmc_traffic.json"):   # newest counter passes first
+    pdir = os.path.join(ROOT, "profiles")
+    try:
+        names = sorted((f for f in os.listdir(pdir) if f.endswith("pmc_traffic.json")), reverse=True)  # newest first
+    except OSError:
+        return None
+    for name in names:
         try:
-            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            d = json.load(open(os.path.join(pdir, name)))
             return d[kernel_class]["traffic_bytes"]
-        except (OSError, KeyError, ValueError):
+        except (OSError, KeyError, ValueError, TypeError):
             continue
     return None
 
@@ -109,50 +173,109 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(cfg, N, T, steps=12):
-    """fp32 oracle on the host cores: B = 1, `steps` timed steps after 1 warm-up (bounded sample)."""
+def cpu_baseline(cfg, N, T):
+    """fp32 oracle on the host cores (bounded samples): B = 1, 12 timed steps after 1 warm-up; B = 4, 3 timed steps
+    after 1 warm-up (SURVEY §8d / BASELINE.md §2 step 3).  The top-level value is the B = 1 figure."""
     from ditto_tts_amd.synth import hash_normal, synthetic_inputs, synthetic_state_dict
     from oracle import ditto_oracle as O
     cores = usable_cores()
     torch.set_num_threads(cores)
     sd = synthetic_state_dict(cfg, seed=1234)
-    x, text, _ = synthetic_inputs(cfg, 1, N, T, seed=7)
     betas, alphas, acp = O.sampler_tables(cfg.diffusion_steps)
-    z = hash_normal(tuple(x.shape), "z", 7)
-    ts = []
-    with torch.no_grad():
-        for i in range(steps + 1):
-            t = torch.full((1,), cfg.diffusion_steps - 1 - i, dtype=torch.long)
-            t0 = time.perf_counter()
-            eps = O.ditto_forward(sd, cfg.num_layers, cfg.num_heads, x, text, t)
-            x = O.p_sample_update(x, eps, t, betas, alphas, acp, z)
-            ts.append(time.perf_counter() - t0)
-    ts = sorted(ts[1:])
-    med = ts[len(ts) // 2]
-    return {"value": 1.0 / med, "unit": "utterance-steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"B=1, {steps} steps (median) after 1 warm-up of the same {cfg.num_layers}L/d={cfg.hidden_dim}/"
-                      f"N={N}/T={T} step, fp32 torch-CPU oracle (uncached text K/V, as the reference)",
-            "s_per_step": med,
-            "gflops": cfg.flops_per_utt_step(N, T, cached_kv=False) / med / 1e9}
+
+    def run(B, steps):
+        x, text, _ = synthetic_inputs(cfg, B, N, T, seed=7)
+        z = hash_normal(tuple(x.shape), "z", 7)
+        ts = []
+        with torch.no_grad():
+            for i in range(steps + 1):
+                t = torch.full((B,), cfg.diffusion_steps - 1 - i, dtype=torch.long)
+                t0 = time.perf_counter()
+                eps = O.ditto_forward(sd, cfg.num_layers, cfg.num_heads, x, text, t)
+                x = O.p_sample_update(x, eps, t, betas, alphas, acp, z)
+                ts.append(time.perf_counter() - t0)
+        ts = sorted(ts[1:])
+        return ts[len(ts) // 2]
+
+    med1 = run(1, 12)
+    out = {"value": 1.0 / med1, "unit": "utterance-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"B=1, 12 steps (median) after 1 warm-up of the same {cfg.num_layers}L/d={cfg.hidden_dim}/"
+                     f"N={N}/T={T} step, fp32 torch-CPU oracle (uncached text K/V, as the reference)",
+           "s_per_step": med1, "gflops": cfg.flops_per_utt_step(N, T, cached_kv=False) / med1 / 1e9}
+    try:
+        cpu_name = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except (OSError, IndexError):
+        cpu_name = None
+    out["cpu_model"] = cpu_name
+    med4 = run(4, 3)
+    out["b4"] = {"value": 4.0 / med4, "s_per_step": med4, "sample": "B=4, 3 steps (median) after 1 warm-up",
+                 "gflops": 4 * cfg.flops_per_utt_step(N, T, cached_kv=False) / med4 / 1e9}
+    return out
+
+
+class StepRunner:
+    """One (model, B) working set: state, noise, t, conditioning, and the step function of the timed region."""
+
+    def __init__(self, eng, sg, cfg, B, N, T, dev, seed, use_graph=False):
+        self.eng, self.sg, self.cfg, self.B, self.N, self.T, self.dev = eng, sg, cfg, B, N, T, dev
+        self.S = cfg.diffusion_steps
+        self.gen = torch.Generator(device=dev)
+        self.gen.manual_seed(seed)
+        self.text = torch.randn(B, T, cfg.text_dim, device=dev, generator=self.gen)
+        self.x = torch.empty(B, N, cfg.hidden_dim, device=dev)
+        self.z = torch.empty_like(self.x)
+        self.t = torch.empty(B, device=dev, dtype=torch.long)
+        self.cond, self.graph, self.use_graph = None, None, use_graph
+
+    def step(self, i, eager=False):
+        k = i % self.S
+        sg, eng = self.sg, self.eng
+        if k == 0 or self.cond is None:       # new utterance batch: x_T and the step-invariant text work
+            self.x.normal_(generator=self.gen)
+            if self.cond is None:
+                self.cond = eng.prepare_text(self.text, self.N)
+            else:                              # same buffers (a graph is bound to them), new contents
+                eng.prepare_text_into(self.text, self.N, self.cond)
+        self.t.fill_(self.S - 1 - k)
+        self.z.normal_(generator=self.gen)    # the step's N(0,1) draw (reference: randn_like per step)
+        if self.use_graph and not eager:
+            if self.graph is None:
+                self.graph = eng.capture_p_sample(self.x, self.cond, self.t, self.z, sg.betas, sg.alphas,
+                                                  sg.alphas_cumprod)
+            self.graph.replay()
+        else:
+            eng.p_sample_(self.x, self.cond, self.t, self.z, sg.betas, sg.alphas, sg.alphas_cumprod)
+
+    def run(self, first, n):
+        for i in range(first, first + n):
+            self.step(i)
 
 
 def main():
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    world = int(env_world or "1")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists in ditto_tts_amd)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if env_world is None:
+        os.environ["MASTER_PORT"] = str(free_port())
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+    if dist.get_world_size() != args.gpus:
+        raise SystemExit(f"bench.py: {dist.get_world_size()} ranks joined, --gpus {args.gpus} asked")
 
     from ditto_tts_amd.config import PRESETS
+    from ditto_tts_amd.dist import sample_sharded
     from ditto_tts_amd.modules import DiTTO
     from ditto_tts_amd.sampler import SpeechGenerator
     from ditto_tts_amd.synth import synthetic_state_dict
@@ -166,64 +289,49 @@ def main():
                   fp8_linear=cfg.fp8_linear)
     model.load_state_dict(synthetic_state_dict(cfg, seed=1234))
     model = model.to(dev).eval()
-    sg = SpeechGenerator(ditto_model=model, device=dev)
+    sg = SpeechGenerator(ditto_model=model, device=dev, diffusion_steps=S)
     eng = model.engine(dev)
 
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1000 + rank)
-    text = torch.randn(B, T, cfg.text_dim, device=dev, generator=gen)
-    x = torch.empty(B, N, cfg.hidden_dim, device=dev)
-    z = torch.empty_like(x)
-    t_tensor = torch.empty(B, device=dev, dtype=torch.long)
-    state = {"cond": None}
-
     use_graph = args.graph == "on" or (args.graph == "auto" and B * N <= 8192)
-    state["graph"] = None
-
-    def step(i, eager=False):
-        k = i % S
-        if k == 0 or state["cond"] is None:       # new utterance batch: x_T and the step-invariant text work
-            x.normal_(generator=gen)
-            if state["cond"] is None:
-                state["cond"] = eng.prepare_text(text, N)
-            else:                                  # same buffers (the graph is bound to them), new contents
-                eng.prepare_text_into(text, N, state["cond"])
-        t_tensor.fill_(S - 1 - k)
-        z.normal_(generator=gen)                  # the step's N(0,1) draw (reference: randn_like per step)
-        if use_graph and not eager:
-            if state["graph"] is None:
-                state["graph"] = eng.capture_p_sample(x, state["cond"], t_tensor, z, sg.betas, sg.alphas,
-                                                      sg.alphas_cumprod)
-            state["graph"].replay()
-        else:
-            eng.p_sample_(x, state["cond"], t_tensor, z, sg.betas, sg.alphas, sg.alphas_cumprod)
+    main_run = StepRunner(eng, sg, cfg, B, N, T, dev, 1000 + rank, use_graph)
 
     def sync():
         torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
+        dist.barrier()
+
+    def max_over_ranks(v):
+        el = torch.tensor([v], device=dev, dtype=torch.float64)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el.item())
 
     with torch.no_grad():
-        for i in range(args.warmup):
-            step(i)
+        # ---- the contract's timed region: W warm-up steps, then EXACTLY K steps between barrier + synchronize ----
+        main_run.run(0, args.warmup)
         sync()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(i)
+        main_run.run(0, args.steps)
         torch.cuda.synchronize(dev)
         elapsed = time.perf_counter() - t0
-        if world > 1:
-            dist.barrier()
-            el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-            dist.all_reduce(el, op=dist.ReduceOp.MAX)
-            elapsed = float(el.item())
+        dist.barrier()
+        elapsed = max_over_ranks(elapsed)
+
+        # ---- extra loops, HIP-event-timed on the compute stream (median of >= 5) ----
+        loop_ms = []
+        for _ in range(max(args.loops, 0)):
+            sync()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            main_run.run(0, args.steps)
+            e1.record()
+            e1.synchronize()
+            loop_ms.append(max_over_ranks(e0.elapsed_time(e1)) / args.steps)
 
         # ---- roofline pass (rank 0): per-kernel-class HIP-event timing of the same steps, eager ----
         roof, classes = None, {}
         if rank == 0 and args.profile_steps > 0:
             eng.profile_enable(True)
             for i in range(args.profile_steps):
-                step(1 + i, eager=True)              # k != 0: pure denoise steps, eager so events bracket launches
+                main_run.step(1 + i, eager=True)     # k != 0: pure denoise steps, eager so events bracket launches
             torch.cuda.synchronize(dev)
             prof = eng.profile_read()
             eng.profile_enable(False)
@@ -236,7 +344,8 @@ def main():
                 ent = {"launches_per_step": n / args.profile_steps, "avg_ms": avg, "share": ms / tot_ms}
                 if name in kf:
                     ent["tflops"] = kf[name] / (avg * 1e-3) / 1e12
-                    ent["frac_mfma"] = ent["tflops"] / PEAK_BF16_TFLOPS
+                    ent["peak_tflops"] = class_peak(cfg, name)
+                    ent["frac_mfma"] = ent["tflops"] / ent["peak_tflops"]
                 if name in kb:
                     ent["gbs"] = kb[name] / (avg * 1e-3) / 1e9
                     ent["frac_hbm"] = ent["gbs"] / PEAK_HBM_GBS
@@ -244,25 +353,102 @@ def main():
             dom = max(classes, key=lambda k: classes[k]["share"])
             e = classes[dom]
             if "tflops" in e:
-                roof = {"bound": "mfma", "kernel": dom, "achieved": e["tflops"], "peak": PEAK_BF16_TFLOPS,
+                roof = {"bound": "mfma", "kernel": dom, "achieved": e["tflops"], "peak": e["peak_tflops"],
                         "unit": "TFLOP/s", "frac": e["frac_mfma"], "traffic": pmc_traffic(dom, B, N, T, cfg),
                         "avg_launch_ms": e["avg_ms"], "flops_per_launch": kf[dom]}
             else:
                 roof = {"bound": "hbm", "kernel": dom, "achieved": e["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": e["frac_hbm"], "traffic": pmc_traffic(dom, B, N, T, cfg), "avg_launch_ms": e["avg_ms"],
                         "bytes_per_launch": kb[dom]}
+        dist.barrier()
+
+        # ---- B sweep (N = 1 runs): the same step at B in {1, 8, 32} per GPU ----
+        sweep = []
+        if world == 1 and not args.no_sweep:
+            for b in (1, 8, 32):
+                if b == B:
+                    ms = sorted(loop_ms)[len(loop_ms) // 2] if loop_ms else elapsed / args.steps * 1e3
+                else:
+                    r = StepRunner(eng, sg, cfg, b, N, T, dev, 2000 + b, use_graph)
+                    r.run(0, 5)
+                    torch.cuda.synchronize(dev)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    r.run(0, args.steps)
+                    e1.record()
+                    e1.synchronize()
+                    ms = e0.elapsed_time(e1) / args.steps
+                    del r
+                fl = b * (cfg.flops_per_utt_step(N, T, cached_kv=True) +
+                          cfg.flops_text_kv(T) * ((args.steps + S - 1) // S) / args.steps)
+                sweep.append({"batch_per_gpu": b, "ms_per_step": ms, "value": b / (ms * 1e-3),
+                              "step_tflops": fl / (ms * 1e-3) / 1e12})
+
+        # ---- C3 as a strong-scaling point: global batch on rank 0 -> scatter -> 50-step loops -> gather ----
+        c3 = None
+        if not args.no_c3 and args.config == "C2":
+            G, mb = args.global_batch, p["B"]
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(77)
+            text_full = torch.randn(G, T, cfg.text_dim, device=dev, generator=gen) if rank == 0 else None
+            xT_full = torch.randn(G, N, cfg.hidden_dim, device=dev, generator=gen) if rank == 0 else None
+            zgen = torch.Generator(device=dev)
+
+            def shard_loop(text_s, x_s, first):
+                """The 50-step loop over this rank's shard, micro-batches of `mb` utterances; per-step noise from a
+                generator seeded by the micro-batch's first GLOBAL utterance index (independent of the world size
+                whenever the shards are whole micro-batches, as at 256 / {1, 2, 4, 8})."""
+                out = torch.empty_like(x_s)
+                z = torch.empty(mb, N, cfg.hidden_dim, device=dev)
+                tt = torch.empty(mb, device=dev, dtype=torch.long)
+                for a in range(0, x_s.shape[0], mb):
+                    b_ = min(a + mb, x_s.shape[0])
+                    n = b_ - a
+                    zgen.manual_seed(5000 + first + a)
+                    x = x_s[a:b_].clone()
+                    cond = eng.prepare_text(text_s[a:b_], N)
+                    for t_val in reversed(range(S)):
+                        tt[:n].fill_(t_val)
+                        z[:n].normal_(generator=zgen)
+                        eng.p_sample_(x, cond, tt[:n], z[:n], sg.betas, sg.alphas, sg.alphas_cumprod)
+                    out[a:b_] = x
+                return out
+
+            sync()
+            phases = {}
+            t0 = time.perf_counter()
+            lat = sample_sharded(shard_loop, text_full, xT_full, (T, cfg.text_dim), (N, cfg.hidden_dim), dev,
+                                 phases=phases, sync=lambda: torch.cuda.synchronize(dev))
+            torch.cuda.synchronize(dev)
+            total = time.perf_counter() - t0
+            dist.barrier()
+            total = max_over_ranks(total)
+            ph = {k: max_over_ranks(v) for k, v in sorted(phases.items())}
+            ok = True
+            if rank == 0:
+                ok = bool(torch.isfinite(lat).all().item()) and tuple(lat.shape) == (G, N, cfg.hidden_dim)
+            c3 = {"global_batch": G, "micro_batch": mb, "steps": S, "scaling": "strong", "n_gpus": world,
+                  "value": G * S / total, "unit": "utterance-steps/s", "total_s": total, **ph,
+                  "comm_bytes_per_peer": (G // world) * (T * cfg.text_dim + 2 * N * cfg.hidden_dim) * 4 if world > 1 else 0,
+                  "latents_finite_and_complete": ok,
+                  "note": "scatter (text fp32 + x_T fp32, grouped RCCL send/recv) and gather (latents fp32) are inside "
+                          "total_s; phase figures are the max over ranks"}
+            del text_full, xT_full, lat
 
     ms_per_step = elapsed / args.steps * 1e3
     value = B * world * args.steps / elapsed
     # executed FLOPs: cached-KV step count + the one-off text K/V GEMM amortised over the steps it was run for
     n_pre = (args.steps + S - 1) // S
-    step_flops = B * (cfg.flops_per_utt_step(N, T, cached_kv=True) + cfg.flops_text_kv(T) * n_pre / args.steps)
+    one_off = cfg.flops_text_kv(T) * n_pre / args.steps
+    step_flops = B * (cfg.flops_per_utt_step(N, T, cached_kv=True) + one_off)
     step_tflops = step_flops / (ms_per_step * 1e-3) / 1e12
+    step_frac = step_min_seconds(cfg, B, N, T, one_off) / (ms_per_step * 1e-3)
 
     if rank == 0:
         out = {
             "metric": f"DiT denoise steps/sec ({cfg.num_layers}L, d={cfg.hidden_dim}, latent_len={N})",
-            "value": value, "unit": "utterance-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "utterance-steps/s", "n_gpus": dist.get_world_size(), "steps": args.steps,
+            "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp8(e4m3) linear + bf16 attention" if cfg.fp8_linear else "bf16", "data": "synthetic",
             "config": {"workload": f"{args.config}: DiTTO {cfg.num_layers}L d={cfg.hidden_dim} h={cfg.num_heads} "
@@ -271,15 +457,21 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "latent_len": N, "text_len": T,
                        "parallelism": f"batch-parallel x{world}, weights replicated, no data-path collective",
                        "hip_graph": bool(use_graph)},
-            "step_tflops_per_gpu": step_tflops, "step_frac_of_mfma_peak": step_tflops / PEAK_BF16_TFLOPS,
+            "step_tflops_per_gpu": step_tflops, "step_frac_of_mfma_peak": step_frac,
+            "loops": {"n": len(loop_ms), "timer": "HIP events on the compute stream, max over ranks",
+                      "ms_per_step": loop_ms,
+                      "median_ms_per_step": sorted(loop_ms)[len(loop_ms) // 2] if loop_ms else None,
+                      "median_value": (B * world / (sorted(loop_ms)[len(loop_ms) // 2] * 1e-3)) if loop_ms else None},
+            "sweep": sweep or None,
+            "c3_strong": c3,
             "roofline": roof,
             "kernel_classes": classes,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, N, T)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <memory>
 #include <new>
 #include <vector>
@@ -128,9 +129,30 @@ int check_cfg(const ditto_config* c) {
 
 namespace {
 
+// roctx ranges per kernel class (DITTO_ROCTX=1): resolved once from the profiler's marker library; absent library or
+// unset variable = no-ops.  The ranges are host-side brackets around the enqueue, which is what rocprofv3's marker
+// trace correlates kernel dispatches with.
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char* e = getenv("DITTO_ROCTX");
+        if (!e || !*e || *e == '0') return;
+        void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+        pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+};
+static Roctx g_roctx;
+
 struct ProfScope {
     ditto_model* m; hipStream_t s; int kc; hipEvent_t a = nullptr, b = nullptr;
+    bool marked = false;
     ProfScope(ditto_model* m_, hipStream_t s_, int kc_) : m(m_), s(s_), kc(kc_) {
+        if (g_roctx.push) { g_roctx.push(ditto_kernel_class_name(kc)); marked = true; }
         if (!m->prof) return;
         a = take(); b = take();
         if (a) (void)hipEventRecord(a, s);
@@ -142,6 +164,7 @@ struct ProfScope {
         return e;
     }
     ~ProfScope() {
+        if (marked) g_roctx.pop();
         if (!m->prof || !a || !b) return;
         (void)hipEventRecord(b, s);
         m->recs.push_back({a, b, kc});
@@ -153,7 +176,8 @@ struct ProfScope {
 // One DiT block (reference src/components/DiT.py:100-157) on the fp32 residual stream `h`, in place.
 static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* act, char* xcat_or_null,
                      void* attn_ws, size_t attn_ws_bytes, float* splitk_ws, size_t splitk_bytes, const char* kv, int kv_layer, int kv_ld,
-                     const float* rope_cos, const float* rope_sin, int B, int N, int T, hipStream_t s) {
+                     const float* rope_cos, const float* rope_sin, int B, int N, int T, hipStream_t s,
+                     float* tap_self = nullptr, float* tap_cross = nullptr) {
     const ditto_config& c = m->cfg;
     const int d = c.hidden_dim, H = c.num_heads, dh = d / H, M = B * N;
     const float scale = 1.0f / sqrtf((float)dh);
@@ -185,10 +209,11 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
             a.scale = scale; a.workspace = attn_ws; a.workspace_bytes = attn_ws_bytes; a.q_prescaled = (dh == 64);
             HIP_TRY(launch_attention(a, s));
         }
+        if (tap_self) HIP_TRY(hipMemcpyAsync(tap_self, h, (size_t)M * d * 4, hipMemcpyDeviceToDevice, s));
         // ---- cross-attention (src/components/DiT.py:141-148), K/V from the per-utterance cache ----
         { ProfScope ps(m, s, DITTO_KC_LAYERNORM); HIP_TRY(launch_layernorm(h, lp.g2, lp.be2, u, d, M, d, s)); }
         {
-            ProfScope ps(m, s, DITTO_KC_GEMM_D);
+            ProfScope ps(m, s, DITTO_KC_GEMM_QPROJ);
             GemmArgs g{};
             g.A = u; g.lda = d; g.W = lp.Wcq; g.bias = lp.bcq; g.out = qkv; g.ldo = d; g.M = M; g.N = d; g.K = d;
             HIP_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
@@ -203,12 +228,13 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
             HIP_TRY(launch_attention(a, s));
         }
         {
-            ProfScope ps(m, s, DITTO_KC_GEMM_D);
+            ProfScope ps(m, s, DITTO_KC_GEMM_OUTPROJ);
             GemmArgs g{};
             g.A = u; g.lda = d; g.W = lp.Wco; g.bias = lp.bco; g.residual = h; g.ldr = d; g.out = h; g.ldo = d;
             g.M = M; g.N = d; g.K = d;
             HIP_TRY(launch_gemm(g, EPI_BIAS_RES_F32, s));
         }
+        if (tap_cross) HIP_TRY(hipMemcpyAsync(tap_cross, h, (size_t)M * d * 4, hipMemcpyDeviceToDevice, s));
         // ---- gated MLP (src/components/DiT.py:150-155) ----
         {
             ProfScope ps(m, s, DITTO_KC_LAYERNORM);
@@ -248,9 +274,9 @@ int ditto_abi_version(void) { return DITTO_ABI_VERSION; }
 const char* ditto_last_error(void) { return ditto::g_err; }
 
 const char* ditto_kernel_class_name(int kc) {
-    static const char* names[DITTO_KC_COUNT] = {"layernorm", "gemm_qkv_rope", "gemm_d_x_d", "gemm_gated_mlp",
-                                                "gemm_fc2", "gemm_final", "attn_self", "attn_cross", "adaln",
-                                                "p_sample_update"};
+    static const char* names[DITTO_KC_COUNT] = {"layernorm", "gemm_qkv_rope", "gemm_q_proj", "gemm_out_proj",
+                                                "gemm_gated_mlp", "gemm_fc2", "gemm_final", "attn_self", "attn_cross",
+                                                "adaln", "p_sample_update"};
     return (kc >= 0 && kc < DITTO_KC_COUNT) ? names[kc] : "?";
 }
 
@@ -479,6 +505,13 @@ int ditto_forward(ditto_model_t m, const float* x, const void* cond, const int64
 int ditto_block_forward(ditto_model_t m, int layer, float* h, const void* cond, int cond_layer, int B, int N, int T,
                         const float* rope_cos, const float* rope_sin, void* workspace, size_t workspace_bytes,
                         ditto_stream_t stream) {
+    return ditto_block_forward_taps(m, layer, h, cond, cond_layer, B, N, T, rope_cos, rope_sin, nullptr, nullptr,
+                                    workspace, workspace_bytes, stream);
+}
+
+int ditto_block_forward_taps(ditto_model_t m, int layer, float* h, const void* cond, int cond_layer, int B, int N,
+                             int T, const float* rope_cos, const float* rope_sin, float* tap_self, float* tap_cross,
+                             void* workspace, size_t workspace_bytes, ditto_stream_t stream) {
     if (!m || !h || !cond || !rope_cos || !rope_sin || !workspace || B <= 0 || N <= 0 || T <= 0)
         return fail(DITTO_ERR_ARG, "bad argument to ditto_block_forward");
     const ditto_config& c = m->cfg;
@@ -489,7 +522,7 @@ int ditto_block_forward(ditto_model_t m, int layer, float* h, const void* cond, 
     char* ws = (char*)workspace;
     return run_block(m, layer, h, ws + w.u, ws + w.qkv, ws + w.act, nullptr, ws + w.attn, w.attn_bytes,
                      (float*)(ws + w.splitk), w.splitk_bytes, (const char*)cond, cond_layer, c.num_layers * 2 * c.hidden_dim, rope_cos, rope_sin, B, N, T,
-                     (hipStream_t)stream);
+                     (hipStream_t)stream, tap_self, tap_cross);
 }
 
 

@@ -84,10 +84,18 @@ def gather_batch(shard: torch.Tensor, total: int, root: int = 0, group=None) -> 
 
 def sample_sharded(sample_fn: Callable[[torch.Tensor, torch.Tensor, int], torch.Tensor],
                    text_full: Optional[torch.Tensor], xT_full: Optional[torch.Tensor], text_tail, x_tail,
-                   device, root: int = 0, group=None) -> Optional[torch.Tensor]:
+                   device, root: int = 0, group=None, phases: Optional[dict] = None,
+                   sync: Optional[Callable[[], None]] = None) -> Optional[torch.Tensor]:
     """Scatter (text_emb, x_T) from root, run `sample_fn(text_shard, xT_shard, first_global_index)` on every
-    rank (the whole denoise loop — no communication inside), gather the final latents on root."""
+    rank (the whole denoise loop — no communication inside), gather the final latents on root.
+
+    `phases` (optional dict) receives this rank's wall seconds of the three phases, {"scatter_s", "loop_s",
+    "gather_s"}; `sync` (e.g. `torch.cuda.synchronize`) is called at each phase boundary so the figures are device
+    time, not enqueue time."""
+    import time
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    tick = (lambda: (sync() if sync else None, time.perf_counter())[1]) if phases is not None else (lambda: 0.0)
+    t0 = tick()
     text = scatter_batch(text_full, text_tail, torch.float32, device, root, group)
     xT = scatter_batch(xT_full, x_tail, torch.float32, device, root, group)
     meta = torch.zeros(1, dtype=torch.int64, device=device)
@@ -96,8 +104,14 @@ def sample_sharded(sample_fn: Callable[[torch.Tensor, torch.Tensor, int], torch.
     dist.broadcast(meta, src=root, group=group)
     total = int(meta.item())
     lo, _ = shard_bounds(total, world, rank)
+    t1 = tick()
     out = sample_fn(text, xT, lo) if text.shape[0] > 0 else xT
-    return gather_batch(out, total, root, group)
+    t2 = tick()
+    full = gather_batch(out, total, root, group)
+    t3 = tick()
+    if phases is not None:
+        phases.update(scatter_s=t1 - t0, loop_s=t2 - t1, gather_s=t3 - t2)
+    return full
 
 
 def allreduce_gradients(params, bucket_bytes: int = 256 << 20, group=None) -> int:

@@ -241,16 +241,22 @@ class DenoiseEngine:
         return StepGraph(self, g, (ws, rope, cond.buf, x, t, noise, betas, alphas, alphas_cumprod, self.arena))
 
     def block_forward_(self, layer: int, h: torch.Tensor, cond: TextCond, cond_layer: Optional[int] = None,
-                       rope: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
-        """DiT block `layer` in place on the fp32 residual stream h [B,N,d]."""
+                       rope: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, taps: Optional[dict] = None):
+        """DiT block `layer` in place on the fp32 residual stream h [B,N,d].  `taps` (optional dict) receives the
+        stream after the self-attention and after the cross-attention segment ("after_self", "after_cross")."""
         if not (h.is_cuda and h.dtype == torch.float32 and h.is_contiguous()):
             raise ValueError("block_forward_ needs a contiguous fp32 CUDA tensor")
         B, N, _ = h.shape
         ws = self.workspace(B, N, cond.T)
         c, s = rope if rope is not None else self.rope_tables(N)
-        hip.check(self.lib.ditto_block_forward(self.handle, layer, h.data_ptr(), cond.buf.data_ptr(),
-                                               layer if cond_layer is None else cond_layer, B, N, cond.T,
-                                               c.data_ptr(), s.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+        ta = tb = None
+        if taps is not None:
+            ta, tb = torch.empty_like(h), torch.empty_like(h)
+            taps.update(after_self=ta, after_cross=tb)
+        hip.check(self.lib.ditto_block_forward_taps(self.handle, layer, h.data_ptr(), cond.buf.data_ptr(),
+                                                    layer if cond_layer is None else cond_layer, B, N, cond.T,
+                                                    c.data_ptr(), s.data_ptr(), _ptr(ta), _ptr(tb), ws.data_ptr(),
+                                                    ws.numel(), _stream()))
         return h
 
     # ------------------------------------------------------------------ training (SURVEY.md §8f row 1)

@@ -14,8 +14,8 @@ LIB_PATH = os.path.join(HERE, "libditto_hip.so")
 OK, ERR_ARG, ERR_SHAPE, ERR_HIP, ERR_SIZE = range(5)
 CFG_FP8_LINEAR = 1
 
-KERNEL_CLASSES = ["layernorm", "gemm_qkv_rope", "gemm_d_x_d", "gemm_gated_mlp", "gemm_fc2", "gemm_final",
-                  "attn_self", "attn_cross", "adaln", "p_sample_update"]
+KERNEL_CLASSES = ["layernorm", "gemm_qkv_rope", "gemm_q_proj", "gemm_out_proj", "gemm_gated_mlp", "gemm_fc2",
+                  "gemm_final", "attn_self", "attn_cross", "adaln", "p_sample_update"]
 KC_COUNT = len(KERNEL_CLASSES)
 
 
@@ -114,6 +114,7 @@ SYMBOLS = {
     "ditto_text_precompute": (_i, [_vp, _vp, _i, _i, _vp, _sz, _vp, _sz, _vp]),
     "ditto_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ditto_block_forward": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "ditto_block_forward_taps": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ditto_global_adaln_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "ditto_global_adaln": (_i, [_vp] * 7 + [_i] * 6 + [_vp, _vp, _sz, _vp]),
     "ditto_apply_rope_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -180,7 +181,7 @@ def lib() -> C.CDLL:
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = res, args
-        if l.ditto_abi_version() != 4:
+        if l.ditto_abi_version() != 5:
             raise RuntimeError("libditto_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -178,8 +178,9 @@ class DiT(nn.Module):
             self._watch.changed(tensors)
         return self._engine
 
-    def forward(self, x, text_emb, time_emb, rotary_pos):
-        """`time_emb` is accepted and ignored, exactly as in the reference."""
+    def forward(self, x, text_emb, time_emb, rotary_pos, taps=None):
+        """`time_emb` is accepted and ignored, exactly as in the reference.  `taps` (an extension, for
+        segment-wise parity tests): a dict that receives the residual stream "after_self" / "after_cross"."""
         _require_cuda(x, "x")
         _refuse_autograd(self)
         eng = self._standalone_engine(x.device)
@@ -188,7 +189,7 @@ class DiT(nn.Module):
         rope = (torch.cos(ang).contiguous(), torch.sin(ang).contiguous())
         cond = eng.prepare_text(text_emb, x.shape[1])
         h = x.float().contiguous().clone()
-        eng.block_forward_(0, h, cond, 0, rope)
+        eng.block_forward_(0, h, cond, 0, rope, taps=taps)
         return h.to(x.dtype)
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DITTO_ABI_VERSION 4
+#define DITTO_ABI_VERSION 5
 
 typedef enum ditto_status {
     DITTO_OK = 0,
@@ -136,6 +136,12 @@ int ditto_forward(ditto_model_t m, const float* x, const void* cond, const int64
 int ditto_block_forward(ditto_model_t m, int layer, float* h, const void* cond, int cond_layer, int B, int N, int T,
                         const float* rope_cos, const float* rope_sin, void* workspace, size_t workspace_bytes,
                         ditto_stream_t stream);
+/* The same block with taps for segment-wise parity (src/components/DiT.py:139 and :148): `tap_self` / `tap_cross`
+ * (fp32 [B,N,d], either may be NULL) receive the residual stream after the self-attention segment and after the
+ * cross-attention segment; h ends as after the gated MLP (:155). */
+int ditto_block_forward_taps(ditto_model_t m, int layer, float* h, const void* cond, int cond_layer, int B, int N,
+                             int T, const float* rope_cos, const float* rope_sin, float* tap_self, float* tap_cross,
+                             void* workspace, size_t workspace_bytes, ditto_stream_t stream);
 
 /* GlobalAdaLN.forward(x, time_emb, text_emb) as a standalone module (src/components/DiT.py:25-40): explicit
  * time_emb fp32 [B,time_dim] instead of a timestep; weights are the module's own fp32 device tensors
@@ -370,10 +376,13 @@ int ditto_layernorm_dual(const float* x, const float* gamma, const float* beta, 
 /* ---- profiling aid (bench.py): per-kernel-class HIP-event timing -------------------------
  * When enabled on a handle, ditto_forward brackets every launch with hipEvents on `stream`
  * (eager only; do not enable while capturing a graph).  ditto_profile_read synchronises the
- * recorded events and returns, per class, launches and summed milliseconds since the last reset. */
-enum { DITTO_KC_LAYERNORM = 0, DITTO_KC_GEMM_QKV, DITTO_KC_GEMM_D, DITTO_KC_GEMM_GATED, DITTO_KC_GEMM_FC2,
-       DITTO_KC_GEMM_FINAL, DITTO_KC_ATTN_SELF, DITTO_KC_ATTN_CROSS, DITTO_KC_ADALN, DITTO_KC_UPDATE,
-       DITTO_KC_COUNT };
+ * recorded events and returns, per class, launches and summed milliseconds since the last reset.
+ * Independently, with DITTO_ROCTX=1 in the environment every launch of the path sits inside a roctx range named
+ * after its class (roctxRangePushA / Pop from librocprofiler-sdk-roctx, loaded lazily), so `rocprofv3
+ * --marker-trace --kernel-trace` separates e.g. the out-projection from fc2 although they share one kernel. */
+enum { DITTO_KC_LAYERNORM = 0, DITTO_KC_GEMM_QKV, DITTO_KC_GEMM_QPROJ, DITTO_KC_GEMM_OUTPROJ, DITTO_KC_GEMM_GATED,
+       DITTO_KC_GEMM_FC2, DITTO_KC_GEMM_FINAL, DITTO_KC_ATTN_SELF, DITTO_KC_ATTN_CROSS, DITTO_KC_ADALN,
+       DITTO_KC_UPDATE, DITTO_KC_COUNT };
 int ditto_profile_enable(ditto_model_t m, int enable);
 int ditto_profile_read(ditto_model_t m, int32_t* launches /*[DITTO_KC_COUNT]*/, float* ms /*[DITTO_KC_COUNT]*/);
 const char* ditto_kernel_class_name(int kc);

@@ -25,9 +25,11 @@ DEV = "cuda"
 
 
 def _assert_indices(idx, want, cb, lat):
-    """Exact, except where the two candidate codes are closer than fp32 can order: |d1-d2| <= 1e-6 * d (fp64)."""
+    """For the RANDOM ragged shapes (oracle-generated, no reference-held fixture): exact, except where the two
+    candidate codes are closer than fp32 can order: |d1-d2| <= 1e-6 * d (fp64).  The mismatch count is printed."""
     idx, want = idx.cpu().flatten(), want.flatten()
     bad = (idx != want).nonzero().flatten()
+    print(f"vq indices: {len(bad)} of {idx.numel()} differ (near-ties)")
     flat = lat.reshape(-1, lat.shape[-1]).double()
     for r in bad.tolist():
         d1 = float(((flat[r] - cb[idx[r]].double()) ** 2).sum())
@@ -47,7 +49,10 @@ def test_vq_indices_golden_g6(golden):
     vq = vq.to(DEV)
     idx = vq(lat.to(DEV))
     assert idx.dtype == torch.int64 and idx.shape == (2, 2, 96)
-    _assert_indices(idx, g["indices"].long(), cb, lat)
+    # the reference-held fixture (G6 = the reference's own VectorQuantizer.forward): bit-exact, no near-tie allowance
+    n_bad = int((idx.cpu() != g["indices"].long()).sum())
+    print(f"G6: {n_bad} of {idx.numel()} indices differ")
+    assert n_bad == 0
     assert idx[0, 0, :8].tolist() == list(range(8))
 
 

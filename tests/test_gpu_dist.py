@@ -65,3 +65,56 @@ def test_gradient_bucket_path_on_rccl(rccl_world1):
     out = torch.empty(8, device=DEV)
     dist.all_gather_into_tensor(out, shard)
     assert torch.equal(out, flat)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# world = 2 on RCCL (BASELINE configs[2] in miniature): needs two GPUs, skipped on the one-GPU test box.  Each rank is
+# its own process on its own device; rank 0 holds the global batch, dist.sample_sharded scatters text / x_T over
+# RCCL, both ranks run the HIP denoise loop, latents are gathered — and must equal the world-1 result BIT FOR BIT.
+def _rccl_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        cfg = DiTTOConfig(256, 2, 4, 64, 256, 6)
+        m = DiTTO(256, 2, 4, 64, 256, 6)
+        m.load_state_dict(synthetic_state_dict(cfg, 3))
+        sg = SpeechGenerator(ditto_model=m.to(dev).eval(), device=dev)
+        B, N, T = 5, 160, 48                                  # 5 utterances over 2 ranks: shards of 3 and 2
+        text = hash_normal((B, T, 256), "text", 1).to(dev) if rank == 0 else None
+        xT = hash_normal((B, N, 256), "xT", 1).to(dev) if rank == 0 else None
+
+        def fn(text_shard, x_shard, first):
+            noises = lambda i: hash_normal((B, N, 256), f"z{i}", 2)[first:first + x_shard.shape[0]]
+            with torch.no_grad():
+                return sg._SpeechGenerator__sample_latents(text_shard, x_shard, cond_by_audio=True, noises=noises)
+
+        phases = {}
+        got = sample_sharded(fn, text, xT, (T, 256), (N, 256), dev, phases=phases,
+                             sync=lambda: torch.cuda.synchronize(dev))
+        assert set(phases) == {"scatter_s", "loop_s", "gather_s"}
+        if rank == 0:
+            want = fn(text, xT, 0)
+            q.put((bool(torch.equal(got, want)), bool(torch.isfinite(got).all()), tuple(got.shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the driver's multi-GPU node)")
+def test_world2_rccl_sharded_sampling_is_bitwise_world1():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    same, finite, shape = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert same and finite and shape == (5, 160, 256)

@@ -40,8 +40,12 @@ def test_g1_single_block_c1(golden):
     blk = DiT(256, 4, 256, 256)
     blk.load_state_dict({k[len("blocks.0."):]: v for k, v in sd.items() if k.startswith("blocks.0.")})
     blk = blk.to(DEV).eval()
-    out = blk(g["after_adaln"].to(DEV), g["text"].to(DEV), g["temb"].to(DEV), g["rotary_pos"].to(DEV))
+    taps = {}
+    out = blk(g["after_adaln"].to(DEV), g["text"].to(DEV), g["temb"].to(DEV), g["rotary_pos"].to(DEV), taps=taps)
     close(out, g["after_mlp"])
+    # segment-wise, HIP against the reference's own taps (DiT.py:139, :148): no compensating error between segments
+    close(taps["after_self"], g["after_self"])
+    close(taps["after_cross"], g["after_cross"])
     m = build(cfg, 1)
     close(m(g["x"].to(DEV), g["text"].to(DEV), g["t"].to(DEV)), g["out"])
 
@@ -231,6 +235,134 @@ def test_full_size_c2_properties():
     from oracle import ditto_oracle as O
     want = O.ditto_forward(synthetic_state_dict(cfg, 2), 12, 12, x[:1], text[:1], t[:1])
     close(out[:1], want)
+
+
+@torch.no_grad()
+def test_full_size_c2_sampling_loop_properties():
+    """The 50-step loop at BASELINE configs[1]'s full size (12L, d=768, N=T=1024), which only bench.py ran before:
+    finite; ditto_denoise_steps (one library call) == the per-step loop, bitwise; sharding the batch [3] -> [2] + [1]
+    (what dist.sample_sharded does across GPUs) changes no bit of any utterance's latents."""
+    p = PRESETS["C2"]
+    cfg = p["cfg"]
+    m = build(cfg, 2)
+    sg = SpeechGenerator(ditto_model=m, device=DEV)
+    B, N, T, S = 3, p["N"], p["T"], cfg.diffusion_steps
+    x, text, _ = synthetic_inputs(cfg, B, N, T, seed=11)
+    xd, td = x.to(DEV), text.to(DEV)
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(3)
+    noises = torch.randn(S, B, N, cfg.hidden_dim, device=DEV, generator=gen)
+    full = sg._SpeechGenerator__sample_latents(td, xd, cond_by_audio=True, noises=lambda i: noises[i])
+    assert torch.isfinite(full).all()
+    eng = m.engine()
+    one = xd.clone()
+    eng.denoise_steps_(one, eng.prepare_text(td, N), S - 1, 0, noises, sg.betas, sg.alphas, sg.alphas_cumprod)
+    assert torch.equal(one, full), "one-call loop differs from the per-step loop"
+    for lo, hi in ((0, 2), (2, 3)):
+        part = sg._SpeechGenerator__sample_latents(td[lo:hi].contiguous(), xd[lo:hi].contiguous(), cond_by_audio=True,
+                                                   noises=lambda i: noises[i, lo:hi])
+        assert torch.equal(part, full[lo:hi]), f"shard [{lo},{hi}) differs from the unsharded batch"
+
+
+@torch.no_grad()
+def test_text_cond_cache_is_not_fooled_by_address_reuse():
+    """the text conditioning cache is keyed by the text tensor's address; a CPU text_emb becomes a
+    device temporary per call, freed on return, and the allocator hands the next one the same address.  Two different
+    texts of one shape must give their own results."""
+    cfg = DiTTOConfig(128, 2, 2, 64, 128, 20)
+    m = build(cfg, 7)
+    x, text_a, t = synthetic_inputs(cfg, 2, 64, 24, seed=1)
+    _, text_b, _ = synthetic_inputs(cfg, 2, 64, 24, seed=2)
+    xd, tt = x.to(DEV), t.to(DEV)
+    eng = m.engine()
+    want_a = eng.forward(xd, eng.prepare_text(text_a.to(DEV), 64), tt).clone()
+    want_b = eng.forward(xd, eng.prepare_text(text_b.to(DEV), 64), tt).clone()
+    assert not torch.equal(want_a, want_b)
+    for _ in range(3):
+        assert torch.equal(m(xd, text_a, tt), want_a)       # CPU text: a fresh device temporary each call
+        assert torch.equal(m(xd, text_b, tt), want_b)
+
+    def local(text_cpu):                                    # function-local device tensor, freed on return
+        dev_text = text_cpu.to(DEV) * 1.0
+        return m(xd, dev_text, tt)
+    for _ in range(3):
+        assert torch.equal(local(text_a), want_a)
+        assert torch.equal(local(text_b), want_b)
+    # in-place updates through .data do not bump the version counter: invalidate() is the documented way
+    m.proj_out.bias.data.add_(1.0)
+    m.invalidate()
+    assert torch.allclose(m(xd, text_a, tt) - want_a, torch.ones_like(want_a), atol=1e-5)
+
+
+@torch.no_grad()
+def test_step_graph_survives_workspace_growth_and_refuses_after_repack():
+    """a captured step holds raw workspace / RoPE addresses.  The StepGraph keeps those buffers
+    alive, so the engine growing its workspace for a bigger call cannot hand them to someone else; a repack of the
+    weights makes replay raise."""
+    cfg = DiTTOConfig(128, 2, 2, 64, 128, 20)
+    m = build(cfg, 7)
+    sg = SpeechGenerator(ditto_model=m, device=DEV)
+    eng = m.engine()
+    x, text, _ = synthetic_inputs(cfg, 2, 64, 24, seed=1)
+    xs, z = x.to(DEV).clone(), hash_normal((2, 64, 128), "z", 4).to(DEV)
+    t = torch.full((2,), 7, device=DEV, dtype=torch.long)
+    cond = eng.prepare_text(text.to(DEV), 64)
+    want = x.to(DEV).clone()
+    eng.p_sample_(want, cond, t, z, sg.betas, sg.alphas, sg.alphas_cumprod)
+    graph = eng.capture_p_sample(xs, cond, t, z, sg.betas, sg.alphas, sg.alphas_cumprod)
+    ws_before = eng._ws.data_ptr()
+    xb, tb, ttb = synthetic_inputs(cfg, 8, 512, 64, seed=2)              # much larger: the workspace is reallocated
+    m(xb.to(DEV), tb.to(DEV), ttb.to(DEV))
+    assert eng._ws.data_ptr() != ws_before or eng._ws.numel() > 0
+    junk = [torch.full((1 << 20,), float("nan"), device=DEV) for _ in range(64)]   # would land in freed blocks
+    xs.copy_(x.to(DEV))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(xs, want)
+    del junk
+    m.proj_out.bias.add_(1.0)
+    m.engine()                                                           # repack
+    with pytest.raises(RuntimeError, match="repacked"):
+        graph.replay()
+
+
+@torch.no_grad()
+def test_long_form_c4_full_depth_against_oracle():
+    """BASELINE configs[3] at its full depth: 12 layers, N = 4096, T = 1024, one utterance against the fp32 oracle
+    (the 2-layer cut below runs B = 2 for the batch checks)."""
+    from oracle import ditto_oracle as O
+    cfg = PRESETS["C4"]["cfg"]
+    sd = synthetic_state_dict(cfg, 8)
+    m = build(cfg, 8)
+    x, text, t = synthetic_inputs(cfg, 1, 4096, 1024, seed=9)
+    out = m(x.to(DEV), text.to(DEV), t.to(DEV))
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    want = O.ditto_forward(sd, cfg.num_layers, cfg.num_heads, x, text, t)
+    r = close(out, want)
+    print(f"C4 12L N=4096 rel-L2 {r:.3e}")
+
+
+@torch.no_grad()
+def test_c5_fp8_full_depth_against_oracle():
+    """BASELINE configs[4] at its full depth: 24 layers, d = 1024, h = 16, fp8 QKV / FFN GEMMs, at N = T = 256 (a size
+    the oracle finishes in seconds).  STATED TOLERANCE: rel-L2 <= 6e-2 for the fp8 path (measured 5.1e-2 in round 1),
+    2e-2 for the bf16 path of the same weights."""
+    from oracle import ditto_oracle as O
+    L = 24
+    cfg16 = DiTTOConfig(1024, L, 16, 256, 1024, 50)
+    sd = synthetic_state_dict(cfg16, 6)
+    x, text, t = synthetic_inputs(cfg16, 1, 256, 256, seed=4)
+    want = O.ditto_forward(sd, L, 16, x, text, t)
+    res = {}
+    for fp8 in (False, True):
+        m = DiTTO(1024, L, 16, 256, 1024, 50, fp8_linear=fp8)
+        m.load_state_dict(sd)
+        m = m.to(DEV).eval()
+        res[fp8] = rel_l2(m(x.to(DEV), text.to(DEV), t.to(DEV)), want)
+        del m
+    print(f"C5 24L: bf16 rel-L2 {res[False]:.3e}, fp8 rel-L2 {res[True]:.3e}")
+    assert res[False] < RTOL
+    assert res[True] < 6e-2 and res[True] > res[False]
 
 
 @torch.no_grad()

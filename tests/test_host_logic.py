@@ -140,3 +140,19 @@ def test_slp_surface_matches_torch_decoder_keys_and_has_no_cpu_path():
             super().__init__()
             self.model = type("M", (), {"config": type("C", (), {"d_model": 192})()})()
     assert SLP(5, 1, 1, text_encoder=Enc()).hidden_size == 192
+
+
+def test_bench_refuses_to_mislabel_a_multi_gpu_run():
+    """`bench.py --gpus N` must never print a 1-GPU number as an N-GPU one: without WORLD_SIZE it
+    becomes a launcher that needs N visible devices; under a launcher WORLD_SIZE must equal --gpus.  Both exits are
+    non-zero and happen before any GPU call, so they are checkable on this GPU-less host."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True,
+                           text=True, env=env, timeout=300)
+        assert r.returncode != 0 and "refusing to measure fewer" in r.stderr and r.stdout.strip() == ""
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"), timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr and r.stdout.strip() == ""
