@@ -743,9 +743,9 @@ int ditto_gemm_fp8(const void* A, int lda, const void* W, const float* wscale, c
 int ditto_set_option(const char* name, int value) {
     if (!name) return fail(DITTO_ERR_ARG, "null option name");
     if (!strcmp(name, "gemm_tile")) {
-        if (value != 0 && value != 127 && value != 128 && value != 256 && value != 129 && value != 130 && value != 192)
+        if (value != 0 && value != 127 && value != 128 && value != 256 && value != 129 && value != 130 && value != 131 && value != 192)
             return fail(DITTO_ERR_ARG, "gemm_tile must be 0, 127 (128x128 deep prefetch), 128, 129 (256x128 ring), 130 (128x256, 3 workgroups/CU), "
-                                       "192 (256x192 where the epilogue allows) or 256");
+                                       "131 (128x256 ping-pong, 2 workgroups/CU), 192 (256x192 where the epilogue allows) or 256");
         g_gemm_tile = value;
         return DITTO_OK;
     }
@@ -765,6 +765,16 @@ int ditto_set_option(const char* name, int value) {
     if (!strcmp(name, "gemm_group")) {
         if (value < 0 || value > 64) return fail(DITTO_ERR_ARG, "gemm_group must be in [0, 64]");
         g_gemm_group = value;
+        return DITTO_OK;
+    }
+    if (!strcmp(name, "pp_mask")) {
+        if (value < -1 || value > 63) return fail(DITTO_ERR_ARG, "pp_mask must be in [-1, 63]");
+        g_pp_mask = value;
+        return DITTO_OK;
+    }
+    if (!strcmp(name, "pp_stagger")) {
+        if (value < -1 || value > 100000) return fail(DITTO_ERR_ARG, "pp_stagger must be in [-1, 100000] (10 ns ticks; -1 = rule)");
+        g_pp_stagger = value;
         return DITTO_OK;
     }
     if (!strcmp(name, "splitk_wgs")) {

@@ -34,6 +34,8 @@ namespace ditto {
 // 291.7 -> 279.1 us per launch, step 13.06 -> 12.99 ms.
 int g_gemm_flags = GF_RELAXED_WAIT | GF_STORE_NT | GF_WIDE_PHASE;
 int g_gemm_group = 0;
+int g_pp_stagger = -1;
+int g_pp_mask = [] { const char* e = getenv("DITTO_PP_MASK"); return e ? atoi(e) : -1; }();   // -1 = built-in rule
 int g_gemm_tile = [] { const char* e = getenv("DITTO_GEMM"); return e ? atoi(e) : 0; }();
 
 namespace {
@@ -325,6 +327,25 @@ hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s) {
     if (epi == EPI_BIAS_RELU_BF16 && forced != 128 && forced != 127 && forced != 256)
         forced = (long)((a.M + 255) / 256) * ((a.N + 255) / 256) >= 4 * 256 ? 256 : 128;
     if (forced == 130) return launch_gemm_o3(p, epi, s);
+    if (forced == 131 && gemm_pp_supports(p, epi)) return launch_gemm_pp(p, epi, s);
+    // Ping-pong 128x256 tiles (gemm_pp.hip) by GEMM class.  pp_mask bits: 1 narrow bf16 output (cross q-proj), 2 narrow
+    // fp32 in-place residual with K <= 1024 (cross out-proj), 4 narrow fp32 output (final projection), 8 narrow residual
+    // with long K (fc2), 16 QKV + RoPE, 32 gated MLP.
+    if (forced == 0 && gemm_pp_supports(p, epi) && a.M >= 128) {
+        const bool narrow = a.N <= 1024;
+        int cls = 0;
+        if (epi == EPI_BIAS_BF16 && narrow) cls = 1;
+        else if (epi == EPI_BIAS_RES_F32 && narrow) cls = a.K <= 1024 ? 2 : 8;
+        else if (epi == EPI_BIAS_F32 && narrow) cls = 4;
+        else if (epi == EPI_QKV_ROPE) cls = 16;
+        else if (epi == EPI_GATED) cls = 32;
+        const long tpp = (long)((a.M + 127) / 128) * ((a.N + 255) / 256);
+        // built-in rule (measured IN-MODEL at M = 32768, tools/step_ab.py ^mask: per launch, 256^2 / 192 kernels -> ping-pong):
+        // cross out-proj 94.5 -> 89.7 us; q-proj 46.9 -> 52.6, final 91 -> 108, fc2 186 -> 217 (worse; in isolation,
+        // with every operand resident in the Infinity Cache, the out-proj showed 96 -> 68 us: bench GEMMs in the model).
+        const int mask = g_pp_mask >= 0 ? g_pp_mask : (tpp >= 512 ? 2 : 0);
+        if (cls & mask) return launch_gemm_pp(p, epi, s);
+    }
     if (forced == 192 && gemm192_supports(epi)) return launch_gemm192(p, epi, s);
     const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
     // Wide outputs (N >= 2048: QKV, fc1|gate) take the 256x256 structure from 144 tiles on — re-measured at the end of

@@ -43,6 +43,7 @@ namespace {
 constexpr int HALF_BYTES = 128 * 64 * 2;  // 16 KiB
 constexpr int KT_BYTES = 4 * HALF_BYTES;  // 64 KiB: A_lo | A_hi | B_lo | B_hi
 constexpr int LDS256 = 2 * KT_BYTES;      // 128 KiB
+constexpr int LDS256_ALLOC = LDS256 + 2 * 1024;   // + two bias rows (256 fp32 each, double-buffered by tile)
 
 template <int V>
 struct IC { static constexpr int value = V; };
@@ -66,6 +67,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     const int srow = lane >> 3;   // row inside a piece
     const int scpos = lane & 7;   // chunk position inside the 128-B row
     int m0 = 0, n0 = 0;           // origin of the tile whose DMA is being issued
+    unsigned bias_slot = 0;       // which of the two 1 KiB bias rows (after the K-tile buffers) the last prologue filled
     auto stage = [&](int buf, auto HALF, int kt) {
         constexpr int half = decltype(HALF)::value;
         if (kt >= nkt) return;    // wave-uniform; the waits below account for it
@@ -97,6 +99,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         tile_to_mn(xcd_remap(tile, ntiles), p.tiles_m, p.tiles_n, p.group_n, tm, tn);
         m0 = tm * 256;
         n0 = tn * 256;
+        bias_slot ^= 1u;
+        if (wid == 0 && p.bias) {   // this tile's bias row -> LDS (read by its FAST epilogue); columns past N are clamped, unused
+            int c = n0 + lane * 4;
+            c = c + 4 <= p.N ? c : 0;
+            glds16(p.bias + c, lds_base + (unsigned)(LDS256 + bias_slot * 1024));
+        }
         stage(0, IC<2>{}, 0);
         stage(0, IC<3>{}, 0);
         stage(0, IC<0>{}, 0);
@@ -355,8 +363,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 
         // next tile's first K-tiles start streaming in now, under this tile's epilogue
         const int next = tile + p.tile_stride;
+        // FAST epilogue: the tile's 256 bias values came in by LDS-DMA with ITS OWN prologue (one 1 KiB piece, wave 0,
+        // the oldest load of the prologue), so the epilogue reads them with ds_read and contains no global load at all.
+        // (As compiler-visible global loads issued after the next tile's prologue DMA they made hipcc open every
+        // epilogue with s_waitcnt vmcnt(0): each tile's epilogue began by waiting for the next tile's first K-tiles.)
+        const bool fast_epi = !FP8 && epilogue_fast_ok<EPI>(p, cur_m0, cur_n0, 256, 256) && !(p.flags & GF_DIAG_NO_EPILOGUE);
+        const unsigned cur_bias_slot = bias_slot;
         if (next < ntiles) prologue(next);
-
         // ---------------- epilogue ----------------
         prev_interior = (cur_m0 + 256 <= p.M) && (cur_n0 + 256 <= p.N) && !p.out2 &&
                         !(p.flags & (GF_DIAG_NO_STORE | GF_DIAG_NO_EPILOGUE));
@@ -368,7 +381,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             continue;
         }
         f32x4 bias4[4];
-        load_bias(p, cur_n0 + wn * 64, fq, bias4);
+        if (fast_epi) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                bias4[n] = *reinterpret_cast<const f32x4*>(smem + LDS256 + cur_bias_slot * 1024 + (wn * 64 + n * 16 + fq * 4) * 4);
+        } else {
+            load_bias(p, cur_n0 + wn * 64, fq, bias4);
+        }
         if constexpr (FP8) {   // per-output-column weight scale of the fp8 quantisation
             f32x4 ws4[4];
 #pragma unroll
@@ -382,7 +401,22 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 #pragma unroll
                 for (int n = 0; n < 4; ++n) acc[m][n] *= ws4[n];
         }
-        if (cur_m0 + 256 <= p.M && !(p.flags & GF_DIAG_SMALL_OUT)) {
+        if (fast_epi) {
+            // interior tile, production flags: straight-line epilogue, the 8 row blocks in one basic block
+            const int cb = cur_n0 + wn * 64, r0 = cur_m0 + wm * 128 + frow;
+            if constexpr (EPI == EPI_QKV_ROPE) {
+                if (cb >= p.rope_cols) {   // a v head: bias only (wave-uniform)
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) epilogue_row<EPI_BIAS_BF16, true>(p, r0 + m * 16, cb, acc[m], bias4, fq);
+                } else {
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) epilogue_row<EPI, true>(p, r0 + m * 16, cb, acc[m], bias4, fq);
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) epilogue_row<EPI, true>(p, r0 + m * 16, cb, acc[m], bias4, fq);
+            }
+        } else if (cur_m0 + 256 <= p.M && !(p.flags & GF_DIAG_SMALL_OUT)) {
             // interior in M: no per-row guard, so the 8 row blocks are ONE basic block and hipcc interleaves their
             // (independent) epilogue arithmetic instead of running 8 short dependent chains one after the other
 #pragma unroll
@@ -404,11 +438,11 @@ hipError_t launch256_tw(const GemmParams& p, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI, WIDE, FP8>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS256);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_ALLOC);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm256_kernel<EPI, WIDE, FP8>), dim3(p.tile_stride), dim3(512), LDS256, s, p);
+    hipLaunchKernelGGL((gemm256_kernel<EPI, WIDE, FP8>), dim3(p.tile_stride), dim3(512), LDS256_ALLOC, s, p);
     return hipGetLastError();
 }
 template <int EPI>

@@ -42,7 +42,10 @@ enum { GF_RELAXED_WAIT = 1,        // tile-start wait skips over the previous ti
        GF_STORE_NT = 64,           // fp32 output stores non-temporal (nt)
        GF_ROWMAJOR_TILES = 128,    // A/B switch: plain row-major tile order instead of super-columns
        GF_WIDE_PHASE = 256,        // gemm256: 32 MFMAs per barrier pair, LDS reads retired before the barrier
-       GF_DIAG_SMALL_OUT = 512 };  // DIAGNOSTIC (wrong results): every tile stores into rows 0..255 (stays in L2)
+       GF_DIAG_SMALL_OUT = 512,    // DIAGNOSTIC (wrong results): every tile stores into rows 0..255 (stays in L2)
+       GF_SLOW_EPILOGUE = 1024,    // A/B: never take the specialised straight-line epilogue (was: RoPE table loads A/B, retired)
+       GF_PP_PARITY = 2048,        // gemm_pp A/B: the late-starting workgroups are the odd blockIdx (default: second LDS allocation of the CU)
+       GF_PP_NO_STAGGER = 4096 };  // gemm_pp A/B: no phase offset between the two workgroups of a CU
 
 // Tile order.  An XCD (private 4 MiB L2) receives a contiguous range of the linear tile index (xcd_remap); within it
 // the tiles run down M inside a SUPER-COLUMN of `G` column tiles, so the tiles an XCD works on at one time are a
@@ -98,6 +101,14 @@ DITTO_DEV void glds16_so(unsigned voff, const void* sbase, unsigned lds_dst) {
                  : "memory");
 }
 
+// 16-byte global load the COMPILER DOES NOT TRACK: the caller waits for it with its own counted s_waitcnt (an asm
+// statement that names the result as an in/out operand, so no use can be scheduled above the wait).
+DITTO_DEV f32x4 gload16_asm(const void* ptr) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+
 // Bias of the lane's 4 x 4 columns, loaded ONCE per wave (the same for every row of the tile): keeps the row
 // loop free of dependent global loads.
 DITTO_DEV void load_bias(const GemmParams& p, int cbase, int fq, f32x4 (&b)[4]) {
@@ -113,8 +124,15 @@ DITTO_DEV void load_bias(const GemmParams& p, int cbase, int fq, f32x4 (&b)[4]) 
 // Measured on MI355X (tools/gemm_bench.py, same-process A/B): nt on the fp32 in-place residual epilogue
 // (d x d out-proj, fc2) -20..-26 % kernel time; on bf16 outputs nt / sc1 are within +-3 %, so nt applies to
 // fp32 outputs only.
-template <bool F32_OUT>
+template <bool F32_OUT, bool FAST = false>
 DITTO_DEV void store16(void* ptr, u32x4 v, int flags) {
+    if constexpr (FAST) {   // production flags known at compile time: nt on fp32 outputs, plain on bf16, no diagnostics
+        // s_nop 1: a 16-byte store reads its data registers over several cycles; hipcc pads its own stores against a
+        // VALU overwrite of them but knows nothing about this one
+        if constexpr (F32_OUT) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
+        else *reinterpret_cast<u32x4*>(ptr) = v;
+        return;
+    }
     if (flags & GF_STORE_SC1) {
         asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
     } else if (F32_OUT && (flags & GF_STORE_NT)) {
@@ -130,6 +148,7 @@ DITTO_DEV void store16(void* ptr, u32x4 v, int flags) {
 // odd-fq lane 8 consecutive columns of block nb+1: one 16-B store per lane instead of two 8-B stores.  The tile
 // epilogue is store-ISSUE-bound (32 dwordx2 per lane measured ~10 us per 256x256 tile), so halving the
 // instruction count at equal bytes is what matters.  Must be called by both lanes of every (l, l^16) pair.
+template <bool FAST = false>
 DITTO_DEV void store_bf16_pair(bf16* rowp, int col0 /* column of block nb */, u32x2 pa, u32x2 pb, int fq, int ncols,
                                 int flags = 0, int ld = 0) {
     const auto r0 = __builtin_amdgcn_permlane16_swap(pa[0], pb[0], false, false);
@@ -137,6 +156,12 @@ DITTO_DEV void store_bf16_pair(bf16* rowp, int col0 /* column of block nb */, u3
     // even fq: [own nb | partner's nb]      odd fq: [partner's nb+1 | own nb+1]
     const int odd = fq & 1;
     int c = col0 + odd * 16 + 4 * (fq - odd);
+    if constexpr (FAST) {   // interior tile, production flags: no guard, no diagnostics -> straight-line code
+        u32x4 st;
+        st[0] = r0[0]; st[1] = r1[0]; st[2] = r0[1]; st[3] = r1[1];
+        *reinterpret_cast<u32x4*>(rowp + c) = st;
+        return;
+    }
     if (flags & GF_DIAG_LINEAR_STORE) {   // same instruction, same bytes, 1 KiB contiguous per wave-instruction
         rowp -= (size_t)(threadIdx.x & 15) * ld;
         c = (col0 & ~63) + (threadIdx.x & 63) * 8;
@@ -155,7 +180,11 @@ DITTO_DEV void store_bf16_pair(bf16* rowp, int col0 /* column of block nb */, u3
 #endif
 
 // One output row x the wave's 64-column span.  `row` < M is checked by the caller.
-template <int EPI>
+// FAST: the tile is interior in M and N, there is no bf16 side copy (out2) and the flags are the production set
+// (GF_STORE_NT, no diagnostics / sc1): every guard and flag test compiles out, so the eight row blocks of a wave tile
+// are ONE basic block and hipcc interleaves their independent dependency chains (as written before, each row block
+// ended in 6-8 wave-uniform branches around its store and the transcendental latencies of a block were exposed).
+template <int EPI, bool FAST = false>
 DITTO_DEV void epilogue_row(const GemmParams& p, int row, int cbase, const f32x4 (&acc)[4], const f32x4 (&bias)[4],
                             int fq) {
     const int c4 = fq * 4;
@@ -189,8 +218,8 @@ DITTO_DEV void epilogue_row(const GemmParams& p, int row, int cbase, const f32x4
             pk[pr][0] = pack_bf16x2(o01[0], o01[1]);
             pk[pr][1] = pack_bf16x2(o23[0], o23[1]);
         }
-        store_bf16_pair((bf16*)p.out + (size_t)row * p.ldo, cbase / 2, pk[0], pk[1], fq, p.N / 2, p.flags, p.ldo);
-        if (p.out2) {   // training forward: the pre-activations (bias added, interleaved packed order) for the backward
+        store_bf16_pair<FAST>((bf16*)p.out + (size_t)row * p.ldo, cbase / 2, pk[0], pk[1], fq, p.N / 2, p.flags, p.ldo);
+        if (!FAST && p.out2) {   // training forward: the pre-activations (bias added, interleaved packed order) for the backward
             u32x2 pr[4];
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
@@ -209,7 +238,7 @@ DITTO_DEV void epilogue_row(const GemmParams& p, int row, int cbase, const f32x4
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[n][e] = acc[n][e] + bias[n][e];
         }
-        if (cbase < p.rope_cols) {  // a q or k head (width 64): half-split RoPE, pair (j, j+32); DiT.py:52-72
+        if (FAST || cbase < p.rope_cols) {  // a q or k head (FAST: the caller runs v columns through EPI_BIAS_BF16) (width 64): half-split RoPE, pair (j, j+32); DiT.py:52-72
             const int pos = row % p.rope_rpb;
             float r[4][4];
 #pragma unroll
@@ -251,8 +280,8 @@ DITTO_DEV void epilogue_row(const GemmParams& p, int row, int cbase, const f32x4
             pk[n][1] = pack_bf16x2(v[n][2], v[n][3]);
         }
         bf16* rowp = (bf16*)p.out + (size_t)row * p.ldo;
-        store_bf16_pair(rowp, cbase, pk[0], pk[1], fq, p.N, p.flags, p.ldo);
-        store_bf16_pair(rowp, cbase + 32, pk[2], pk[3], fq, p.N, p.flags, p.ldo);
+        store_bf16_pair<FAST>(rowp, cbase, pk[0], pk[1], fq, p.N, p.flags, p.ldo);
+        store_bf16_pair<FAST>(rowp, cbase + 32, pk[2], pk[3], fq, p.N, p.flags, p.ldo);
     } else if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_RELU_BF16) {
         u32x2 pk[4];
 #pragma unroll
@@ -266,21 +295,21 @@ DITTO_DEV void epilogue_row(const GemmParams& p, int row, int cbase, const f32x4
             pk[n][1] = pack_bf16x2(v[2], v[3]);
         }
         bf16* rowp = (bf16*)p.out + (size_t)row * p.ldo;
-        store_bf16_pair(rowp, cbase, pk[0], pk[1], fq, p.N, p.flags, p.ldo);
-        store_bf16_pair(rowp, cbase + 32, pk[2], pk[3], fq, p.N, p.flags, p.ldo);
+        store_bf16_pair<FAST>(rowp, cbase, pk[0], pk[1], fq, p.N, p.flags, p.ldo);
+        store_bf16_pair<FAST>(rowp, cbase + 32, pk[2], pk[3], fq, p.N, p.flags, p.ldo);
     } else {
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             const int c = cbase + n * 16 + c4;
-            if (c >= p.N) continue;
+            if (!FAST && c >= p.N) continue;
             f32x4 v = acc[n] + bias[n];
             if constexpr (EPI == EPI_BIAS_RES_F32) {
-                if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)row * p.ldr + c);
+                if (FAST || p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)row * p.ldr + c);
             }
-            if (p.flags & GF_DIAG_NO_STORE) asm volatile("" ::"v"(v));
-            else store16<true>((float*)p.out + (size_t)row * p.ldo + c, __builtin_bit_cast(u32x4, v), p.flags);
+            if (!FAST && (p.flags & GF_DIAG_NO_STORE)) asm volatile("" ::"v"(v));
+            else store16<true, FAST>((float*)p.out + (size_t)row * p.ldo + c, __builtin_bit_cast(u32x4, v), p.flags);
             if constexpr (EPI == EPI_BIAS_RES_F32) {
-                if (p.out2) {   // bf16 side copy (last layer only): plain 8-B stores, off the hot path
+                if (!FAST && p.out2) {   // bf16 side copy (last layer only): plain 8-B stores, off the hot path
                     u32x2 st;
                     st[0] = pack_bf16x2(v[0], v[1]);
                     st[1] = pack_bf16x2(v[2], v[3]);
@@ -289,6 +318,17 @@ DITTO_DEV void epilogue_row(const GemmParams& p, int row, int cbase, const f32x4
             }
         }
     }
+}
+
+// May the tile at (m0, n0) of extent (BM_, BN_) take the FAST epilogue?  (wave-uniform)
+template <int EPI>
+DITTO_DEV bool epilogue_fast_ok(const GemmParams& p, int m0, int n0, int BM_, int BN_) {
+    constexpr int must_off = GF_DIAG_NO_STORE | GF_DIAG_NO_EPILOGUE | GF_DIAG_LINEAR_STORE | GF_DIAG_SMALL_OUT | GF_STORE_SC1;
+    if (m0 + BM_ > p.M || n0 + BN_ > p.N || p.out2 || (p.flags & must_off) || !(p.flags & GF_STORE_NT)) return false;
+    if ((p.flags & GF_SLOW_EPILOGUE) || !p.bias) return false;
+    if constexpr (EPI == EPI_BIAS_RES_F32) return p.residual != nullptr;
+    if constexpr (EPI == EPI_QKV_ROPE) return p.rope_freq_rev != nullptr;   // table-free angles (the model path)
+    return true;
 }
 
 // gemm256.hip
@@ -301,5 +341,8 @@ bool gemm192_supports(GemmEpilogue epi);
 hipError_t launch_gemm192(const GemmParams& p, GemmEpilogue epi, hipStream_t s);
 // gemm_o3.hip
 hipError_t launch_gemm_o3(const GemmParams& p, GemmEpilogue epi, hipStream_t s);
+// gemm_pp.hip
+bool gemm_pp_supports(const GemmParams& p, GemmEpilogue epi);
+hipError_t launch_gemm_pp(const GemmParams& p, GemmEpilogue epi, hipStream_t s);
 
 }  // namespace ditto

@@ -212,7 +212,11 @@ int ditto_attention_bf16(const void* q, int ldq, const void* k, int ldk, const v
 size_t ditto_attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh);
 
 /* Process-wide tuning switches (tests / experiments).  "gemm_tile": 0 = automatic choice between the three GEMM
- * tile structures, 128 (128x128) / 129 (persistent 256x128 ring) / 256 (persistent 256x256) = force one.  Results are identical up to fp32 summation order.
+ * tile structures, 128 (128x128) / 129 (persistent 256x128 ring) / 131 (128x256 ping-pong, two workgroups per CU) /
+ * 256 (persistent 256x256) = force one.  Results are identical up to fp32 summation order.
+ * "pp_mask": GEMM classes that take the ping-pong kernel (bit 0 cross q-proj, 1 cross out-proj, 2 final projection,
+ * 3 fc2, 4 QKV + RoPE, 5 gated MLP; -1 = the built-in rule).
+ * "pp_stagger": phase offset between the two workgroups of a CU in the ping-pong GEMM, 10 ns ticks (-1 = built-in rule).
  * "gemm_flags": bit mask for kernel experiments (bit 0 = relaxed tile-start wait, default on; bits 1, 2 are
  * DIAGNOSTIC timing switches that skip stores / the epilogue and produce WRONG results — tools/ only).
  * "gemm_group": forced super-column width of the GEMM tile order (A/B tool; 0 = the built-in rule, which a sweep of

@@ -55,9 +55,11 @@ def test_gemm(lib, M, N, K, epi):
         assert max_abs(out, want + res) < 1e-4
 
 
-@pytest.fixture(params=[(256, 73), (256, 73 + 256), (129, 73), (130, 73), (192, 73), (127, 73)])
+@pytest.fixture(params=[(256, 73), (256, 73 + 256), (129, 73), (130, 73), (192, 73), (127, 73), (131, 321),
+                        (131, 321 + 4096)])
 def tile256(lib, request):
-    """forces one persistent structure: 256x256 eight-phase, 256x256 wide-phase, 256x128 ring"""
+    """forces one structure: 256x256 eight-phase, 256x256 wide-phase, 256x128 ring, 128x256 x 3 WGs, 256x192, 128x128
+    deep, 128x256 ping-pong (with and without the phase offset)"""
     hip.check(lib.ditto_set_option(b"gemm_tile", request.param[0]))
     hip.check(lib.ditto_set_option(b"gemm_flags", request.param[1]))
     yield
@@ -91,6 +93,38 @@ def test_gemm_256_tile_structure(lib, tile256, M, N, K, epi):
             first = out.clone()
         else:
             assert torch.equal(out, first)
+
+
+@pytest.mark.parametrize("tile", [256, 131, 192, 129, 130, 127])
+@pytest.mark.parametrize("flags", [321, 321 + 1024])
+def test_every_epilogue_on_every_structure(lib, tile, flags):
+    """All four C-ABI epilogues (0 bias->bf16, 1 bias+residual->fp32 in place, 3 gelu*sigmoid gate, 4 bias->fp32) on each
+    tile structure, with the specialised straight-line epilogue (production flags) and without it (flag 1024), against
+    the 128x128 kernel: interior and ragged tiles.  (Round 2: the fp32 fast path first shipped without the wait state its
+    hand-written store needs; only epilogue 4 showed it.)"""
+    try:
+        for (M, N, K) in [(512, 1536, 768), (300, 768, 256), (1024, 768, 1536)]:
+            A = bf16(asym((M, K), 4).to(DEV))
+            W = bf16((asym((N, K), 5) / math.sqrt(K)).to(DEV))
+            bias = (0.1 * asym((N,), 6)).to(DEV)
+            res = asym((M, N), 7).to(DEV)
+            for epi in (0, 1, 3, 4):
+                def run(t, fl):
+                    hip.check(lib.ditto_set_option(b"gemm_tile", t))
+                    hip.check(lib.ditto_set_option(b"gemm_flags", fl))
+                    ldo = N // 2 if epi == 3 else N
+                    out = res.clone() if epi == 1 else torch.zeros(M, ldo, device=DEV,
+                                                                   dtype=torch.bfloat16 if epi in (0, 3) else torch.float32)
+                    hip.check(lib.ditto_gemm_bf16(A.data_ptr(), K, W.data_ptr(), bias.data_ptr(),
+                                                  out.data_ptr() if epi == 1 else None, out.data_ptr(), ldo, M, N, K, epi,
+                                                  stream()))
+                    return out.float()
+                ref, got = run(128, 321), run(tile, flags)
+                tol = 1e-2 if epi in (0, 3) else 2e-5            # bf16 outputs may differ by one rounding; fp32 by summation order
+                assert max_abs(got, ref) <= tol * max(1.0, float(ref.abs().max())), (M, N, K, epi)
+    finally:
+        hip.check(lib.ditto_set_option(b"gemm_tile", 0))
+        hip.check(lib.ditto_set_option(b"gemm_flags", 321))
 
 
 def test_gemm_identity_asymmetric_256(lib, tile256):

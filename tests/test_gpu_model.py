@@ -64,7 +64,7 @@ def test_g2_full_ditto_s(golden):
 
 
 @torch.no_grad()
-@pytest.mark.parametrize("tile", [127, 128, 129, 130, 192, 256])
+@pytest.mark.parametrize("tile", [127, 128, 129, 130, 131, 192, 256])
 def test_g2_with_forced_gemm_structure(golden, tile):
     """Every fused epilogue (RoPE, gated MLP, residual, K-concatenated final) through BOTH GEMM tile structures."""
     from ditto_tts_amd import hip

@@ -2,7 +2,7 @@
 """In-model A/B of GEMM variants: per-kernel-class average launch time of the real denoise step (C2, B=32),
 variants interleaved round-robin in ONE process on ONE device (cross-run numbers differ by >10 % between boxes).
     python tools/step_ab.py --variants 128/73,256/73,0/73 [--rounds 4] [--steps 3]
-variant = gemm_tile/gemm_flags[@attn_flags][#splitk_wgs][%gemm_group]"""
+variant = gemm_tile/gemm_flags[@attn_flags][#splitk_wgs][%gemm_group][^pp_mask]"""
 import argparse
 import os
 import sys
@@ -44,6 +44,8 @@ wall = {v: [] for v in variants}
 
 
 def select(v):
+    v, _, pm = v.partition("^")          # ...^pp_mask (GEMM classes on the ping-pong kernel; default -1 = rule)
+    hip.check(lib.ditto_set_option(b"pp_mask", int(pm) if pm else -1))
     v, _, gg = v.partition("%")          # ...%gemm_group (forced super-column width of the tile order; 0 = rule)
     hip.check(lib.ditto_set_option(b"gemm_group", int(gg) if gg else 0))
     v, _, sk = v.partition("#")          # ...#splitk_wgs (small-batch split-K target; default 0 = off)
