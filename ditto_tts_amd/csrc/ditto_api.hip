@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "model.h"
+#include "gemm_common.h"
 
 using namespace ditto;
 
@@ -642,6 +643,20 @@ int ditto_gemm_bf16(const void* A, int lda, const void* W, const float* bias, co
         default: return fail(DITTO_ERR_ARG, "epilogue must be 0, 1, 3, 4 or 6");
     }
     HIP_TRY(launch_gemm(g, e, (hipStream_t)stream));
+    return DITTO_OK;
+}
+
+int ditto_gemm_ln_bf16(const void* A, int lda, const void* W, const float* bias, const float* residual, float* out,
+                       int ldo, const float* gamma, const float* beta, void* u_bf16, int ldu, int M, int N, int K,
+                       ditto_stream_t stream) {
+    if (!A || !W || !out || (gamma == nullptr) != (beta == nullptr) || (gamma == nullptr) != (u_bf16 == nullptr))
+        return fail(DITTO_ERR_ARG, "bad argument to ditto_gemm_ln_bf16");
+    if (!gemm_fr_supports(M, N, K, (size_t)lda, (size_t)K) || lda % 8)
+        return fail(DITTO_ERR_SHAPE, "ditto_gemm_ln_bf16 needs N == 768, K %% 32 == 0, M >= 128, lda %% 8 == 0");
+    GemmParams p{};
+    p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)W; p.ldw = K; p.w_rows = N; p.bias = bias;
+    p.residual = residual; p.ldr = ldo; p.out = out; p.ldo = ldo; p.M = M; p.N = N; p.K = K;
+    HIP_TRY(launch_gemm_fr(p, gamma, beta, u_bf16, ldu, (hipStream_t)stream));
     return DITTO_OK;
 }
 

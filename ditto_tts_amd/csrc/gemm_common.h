@@ -159,7 +159,11 @@ DITTO_DEV void store_bf16_pair(bf16* rowp, int col0 /* column of block nb */, u3
     if constexpr (FAST) {   // interior tile, production flags: no guard, no diagnostics -> straight-line code
         u32x4 st;
         st[0] = r0[0]; st[1] = r1[0]; st[2] = r0[1]; st[3] = r1[1];
+#ifdef DITTO_DIAG_FAST_NOSTORE   // timing experiment (WRONG results): the fast epilogue computes, keeps live, does not store
+        asm volatile("" ::"v"(st), "v"(rowp + c));
+#else
         *reinterpret_cast<u32x4*>(rowp + c) = st;
+#endif
         return;
     }
     if (flags & GF_DIAG_LINEAR_STORE) {   // same instruction, same bytes, 1 KiB contiguous per wave-instruction
@@ -341,6 +345,9 @@ bool gemm192_supports(GemmEpilogue epi);
 hipError_t launch_gemm192(const GemmParams& p, GemmEpilogue epi, hipStream_t s);
 // gemm_o3.hip
 hipError_t launch_gemm_o3(const GemmParams& p, GemmEpilogue epi, hipStream_t s);
+// gemm_fr.hip: full-row N = 768 GEMM, fp32 residual in place, fused LayerNorm -> u bf16 (gamma/u null: none)
+bool gemm_fr_supports(int M, int N, int K, size_t lda, size_t ldw);
+hipError_t launch_gemm_fr(const GemmParams& p, const float* gamma, const float* beta, void* u_bf16, int ldu, hipStream_t s);
 // gemm_pp.hip
 bool gemm_pp_supports(const GemmParams& p, GemmEpilogue epi);
 hipError_t launch_gemm_pp(const GemmParams& p, GemmEpilogue epi, hipStream_t s);

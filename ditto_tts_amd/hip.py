@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libditto_hip.so")
+LIB_PATH = os.environ.get("DITTO_HIP_LIB") or os.path.join(HERE, "libditto_hip.so")   # override: diagnostic builds (tools/)
 
 OK, ERR_ARG, ERR_SHAPE, ERR_HIP, ERR_SIZE = range(5)
 CFG_FP8_LINEAR = 1
@@ -124,6 +124,7 @@ SYMBOLS = {
     "ditto_q_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _sz, _vp]),
     "ditto_layernorm_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "ditto_gemm_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ditto_gemm_ln_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ditto_attention_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
     "ditto_attention_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "ditto_vq_argmin": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),

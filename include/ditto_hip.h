@@ -211,6 +211,14 @@ int ditto_attention_bf16(const void* q, int ldq, const void* k, int ldk, const v
 /* scratch bytes ditto_attention_bf16 needs (0 for the fused dh = 64 kernel) */
 size_t ditto_attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh);
 
+/* Full-row GEMM with the residual add and the FOLLOWING LayerNorm fused (N = 768 only; csrc/gemm_fr.hip):
+ *   out fp32 [M,768] = residual + A[M,K] W[768,K]^T + bias   (residual may alias out: the in-place stream update of
+ *   src/components/DiT.py:148 / :155),   u bf16 [M,ldu] = LayerNorm(out) * gamma + beta  (eps 1e-5; the norm of :152 / the
+ *   next block's :105).  gamma = beta = u = NULL: no LayerNorm output.  K % 32 == 0, M >= 128. */
+int ditto_gemm_ln_bf16(const void* A, int lda, const void* W, const float* bias, const float* residual, float* out,
+                       int ldo, const float* gamma, const float* beta, void* u_bf16, int ldu, int M, int N, int K,
+                       ditto_stream_t stream);
+
 /* Process-wide tuning switches (tests / experiments).  "gemm_tile": 0 = automatic choice between the three GEMM
  * tile structures, 128 (128x128) / 129 (persistent 256x128 ring) / 131 (128x256 ping-pong, two workgroups per CU) /
  * 256 (persistent 256x256) = force one.  Results are identical up to fp32 summation order.

@@ -344,3 +344,36 @@ def test_fp8_gemm_gated(lib):
     want = torch.nn.functional.gelu(h) * torch.sigmoid(g)
     assert rel_l2(_deq(out), want) < 4e-2      # one e4m3 rounding of the result
     assert max_abs(_deq(out), want.clamp(-448, 448)) < 0.07 * (1 + float(want.abs().max()))
+
+
+@pytest.mark.parametrize("M,K,ln", [(128, 768, True), (300, 256, True), (1024, 3072, True), (257, 64, False)])
+def test_full_row_gemm_with_fused_layernorm(lib, M, K, ln):
+    """ditto_gemm_ln_bf16 (csrc/gemm_fr.hip): out = residual + A W^T + bias in place, u = LayerNorm(out) * gamma + beta, in ONE
+    kernel whose workgroups own whole rows — against the fp32 ops.  Experimental (not on the model path: measured slower
+    than GEMM + LayerNorm), kept correct.  Ragged M (row clamp / masks), short and long K, repeated for
+    run-to-run determinism."""
+    N = 768
+    A = bf16(asym((M, K), 4).to(DEV))
+    W = bf16((asym((N, K), 5) / math.sqrt(K)).to(DEV))
+    bias = (0.1 * asym((N,), 6)).to(DEV)
+    res = asym((M, N), 7).to(DEV)
+    g = (1 + 0.1 * asym((N,), 8)).to(DEV)
+    b = (0.1 * asym((N,), 9)).to(DEV)
+    want = res + A.float() @ W.float().T + bias
+    wu = torch.nn.functional.layer_norm(want, (N,), g, b, 1e-5)
+    first = None
+    for rep in range(3):
+        h = res.clone()
+        u = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        hip.check(lib.ditto_gemm_ln_bf16(A.data_ptr(), K, W.data_ptr(), bias.data_ptr(), h.data_ptr(), h.data_ptr(), N,
+                                         g.data_ptr() if ln else None, b.data_ptr() if ln else None,
+                                         u.data_ptr() if ln else None, N, M, N, K, stream()))
+        assert rel_l2(h, want) < 1e-5 and max_abs(h, want) < 2e-4
+        if ln:
+            assert max_abs(u.float(), wu) < 4e-2 and rel_l2(u.float(), wu) < 4e-3      # bf16 output
+        if first is None:
+            first = (h.clone(), u.clone())
+        else:
+            assert torch.equal(h, first[0]) and torch.equal(u, first[1])
+    assert lib.ditto_gemm_ln_bf16(A.data_ptr(), K, W.data_ptr(), None, None, h.data_ptr(), 512, None, None, None, 0, M, 512,
+                                  K, stream()) == hip.ERR_SHAPE

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Build a DIAGNOSTIC copy of the library with extra -D flags (wrong results by design) next to the real one:
+#   tools/build_diag.sh libditto_diag_nostore.so -DDITTO_DIAG_FAST_NOSTORE
+# and select it with DITTO_HIP_LIB=$PWD/ditto_tts_amd/<name> for tools/gemm_bench.py.
+set -e
+out=$1; shift
+cd "$(dirname "$0")/../ditto_tts_amd/csrc"
+mkdir -p /tmp/diag_objs
+for f in *.hip; do
+  extra=""; [ "$f" = attention.hip ] && extra="-fno-honor-nans"
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I ../../include -I . -Wno-unused-function $extra "$@" -c $f -o /tmp/diag_objs/${f%.hip}.o &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../$out /tmp/diag_objs/*.o
+echo built ../$out
