@@ -10,9 +10,9 @@
 //   cfg_combine      eps = eps_u + w*(eps_c - eps_u) (classifier-free guidance, paper App. A).
 //
 // All HBM-bound or tiny next to the loop (VQ: 2*R*K*D = 103 GFLOP fp32 once per 50 x 355 GFLOP x B); the VQ
-// result is an INTEGER index, so its distances are computed in fp32 FMAs (no bf16 rounding that could flip a
-// near-tie), with the reference's expression order (||x||^2 - 2 x.c) + ||c||^2 and torch.argmin's first-minimum
-// tie rule.
+// result is an INTEGER index, so its distances are computed in exact fp32 (the fp32-input MFMA: no bf16 rounding that
+// could flip a near-tie), with the reference's expression order (||x||^2 - 2 x.c) + ||c||^2 and torch.argmin's
+// first-minimum tie rule.
 #include "common.h"
 #include "kernels.h"
 
@@ -32,85 +32,127 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// 64 latent rows per workgroup; codes in tiles of 64; k in chunks of 32 through LDS; 4x4 register tile per thread.
+// -2 x.c on the fp32 MATRIX pipe: v_mfma_f32_32x32x2_f32 is an exact fp32 fused-multiply-add chain (bitwise the
+// fmaf chain over k, two k per instruction, at the fp32 vector peak of 64 FLOP/clk/SIMD without occupying the VALU),
+// so the distances — and therefore every index, near-ties included — are those of the scalar form
+// acc = fmaf(x[k], c[k], acc), k ascending, which is what the VALU kernel of round 1 computed.
+//
+//   workgroup 128 latent rows; 4 waves = 2 (codes) x 2 (rows); codes in tiles of 128, k in steps of 32 through LDS.
+//   operands  the CODEBOOK is the instruction's A operand, the latents its B operand: the 32x32 result block then
+//             keeps one latent ROW per lane (column = lane & 31) and 16 codes in its 16 registers (code =
+//             8 (i/4) + 4 (lane/32) + i%4, ascending in i), so the running (min distance, first index) of a row is
+//             updated in-lane with a strict '<' and no cross-lane traffic until the very end.
+//   LDS       k de-interleaved at staging time: even k and odd k of a row are separate arrays, because the instruction
+//             takes k = 2p from lanes 0-31 and k = 2p+1 from lanes 32-63: a lane's ds_read_b128 then yields its operand
+//             for FOUR consecutive instructions, in ascending-k order.  Row pitch 20 floats: conflict-free b128 reads.
+//   distance  (||x||^2 - 2 acc) + ||c||^2 with explicit round-to-nearest ops, as VectorQuantizer.py:34-38.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void vq_argmin_kernel(const float* __restrict__ x, const float* __restrict__ cb,
-                                                        const float* __restrict__ cc, int64_t* __restrict__ idx, int R,
-                                                        int K, int D) {
-    __shared__ float xs[32][64 + 4];   // [k][row]
-    __shared__ float cs[32][64 + 4];   // [k][code]
-    __shared__ float xx[64];
-    __shared__ float best_d[64][16];
-    __shared__ int best_i[64][16];
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int r0 = blockIdx.x * 64;
+constexpr int VQ_R = 128, VQ_C = 128, VQ_K = 32, VQ_P = 20;   // rows, codes per tile, k per stage, LDS row pitch (floats)
+__global__ __launch_bounds__(256, 2) void vq_argmin_mfma_kernel(const float* __restrict__ x, const float* __restrict__ cb,
+                                                                const float* __restrict__ cc, int64_t* __restrict__ idx,
+                                                                int R, int K, int D) {
+    __shared__ __attribute__((aligned(16))) float xe[VQ_R * VQ_P], xo[VQ_R * VQ_P];   // latents: even / odd k
+    __shared__ __attribute__((aligned(16))) float ce[VQ_C * VQ_P], co[VQ_C * VQ_P];   // codes:   even / odd k
+    __shared__ float xx[VQ_R];
+    __shared__ float best_d[VQ_R][4];
+    __shared__ int best_i[VQ_R][4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wc = wid >> 1, wr = wid & 1;           // code half / row half of this wave
+    const int l32 = lane & 31, half = lane >> 5;
+    const int r0 = blockIdx.x * VQ_R;
 
-    // ||x||^2 of this block's rows: 4 threads per row
+    // ||x||^2 of this block's rows: 2 threads per row, sequential halves, fixed order
     {
-        const int row = tid >> 2, part = tid & 3;
+        const int row = tid >> 1, part = tid & 1;
         const int gr = min(r0 + row, R - 1);
         float s = 0.f;
-        for (int j = part; j < D; j += 4) { const float v = x[(size_t)gr * D + j]; s = fmaf(v, v, s); }
+        for (int j = part; j < D; j += 2) { const float v = x[(size_t)gr * D + j]; s = fmaf(v, v, s); }
         s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
         if (part == 0) xx[row] = s;
     }
-    float bd[4];
-    int bi[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { bd[i] = 3.4e38f; bi[i] = 0; }
+    float bd[2] = {3.4e38f, 3.4e38f};
+    int bi[2] = {0, 0};
+    const float* xbase = half ? xo : xe;
+    const float* cbase = half ? co : ce;
 
-    for (int c0 = 0; c0 < K; c0 += 64) {
-        float acc[4][4];
+    for (int c0 = 0; c0 < K; c0 += VQ_C) {
+        f32x16 acc[2][2];   // [code block][row block]
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-        for (int k0 = 0; k0 < D; k0 += 32) {
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int k0 = 0; k0 < D; k0 += VQ_K) {
             __syncthreads();
-            // stage 64 rows x 32 k of x and of the codebook, transposed to [k][row]
+            // stage 128 rows x 32 k of the latents and of the codebook; 4 consecutive k per thread, split even / odd
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int e = tid + 256 * i;           // 0..2047
-                const int row = e >> 5, k = e & 31;
+            for (int i = 0; i < 4; ++i) {
+                const int e = tid + 256 * i;           // 0..1023
+                const int row = e >> 3, kq = e & 7;    // k = k0 + 4 kq .. + 3
                 const int gr = min(r0 + row, R - 1), gc = min(c0 + row, K - 1);
-                const bool kin = k0 + k < D;
-                xs[k][row] = kin ? x[(size_t)gr * D + k0 + k] : 0.f;
-                cs[k][row] = kin ? cb[(size_t)gc * D + k0 + k] : 0.f;
+                f32x4 xv = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
+                const int k = k0 + 4 * kq;
+                if (k + 4 <= D && (D & 3) == 0) {
+                    xv = *reinterpret_cast<const f32x4*>(x + (size_t)gr * D + k);
+                    cv = *reinterpret_cast<const f32x4*>(cb + (size_t)gc * D + k);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (k + t < D) { xv[t] = x[(size_t)gr * D + k + t]; cv[t] = cb[(size_t)gc * D + k + t]; }
+                }
+                float* pe = xe + row * VQ_P + 2 * kq;
+                float* po = xo + row * VQ_P + 2 * kq;
+                pe[0] = xv[0]; pe[1] = xv[2]; po[0] = xv[1]; po[1] = xv[3];
+                pe = ce + row * VQ_P + 2 * kq;
+                po = co + row * VQ_P + 2 * kq;
+                pe[0] = cv[0]; pe[1] = cv[2]; po[0] = cv[1]; po[1] = cv[3];
             }
             __syncthreads();
-#pragma unroll 8
-            for (int k = 0; k < 32; ++k) {
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(&xs[k][ty * 4]);
-                const f32x4 cv = *reinterpret_cast<const f32x4*>(&cs[k][tx * 4]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+            for (int q = 0; q < 4; ++q) {              // 4 x (4 k-pairs)
+                f32x4 av[2], bv[2];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(xv[i], cv[j], acc[i][j]);
+                for (int i = 0; i < 2; ++i) {
+                    av[i] = *reinterpret_cast<const f32x4*>(cbase + (wc * 64 + i * 32 + l32) * VQ_P + 4 * q);
+                    bv[i] = *reinterpret_cast<const f32x4*>(xbase + (wr * 64 + i * 32 + l32) * VQ_P + 4 * q);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], bv[j][t], acc[i][j], 0, 0, 0);
             }
         }
-        // distances of this code tile; strict '<' keeps the FIRST minimum (codes ascend within a thread)
+        // distances of this code tile: a lane owns ONE row per row block and visits its codes in ascending order
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int code = c0 + tx * 4 + j;
-            if (code < K) {
-                const float ccj = cc[code];
+        for (int j = 0; j < 2; ++j) {
+            const float xr = xx[wr * 64 + j * 32 + l32];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float dist = __fadd_rn(__fsub_rn(xx[ty * 4 + i], __fmul_rn(2.0f, acc[i][j])), ccj);
-                    if (dist < bd[i]) { bd[i] = dist; bi[i] = code; }
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int code = c0 + wc * 64 + i * 32 + (e >> 2) * 8 + half * 4 + (e & 3);
+                    if (code < K) {
+                        const float dist = __fadd_rn(__fsub_rn(xr, __fmul_rn(2.0f, acc[i][j][e])), cc[code]);
+                        if (dist < bd[j]) { bd[j] = dist; bi[j] = code; }
+                    }
                 }
-            }
         }
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { best_d[ty * 4 + i][tx] = bd[i]; best_i[ty * 4 + i][tx] = bi[i]; }
+    for (int j = 0; j < 2; ++j) {
+        best_d[wr * 64 + j * 32 + l32][wc * 2 + half] = bd[j];
+        best_i[wr * 64 + j * 32 + l32][wc * 2 + half] = bi[j];
+    }
     __syncthreads();
-    if (tid < 64 && r0 + tid < R) {
+    if (tid < VQ_R && r0 + tid < R) {
         float d0 = best_d[tid][0];
         int i0 = best_i[tid][0];
-        for (int t = 1; t < 16; ++t) {
+        for (int t = 1; t < 4; ++t) {
             const float dt = best_d[tid][t];
             const int it = best_i[tid][t];
             if (dt < d0 || (dt == d0 && it < i0)) { d0 = dt; i0 = it; }
@@ -124,7 +166,8 @@ hipError_t launch_vq_argmin(const float* x, const float* codebook, float* cc_scr
     hipLaunchKernelGGL(row_sqnorm_kernel, dim3((K + 3) / 4), dim3(256), 0, s, codebook, cc_scratch, K, D);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(vq_argmin_kernel, dim3((R + 63) / 64), dim3(256), 0, s, x, codebook, cc_scratch, idx, R, K, D);
+    hipLaunchKernelGGL(vq_argmin_mfma_kernel, dim3((R + VQ_R - 1) / VQ_R), dim3(256), 0, s, x, codebook, cc_scratch, idx, R,
+                       K, D);
     return hipGetLastError();
 }
 

@@ -44,8 +44,8 @@ enum { GF_RELAXED_WAIT = 1,        // tile-start wait skips over the previous ti
        GF_WIDE_PHASE = 256,        // gemm256: 32 MFMAs per barrier pair, LDS reads retired before the barrier
        GF_DIAG_SMALL_OUT = 512,    // DIAGNOSTIC (wrong results): every tile stores into rows 0..255 (stays in L2)
        GF_SLOW_EPILOGUE = 1024,    // A/B: never take the specialised straight-line epilogue (was: RoPE table loads A/B, retired)
-       GF_PP_PARITY = 2048,        // gemm_pp A/B: the late-starting workgroups are the odd blockIdx (default: second LDS allocation of the CU)
-       GF_PP_NO_STAGGER = 4096 };  // gemm_pp A/B: no phase offset between the two workgroups of a CU
+       GF_TN_TWO_BUFFER = 2048,    // gemm_tn.hip A/B: the first (two-buffer) weight-gradient kernel
+       GF_PP_PARITY = 8192 };      // gemm_pp with pp_stagger > 0: the late-starting workgroups are the odd blockIdx (default: second LDS allocation of the CU)
 
 // Tile order.  An XCD (private 4 MiB L2) receives a contiguous range of the linear tile index (xcd_remap); within it
 // the tiles run down M inside a SUPER-COLUMN of `G` column tiles, so the tiles an XCD works on at one time are a
