@@ -10,8 +10,8 @@ import json
 import sys
 
 CLASSES = [("gemm_gated_mlp", "gemm256_kernel<3"), ("gemm_qkv_rope", "gemm256_kernel<2"), ("gemm_fc2", "gemm192_kernel<1"),
-           ("gemm_d_x_d_q", "gemm128_kernel<0"), ("gemm_d_x_d_out", "gemm128_kernel<1"), ("attn_self", "attn64v2_kernel<true"),
-           ("attn_cross", "attn64v2_kernel<false"), ("layernorm", "ln_kernel<3, 0>")]
+           ("gemm_q_proj", "gemm192_kernel<0"), ("gemm_out_proj", "gemm_pp_kernel<1"), ("gemm_final", "gemm192_kernel<4"),
+           ("attn_self", "attn64v2_kernel<true"), ("attn_cross", "attn64v2_kernel<false"), ("layernorm", "ln_kernel<3, 0>")]
 
 
 def avg(path, counter):

@@ -1,0 +1,31 @@
+#!/bin/bash
+# All rocprofv3 passes the judge reads, on the GPU box (run through gpurun):  tools/profile_round.sh r02_v1
+#   1. --kernel-trace --stats (+ a marker-trace run with DITTO_ROCTX=1: roctx ranges per kernel class)
+#   2. --pmc FETCH_SIZE, 3. --pmc WRITE_SIZE (separate passes), 4. --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES
+# Counter passes carry NO trace flags (gpurun refuses the combination); the program follows `--` directly.
+set -u
+TAG=$1
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+BENCH="python3 bench.py --no-cpu-baseline --profile-steps 0 --loops 0 --no-sweep --no-c3"
+python bench.py > $OUT/bench.json 2> $OUT/bench.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $BENCH --steps 10 --warmup 2 > $OUT/kt.log 2>&1
+DITTO_ROCTX=1 timeout 600 rocprofv3 --kernel-trace --marker-trace --output-format csv -d $OUT/mk -o mk -- $BENCH --steps 2 --warmup 1 > $OUT/mk.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o p -- $BENCH --steps 2 --warmup 1 > $OUT/pmc_$c.log 2>&1
+done
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --output-format csv -d $OUT/pmc_mfma -o p -- $BENCH --steps 2 --warmup 1 > $OUT/pmc_mfma.log 2>&1
+find $OUT -name "*.csv" | head -40
+# keep only what is small enough to come back (<= 64 MiB merged): the stats csv, the counter csvs, the marker csv
+mkdir -p $OUT/keep
+cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/keep/${TAG}_kernel_stats.csv 2>/dev/null
+cp $(find $OUT/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) $OUT/keep/${TAG}_pmc_FETCH_SIZE.csv 2>/dev/null
+cp $(find $OUT/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) $OUT/keep/${TAG}_pmc_WRITE_SIZE.csv 2>/dev/null
+cp $(find $OUT/pmc_mfma -name "*counter_collection.csv" | head -1) $OUT/keep/${TAG}_pmc_mfma.csv 2>/dev/null
+cp $(find $OUT/mk -name "*marker_api_trace.csv" | head -1) $OUT/keep/${TAG}_marker_trace.csv 2>/dev/null
+cp $OUT/bench.json $OUT/keep/${TAG}_bench.json
+python tools/pmc_traffic.py $OUT/keep/${TAG}_pmc_FETCH_SIZE.csv $OUT/keep/${TAG}_pmc_WRITE_SIZE.csv $OUT/keep/${TAG}_pmc_traffic.json > /dev/null
+python tools/pmc_mfma.py $OUT/keep/${TAG}_pmc_mfma.csv > $OUT/keep/${TAG}_mfma_busy.txt
+rm -rf $OUT/kt $OUT/mk $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_mfma
+ls -la $OUT/keep; head -12 $OUT/keep/${TAG}_mfma_busy.txt; head -8 $OUT/keep/${TAG}_kernel_stats.csv | cut -c1-150
