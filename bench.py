@@ -63,6 +63,10 @@ def parse():
     ap.add_argument("--no-sweep", action="store_true", help="skip the B in {1, 8, 32} sweep (N = 1 only)")
     ap.add_argument("--global-batch", type=int, default=256, help="C3 strong-scaling point: utterances held by rank 0")
     ap.add_argument("--no-c3", action="store_true", help="skip the C3 strong-scaling point")
+    ap.add_argument("--noise", choices=["seeded", "torch"], default="seeded",
+                    help="the step's N(0,1) draw: 'seeded' = the library's per-utterance counter-based generator inside the "
+                         "update kernel (ditto_p_sample_seeded: what batch-sharded sampling uses, independent of the world "
+                         "size); 'torch' = torch's generator filling a noise tensor (the reference's randn_like)")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="off",
                     help="replay the step from a HIP graph.  Measured: no gain at B = 1 / 8 (2.35 / 4.59 ms per step "
                          "either way: small batches are bound by per-kernel latency on sparse grids, not by launches)")
@@ -216,8 +220,11 @@ def cpu_baseline(cfg, N, T):
 class StepRunner:
     """One (model, B) working set: state, noise, t, conditioning, and the step function of the timed region."""
 
-    def __init__(self, eng, sg, cfg, B, N, T, dev, seed, use_graph=False):
+    def __init__(self, eng, sg, cfg, B, N, T, dev, seed, use_graph=False, seeded=True):
         self.eng, self.sg, self.cfg, self.B, self.N, self.T, self.dev = eng, sg, cfg, B, N, T, dev
+        self.seeded = seeded and not use_graph          # the step index is a kernel argument: not replayable from a graph
+        self.seeds = torch.arange(B, device=dev, dtype=torch.long) + 7919 * seed
+        self.batches = 0
         self.S = cfg.diffusion_steps
         self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(seed)
@@ -231,12 +238,21 @@ class StepRunner:
         k = i % self.S
         sg, eng = self.sg, self.eng
         if k == 0 or self.cond is None:       # new utterance batch: x_T and the step-invariant text work
-            self.x.normal_(generator=self.gen)
+            self.batches += 1
+            if self.seeded:
+                self.seeds += self.B               # new utterances, new seeds
+                eng.noise_normal_(self.x, self.seeds, 0xFFFFFFFF)
+            else:
+                self.x.normal_(generator=self.gen)
             if self.cond is None:
                 self.cond = eng.prepare_text(self.text, self.N)
             else:                              # same buffers (a graph is bound to them), new contents
                 eng.prepare_text_into(self.text, self.N, self.cond)
         self.t.fill_(self.S - 1 - k)
+        if self.seeded:                       # the step's N(0,1) draw happens inside the update kernel
+            eng.p_sample_seeded_(self.x, self.cond, self.t, self.seeds, self.S - 1 - k, sg.betas, sg.alphas,
+                                 sg.alphas_cumprod)
+            return
         self.z.normal_(generator=self.gen)    # the step's N(0,1) draw (reference: randn_like per step)
         if self.use_graph and not eager:
             if self.graph is None:
@@ -298,7 +314,7 @@ def main():
     eng = model.engine(dev)
 
     use_graph = args.graph == "on" or (args.graph == "auto" and B * N <= 8192)
-    main_run = StepRunner(eng, sg, cfg, B, N, T, dev, 1000 + rank, use_graph)
+    main_run = StepRunner(eng, sg, cfg, B, N, T, dev, 1000 + rank, use_graph, args.noise == "seeded")
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -374,7 +390,7 @@ def main():
                 if b == B:
                     ms = sorted(loop_ms)[len(loop_ms) // 2] if loop_ms else elapsed / args.steps * 1e3
                 else:
-                    r = StepRunner(eng, sg, cfg, b, N, T, dev, 2000 + b, use_graph)
+                    r = StepRunner(eng, sg, cfg, b, N, T, dev, 2000 + b, use_graph, args.noise == "seeded")
                     r.run(0, 5)
                     torch.cuda.synchronize(dev)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -397,25 +413,22 @@ def main():
             gen.manual_seed(77)
             text_full = torch.randn(G, T, cfg.text_dim, device=dev, generator=gen) if rank == 0 else None
             xT_full = torch.randn(G, N, cfg.hidden_dim, device=dev, generator=gen) if rank == 0 else None
-            zgen = torch.Generator(device=dev)
 
             def shard_loop(text_s, x_s, first):
-                """The 50-step loop over this rank's shard, micro-batches of `mb` utterances; per-step noise from a
-                generator seeded by the micro-batch's first GLOBAL utterance index (independent of the world size
-                whenever the shards are whole micro-batches, as at 256 / {1, 2, 4, 8})."""
+                """The 50-step loop over this rank's shard, micro-batches of `mb` utterances; every step's noise comes from
+                the per-utterance generator keyed by the GLOBAL utterance index (ditto_p_sample_seeded), so the gathered
+                latents are the same bits at every world size."""
                 out = torch.empty_like(x_s)
-                z = torch.empty(mb, N, cfg.hidden_dim, device=dev)
                 tt = torch.empty(mb, device=dev, dtype=torch.long)
                 for a in range(0, x_s.shape[0], mb):
                     b_ = min(a + mb, x_s.shape[0])
                     n = b_ - a
-                    zgen.manual_seed(5000 + first + a)
+                    seeds = torch.arange(first + a, first + b_, device=dev, dtype=torch.long) + 5000
                     x = x_s[a:b_].clone()
                     cond = eng.prepare_text(text_s[a:b_], N)
                     for t_val in reversed(range(S)):
                         tt[:n].fill_(t_val)
-                        z[:n].normal_(generator=zgen)
-                        eng.p_sample_(x, cond, tt[:n], z[:n], sg.betas, sg.alphas, sg.alphas_cumprod)
+                        eng.p_sample_seeded_(x, cond, tt[:n], seeds, t_val, sg.betas, sg.alphas, sg.alphas_cumprod)
                     out[a:b_] = x
                 return out
 
@@ -429,13 +442,16 @@ def main():
             dist.barrier()
             total = max_over_ranks(total)
             ph = {k: max_over_ranks(v) for k, v in sorted(phases.items())}
-            ok = True
+            ok, digest = True, None
             if rank == 0:
                 ok = bool(torch.isfinite(lat).all().item()) and tuple(lat.shape) == (G, N, cfg.hidden_dim)
+                # a world-size-independent fingerprint of the gathered latents (same value at N = 1, 2, 4, 8 <=> sharding
+                # changed no bit): the sum of the fp32 bit patterns, mod 2^63
+                digest = int(lat.view(torch.int32).to(torch.int64).sum().item() & 0x7FFFFFFFFFFFFFFF)
             c3 = {"global_batch": G, "micro_batch": mb, "steps": S, "scaling": "strong", "n_gpus": world,
                   "value": G * S / total, "unit": "utterance-steps/s", "total_s": total, **ph,
                   "comm_bytes_per_peer": (G // world) * (T * cfg.text_dim + 2 * N * cfg.hidden_dim) * 4 if world > 1 else 0,
-                  "latents_finite_and_complete": ok,
+                  "latents_finite_and_complete": ok, "latents_digest": digest,
                   "note": "scatter (text fp32 + x_T fp32, grouped RCCL send/recv) and gather (latents fp32) are inside "
                           "total_s; phase figures are the max over ranks"}
             del text_full, xT_full, lat
@@ -461,7 +477,8 @@ def main():
                                    f"B={B} utterances per GPU, text K/V cached per utterance batch",
                        "batch_per_gpu": B, "global_batch": B * world, "latent_len": N, "text_len": T,
                        "parallelism": f"batch-parallel x{world}, weights replicated, no data-path collective",
-                       "hip_graph": bool(use_graph)},
+                       "hip_graph": bool(use_graph),
+                       "noise": "per-utterance Philox4x32-10 inside the update kernel" if main_run.seeded else "torch generator -> noise tensor"},
             "step_tflops_per_gpu": step_tflops, "step_frac_of_mfma_peak": step_frac,
             "loops": {"n": len(loop_ms), "timer": "HIP events on the compute stream, max over ranks",
                       "ms_per_step": loop_ms,

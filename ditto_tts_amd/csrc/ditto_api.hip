@@ -589,6 +589,33 @@ int ditto_p_sample(ditto_model_t m, float* x, const void* cond, const int64_t* t
                                  (size_t)N * m->cfg.hidden_dim, stream);
 }
 
+int ditto_noise_normal(float* out, const int64_t* seeds, uint32_t step, int B, size_t elems_per_utt,
+                       ditto_stream_t stream) {
+    if (!out || !seeds || B <= 0 || elems_per_utt == 0) return fail(DITTO_ERR_ARG, "bad argument to ditto_noise_normal");
+    if (elems_per_utt % 4) return fail(DITTO_ERR_SHAPE, "elems_per_utt must be a multiple of 4");
+    HIP_TRY(launch_noise_normal(out, seeds, step, B, elems_per_utt, (hipStream_t)stream));
+    return DITTO_OK;
+}
+
+int ditto_p_sample_seeded(ditto_model_t m, float* x, const void* cond, const int64_t* t, const int64_t* seeds,
+                          uint32_t step, const float* betas, const float* alphas, const float* alphas_cumprod, int B,
+                          int N, int T, const float* rope_cos, const float* rope_sin, void* workspace,
+                          size_t workspace_bytes, ditto_stream_t stream) {
+    if (!m || !workspace || !seeds || !betas || !alphas || !alphas_cumprod)
+        return fail(DITTO_ERR_ARG, "bad argument to ditto_p_sample_seeded");
+    const WsPlan w = plan_ws(m->cfg, B, N, T);
+    if (workspace_bytes < w.total) return fail(DITTO_ERR_SIZE, "workspace too small: %zu < %zu", workspace_bytes, w.total);
+    float* eps = (float*)((char*)workspace + w.eps);
+    if (int rc = ditto_forward(m, x, cond, t, B, N, T, rope_cos, rope_sin, eps, workspace, workspace_bytes, stream))
+        return rc;
+    ProfScope ps(m, (hipStream_t)stream, DITTO_KC_UPDATE);
+    const size_t per = (size_t)N * m->cfg.hidden_dim;
+    if (per % 4) return fail(DITTO_ERR_SHAPE, "elems_per_utt must be a multiple of 4");
+    HIP_TRY(launch_p_sample_update_seeded(x, eps, seeds, step, t, betas, alphas, alphas_cumprod, B, per,
+                                          (hipStream_t)stream));
+    return DITTO_OK;
+}
+
 int ditto_denoise_steps(ditto_model_t m, float* x, const void* cond, int t_begin, int t_end, const float* noise,
                         const float* betas, const float* alphas, const float* alphas_cumprod, int B, int N, int T,
                         const float* rope_cos, const float* rope_sin, int64_t* t_scratch, void* workspace,

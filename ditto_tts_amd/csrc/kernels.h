@@ -29,6 +29,11 @@ hipError_t launch_splitk_finish(const float* partial, int nsplit, size_t stride,
 hipError_t launch_p_sample_update(float* x, const float* eps, const float* noise, const int64_t* t,
                                   const float* betas, const float* alphas, const float* acp, int B,
                                   size_t elems_per_utt, hipStream_t s);
+// Philox4x32-10 + Box-Muller N(0,1) keyed by per-utterance seeds (rowwise.hip): out[b, i] = f(seeds[b], step, i)
+hipError_t launch_noise_normal(float* out, const int64_t* seeds, unsigned step, int B, size_t elems_per_utt, hipStream_t s);
+hipError_t launch_p_sample_update_seeded(float* x, const float* eps, const int64_t* seeds, unsigned step, const int64_t* t,
+                                         const float* betas, const float* alphas, const float* acp, int B,
+                                         size_t elems_per_utt, hipStream_t s);
 hipError_t launch_q_sample(const float* x0, const float* noise, const int64_t* t, const float* buffer, float* out,
                            int B, size_t elems_per_utt, hipStream_t s);
 // ttab[step, 0:2d] = time_mlp(time_embed(t_embedding[step]))

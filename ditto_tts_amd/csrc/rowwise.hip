@@ -261,6 +261,100 @@ hipError_t launch_p_sample_update(float* x, const float* eps, const float* noise
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Per-utterance counter-based N(0,1): Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3",
+// SC'11; the Random123 constants) keyed by the utterance's 64-bit seed, counter = (element quad, step, stream), then
+// Box-Muller on the four 32-bit words.  Element i of utterance b at step s depends on (seed[b], s, i) ONLY — not on
+// the batch the utterance sits in, its position in it, or the GPU: what makes batch-sharded sampling reproduce the
+// unsharded result bit for bit.  The reference draws from torch's global generator
+// (src/model/SpeechGenerator.py:141,154), whose stream cannot be sharded; that path stays the default.
+// ------------------------------------------------------------------------------------------------
+DITTO_DEV void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&o)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+// four N(0,1) of (seed, step, quad index): u = (word + 0.5) 2^-32 in (0,1); r = sqrt(-2 ln u1); angle = 2 pi u2
+DITTO_DEV f32x4 normal4(unsigned long long seed, unsigned step, unsigned long long quad) {
+    unsigned w[4];
+    philox4x32_10((unsigned)quad, (unsigned)(quad >> 32), step, 0x44695454u /* "DiTT" */, (unsigned)seed,
+                  (unsigned)(seed >> 32), w);
+    f32x4 z;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float u1 = ((float)(w[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);        // 24 bits: exact in fp32, never 0 or 1
+        const float u2 = ((float)(w[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float r = __fsqrt_rn(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // -2 ln u = -2 ln2 log2 u
+        z[2 * h] = r * __builtin_amdgcn_cosf(u2);                                        // v_cos / v_sin take revolutions
+        z[2 * h + 1] = r * __builtin_amdgcn_sinf(u2);
+    }
+    return z;
+}
+__global__ __launch_bounds__(256) void noise_normal_kernel(float* __restrict__ out, const int64_t* __restrict__ seeds,
+                                                           unsigned step, size_t n4_per_utt) {
+    const int b = blockIdx.y;
+    const unsigned long long seed = (unsigned long long)seeds[b];
+    const size_t base = (size_t)b * n4_per_utt;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4_per_utt; i += (size_t)gridDim.x * blockDim.x)
+        reinterpret_cast<f32x4*>(out)[base + i] = normal4(seed, step, i);
+}
+hipError_t launch_noise_normal(float* out, const int64_t* seeds, unsigned step, int B, size_t elems_per_utt, hipStream_t s) {
+    if (elems_per_utt % 4) return hipErrorInvalidValue;
+    const size_t n4 = elems_per_utt / 4;
+    size_t gx = (n4 + 255) / 256;
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(noise_normal_kernel, dim3((unsigned)gx, B), dim3(256), 0, s, out, seeds, step, n4);
+    return hipGetLastError();
+}
+// the DDPM update with the step's noise generated in registers (no z buffer: 2 x 4 bytes per element less HBM traffic,
+// one launch less); the noise of utterance b is normal4(seeds[b], step, .), i.e. exactly what launch_noise_normal
+// would have written
+__global__ __launch_bounds__(256) void p_sample_update_seeded_kernel(float* __restrict__ x, const float* __restrict__ eps,
+                                                                     const int64_t* __restrict__ seeds, unsigned step,
+                                                                     const int64_t* __restrict__ t,
+                                                                     const float* __restrict__ betas,
+                                                                     const float* __restrict__ alphas,
+                                                                     const float* __restrict__ acp, size_t n4_per_utt) {
+    const int b = blockIdx.y;
+    const long long ts = t[b];
+    const float beta = betas[ts], alpha = alphas[ts], ac = acp[ts];
+    const float inv_sqrt_alpha = __fdiv_rn(1.0f, __fsqrt_rn(alpha));
+    const float c_eps = __fdiv_rn(__fsub_rn(1.0f, alpha), __fsqrt_rn(__fsub_rn(1.0f, ac)));
+    const float sigma = (ts > 0 ? 1.0f : 0.0f) * __fsqrt_rn(beta);
+    const unsigned long long seed = (unsigned long long)seeds[b];
+    const size_t base = (size_t)b * n4_per_utt;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4_per_utt;
+         i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 xv = reinterpret_cast<f32x4*>(x)[base + i];
+        const f32x4 ev = reinterpret_cast<const f32x4*>(eps)[base + i];
+        f32x4 zv = {0.f, 0.f, 0.f, 0.f};
+        if (ts > 0) zv = normal4(seed, step, i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float mean = __fmul_rn(inv_sqrt_alpha, __fsub_rn(xv[e], __fmul_rn(c_eps, ev[e])));
+            xv[e] = __fadd_rn(mean, __fmul_rn(sigma, zv[e]));
+        }
+        reinterpret_cast<f32x4*>(x)[base + i] = xv;
+    }
+}
+hipError_t launch_p_sample_update_seeded(float* x, const float* eps, const int64_t* seeds, unsigned step, const int64_t* t,
+                                         const float* betas, const float* alphas, const float* acp, int B,
+                                         size_t elems_per_utt, hipStream_t s) {
+    if (elems_per_utt % 4) return hipErrorInvalidValue;
+    const size_t n4 = elems_per_utt / 4;
+    size_t gx = (n4 + 255) / 256;
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(p_sample_update_seeded_kernel, dim3((unsigned)gx, B), dim3(256), 0, s, x, eps, seeds, step, t, betas,
+                       alphas, acp, n4);
+    return hipGetLastError();
+}
+
 // q_sample, reference src/model/DiTTO.py:106-126 (bug-for-bug: `buffer` holds clipped betas).
 __global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise,
                                                        const int64_t* __restrict__ t,

@@ -196,6 +196,33 @@ class DenoiseEngine:
                                           c.data_ptr(), s.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
         return x
 
+    def noise_normal_(self, out: torch.Tensor, seeds: torch.Tensor, step: int):
+        """out[b] <- N(0,1) of (seeds[b], step): Philox4x32-10 + Box-Muller in libditto_hip (ditto_noise_normal).  A function
+        of the utterance's seed, the step and the element index only — independent of batch composition and GPU."""
+        if not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()):
+            raise ValueError("noise_normal_ needs a contiguous fp32 CUDA tensor")
+        B = out.shape[0]
+        sd = self._t64(seeds, B)
+        hip.check(self.lib.ditto_noise_normal(out.data_ptr(), sd.data_ptr(), int(step) & 0xFFFFFFFF, B,
+                                              out.numel() // B, _stream()))
+        return out
+
+    def p_sample_seeded_(self, x: torch.Tensor, cond: TextCond, t: torch.Tensor, seeds: torch.Tensor, step: int,
+                         betas: torch.Tensor, alphas: torch.Tensor, alphas_cumprod: torch.Tensor):
+        """p_sample_ with the step's noise generated inside the update kernel from per-utterance seeds
+        (bit-identical to noise_normal_(z, seeds, step) + p_sample_(x, ..., z))."""
+        if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()):
+            raise ValueError("p_sample_seeded_ needs a contiguous fp32 CUDA state tensor (it is updated in place)")
+        B, N, d = x.shape
+        tt, sd = self._t64(t, B), self._t64(seeds, B)
+        ws = self.workspace(B, N, cond.T)
+        c, s = self.rope_tables(N)
+        hip.check(self.lib.ditto_p_sample_seeded(self.handle, x.data_ptr(), cond.buf.data_ptr(), tt.data_ptr(),
+                                                 sd.data_ptr(), int(step) & 0xFFFFFFFF, betas.data_ptr(),
+                                                 alphas.data_ptr(), alphas_cumprod.data_ptr(), B, N, cond.T, c.data_ptr(),
+                                                 s.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+        return x
+
     def denoise_steps_(self, x: torch.Tensor, cond: TextCond, t_begin: int, t_end: int, noises: Optional[torch.Tensor],
                        betas: torch.Tensor, alphas: torch.Tensor, alphas_cumprod: torch.Tensor):
         """The sampling loop t_begin .. t_end (inclusive, descending) as ONE library call, in place on x;

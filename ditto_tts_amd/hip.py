@@ -121,6 +121,8 @@ SYMBOLS = {
     "ditto_p_sample_update": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _sz, _vp]),
     "ditto_p_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "ditto_denoise_steps": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ditto_noise_normal": (_i, [_vp, _vp, C.c_uint32, _i, _sz, _vp]),
+    "ditto_p_sample_seeded": (_i, [_vp, _vp, _vp, _vp, _vp, C.c_uint32, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "ditto_q_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _sz, _vp]),
     "ditto_layernorm_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "ditto_gemm_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

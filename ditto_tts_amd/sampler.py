@@ -114,11 +114,16 @@ class SpeechGenerator:
 
     @torch.no_grad()
     def __sample_latents(self, text_emb, audio_emb, text_prompt=None, audio=None, is_slp=False, cond_by_audio=False,
-                         noises=None, keep=None, use_graph=None):
+                         noises=None, keep=None, use_graph=None, seeds=None):
         """All reverse diffusion steps (reference :149-164).
 
         `noises` (optional): a sequence / callable giving the z of executed step i, for parity tests;
         `keep` (optional): dict filled with {i: state after step i} for the i it already has as keys;
+        `seeds` (optional, int64 [B]): per-utterance seeds.  x_T and every step's z then come from the library's
+        counter-based generator (Philox4x32-10 keyed by the utterance's seed, engine.noise_normal_), generated inside
+        the update kernel: an utterance's trajectory is a function of (seed, text, weights) only — the same bits
+        whatever batch or GPU it is sampled on (dist.sample_sharded).  Default None = the reference's behaviour,
+        torch.randn_like from the global generator;
         `use_graph`: replay the step from a HIP graph (default off: measured no gain even at B = 1, the step is
         bound by per-kernel latency, not by its 122 launches; bit-identical to eager either way)."""
         if is_slp:
@@ -126,8 +131,17 @@ class SpeechGenerator:
                                       "as a tensor shape, SURVEY.md App. B-6); length logits are available from "
                                       "self.slp.decode(z_text, z_audio)")
         m = self.ditto_model
-        x = torch.randn_like(audio_emb) if not cond_by_audio else audio_emb.clone()
-        x = x.to(self.device).float().contiguous()
+        if seeds is not None and (noises is not None or use_graph):
+            raise ValueError("seeds= excludes noises= and use_graph=")
+        if seeds is not None and not cond_by_audio:
+            x = torch.empty(audio_emb.shape, dtype=torch.float32, device=self.device)
+            seeds = seeds.to(self.device).long().contiguous()
+            m.engine(x.device).noise_normal_(x, seeds, 0xFFFFFFFF)        # x_T: step index no loop step uses
+        else:
+            x = torch.randn_like(audio_emb) if not cond_by_audio else audio_emb.clone()
+            x = x.to(self.device).float().contiguous()
+            if seeds is not None:
+                seeds = seeds.to(self.device).long().contiguous()
         eng = m.engine(x.device)
         cond = m.text_cond(text_emb.to(x.device), x.shape[1])
         B = x.shape[0]
@@ -144,6 +158,11 @@ class SpeechGenerator:
             x.copy_(keep_x)
         for i, t_val in enumerate(reversed(range(n_loop))):
             t_tensor.fill_(t_val)
+            if seeds is not None:
+                eng.p_sample_seeded_(x, cond, t_tensor, seeds, t_val, self.betas, self.alphas, self.alphas_cumprod)
+                if keep is not None and i in keep:
+                    keep[i] = x.clone()
+                continue
             if noises is None:
                 z.normal_()                          # same generator stream as randn_like(x)
             else:

@@ -182,6 +182,20 @@ int ditto_denoise_steps(ditto_model_t m, float* x, const void* cond, int t_begin
                         const float* rope_cos, const float* rope_sin, int64_t* t_scratch, void* workspace,
                         size_t workspace_bytes, ditto_stream_t stream);
 
+/* Per-utterance counter-based N(0,1) (no reference counterpart: the reference draws `torch.randn_like` from torch's
+ * global generator, src/model/SpeechGenerator.py:141,154, a stream that cannot be sharded over GPUs).
+ * out[b, i] = Philox4x32-10(key = seeds[b], counter = (i / 4, step, tag)) -> Box-Muller: a function of (seeds[b], step, i)
+ * only, so an utterance's noise does not depend on its batch, its place in it or the GPU it runs on (SURVEY.md 8e:
+ * per-utterance seeds make the sharded result independent of the world size).  seeds int64 [B] (device).
+ * ditto_p_sample_seeded = ditto_p_sample with the step's noise generated inside the update kernel: bit-identical to
+ * ditto_noise_normal(step) followed by ditto_p_sample(noise), without the noise buffer. */
+int ditto_noise_normal(float* out, const int64_t* seeds, uint32_t step, int B, size_t elems_per_utt,
+                       ditto_stream_t stream);
+int ditto_p_sample_seeded(ditto_model_t m, float* x, const void* cond, const int64_t* t, const int64_t* seeds,
+                          uint32_t step, const float* betas, const float* alphas, const float* alphas_cumprod, int B,
+                          int N, int T, const float* rope_cos, const float* rope_sin, void* workspace,
+                          size_t workspace_bytes, ditto_stream_t stream);
+
 /* DiTTO.q_sample (src/model/DiTTO.py:106-126), bug-for-bug: `buffer` is the module's
  * `alphas_cumprod` buffer, which holds clipped betas.  out may alias x_start. */
 int ditto_q_sample(const float* x_start, const float* noise, const int64_t* t, const float* buffer,

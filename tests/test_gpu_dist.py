@@ -90,13 +90,20 @@ def _rccl_worker(rank, world, port, q):
             with torch.no_grad():
                 return sg._SpeechGenerator__sample_latents(text_shard, x_shard, cond_by_audio=True, noises=noises)
 
+        def fn_seeded(text_shard, x_shard, first):       # per-utterance seeds = global utterance index: no noise tensors at all
+            seeds = torch.arange(first, first + x_shard.shape[0], device=dev) + 1000
+            with torch.no_grad():
+                return sg._SpeechGenerator__sample_latents(text_shard, x_shard, seeds=seeds)
+
         phases = {}
         got = sample_sharded(fn, text, xT, (T, 256), (N, 256), dev, phases=phases,
                              sync=lambda: torch.cuda.synchronize(dev))
         assert set(phases) == {"scatter_s", "loop_s", "gather_s"}
+        got2 = sample_sharded(fn_seeded, text, xT, (T, 256), (N, 256), dev)
         if rank == 0:
-            want = fn(text, xT, 0)
-            q.put((bool(torch.equal(got, want)), bool(torch.isfinite(got).all()), tuple(got.shape)))
+            want, want2 = fn(text, xT, 0), fn_seeded(text, xT, 0)
+            q.put((bool(torch.equal(got, want)) and bool(torch.equal(got2, want2)), bool(torch.isfinite(got).all()),
+                   tuple(got.shape)))
     finally:
         dist.destroy_process_group()
 

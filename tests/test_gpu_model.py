@@ -461,3 +461,43 @@ def test_low_latency_split_k_mode():
         hip.set_low_latency(False)
     assert torch.equal(m(xd, td, tt), base4) and torch.equal(m(xd[:1], td[:1], tt[:1]), base1)
     assert lib.ditto_set_option(b"splitk_wgs", -1) == hip.ERR_ARG
+
+
+@torch.no_grad()
+def test_per_utterance_seeded_noise_and_sampling():
+    """ditto_noise_normal / ditto_p_sample_seeded (the W-independent noise of SURVEY.md 8e): device values against the
+    numpy Philox4x32-10 + Box-Muller restatement (pinned by Random123's known-answer vectors on CPU); the fused seeded step
+    == explicit noise + step, bitwise; a seeded sampling loop gives an utterance the same bits whatever batch it is in."""
+    import numpy as np
+    from oracle.philox import noise_normal
+    cfg = DiTTOConfig(128, 2, 2, 64, 128, 12)
+    m = build(cfg, 7)
+    sg = SpeechGenerator(ditto_model=m, device=DEV)
+    eng = m.engine()
+    B, N, T = 3, 40, 24
+    seeds = torch.tensor([11, 0x7FFFFFFFFFFFFFF0, 123456789012345], dtype=torch.long, device=DEV)
+    z = torch.empty(B, N, 128, device=DEV)
+    eng.noise_normal_(z, seeds, 5)
+    for b in range(B):
+        want = noise_normal(int(seeds[b]), 5, N * 128)
+        got = z[b].flatten().cpu().double().numpy()
+        assert np.abs(got - want).max() < 2e-4, f"utterance {b}: {np.abs(got - want).max():.2e}"
+    assert abs(float(z.mean())) < 0.05 and abs(float(z.std()) - 1) < 0.05
+    # fused == explicit, bitwise
+    x, text, _ = synthetic_inputs(cfg, B, N, T, seed=3)
+    cond = eng.prepare_text(text.to(DEV), N)
+    t = torch.full((B,), 5, device=DEV, dtype=torch.long)
+    a, b_ = x.to(DEV).clone(), x.to(DEV).clone()
+    eng.p_sample_seeded_(a, cond, t, seeds, 5, sg.betas, sg.alphas, sg.alphas_cumprod)
+    eng.p_sample_(b_, cond, t, z, sg.betas, sg.alphas, sg.alphas_cumprod)
+    assert torch.equal(a, b_)
+    # seeded loop: shard invariance [3] == [2] + [1], and a different seed changes the result
+    full = sg._SpeechGenerator__sample_latents(text.to(DEV), x.to(DEV), seeds=seeds)
+    assert torch.isfinite(full).all()
+    for lo, hi in ((0, 2), (2, 3)):
+        part = sg._SpeechGenerator__sample_latents(text[lo:hi].to(DEV), x[lo:hi].to(DEV), seeds=seeds[lo:hi])
+        assert torch.equal(part, full[lo:hi])
+    other = sg._SpeechGenerator__sample_latents(text[:1].to(DEV), x[:1].to(DEV), seeds=seeds[:1] + 1)
+    assert not torch.equal(other, full[:1])
+    with pytest.raises(ValueError, match="excludes"):
+        sg._SpeechGenerator__sample_latents(text.to(DEV), x.to(DEV), seeds=seeds, noises=lambda i: z)

@@ -146,3 +146,21 @@ def test_slp_oracle_matches_torch_transformer_decoder_live():
         want = dec(z_audio, z_text, tgt_mask=torch.triu(torch.ones(S, S), diagonal=1).bool())
     _, decoded = O.slp_decode(sd, nl, nhead, z_text, z_audio)
     assert rel_l2(decoded, want) < RTOL
+
+
+def test_philox_known_answer_vectors():
+    """The counter-based generator behind ditto_noise_normal is Philox4x32-10; oracle/philox.py (its numpy restatement,
+    used by the GPU tests as the checker) is pinned by Random123's published known-answer vectors."""
+    import numpy as np
+    from oracle.philox import noise_normal, philox4x32_10
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = tuple(int(v) for v in philox4x32_10(*[np.uint32(x) for x in ctr], *[np.uint32(x) for x in key]))
+        assert got == want
+    z = noise_normal(0x1234567890ABCDEF, 17, 1 << 18)
+    assert abs(z.mean()) < 1e-2 and abs(z.std() - 1.0) < 1e-2 and np.isfinite(z).all()
+    assert not np.array_equal(z, noise_normal(0x1234567890ABCDEF, 18, 1 << 18))         # the step is part of the counter
+    assert not np.array_equal(z[:64], noise_normal(0x1234567890ABCDEE, 17, 64))          # the seed is the key
