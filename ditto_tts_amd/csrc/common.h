@@ -70,7 +70,7 @@ DITTO_DEV float fast_gelu_erf(float x) {
 // with the no-epilogue diagnostic), the four transcendentals per pair stay scalar.  Same formulas as the scalar forms.
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 // The same formulas with the scalings folded and the sign handled by |x| source modifiers (23 VALU per pair instead of
-// 29; the gated epilogue is issue-bound at 1 750 instructions per wave per tile, DESIGN.md §8):
+// 29; the gated epilogue is issue-bound at 1 750 instructions per wave per tile, DESIGN.md §4.1 / §9):
 //     gelu(x) sigmoid(g) = (x + |x| erf(|x|/sqrt2)) * 1 / (2 + 2 e^-g)
 //     erf(|z|) = 1 - poly(t) e^(-x^2/2),   t = 1 / (1 + (p/sqrt2) |x|)          (A&S 7.1.26, as fast_gelu_erf)
 DITTO_DEV f32x2 fast_gelu_sigmoid2(f32x2 x, f32x2 g) {
