@@ -43,7 +43,7 @@ namespace {
 constexpr int HALF_BYTES = 128 * 64 * 2;  // 16 KiB
 constexpr int KT_BYTES = 4 * HALF_BYTES;  // 64 KiB: A_lo | A_hi | B_lo | B_hi
 constexpr int LDS256 = 2 * KT_BYTES;      // 128 KiB
-constexpr int LDS256_ALLOC = LDS256 + 2 * 1024;   // + two bias rows (256 fp32 each, double-buffered by tile)
+constexpr int LDS256_ALLOC = LDS256 + 4 * 1024;   // + two (bias row, fp8 weight-scale row) pairs of 256 fp32, double-buffered by tile
 
 template <int V>
 struct IC { static constexpr int value = V; };
@@ -103,7 +103,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         if (wid == 0 && p.bias) {   // this tile's bias row -> LDS (read by its FAST epilogue); columns past N are clamped, unused
             int c = n0 + lane * 4;
             c = c + 4 <= p.N ? c : 0;
-            glds16(p.bias + c, lds_base + (unsigned)(LDS256 + bias_slot * 1024));
+            glds16(p.bias + c, lds_base + (unsigned)(LDS256 + bias_slot * 2048));
+        }
+        if constexpr (FP8) {
+            if (wid == 1 && p.wscale) {   // fp8: the per-output-column weight scales of the tile, same route
+                int c = n0 + lane * 4;
+                c = c + 4 <= p.N ? c : 0;
+                glds16(p.wscale + c, lds_base + (unsigned)(LDS256 + bias_slot * 2048 + 1024));
+            }
         }
         stage(0, IC<2>{}, 0);
         stage(0, IC<3>{}, 0);
@@ -367,7 +374,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         // the oldest load of the prologue), so the epilogue reads them with ds_read and contains no global load at all.
         // (As compiler-visible global loads issued after the next tile's prologue DMA they made hipcc open every
         // epilogue with s_waitcnt vmcnt(0): each tile's epilogue began by waiting for the next tile's first K-tiles.)
-        const bool fast_epi = !FP8 && epilogue_fast_ok<EPI>(p, cur_m0, cur_n0, 256, 256) && !(p.flags & GF_DIAG_NO_EPILOGUE);
+        const bool fast_epi = epilogue_fast_ok<EPI>(p, cur_m0, cur_n0, 256, 256) && !(p.flags & GF_DIAG_NO_EPILOGUE) &&
+                              (!FP8 || p.wscale);
         const unsigned cur_bias_slot = bias_slot;
         if (next < ntiles) prologue(next);
         // ---------------- epilogue ----------------
@@ -384,7 +392,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         if (fast_epi) {
 #pragma unroll
             for (int n = 0; n < 4; ++n)
-                bias4[n] = *reinterpret_cast<const f32x4*>(smem + LDS256 + cur_bias_slot * 1024 + (wn * 64 + n * 16 + fq * 4) * 4);
+                bias4[n] = *reinterpret_cast<const f32x4*>(smem + LDS256 + cur_bias_slot * 2048 + (wn * 64 + n * 16 + fq * 4) * 4);
         } else {
             load_bias(p, cur_n0 + wn * 64, fq, bias4);
         }
@@ -394,7 +402,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             for (int n = 0; n < 4; ++n) {
                 const int c = cur_n0 + wn * 64 + n * 16 + fq * 4;
                 ws4[n] = f32x4{1.f, 1.f, 1.f, 1.f};
-                if (p.wscale && c < p.N) ws4[n] = *reinterpret_cast<const f32x4*>(p.wscale + c);
+                if (fast_epi)
+                    ws4[n] = *reinterpret_cast<const f32x4*>(smem + LDS256 + cur_bias_slot * 2048 + 1024 + (wn * 64 + n * 16 + fq * 4) * 4);
+                else if (p.wscale && c < p.N) ws4[n] = *reinterpret_cast<const f32x4*>(p.wscale + c);
             }
 #pragma unroll
             for (int m = 0; m < 8; ++m)
