@@ -814,6 +814,11 @@ int ditto_set_option(const char* name, int value) {
         g_pp_mask = value;
         return DITTO_OK;
     }
+    if (!strcmp(name, "pp_nb")) {
+        if (value != 0 && value != 3 && value != 4) return fail(DITTO_ERR_ARG, "pp_nb must be 0 (rule), 3 (192-wide tiles) or 4 (256-wide)");
+        g_pp_nb = value;
+        return DITTO_OK;
+    }
     if (!strcmp(name, "pp_stagger")) {
         if (value < -1 || value > 100000) return fail(DITTO_ERR_ARG, "pp_stagger must be in [-1, 100000] (10 ns ticks; -1 = rule)");
         g_pp_stagger = value;

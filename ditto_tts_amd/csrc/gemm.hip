@@ -35,6 +35,7 @@ namespace ditto {
 int g_gemm_flags = GF_RELAXED_WAIT | GF_STORE_NT | GF_WIDE_PHASE;
 int g_gemm_group = 0;
 int g_pp_stagger = -1;
+int g_pp_nb = 0;
 int g_pp_mask = [] { const char* e = getenv("DITTO_PP_MASK"); return e ? atoi(e) : -1; }();   // -1 = built-in rule
 int g_gemm_tile = [] { const char* e = getenv("DITTO_GEMM"); return e ? atoi(e) : 0; }();
 

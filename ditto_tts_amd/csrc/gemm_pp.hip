@@ -33,17 +33,27 @@ namespace ditto {
 
 namespace {
 
-constexpr int PM = 128, PN = 256, PK = 32;
+constexpr int PM = 128, PK = 32;
 constexpr int P_A_BYTES = PM * PK * 2;            // 8 KiB
-constexpr int P_W_BYTES = PN * PK * 2;            // 16 KiB
-constexpr int P_STAGE = P_A_BYTES + P_W_BYTES;    // 24 KiB
 constexpr int P_NSTAGE = 3;
-constexpr int P_LDS = P_NSTAGE * P_STAGE;         // 72 KiB
+// NB = 16-column blocks per wave: 4 -> 128 x 256 tiles (every epilogue), 3 -> 128 x 192 tiles (the plain epilogues; at
+// N = 768 and M = 32768 that is 1024 tiles = exactly two per workgroup slot, where 256-wide tiles make 1.5 rounds)
+template <int NB> struct PP {
+    static constexpr int PN = 64 * NB;
+    static constexpr int W_BYTES = PN * PK * 2;               // 16 / 12 KiB
+    static constexpr int STAGE = P_A_BYTES + W_BYTES;         // 24 / 20 KiB
+    static constexpr int LDS = P_NSTAGE * STAGE;              // 72 / 60 KiB
+    static constexpr int PIECES = STAGE / 1024;               // 24 / 20
+    static constexpr int PER_WAVE = PIECES / 4;               // 6 / 5
+};
 
 #define PP_BAR() asm volatile("s_barrier" ::: "memory")
 
-template <int EPI>
+template <int EPI, int NB>
 __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(GemmParams p) {
+    constexpr int PN = PP<NB>::PN, P_STAGE = PP<NB>::STAGE, P_LDS = PP<NB>::LDS, NPW = PP<NB>::PER_WAVE;
+    static_assert(NB == 4 || (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_RES_F32 || EPI == EPI_BIAS_F32),
+                  "the RoPE / gated epilogues need 64-column spans");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -66,14 +76,14 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(GemmParams p) {
     //      pieces 6w .. 6w+5.  Address = (A or W + kt * 64 B) [scalar] + this lane's row / chunk offset [voff] ----
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;
     const int prow = lane >> 2, cpos = lane & 3;
-    unsigned voff[6];
+    unsigned voff[NPW];
     auto set_issue_tile = [&](int tile) {
         int tm, tn;
         tile_to_mn(xcd_remap(tile, ntiles), p.tiles_m, p.tiles_n, p.group_n, tm, tn);
         const int m0 = tm * PM, n0 = tn * PN;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int piece = wn * 6 + i;
+        for (int i = 0; i < NPW; ++i) {
+            const int piece = wn * NPW + i;
             const int row = (piece < 8 ? piece : piece - 8) * 16 + prow;
             const int c = cpos ^ ((0 - (row >> 2)) & 3);
             if (piece < 8) {
@@ -92,8 +102,8 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(GemmParams p) {
         const char* abase = (const char*)p.A + (size_t)i_kt * (PK * 2);
         const char* wbase = (const char*)p.W + (size_t)i_kt * (PK * 2);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int piece = wn * 6 + i;
+        for (int i = 0; i < NPW; ++i) {
+            const int piece = wn * NPW + i;
             glds16_so(voff[i], piece < 8 ? abase : wbase, lds_base + i_slot + (unsigned)(piece * 1024));
         }
         i_slot = i_slot + P_STAGE == P_LDS ? 0u : i_slot + P_STAGE;
@@ -109,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(GemmParams p) {
     const int frow = lane & 15, fq = lane >> 4;
     const int coff = (fq ^ ((0 - (frow >> 2)) & 3)) << 4;
     const int a_off = frow * 64 + coff;                                 // + m * 16 * 64
-    const int w_off = P_A_BYTES + (wn * 64 + frow) * 64 + coff;          // + n * 16 * 64
+    const int w_off = P_A_BYTES + (wn * 16 * NB + frow) * 64 + coff;     // + n * 16 * 64
 
     int tile = blockIdx.x;
     if (tile >= ntiles) return;
@@ -119,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(GemmParams p) {
     (void)ahead1;
     unsigned c_slot = 0;                    // LDS byte offset of the slot being multiplied
 
-    f32x4 acc[8][4];
+    f32x4 acc[8][NB];
     for (; tile < ntiles; tile += stride) {
         int tm, tn;
         tile_to_mn(xcd_remap(tile, ntiles), p.tiles_m, p.tiles_n, p.group_n, tm, tn);
@@ -127,19 +137,23 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(GemmParams p) {
 #pragma unroll
         for (int m = 0; m < 8; ++m)
 #pragma unroll
-            for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int n = 0; n < NB; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         for (int kt = 0; kt < nkt; ++kt) {
             // stage (tile, kt) has landed: everything but the one younger stage (if one was issued).  At kt = 0 the
             // previous tile's epilogue stores are younger than this stage's DMA: drain them too (the partner workgroup
             // has the matrix pipe meanwhile).
-            if (kt != 0 && ahead2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (kt != 0 && ahead2) {
+                if constexpr (NPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             PP_BAR();
             const char* cur = smem + c_slot;
-            bf16x8 af[8], wf[4];
+            bf16x8 af[8], wf[NB];
 #pragma unroll
-            for (int n = 0; n < 4; ++n) wf[n] = *reinterpret_cast<const bf16x8*>(cur + w_off + n * 16 * 64);
+            for (int n = 0; n < NB; ++n) wf[n] = *reinterpret_cast<const bf16x8*>(cur + w_off + n * 16 * 64);
 #pragma unroll
             for (int m = 0; m < 8; ++m) af[m] = *reinterpret_cast<const bf16x8*>(cur + a_off + m * 16 * 64);
             // the stage's 6 DMA pieces go out BETWEEN the MFMAs (one per 5-6), not in front of them: a piece costs the
@@ -152,13 +166,14 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(GemmParams p) {
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
 #pragma unroll
-                for (int n = 0; n < 4; ++n) {
+                for (int n = 0; n < NB; ++n) {
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], af[m], acc[m][n], 0, 0, 0);
-                    const int idx = m * 4 + n;
-                    if (idx == 5 || idx == 10 || idx == 15 || idx == 21 || idx == 26 || idx == 31) {
+                    const int idx = m * NB + n;
+                    // piece k goes out behind MFMA ((k + 1) * 8 NB) / NPW - 1: evenly spread, the last behind the last
+                    if (piece_i < NPW && idx == ((piece_i + 1) * 8 * NB) / NPW - 1) {
                         __builtin_amdgcn_sched_barrier(0);
                         if (do_issue) {
-                            const int piece = wn * 6 + piece_i;
+                            const int piece = wn * NPW + piece_i;
                             glds16_so(voff[piece_i], piece < 8 ? abase : wbase, lds_base + i_slot + (unsigned)(piece * 1024));
                         }
                         __builtin_amdgcn_sched_barrier(0);
@@ -179,6 +194,49 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(GemmParams p) {
         }
 
         // ---------------- epilogue (gemm_common.h): the next tile's first two stages are already in flight ----------------
+        if constexpr (NB == 3) {
+            // three 16-column blocks per wave: the plain epilogues, written out (as gemm192.hip)
+            const int cb = n0 + wn * 48 + fq * 4;
+            f32x4 bias3[3];
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+                const int c = cb + n * 16;
+                bias3[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p.bias && c < p.N) bias3[n] = *reinterpret_cast<const f32x4*>(p.bias + c);
+            }
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int row = m0 + m * 16 + frow;
+                if (row >= p.M) continue;
+#pragma unroll
+                for (int n = 0; n < 3; ++n) {
+                    const int c = cb + n * 16;
+                    if (c >= p.N) continue;
+                    f32x4 v = acc[m][n] + bias3[n];
+                    if constexpr (EPI == EPI_BIAS_BF16) {
+                        u32x2 st;
+                        st[0] = pack_bf16x2(v[0], v[1]);
+                        st[1] = pack_bf16x2(v[2], v[3]);
+                        *reinterpret_cast<u32x2*>((bf16*)p.out + (size_t)row * p.ldo + c) = st;
+                    } else {
+                        if constexpr (EPI == EPI_BIAS_RES_F32) {
+                            if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)row * p.ldr + c);
+                        }
+                        store16<true>((float*)p.out + (size_t)row * p.ldo + c, __builtin_bit_cast(u32x4, v), p.flags);
+                        if constexpr (EPI == EPI_BIAS_RES_F32) {
+                            if (p.out2) {
+                                u32x2 st;
+                                st[0] = pack_bf16x2(v[0], v[1]);
+                                st[1] = pack_bf16x2(v[2], v[3]);
+                                *reinterpret_cast<u32x2*>(p.out2 + (size_t)row * p.ldo2 + c) = st;
+                            }
+                        }
+                    }
+                }
+            }
+            continue;
+        }
+        if constexpr (NB == 4) {
         f32x4 bias4[4];
         load_bias(p, n0 + wn * 64, fq, bias4);
         if (epilogue_fast_ok<EPI>(p, m0, n0, PM, PN)) {
@@ -205,19 +263,20 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(GemmParams p) {
                 if (row < p.M) epilogue_row<EPI>(p, row, n0 + wn * 64, acc[m], bias4, fq);
             }
         }
+        }   // NB == 4
     }
 }
 
-template <int EPI>
+template <int EPI, int NB>
 hipError_t launch_pp_t(const GemmParams& p, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<EPI, NB>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, PP<NB>::LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_pp_kernel<EPI>), dim3(p.tile_stride), dim3(256), P_LDS, s, p);
+    hipLaunchKernelGGL((gemm_pp_kernel<EPI, NB>), dim3(p.tile_stride), dim3(256), PP<NB>::LDS, s, p);
     return hipGetLastError();
 }
 
@@ -240,6 +299,13 @@ hipError_t launch_gemm_pp(const GemmParams& p_in, GemmEpilogue epi, hipStream_t 
         return n;
     }();
     GemmParams p = p_in;
+    // 192-wide tiles (three 16-column blocks per wave) exist for the plain epilogues but are OPT-IN (pp_nb = 3): at N = 768,
+    // M = 32768 they make exactly two tiles per workgroup slot where 256-wide tiles make 1.5 rounds, yet measured in-model
+    // (tools/step_ab.py ...!3) the out-proj went 90.1 -> 105.2 us, q-proj 48 -> 60, fc2 187 -> 241: the extra LDS-DMA bytes
+    // per FLOP of the narrower tile outweigh the idle half round.
+    const bool plain = epi == EPI_BIAS_BF16 || epi == EPI_BIAS_RES_F32 || epi == EPI_BIAS_F32;
+    const bool use192 = plain && p.N % 192 == 0 && g_pp_nb == 3;
+    const int PN = use192 ? 192 : 256;
     p.tiles_m = (p.M + PM - 1) / PM;
     p.tiles_n = (p.N + PN - 1) / PN;
     const int ntiles = p.tiles_m * p.tiles_n;
@@ -251,13 +317,21 @@ hipError_t launch_gemm_pp(const GemmParams& p_in, GemmEpilogue epi, hipStream_t 
     // offset of half a tile changes the K = 768 gated GEMM by < 0.5 % and costs the short GEMMs their delay
     // (q-proj 47.7 -> 57.1 us): the workgroups de-phase on their own at the first tile switch (store drain).
     p.stagger_ticks = g_pp_stagger > 0 && ntiles > n_cu ? g_pp_stagger : 0;
+    if (use192) {
+        switch (epi) {
+            case EPI_BIAS_BF16: return launch_pp_t<EPI_BIAS_BF16, 3>(p, s);
+            case EPI_BIAS_RES_F32: return launch_pp_t<EPI_BIAS_RES_F32, 3>(p, s);
+            case EPI_BIAS_F32: return launch_pp_t<EPI_BIAS_F32, 3>(p, s);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (epi) {
-        case EPI_BIAS_BF16: return launch_pp_t<EPI_BIAS_BF16>(p, s);
-        case EPI_BIAS_RES_F32: return launch_pp_t<EPI_BIAS_RES_F32>(p, s);
-        case EPI_QKV_ROPE: return launch_pp_t<EPI_QKV_ROPE>(p, s);
-        case EPI_GATED: return launch_pp_t<EPI_GATED>(p, s);
-        case EPI_BIAS_F32: return launch_pp_t<EPI_BIAS_F32>(p, s);
-        case EPI_BIAS_RELU_BF16: return launch_pp_t<EPI_BIAS_RELU_BF16>(p, s);
+        case EPI_BIAS_BF16: return launch_pp_t<EPI_BIAS_BF16, 4>(p, s);
+        case EPI_BIAS_RES_F32: return launch_pp_t<EPI_BIAS_RES_F32, 4>(p, s);
+        case EPI_QKV_ROPE: return launch_pp_t<EPI_QKV_ROPE, 4>(p, s);
+        case EPI_GATED: return launch_pp_t<EPI_GATED, 4>(p, s);
+        case EPI_BIAS_F32: return launch_pp_t<EPI_BIAS_F32, 4>(p, s);
+        case EPI_BIAS_RELU_BF16: return launch_pp_t<EPI_BIAS_RELU_BF16, 4>(p, s);
         default: break;
     }
     return hipErrorInvalidValue;

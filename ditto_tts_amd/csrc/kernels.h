@@ -92,6 +92,7 @@ hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s);
 extern int g_gemm_tile;  // 0 auto | 128 | 256
 extern int g_gemm_flags; // GF_* (gemm_common.h)
 extern int g_pp_mask;    // gemm.hip: GEMM classes that take the ping-pong kernel (ditto_set_option("pp_mask")), -1 = rule
+extern int g_pp_nb;      // gemm_pp.hip A/B: 0 = rule, 3 / 4 = force 192- / 256-wide tiles (ditto_set_option("pp_nb"))
 extern int g_pp_stagger; // gemm_pp.hip: forced phase offset (10 ns ticks), -1 = rule
 extern int g_gemm_group; // > 0: forced super-column width of the tile order (A/B); 0 = pick_group_n's rule
 extern int g_attn_flags; // attention.hip

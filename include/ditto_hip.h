@@ -238,6 +238,7 @@ int ditto_gemm_ln_bf16(const void* A, int lda, const void* W, const float* bias,
  * 256 (persistent 256x256) = force one.  Results are identical up to fp32 summation order.
  * "pp_mask": GEMM classes that take the ping-pong kernel (bit 0 cross q-proj, 1 cross out-proj, 2 final projection,
  * 3 fc2, 4 QKV + RoPE, 5 gated MLP; -1 = the built-in rule).
+ * "pp_nb": tile width of the ping-pong kernel's plain epilogues: 0 = rule, 3 = 128x192, 4 = 128x256.
  * "pp_stagger": phase offset between the two workgroups of a CU in the ping-pong GEMM, 10 ns ticks (-1 = built-in rule).
  * "gemm_flags": bit mask for kernel experiments (bit 0 = relaxed tile-start wait, default on; bits 1, 2 are
  * DIAGNOSTIC timing switches that skip stores / the epilogue and produce WRONG results — tools/ only).
