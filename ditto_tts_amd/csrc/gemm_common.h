@@ -161,6 +161,10 @@ DITTO_DEV void store_bf16_pair(bf16* rowp, int col0 /* column of block nb */, u3
         st[0] = r0[0]; st[1] = r1[0]; st[2] = r0[1]; st[3] = r1[1];
 #ifdef DITTO_DIAG_FAST_NOSTORE   // timing experiment (WRONG results): the fast epilogue computes, keeps live, does not store
         asm volatile("" ::"v"(st), "v"(rowp + c));
+#elif defined(DITTO_BF16_STORE_NT)   // A/B build: non-temporal bf16 output stores
+        asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(rowp + c), "v"(st) : "memory");
+#elif defined(DITTO_BF16_STORE_SC1)  // A/B build: write-through bf16 output stores
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(rowp + c), "v"(st) : "memory");
 #else
         *reinterpret_cast<u32x4*>(rowp + c) = st;
 #endif
