@@ -53,6 +53,9 @@ ArenaPlan plan_arena(const ditto_config& c) {
         q.bqkv = take(3 * d * 4); q.bcq = take(d * 4); q.bco = take(d * 4); q.b1g = take(8 * d * 4); q.b2 = take(d * 4);
         q.g1 = take(d * 4); q.be1 = take(d * 4); q.g2 = take(d * 4); q.be2 = take(d * 4); q.g3 = take(d * 4);
         q.be3 = take(d * 4);
+        // stage-major bf16 copies of the two N = d projections for the full-row kernel (gemm_fr.hip; d == 768, bf16 only)
+        const bool fr = d == 768 && !(c.flags & DITTO_CFG_FP8_LINEAR);
+        q.WcoP = fr ? take(d * d * 2) : 0; q.W2P = fr ? take(4 * d * d * 2) : 0;
     }
     p.Wkv = take(L * 2 * d * d * 2); p.bkv = take(L * 2 * d * 4);
     p.Wfin = take(d * 2 * d * 2); p.bfin = take(d * 4);
@@ -178,15 +181,21 @@ struct ProfScope {
 static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* act, char* xcat_or_null,
                      void* attn_ws, size_t attn_ws_bytes, float* splitk_ws, size_t splitk_bytes, const char* kv, int kv_layer, int kv_ld,
                      const float* rope_cos, const float* rope_sin, int B, int N, int T, hipStream_t s,
-                     float* tap_self = nullptr, float* tap_cross = nullptr) {
+                     float* tap_self = nullptr, float* tap_cross = nullptr, bool ln1_done = false,
+                     const float* next_g1 = nullptr, const float* next_be1 = nullptr) {
     const ditto_config& c = m->cfg;
     const int d = c.hidden_dim, H = c.num_heads, dh = d / H, M = B * N;
     const float scale = 1.0f / sqrtf((float)dh);
     const bool fused_rope = (dh == 64);
     const bool fp8 = (c.flags & DITTO_CFG_FP8_LINEAR) != 0;   // u / act hold fp8 bytes for the fp8 GEMMs
     const LayerPack& lp = m->layers[l];
+    // full-row GEMM with the residual add and the FOLLOWING LayerNorm fused (gemm_fr.hip): bit 0 = cross out-proj + norm3,
+    // bit 1 = fc2 + the next block's norm1 (ln1_done tells that block its norm1 output is already in u)
+    // (N >= 128, not M: the choice of kernel must not depend on the batch size, or an utterance's bits would)
+    const bool fr_ok = !fp8 && lp.WcoP && N >= 128 && gemm_fr_supports(M, d, d, (size_t)d, (size_t)d);
+    const bool fr_out = fr_ok && (g_fr_mask & 1), fr_fc2 = fr_ok && (g_fr_mask & 2);
         // ---- self-attention (src/components/DiT.py:103-139) ----
-        {
+        if (!ln1_done) {
             ProfScope ps(m, s, DITTO_KC_LAYERNORM);
             if (fp8) HIP_TRY(launch_layernorm_fp8(h, lp.g1, lp.be1, u, d, M, d, s));
             else HIP_TRY(launch_layernorm(h, lp.g1, lp.be1, u, d, M, d, s));
@@ -228,7 +237,15 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
             a.workspace = attn_ws; a.workspace_bytes = attn_ws_bytes; a.q_prescaled = (dh == 64);
             HIP_TRY(launch_attention(a, s));
         }
-        {
+        if (fr_out) {
+            // out-proj + residual + norm3 in one launch.  A = the attention output in u; the LayerNorm output goes to the first
+            // M x d of the qkv buffer (the cross q it held has been consumed) because u is still being read as the A operand
+            ProfScope ps(m, s, DITTO_KC_GEMM_OUTPROJ);
+            GemmParams gp{};
+            gp.A = (const bf16*)u; gp.lda = d; gp.W = (const bf16*)lp.WcoP; gp.ldw = d; gp.w_rows = d; gp.bias = lp.bco;
+            gp.residual = h; gp.ldr = d; gp.out = h; gp.ldo = d; gp.M = M; gp.N = d; gp.K = d;
+            HIP_TRY(launch_gemm_fr(gp, lp.g3, lp.be3, qkv, d, s));
+        } else {
             ProfScope ps(m, s, DITTO_KC_GEMM_OUTPROJ);
             GemmArgs g{};
             g.A = u; g.lda = d; g.W = lp.Wco; g.bias = lp.bco; g.residual = h; g.ldr = d; g.out = h; g.ldo = d;
@@ -237,7 +254,8 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
         }
         if (tap_cross) HIP_TRY(hipMemcpyAsync(tap_cross, h, (size_t)M * d * 4, hipMemcpyDeviceToDevice, s));
         // ---- gated MLP (src/components/DiT.py:150-155) ----
-        {
+        const void* u3 = fr_out ? (const void*)qkv : (const void*)u;   // where norm3's output is
+        if (!fr_out) {
             ProfScope ps(m, s, DITTO_KC_LAYERNORM);
             if (fp8) HIP_TRY(launch_layernorm_fp8(h, lp.g3, lp.be3, u, d, M, d, s));
             else HIP_TRY(launch_layernorm(h, lp.g3, lp.be3, u, d, M, d, s));
@@ -245,11 +263,19 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
         {
             ProfScope ps(m, s, DITTO_KC_GEMM_GATED);
             GemmArgs g{};
-            g.A = u; g.lda = d; g.W = lp.W1g; g.bias = lp.b1g; g.out = act; g.ldo = 4 * d; g.M = M; g.N = 8 * d;
+            g.A = u3; g.lda = d; g.W = lp.W1g; g.bias = lp.b1g; g.out = act; g.ldo = 4 * d; g.M = M; g.N = 8 * d;
             g.K = d; g.fp8 = fp8; g.wscale = fp8 ? lp.s1g : nullptr;
             HIP_TRY(launch_gemm(g, fp8 ? EPI_GATED_FP8 : EPI_GATED, s));
         }
-        {
+        if (fr_fc2) {
+            // fc2 + residual (+ the NEXT block's norm1 into u, or the bf16 copy of h_L for proj_out on the last block)
+            ProfScope ps(m, s, DITTO_KC_GEMM_FC2);
+            GemmParams gp{};
+            gp.A = (const bf16*)act; gp.lda = 4 * d; gp.W = (const bf16*)lp.W2P; gp.ldw = 4 * d; gp.w_rows = d; gp.bias = lp.b2;
+            gp.residual = h; gp.ldr = d; gp.out = h; gp.ldo = d; gp.M = M; gp.N = d; gp.K = 4 * d;
+            if (xcat_or_null) { gp.out2 = (bf16*)(xcat_or_null + (size_t)d * 2); gp.ldo2 = 2 * d; }
+            HIP_TRY(launch_gemm_fr(gp, next_g1, next_be1, next_g1 ? u : nullptr, d, s));
+        } else {
             ProfScope ps(m, s, DITTO_KC_GEMM_FC2);
             GemmArgs g{};
             g.A = act; g.lda = 4 * d; g.W = lp.W2; g.bias = lp.b2; g.residual = h; g.ldr = d; g.out = h; g.ldo = d;
@@ -356,6 +382,10 @@ int ditto_model_create(const ditto_config* cfg, const ditto_weights* w, void* ar
         HIP_TRY(hipMemcpyAsync(A + plan.bkv + (size_t)l * 2 * d * 4, lw.cross_in_proj_bias + d, 2 * d * 4,
                                hipMemcpyDeviceToDevice, s));
         HIP_TRY(launch_pack_bf16(lw.cross_out_proj_weight, A + q.Wco, d, d, d, 0, BIG, 1, 0, s));
+        if (d == 768 && !fp8) {
+            HIP_TRY(launch_pack_bf16_stage_major(lw.cross_out_proj_weight, A + q.WcoP, d, d, s));
+            HIP_TRY(launch_pack_bf16_stage_major(lw.mlp_fc2_weight, A + q.W2P, d, 4 * d, s));
+        }
         HIP_TRY(hipMemcpyAsync(A + q.bco, lw.cross_out_proj_bias, d * 4, hipMemcpyDeviceToDevice, s));
         // gated MLP: rows interleaved [16 x fc1 | 16 x gate] so both halves of a product meet in one lane
         HIP_TRY(launch_pack_vec(lw.mlp_fc1_bias, (float*)(A + q.b1g), 4 * d, 16, 2, 0, s));
@@ -371,6 +401,7 @@ int ditto_model_create(const ditto_config* cfg, const ditto_weights* w, void* ar
         lp.bqkv = (const float*)(A + q.bqkv); lp.bcq = (const float*)(A + q.bcq); lp.bco = (const float*)(A + q.bco);
         lp.b1g = (const float*)(A + q.b1g); lp.b2 = (const float*)(A + q.b2);
         lp.sqkv = (const float*)(A + q.sqkv); lp.s1g = (const float*)(A + q.s1g); lp.s2 = (const float*)(A + q.s2);
+        if (d == 768 && !fp8) { lp.WcoP = A + q.WcoP; lp.W2P = A + q.W2P; }
         lp.g1 = (const float*)(A + q.g1); lp.be1 = (const float*)(A + q.be1); lp.g2 = (const float*)(A + q.g2);
         lp.be2 = (const float*)(A + q.be2); lp.g3 = (const float*)(A + q.g3); lp.be3 = (const float*)(A + q.be3);
     }
@@ -479,10 +510,15 @@ int ditto_forward(ditto_model_t m, const float* x, const void* cond, const int64
         ProfScope ps(m, s, DITTO_KC_ADALN);
         HIP_TRY(launch_adaln(x, m->ttab, tmod, t, c.diffusion_steps, h, xcat, 2 * d, B, N, d, s));
     }
+    // fc2 on the full-row kernel also emits the NEXT block's norm1 (fr_mask bit 1): that block then skips its LayerNorm
+    const bool chain_ln1 = (g_fr_mask & 2) && !(c.flags & DITTO_CFG_FP8_LINEAR) && m->layers[0].WcoP && N >= 128 &&
+                           gemm_fr_supports(M, d, d, (size_t)d, (size_t)d);
     for (int l = 0; l < L; ++l)
         if (int rc = run_block(m, l, h, u, qkv, act, l == L - 1 ? xcat : nullptr, attn_ws, w.attn_bytes,
                                (float*)(ws + w.splitk), w.splitk_bytes, kv, l,
-                               L * 2 * d, rope_cos, rope_sin, B, N, T, s))
+                               L * 2 * d, rope_cos, rope_sin, B, N, T, s, nullptr, nullptr, chain_ln1 && l > 0,
+                               chain_ln1 && l + 1 < L ? m->layers[l + 1].g1 : nullptr,
+                               chain_ln1 && l + 1 < L ? m->layers[l + 1].be1 : nullptr))
             return rc;
     {   // eps = proj_in(x_raw) + proj_out(h_L)  (src/model/DiTTO.py:83,93-94), one K = 2d GEMM
         ProfScope ps(m, s, DITTO_KC_GEMM_FINAL);
@@ -812,6 +848,11 @@ int ditto_set_option(const char* name, int value) {
     if (!strcmp(name, "pp_mask")) {
         if (value < -1 || value > 63) return fail(DITTO_ERR_ARG, "pp_mask must be in [-1, 63]");
         g_pp_mask = value;
+        return DITTO_OK;
+    }
+    if (!strcmp(name, "fr_mask")) {
+        if (value < 0 || value > 3) return fail(DITTO_ERR_ARG, "fr_mask must be in [0, 3]");
+        g_fr_mask = value;
         return DITTO_OK;
     }
     if (!strcmp(name, "pp_nb")) {

@@ -49,6 +49,9 @@ hipError_t launch_rope_tables(const float* inv_freq, float* cos_out, float* sin_
 hipError_t launch_pack_bf16(const float* src, void* dst_bf16, int rows, int cols, int dst_ld, int col_off, int blk,
                             int mult, int row_off, hipStream_t s, float scale = 1.0f);
 hipError_t launch_scale_vec(float* v, int n, float f, hipStream_t s);
+// fp32 [N, K] -> bf16 stage-major [K/16][N][16] (the full-row GEMM's weight layout, gemm_fr.hip)
+hipError_t launch_pack_bf16_stage_major(const float* src, void* dst, int N, int K, hipStream_t s);
+extern int g_fr_mask;    // gemm.hip: 1 = cross out-proj + LayerNorm3, 2 = fc2 + next block's LayerNorm1 on the full-row kernel
 // same row map for an fp32 vector (bias)
 hipError_t launch_pack_vec(const float* src, float* dst, int rows, int blk, int mult, int row_off, hipStream_t s);
 hipError_t launch_add_vec(const float* a, const float* b, float* dst, int n, hipStream_t s);

@@ -20,6 +20,7 @@ inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct LayerPack {
     const void *Wqkv, *Wcq, *Wco, *W1g, *W2;
+    const void *WcoP = nullptr, *W2P = nullptr;   // stage-major copies for the full-row kernel (d == 768, bf16 path)
     const float *sqkv, *s1g, *s2;   // fp8 weight scales (DITTO_CFG_FP8_LINEAR)
     const float *bqkv, *bcq, *bco, *b1g, *b2;
     const float *g1, *be1, *g2, *be2, *g3, *be3;
@@ -33,7 +34,7 @@ struct LayerPackT {
 
 struct ArenaPlan {
     size_t total = 0;
-    struct L { size_t Wqkv, Wcq, Wco, W1g, W2, bqkv, bcq, bco, b1g, b2, g1, be1, g2, be2, g3, be3, sqkv, s1g, s2; };
+    struct L { size_t Wqkv, Wcq, Wco, W1g, W2, bqkv, bcq, bco, b1g, b2, g1, be1, g2, be2, g3, be3, sqkv, s1g, s2, WcoP, W2P; };
     std::vector<L> layers;
     size_t Wkv, bkv, Wfin, bfin, ttab, wx, bx, invf, invf_rev;
 };

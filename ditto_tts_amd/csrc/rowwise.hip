@@ -528,6 +528,23 @@ hipError_t launch_pack_bf16(const float* src, void* dst, int rows, int cols, int
                        dst_ld, col_off, blk, mult, row_off, scale);
     return hipGetLastError();
 }
+// fp32 [N, K] (nn.Linear.weight) -> bf16 stage-major [K/16][N][16] for the full-row GEMM (gemm_fr.hip): each K-step's
+// N x 16 slab is contiguous
+__global__ __launch_bounds__(256) void pack_bf16_stage_major_kernel(const float* __restrict__ src, bf16* __restrict__ dst,
+                                                                    int N, int K) {
+    const size_t n = (size_t)N * K;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / K), c = (int)(i % K);
+        dst[((size_t)(c >> 4) * N + r) * 16 + (c & 15)] = (bf16)src[i];
+    }
+}
+hipError_t launch_pack_bf16_stage_major(const float* src, void* dst, int N, int K, hipStream_t s) {
+    const size_t n = (size_t)N * K;
+    size_t g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(pack_bf16_stage_major_kernel, dim3((unsigned)(g ? g : 1)), dim3(256), 0, s, src, (bf16*)dst, N, K);
+    return hipGetLastError();
+}
 __global__ void scale_vec_kernel(float* __restrict__ v, int n, float f) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) v[i] *= f;

@@ -361,6 +361,7 @@ def test_full_row_gemm_with_fused_layernorm(lib, M, K, ln):
     N = 768
     A = bf16(asym((M, K), 4).to(DEV))
     W = bf16((asym((N, K), 5) / math.sqrt(K)).to(DEV))
+    Wp = W.view(N, K // 16, 16).permute(1, 0, 2).contiguous()      # the kernel's stage-major weight layout [K/16][N][16]
     bias = (0.1 * asym((N,), 6)).to(DEV)
     res = asym((M, N), 7).to(DEV)
     g = (1 + 0.1 * asym((N,), 8)).to(DEV)
@@ -371,7 +372,7 @@ def test_full_row_gemm_with_fused_layernorm(lib, M, K, ln):
     for rep in range(3):
         h = res.clone()
         u = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
-        hip.check(lib.ditto_gemm_ln_bf16(A.data_ptr(), K, W.data_ptr(), bias.data_ptr(), h.data_ptr(), h.data_ptr(), N,
+        hip.check(lib.ditto_gemm_ln_bf16(A.data_ptr(), K, Wp.data_ptr(), bias.data_ptr(), h.data_ptr(), h.data_ptr(), N,
                                          g.data_ptr() if ln else None, b.data_ptr() if ln else None,
                                          u.data_ptr() if ln else None, N, M, N, K, stream()))
         assert rel_l2(h, want) < 1e-5 and max_abs(h, want) < 2e-4
@@ -381,5 +382,5 @@ def test_full_row_gemm_with_fused_layernorm(lib, M, K, ln):
             first = (h.clone(), u.clone())
         else:
             assert torch.equal(h, first[0]) and torch.equal(u, first[1])
-    assert lib.ditto_gemm_ln_bf16(A.data_ptr(), K, W.data_ptr(), None, None, h.data_ptr(), 512, None, None, None, 0, M, 512,
+    assert lib.ditto_gemm_ln_bf16(A.data_ptr(), K, Wp.data_ptr(), None, None, h.data_ptr(), 512, None, None, None, 0, M, 512,
                                   K, stream()) == hip.ERR_SHAPE

@@ -24,10 +24,11 @@ for K in (768, 3072):
             hip.check(lib.ditto_gemm_bf16(A.data_ptr(), K, W.data_ptr(), bias.data_ptr(), h.data_ptr(), h.data_ptr(), N, M, N, K, 1, st))
             hip.check(lib.ditto_layernorm_bf16(h.data_ptr(), g.data_ptr(), b.data_ptr(), u.data_ptr(), M, N, st))
         return h, u, run
+    Wp = W.view(N, K // 16, 16).permute(1, 0, 2).contiguous()      # stage-major [K/16][N][16]
     def new():
         h = res.clone(); u = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
         def run():
-            hip.check(lib.ditto_gemm_ln_bf16(A.data_ptr(), K, W.data_ptr(), bias.data_ptr(), h.data_ptr(), h.data_ptr(), N,
+            hip.check(lib.ditto_gemm_ln_bf16(A.data_ptr(), K, Wp.data_ptr(), bias.data_ptr(), h.data_ptr(), h.data_ptr(), N,
                                              g.data_ptr(), b.data_ptr(), u.data_ptr(), N, M, N, K, st))
         return h, u, run
     h0, u0, r0 = old(); r0(); h1, u1, r1 = new(); r1(); torch.cuda.synchronize()

@@ -44,6 +44,8 @@ wall = {v: [] for v in variants}
 
 
 def select(v):
+    v, _, fm = v.partition("~")          # ...~fr_mask (full-row GEMM + fused LayerNorm: 1 out-proj, 2 fc2)
+    hip.check(lib.ditto_set_option(b"fr_mask", int(fm) if fm else 0))
     v, _, nb = v.partition("!")          # ...!pp_nb (ping-pong tile width: 3 = 192, 4 = 256; default 0 = rule)
     hip.check(lib.ditto_set_option(b"pp_nb", int(nb) if nb else 0))
     v, _, pm = v.partition("^")          # ...^pp_mask (GEMM classes on the ping-pong kernel; default -1 = rule)
