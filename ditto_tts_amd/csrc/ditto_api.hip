@@ -194,6 +194,7 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
     // (N >= 128, not M: the choice of kernel must not depend on the batch size, or an utterance's bits would)
     const bool fr_ok = !fp8 && lp.WcoP && N >= 128 && gemm_fr_supports(M, d, d, (size_t)d, (size_t)d);
     const bool fr_out = fr_ok && (g_fr_mask & 1), fr_fc2 = fr_ok && (g_fr_mask & 2);
+    const int fr_rot = N % 128 == 0 ? N / 128 : 0;   // tiles per utterance: the K-loop rotation period (gemm_fr.hip)
         // ---- self-attention (src/components/DiT.py:103-139) ----
         if (!ln1_done) {
             ProfScope ps(m, s, DITTO_KC_LAYERNORM);
@@ -244,7 +245,7 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
             GemmParams gp{};
             gp.A = (const bf16*)u; gp.lda = d; gp.W = (const bf16*)lp.WcoP; gp.ldw = d; gp.w_rows = d; gp.bias = lp.bco;
             gp.residual = h; gp.ldr = d; gp.out = h; gp.ldo = d; gp.M = M; gp.N = d; gp.K = d;
-            HIP_TRY(launch_gemm_fr(gp, lp.g3, lp.be3, qkv, d, s));
+            HIP_TRY(launch_gemm_fr(gp, lp.g3, lp.be3, qkv, d, fr_rot, s));
         } else {
             ProfScope ps(m, s, DITTO_KC_GEMM_OUTPROJ);
             GemmArgs g{};
@@ -274,7 +275,7 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
             gp.A = (const bf16*)act; gp.lda = 4 * d; gp.W = (const bf16*)lp.W2P; gp.ldw = 4 * d; gp.w_rows = d; gp.bias = lp.b2;
             gp.residual = h; gp.ldr = d; gp.out = h; gp.ldo = d; gp.M = M; gp.N = d; gp.K = 4 * d;
             if (xcat_or_null) { gp.out2 = (bf16*)(xcat_or_null + (size_t)d * 2); gp.ldo2 = 2 * d; }
-            HIP_TRY(launch_gemm_fr(gp, next_g1, next_be1, next_g1 ? u : nullptr, d, s));
+            HIP_TRY(launch_gemm_fr(gp, next_g1, next_be1, next_g1 ? u : nullptr, d, fr_rot, s));
         } else {
             ProfScope ps(m, s, DITTO_KC_GEMM_FC2);
             GemmArgs g{};
@@ -715,11 +716,11 @@ int ditto_gemm_ln_bf16(const void* A, int lda, const void* W, const float* bias,
     if (!A || !W || !out || (gamma == nullptr) != (beta == nullptr) || (gamma == nullptr) != (u_bf16 == nullptr))
         return fail(DITTO_ERR_ARG, "bad argument to ditto_gemm_ln_bf16");
     if (!gemm_fr_supports(M, N, K, (size_t)lda, (size_t)K) || lda % 8)
-        return fail(DITTO_ERR_SHAPE, "ditto_gemm_ln_bf16 needs N == 768, K %% 32 == 0, M >= 128, lda %% 8 == 0");
+        return fail(DITTO_ERR_SHAPE, "ditto_gemm_ln_bf16 needs N == 768, K %% 64 == 0, M >= 128, lda %% 8 == 0");
     GemmParams p{};
     p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)W; p.ldw = K; p.w_rows = N; p.bias = bias;
     p.residual = residual; p.ldr = ldo; p.out = out; p.ldo = ldo; p.M = M; p.N = N; p.K = K;
-    HIP_TRY(launch_gemm_fr(p, gamma, beta, u_bf16, ldu, (hipStream_t)stream));
+    HIP_TRY(launch_gemm_fr(p, gamma, beta, u_bf16, ldu, g_fr_rot > 1 ? g_fr_rot : 0, (hipStream_t)stream));
     return DITTO_OK;
 }
 
@@ -853,6 +854,11 @@ int ditto_set_option(const char* name, int value) {
     if (!strcmp(name, "fr_mask")) {
         if (value < 0 || value > 3) return fail(DITTO_ERR_ARG, "fr_mask must be in [0, 3]");
         g_fr_mask = value;
+        return DITTO_OK;
+    }
+    if (!strcmp(name, "fr_rot")) {
+        if (value < 0 || value > 4096) return fail(DITTO_ERR_ARG, "fr_rot must be in [0, 4096]");
+        g_fr_rot = value;
         return DITTO_OK;
     }
     if (!strcmp(name, "pp_nb")) {

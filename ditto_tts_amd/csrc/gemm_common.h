@@ -351,7 +351,8 @@ hipError_t launch_gemm192(const GemmParams& p, GemmEpilogue epi, hipStream_t s);
 hipError_t launch_gemm_o3(const GemmParams& p, GemmEpilogue epi, hipStream_t s);
 // gemm_fr.hip: full-row N = 768 GEMM, fp32 residual in place, fused LayerNorm -> u bf16 (gamma/u null: none)
 bool gemm_fr_supports(int M, int N, int K, size_t lda, size_t ldw);
-hipError_t launch_gemm_fr(const GemmParams& p, const float* gamma, const float* beta, void* u_bf16, int ldu, hipStream_t s);
+hipError_t launch_gemm_fr(const GemmParams& p, const float* gamma, const float* beta, void* u_bf16, int ldu, int rot_period,
+                          hipStream_t s);
 // gemm_pp.hip
 bool gemm_pp_supports(const GemmParams& p, GemmEpilogue epi);
 hipError_t launch_gemm_pp(const GemmParams& p, GemmEpilogue epi, hipStream_t s);

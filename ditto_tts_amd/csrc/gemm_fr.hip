@@ -17,20 +17,36 @@
 //             accumulators between the two halves of the file: 1 591 v_accvgpr moves and 540 scratch accesses per 96
 //             MFMAs), so every MFMA is an asm statement whose tied operand fixes the home: column blocks 0..6 in
 //             AGPRs (224), 7..11 in VGPRs (160).
-//   LDS       ring of FIVE stages x 28 KiB (K = 16: A 128 rows x 32 B, W 768 rows x 32 B) = 140 KiB, LDS-DMA three
-//             stages ahead behind a counted vmcnt; + bias / gamma / beta rows (9 KiB, DMA'd once) + 2 KiB of row
-//             statistics.  The K = 16 instruction is what makes five stages fit: with 16x16x32 MFMAs (K = 32) the
-//             same LDS holds two stages, one stage of look-ahead, and the first version ran at 1.93 us per K = 32.
-//             16-B chunk h (0 / 1) of 32-B row r sits at h ^ ((r >> 3) & 1): conflict-free ds_read_b128.
-//   stage s   { nb = 0..6: 2 MFMAs + one DMA piece of stage s+3 each ; nb = 7 ; nb = 8: vmcnt(14) + s_barrier (stage s+1
-//               has landed for everyone, and everyone is past stage s-1), prefetch stage s+1's A fragments ;
-//               nb = 9..11: prefetch stage s+1's first W fragments }   W fragments run 3 ahead in a 4-register ring,
-//             A fragments ping-pong between two named sets (two stages per loop iteration): one barrier per stage.
-//   epilogue  no compiler-visible global load (each would make hipcc wait for every DMA in flight): bias / gamma / beta
-//             come from LDS, the fp32 residual tile streams through the idle ring in six 64 KiB chunks by LDS-DMA
-//             (double-buffered; 16-B chunk q of row r at q ^ (r & 15)), v = acc + bias + residual goes back into the
-//             accumulators' home registers; row sums -> lane l ^ 32 -> the other column half through LDS; mean; the same
-//             for sum (v - mean)^2; h stored fp32 (nt), u = LN(v) bf16.  Two-pass statistics, like nn.LayerNorm.
+//   operands  W arrives PACKED stage-major, Wp[K/16][768][16] (launch_pack_bf16_stage_major, once per weight load): a
+//             K = 16 stage is 24 contiguous KiB, every 1-KiB DMA piece a run of whole cache lines.  A is the previous
+//             kernel's row-major output and comes in SLABS of 64 k (one whole 128-B line per row, four stages of work).
+//             (Both read as 32-B row pieces from row-major images, the L2 -> CU path moved 4x the payload: 2.6 us per
+//             K = 32; W packed: 1.52; A in slabs: 1.31; tiles remapped to XCD-contiguous runs + K-loop rotation: 1.10.
+//             The MFMAs need 0.64, the loop without its DMA runs at 0.85.)
+//   LDS       W ring of FIVE stages x 24 KiB, LDS-DMA three stages ahead behind a counted vmcnt; two A slabs x 16 KiB,
+//             the next slab's pieces issued during the first two stages of the current one; 2 KiB of row statistics;
+//             the bias row (3 KiB).  157 KiB.  The K = 16 instruction is what makes five stages fit: with 16x16x32 MFMAs
+//             (K = 32) the same LDS holds two stages, one stage of look-ahead, and the first version ran at 1.93 us per
+//             K = 32.  W: 16-B chunk h (0 / 1) of 32-B row r sits at h ^ ((r >> 3) & 1); A: chunk c of 128-B row r at
+//             c ^ ((r >> 1) & 7): conflict-free ds_read_b128 both.
+//   stage s   { nb = 0..5: 2 MFMAs + one W piece of stage s+3 each ; nb = 6, 7: + one piece of the next A slab (first two
+//               stages of a slab) ; nb = 8: counted vmcnt + s_barrier (stage s+1 has landed for everyone, and everyone is
+//               past stage s-1), prefetch stage s+1's A fragments ; nb = 9..11: prefetch stage s+1's first W fragments }
+//             W fragments run 3 ahead in a 4-register ring, A fragments ping-pong between two named sets: one barrier
+//             per stage, four stages (one slab) per loop iteration.
+//   init      the accumulators START as residual + bias: the fp32 residual tile is loaded straight into registers in the
+//             accumulator layout (96 hand-written global_load_dwordx4 per lane, a window of 24 in flight), behind the
+//             ring's prologue DMA.  The epilogue then only READS the accumulators.
+//   epilogue  no compiler-visible global load (each would make hipcc wait for every DMA in flight): gamma / beta are
+//             DMA'd into the idle A ring; row sums -> lane l ^ 32 -> the other column half through LDS; mean; the same
+//             for sum (v - mean)^2 (two-pass statistics, like nn.LayerNorm); every output row leaves through a wave-private
+//             LDS stage so that the stores are whole 128-B lines: h fp32 (nt), u = LN(h) bf16.
+//   measured  (M = 32768, Infinity Cache flushed) K = 768: 97 us against 132 for GEMM + LayerNorm; K = 3072: 178 against
+//             240.  Of the 97: main loop 26, residual read 28 (100 MB: HBM alone 13-17), stores 13, LayerNorm 8, the rest
+//             launch / prologue / epilogue arithmetic.  All 256 workgroups run in lockstep (one tile each, one wave of
+//             workgroups), so the residual read, the MFMA loop and the 150 MB of stores do NOT overlap one another: that
+//             is the structural cost of owning whole rows with one wave per SIMD (staggering every other workgroup's
+//             start by 4-16 us gained 2 us at best).
 #include "gemm_common.h"
 
 namespace ditto {
@@ -38,17 +54,21 @@ namespace ditto {
 namespace {
 
 constexpr int FM = 128, FN = 768, FK = 16, NST = 5;
-constexpr int F_A_BYTES = FM * FK * 2;             // 4 KiB
-constexpr int F_W_BYTES = FN * FK * 2;             // 24 KiB
-constexpr int F_STAGE = F_A_BYTES + F_W_BYTES;     // 28 KiB
-constexpr int F_RING = NST * F_STAGE;              // 140 KiB
-constexpr int F_VEC = F_RING;                      // bias | gamma | beta rows, 3 KiB each
-constexpr int F_RED = F_VEC + 3 * FN * 4;          // row statistics [2 passes][2 column halves][128 rows] fp32
-constexpr int F_LDS = F_RED + 2 * 2 * FM * 4;      // 151 KiB
-constexpr int F_RES = 2 * FM * 64 * 4;             // one residual chunk: [2 column halves][128 rows][64 fp32] = 64 KiB
+constexpr int F_W_BYTES = FN * FK * 2;             // 24 KiB: one K = 16 stage of W (stage-major packed: contiguous)
+constexpr int F_WRING = NST * F_W_BYTES;           // 120 KiB
+constexpr int F_ASLAB = FM * 64 * 2;               // 16 KiB: 128 rows x 64 k of A = FOUR stages, one whole 128-B line per row
+constexpr int F_ARING = F_WRING;                   // two slabs
+constexpr int F_RED = F_ARING + 2 * F_ASLAB;       // row statistics [2 passes][2 column halves][128 rows] fp32
+constexpr int F_BIAS = F_RED + 2 * 2 * FM * 4;     // bias row (read while the accumulators are initialised)
+constexpr int F_LDS = F_BIAS + FN * 4;             // 157 KiB
+constexpr int F_GB = F_ARING;                      // gamma | beta rows during the epilogue (the A ring is idle by then)
 constexpr int NA = 7;                              // column blocks whose accumulators live in AGPRs
-static_assert(2 * F_RES <= F_RING, "residual double buffer must fit the idle ring");
 
+#ifdef DITTO_DIAG_FR_NOSTORE    // tools/build_diag.sh: epilogue without its global stores (timing only)
+#define FR_DIAG_M (p.M - (1 << 30))
+#else
+#define FR_DIAG_M p.M
+#endif
 #define FR_BAR() asm volatile("s_barrier" ::: "memory")
 #define PIN_A(x) asm volatile("" : "+a"(x))
 #define PIN_V(x) asm volatile("" : "+v"(x))
@@ -57,6 +77,7 @@ struct FrParams {
     GemmParams g;
     const float* gamma; const float* beta;   // LayerNorm affine of the fused norm (null: no LayerNorm output)
     bf16* u; int ldu;                         // LayerNorm output
+    int rot_period;                           // > 0: tiles t and t + rot_period start their K loop at the same place (below)
 };
 
 template <int V>
@@ -69,179 +90,242 @@ DITTO_DEV void mfma_v(f32x16& c, const bf16x8& w, const bf16x8& a) {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(w), "v"(a));
 }
 
-template <bool LN>
+template <bool LN, bool RES>
 __global__ __launch_bounds__(256, 1) void gemm_fr_kernel(FrParams fp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const GemmParams& p = fp.g;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 1, wn = wid & 1;
-    const int nkt = p.K / FK;                  // even and >= 4 (K % 32 == 0, K >= 64)
-    const int m0 = blockIdx.x * FM;
+    const int nkt = p.K / FK;                  // a multiple of 4 (K % 64 == 0)
+    // Workgroups go to the XCDs round-robin; tile = consecutive runs per XCD, so that the 32 workgroups sharing an L2 hold
+    // NEIGHBOURING tiles (all eight K-loop rotations below, and adjacent residual / output rows).
+    const int ntile = gridDim.x;
+    const int tile = (ntile & 7) == 0 ? (int)(blockIdx.x & 7) * (ntile >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int m0 = tile * FM;
+    // K-loop ROTATION.  Every workgroup reads the whole of W, and unrotated all 32 workgroups of an XCD ask their L2 for the
+    // SAME 24 KiB at the same time: a handful of L2 channels serve everything while the others idle (measured: 1.31 us per
+    // K = 32 where the MFMAs need 0.64).  Tile t starts at slab s0(t) and wraps, so that eight different stretches of W are
+    // in demand at any time.  The sum over k is the same set of products in a rotated ORDER: a row's bits depend on its
+    // tile's rotation, so the rotation is a function of (t mod rot_period) only and the caller passes the number of tiles
+    // per utterance: an utterance's rows are then computed identically wherever it sits in the batch (the sharded sampler
+    // relies on that).  rot_period = 0: no rotation.
+    const int nslab = nkt >> 2;
+    const int s0 = fp.rot_period > 0 ? (((tile % fp.rot_period) & 7) * nslab) >> 3 : 0;
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;
 
-    // ---- stage DMA: 28 pieces of 1 KiB (32 rows x 32 B): 0..3 = A, 4..27 = W; wave w moves pieces 7w .. 7w+6.
-    //      Per piece the source is (loop-invariant scalar base) + (per-lane offset that advances 32 B per stage); the
-    //      destination goes straight into M0 (s_add_u32 m0, ring slot, piece * 1024).  M0 is not restored: nothing else in
-    //      this kernel reads it.  With one wave per SIMD every scalar instruction of the loop is issue time the MFMAs
-    //      wait behind (a first version spent 184 SALU instructions per 24 MFMAs on these addresses). ----
+    // ---- operand DMA.  W: stage-major packed Wp[K/16][768][16] (launch_pack_bf16_stage_major), a stage = 24 contiguous
+    //      pieces of 1 KiB (32 rows x 32 B), 6 per wave, into a five-slot ring.  (Read from the row-major [768][K] image, a
+    //      piece touched 32 lines for 32 B each and the L2 -> CU path moved 4x the payload.)  A is row-major [M, K] and cannot
+    //      be packed (it is the previous kernel's output), so it comes in SLABS of 64 k: 128 B = one whole line per row,
+    //      four stages of work, 16 pieces of 8 rows x 128 B, 4 per wave per slab, two slabs double-buffered; the next
+    //      slab's pieces go out during the first two stages of the current one.  Sources are (loop-invariant scalar base) +
+    //      (per-lane offset that advances per stage / slab); the destination goes straight into M0, which is not restored:
+    //      nothing else in this kernel reads it (with one wave per SIMD every scalar instruction is issue time). ----
     const int prow = lane >> 1, ppos = lane & 1;
-    const int pc = ppos ^ ((prow >> 3) & 1);                     // source chunk landing at position ppos of row prow
-    // W arrives PACKED stage-major, Wp[K/16][768][16] (launch_pack_w_fr): a stage's 24 KiB are contiguous, every 1-KiB piece
-    // a run of whole cache lines.  (Read from the row-major [768][K] image, a piece touched 32 lines for 32 B each and the
-    // L2 -> CU path moved 4x the payload: 2.6 us per K = 32 instead of ~1.)
-    unsigned vwk = (unsigned)(prow * 32 + pc * 16);                   // W pieces: per-lane byte offset (+ 24 KiB per stage)
-    unsigned vak[4];                                             // A pieces (wave 0): row clamp makes them per piece
+    const int pc = ppos ^ ((prow >> 3) & 1);                     // W: source chunk landing at position ppos of row prow
+    unsigned vwk = (unsigned)(prow * 32 + pc * 16 + s0 * 4 * F_W_BYTES);   // W pieces: per-lane byte offset (+ 24 KiB per stage)
+    int w_left = nkt - 4 * s0, a_left = nslab - s0;               // stages / slabs until the rotated K loop wraps to k = 0
+    const char* wbase[6];                                         // wave-uniform
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int ar = m0 + i * 32 + prow;
+    for (int i = 0; i < 6; ++i) wbase[i] = (const char*)p.W + (size_t)(wid * 6 + i) * 1024;
+    const int arow = lane >> 3, apos = lane & 7;                  // A piece: 8 rows x 8 chunks of 16 B
+    unsigned vak[4];                                              // per-lane byte offsets of this wave's 4 slab pieces
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = 8 * (wid * 4 + j) + arow;                 // row inside the tile
+        int ar = m0 + row;
         ar = ar < p.M ? ar : p.M - 1;
-        vak[i] = (unsigned)(((size_t)ar * p.lda + pc * 8) * 2);
+        vak[j] = (unsigned)(((size_t)ar * p.lda + (apos ^ ((row >> 1) & 7)) * 8) * 2) + (unsigned)(s0 * 128);   // chunk c of row r sits at c ^ ((r >> 1) & 7)
     }
-    const char* pbase[7];                                        // wave-uniform: SGPR pairs
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        const int piece = wid * 7 + i;
-        pbase[i] = piece < 4 ? (const char*)p.A : (const char*)p.W + (size_t)(piece - 4) * 1024;
-    }
-    unsigned i_slot = lds_base;                                  // LDS byte address of the ring slot the next stage goes to
-    auto issue_piece = [&](auto I) {                             // piece I (0..6) of the stage at the issue cursor
-        constexpr int i = decltype(I)::value;
-        const int piece = wid * 7 + i;
-        const unsigned voff = piece < 4 ? vak[i < 4 ? i : 0] : vwk;   // wave 0's first four pieces are A
-        const unsigned dst = i_slot + (unsigned)(piece * 1024);
-        const char* base = pbase[i];
+    unsigned w_slot = lds_base;                                   // LDS byte address of the W ring slot the next stage goes to
+    unsigned a_buf = lds_base + F_ARING;                          // ... and of the A buffer the next slab goes to
+    auto dma = [&](unsigned voff, const char* base, unsigned dst) {
+#ifndef DITTO_DIAG_FR_NODMA     // tools/build_diag.sh: main loop without its global -> LDS traffic (timing only, wrong results)
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(dst) : "memory");
+#endif
     };
-    auto advance_issue = [&]() {
-        i_slot = i_slot + F_STAGE == lds_base + F_RING ? lds_base : i_slot + F_STAGE;
-        vwk += F_W_BYTES;
+    auto issue_w_piece = [&](auto I) {                            // piece I (0..5) of the W stage at the issue cursor
+        constexpr int i = decltype(I)::value;
+        const char* base = wbase[i];
+        dma(vwk, base, w_slot + (unsigned)((wid * 6 + i) * 1024));
+    };
+    auto advance_w = [&]() {
+        w_slot = w_slot + F_W_BYTES == lds_base + F_WRING ? lds_base : w_slot + F_W_BYTES;
+        --w_left;
+        vwk += w_left == 0 ? (unsigned)F_W_BYTES - (unsigned)nkt * F_W_BYTES : (unsigned)F_W_BYTES;
+    };
+    auto issue_a_piece = [&](auto J) {                            // piece J (0..3) of the A slab at the issue cursor
+        constexpr int j = decltype(J)::value;
+        const unsigned voff = vak[j];
+        dma(voff, (const char*)p.A, a_buf + (unsigned)((wid * 4 + j) * 1024));
+    };
+    auto advance_a = [&]() {
+        a_buf = a_buf == lds_base + F_ARING ? lds_base + F_ARING + F_ASLAB : lds_base + F_ARING;
+        --a_left;
+        const unsigned inc = a_left == 0 ? 128u - (unsigned)nslab * 128u : 128u;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) vak[i] += FK * 2;
+        for (int j = 0; j < 4; ++j) vak[j] += inc;
     };
-    auto issue_stage = [&]() {
-        issue_piece(IC<0>{}); issue_piece(IC<1>{}); issue_piece(IC<2>{}); issue_piece(IC<3>{});
-        issue_piece(IC<4>{}); issue_piece(IC<5>{}); issue_piece(IC<6>{});
-        advance_issue();
+    auto issue_w_stage = [&]() {
+        issue_w_piece(IC<0>{}); issue_w_piece(IC<1>{}); issue_w_piece(IC<2>{});
+        issue_w_piece(IC<3>{}); issue_w_piece(IC<4>{}); issue_w_piece(IC<5>{});
+        advance_w();
     };
 
-    // bias / gamma / beta rows -> LDS (3 pieces of 1 KiB each = 768 fp32), oldest loads of the kernel
-    if (wid < 3) {
-        const float* src = wid == 0 ? p.bias : (wid == 1 ? fp.gamma : fp.beta);
-        if (src) {
+    // bias row -> LDS (3 pieces of 1 KiB = 768 fp32): the oldest loads of the kernel
+    if (wid == 0) {
+        if (p.bias) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) glds16(src + i * 256 + lane * 4, lds_base + (unsigned)(F_VEC + wid * FN * 4 + i * 1024));
+            for (int i = 0; i < 3; ++i) glds16(p.bias + i * 256 + lane * 4, lds_base + (unsigned)(F_BIAS + i * 1024));
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) *reinterpret_cast<f32x4*>(smem + F_BIAS + i * 1024 + lane * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
     // ---- fragment addressing: lane reads row (lane & 31) of a 32-row block, 16-B half (lane >> 5) ----
     const int r32 = lane & 31, hh = lane >> 5;
     const int fpos = (hh ^ ((r32 >> 3) & 1)) << 4;
-    const int a_off = (wm * 64 + r32) * 32 + fpos;                         // + mb * 1024
-    const int w_off = F_A_BYTES + (wn * 384 + r32) * 32 + fpos;             // + nb * 1024
+    const int w_off = (wn * 384 + r32) * 32 + fpos;                         // in a W slot: + nb * 1024
+    // A slab: row (64 wm + 32 mb + r32) x 128 B; stage j of the slab = 16-B chunks 2j + hh, sitting at (2j + hh) ^ ((row >> 1) & 7)
+    const int a_row = (wm * 64 + r32) * 128;                                // + mb * 4096   (32 and 64 drop out of the swizzle)
+    const int a_x = (hh ^ ((r32 >> 1) & 7)) << 4;                           // ^ (j << 5)
 
-    // ---- the accumulators START as bias + residual: the fp32 residual tile streams through the (still empty) ring in six
-    //      64 KiB chunks by LDS-DMA (double-buffered; 16-B chunk q of row r at q ^ (r & 15): conflict-free reads), so the
-    //      epilogue only READS the accumulators.  (Adding the residual afterwards meant writing 384 updated values back into
-    //      their AGPR / VGPR homes, which hipcc turned into a scratch copy of every block and reloads behind vmcnt(0) in the
-    //      later passes: a 170 us epilogue.)  Chunk c = column blocks nb in {2c, 2c+1} of both column halves: 64 pieces of
-    //      1 KiB (4 rows x 256 B), 16 per wave.
-    const float* lbias = reinterpret_cast<const float*>(smem + F_VEC);
-    const float* lgamma = lbias + FN;
+    // ---- prologue DMA, in this order: A slab 0 (4 pieces per wave), W stages 0, 1, 2 (6 pieces per wave each): in flight
+    //      while the accumulators are initialised ----
+    issue_a_piece(IC<0>{}); issue_a_piece(IC<1>{}); issue_a_piece(IC<2>{}); issue_a_piece(IC<3>{});
+    advance_a();
+    issue_w_stage(); issue_w_stage(); issue_w_stage();
+
+    // ---- the accumulators START as bias + residual, so the epilogue only READS them.  (Adding the residual afterwards
+    //      meant writing 384 updated values back into their AGPR / VGPR homes, which hipcc turned into a scratch copy of
+    //      every block and reloads behind vmcnt(0) in the later passes: a 170 us epilogue.)  The fp32 residual tile is read
+    //      straight into registers in the accumulator layout: a lane owns 4 consecutive columns (16 B) at 4 places of a row
+    //      per block, so a load instruction touches 32 rows x 32 B and the four loads of a block complete its lines in L2.
+    //      96 loads per lane, a window of three column blocks (24 loads = 96 KiB per CU) in flight; no LDS, no barriers.
+    //      (The first version staged the tile through LDS in six double-buffered 64 KiB chunks behind two barriers each:
+    //      24 us for a 100 MB read whose HBM time is 12.6 us.)  Hand-written loads: hipcc does not count them, the waits
+    //      are explicit and tie the registers they cover so that no use moves above them. ----
+    const float* lbias = reinterpret_cast<const float*>(smem + F_BIAS);
+    const float* lgamma = reinterpret_cast<const float*>(smem + F_GB);     // these two: valid in the epilogue only
     const float* lbeta = lgamma + FN;
-    const bool has_res = p.residual != nullptr;
-    const bool has_bias = p.bias != nullptr;
-    const int rrow = lane >> 4, rpos = lane & 15;
-    auto issue_chunk = [&](int c) {
-        const unsigned buf = (unsigned)((c & 1) * F_RES);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int q = wid * 16 + i;                              // wave-uniform: column half q >> 5, rows 4 (q & 31) ..
-            const int row = 4 * (q & 31) + rrow;
-            int gr = m0 + row;
-            gr = gr < p.M ? gr : p.M - 1;
-            const int srcq = rpos ^ (row & 15);
-            const float* src = p.residual + (size_t)gr * p.ldr + (q >> 5) * 384 + c * 64 + srcq * 4;
-            glds16(src, lds_base + buf + (unsigned)(q * 1024));
-        }
-    };
     f32x16 acca[NA][2], accv[12 - NA][2];
-    if (has_res) issue_chunk(0);
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-        if (has_res) {
-            if (c > 0) FR_BAR();                                     // every wave has read chunk c-1: its buffer is free
-            if (c + 1 < 6) {
-                issue_chunk(c + 1);
-                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            FR_BAR();                                                // everyone's pieces of chunk c have landed
-        } else if (c == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the bias row
-            FR_BAR();
-        }
-        const char* rb = smem + (c & 1) * F_RES + wn * (FM * 64 * 4);
-#pragma unroll
-        for (int nbl = 0; nbl < 2; ++nbl) {
-            const int nb = 2 * c + nbl;
+    {
+        const float* rp[2] = {nullptr, nullptr};
+        if constexpr (RES) {
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
-                const int row = wm * 64 + mb * 32 + r32;
+                int gr = m0 + wm * 64 + mb * 32 + r32;
+                gr = gr < p.M ? gr : p.M - 1;
+                rp[mb] = p.residual + (size_t)gr * p.ldr + wn * 384 + 4 * hh;
+            }
+        }
+        f32x4 T[3][8];                                               // [window slot][mb * 4 + g]
+        auto issue_group = [&](auto NB, f32x4 (&t)[8]) {             // the 8 loads of column block NB
+            constexpr int nb = decltype(NB)::value;
+            if constexpr (RES) {
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    const float* ptr = rp[mb];
+                    asm volatile("global_load_dwordx4 %0, %4, off offset:%5\n\t"
+                                 "global_load_dwordx4 %1, %4, off offset:%6\n\t"
+                                 "global_load_dwordx4 %2, %4, off offset:%7\n\t"
+                                 "global_load_dwordx4 %3, %4, off offset:%8"
+                                 : "=&v"(t[mb * 4 + 0]), "=&v"(t[mb * 4 + 1]), "=&v"(t[mb * 4 + 2]), "=&v"(t[mb * 4 + 3])
+                                 : "v"(ptr), "n"(nb * 128), "n"(nb * 128 + 32), "n"(nb * 128 + 64), "n"(nb * 128 + 96)
+                                 : "memory");
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) t[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        auto finish_group = [&](auto NB, auto INFLIGHT, f32x4 (&t)[8]) {
+            constexpr int nb = decltype(NB)::value, inflight = decltype(INFLIGHT)::value;
+            if constexpr (RES) {
+                if constexpr (inflight == 16)
+                    asm volatile("s_waitcnt vmcnt(16)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7])::"memory");
+                else if constexpr (inflight == 8)
+                    asm volatile("s_waitcnt vmcnt(8)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7])::"memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7])::"memory");
+            }
+            if constexpr (nb == 0) {
+                if constexpr (!RES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                FR_BAR();      // every wave is past a wait that covers wave 0's bias row (the oldest load): visible to all
+            }
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
                 f32x16 v;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int col = wn * 384 + nb * 32 + 8 * g + 4 * hh;
-                    f32x4 add = {0.f, 0.f, 0.f, 0.f};
-                    if (has_bias) add = *reinterpret_cast<const f32x4*>(lbias + col);
-                    if (has_res) {
-                        const int q = nbl * 8 + 2 * g + hh;
-                        add += *reinterpret_cast<const f32x4*>(rb + row * 256 + ((q ^ (row & 15)) << 4));
-                    }
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(lbias + wn * 384 + nb * 32 + 8 * g + 4 * hh);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[4 * g + e] = add[e];
+                    for (int e = 0; e < 4; ++e) v[4 * g + e] = t[mb * 4 + g][e] + b4[e];
                 }
-                if (nb < NA) { acca[nb < NA ? nb : 0][mb] = v; PIN_A(acca[nb < NA ? nb : 0][mb]); }
+                if constexpr (nb < NA) { acca[nb < NA ? nb : 0][mb] = v; PIN_A(acca[nb < NA ? nb : 0][mb]); }
                 else { accv[nb < NA ? 0 : nb - NA][mb] = v; PIN_V(accv[nb < NA ? 0 : nb - NA][mb]); }
-                __builtin_amdgcn_sched_barrier(0);
             }
-        }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        issue_group(IC<0>{}, T[0]); issue_group(IC<1>{}, T[1]); issue_group(IC<2>{}, T[2]);
+        finish_group(IC<0>{}, IC<16>{}, T[0]); issue_group(IC<3>{}, T[0]);
+        finish_group(IC<1>{}, IC<16>{}, T[1]); issue_group(IC<4>{}, T[1]);
+        finish_group(IC<2>{}, IC<16>{}, T[2]); issue_group(IC<5>{}, T[2]);
+        finish_group(IC<3>{}, IC<16>{}, T[0]); issue_group(IC<6>{}, T[0]);
+        finish_group(IC<4>{}, IC<16>{}, T[1]); issue_group(IC<7>{}, T[1]);
+        finish_group(IC<5>{}, IC<16>{}, T[2]); issue_group(IC<8>{}, T[2]);
+        finish_group(IC<6>{}, IC<16>{}, T[0]); issue_group(IC<9>{}, T[0]);
+        finish_group(IC<7>{}, IC<16>{}, T[1]); issue_group(IC<10>{}, T[1]);
+        finish_group(IC<8>{}, IC<16>{}, T[2]); issue_group(IC<11>{}, T[2]);
+        finish_group(IC<9>{}, IC<16>{}, T[0]);
+        finish_group(IC<10>{}, IC<8>{}, T[1]);
+        finish_group(IC<11>{}, IC<0>{}, T[2]);
     }
-    FR_BAR();   // every wave is done with the chunk buffers: the ring may fill
-    issue_stage(); issue_stage(); issue_stage();                 // stages 0, 1, 2 (nkt >= 4)
 
-    // stage 0 has landed (the two younger stages stay in flight)
-    asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    // slab 0 and W stages 0..2 landed long ago for this wave (they are older than the residual loads); for everyone:
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     FR_BAR();
+    unsigned c_off = 0;          // W ring byte offset of the stage being multiplied
+    unsigned a_cur = F_ARING;    // byte offset of the A slab being multiplied
     bf16x8 a0[2], a1[2], wf[4];
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) a0[mb] = *reinterpret_cast<const bf16x8*>(smem + a_off + mb * 1024);
+    for (int mb = 0; mb < 2; ++mb) a0[mb] = *reinterpret_cast<const bf16x8*>(smem + a_cur + a_row + mb * 4096 + a_x);
 #pragma unroll
     for (int n = 0; n < 3; ++n) wf[n] = *reinterpret_cast<const bf16x8*>(smem + w_off + n * 1024);
 
-    unsigned c_off = 0;   // ring byte offset of the stage being multiplied
-    // One stage.  ACUR: its A fragments (resident), ANXT receives the next stage's.  ISSUE: the stage three ahead exists
-    // and its 7 DMA pieces go out between the first MFMAs; NEXT: a next stage exists; YOUNGER: how many whole stages
-    // issued after stage kt+1 are in flight at its wait (compile-time: counted vmcnt needs an immediate).
-    auto stage = [&](auto ISSUE, auto NEXT, auto YOUNGER, bf16x8 (&ACUR)[2], bf16x8 (&ANXT)[2]) {
-        constexpr bool do_issue = decltype(ISSUE)::value != 0, has_next = decltype(NEXT)::value != 0;
-        constexpr int younger = decltype(YOUNGER)::value;
+    // One stage = K 16.  J: its position in the A slab.  ACUR: its A fragments (resident), ANXT receives the next stage's.
+    // ISSUE_W: stage t+3 exists and its 6 pieces go out behind the first MFMAs; ISSUE_A: a next slab exists and (J < 2) two
+    // of its 4 pieces go out behind those; NEXT: a next stage exists.  VM: the loads this wave may leave in flight when it
+    // needs stage t+1 (and, at J = 3, the next slab) landed = everything issued during stages t-1 and t — counted vmcnt
+    // takes an immediate, hence all of this at compile time.
+    auto stage = [&](auto J, auto ISSUE_W, auto ISSUE_A, auto NEXT, auto VM, bf16x8 (&ACUR)[2], bf16x8 (&ANXT)[2]) {
+        constexpr int j = decltype(J)::value, vm = decltype(VM)::value;
+        constexpr bool do_w = decltype(ISSUE_W)::value != 0, do_a = decltype(ISSUE_A)::value != 0 && j < 2;
+        constexpr bool has_next = decltype(NEXT)::value != 0;
         const char* cur = smem + c_off;
-        const unsigned n_off = c_off + F_STAGE == F_RING ? 0u : c_off + F_STAGE;
+        const unsigned n_off = c_off + F_W_BYTES == F_WRING ? 0u : c_off + F_W_BYTES;
         const char* nxt = smem + n_off;
+        const unsigned a_nxt = j == 3 ? (unsigned)(2 * F_ARING + F_ASLAB) - a_cur : a_cur;
 #pragma unroll
         for (int nb = 0; nb < 12; ++nb) {
             if (nb + 3 < 12) wf[(nb + 3) & 3] = *reinterpret_cast<const bf16x8*>(cur + w_off + (nb + 3) * 1024);
             if (nb == 8 && has_next) {
-                // stage kt+1 has landed: this wave's pieces by the counted vmcnt (the stages issued after it stay in
-                // flight), everyone's by the barrier — which also certifies that every wave is past stage kt-1, whose
-                // slot the NEXT stage's DMA issue overwrites
-                if constexpr (younger >= 2) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-                else if constexpr (younger == 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+                // stage t+1 has landed: this wave's pieces by the counted vmcnt (what was issued after them stays in
+                // flight), everyone's by the barrier — which also certifies that every wave is past stage t-1, whose W
+                // slot (and, at J = 3, whose A slab) the NEXT stage's DMA issue overwrites
+                static_assert(vm == 16 || vm == 14 || vm == 12 || vm == 6 || vm == 0, "");
+                if constexpr (vm == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else if constexpr (vm == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+                else if constexpr (vm == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else if constexpr (vm == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef DITTO_DIAG_FR_NOBAR     // main loop without its per-stage barrier (timing only, racy)
                 FR_BAR();
+#endif
 #pragma unroll
-                for (int mb = 0; mb < 2; ++mb) ANXT[mb] = *reinterpret_cast<const bf16x8*>(nxt + a_off + mb * 1024);
+                for (int mb = 0; mb < 2; ++mb)
+                    ANXT[mb] = *reinterpret_cast<const bf16x8*>(smem + a_nxt + a_row + mb * 4096 + (a_x ^ (((j + 1) & 3) << 5)));
             }
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
@@ -252,31 +336,38 @@ __global__ __launch_bounds__(256, 1) void gemm_fr_kernel(FrParams fp) {
             // asm (it spilled a just-written AGPR block with scratch_store two instructions later: garbage in some lanes
             // of some launches).  An MFMA's result needs its wait states before ANY reader but the next MFMA of its chain.
             if constexpr (!has_next) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
-            if constexpr (do_issue) {
-                if (nb == 0) issue_piece(IC<0>{});
-                if (nb == 1) issue_piece(IC<1>{});
-                if (nb == 2) issue_piece(IC<2>{});
-                if (nb == 3) issue_piece(IC<3>{});
-                if (nb == 4) issue_piece(IC<4>{});
-                if (nb == 5) issue_piece(IC<5>{});
-                if (nb == 6) issue_piece(IC<6>{});
+            if constexpr (do_w) {
+                if (nb == 0) issue_w_piece(IC<0>{});
+                if (nb == 1) issue_w_piece(IC<1>{});
+                if (nb == 2) issue_w_piece(IC<2>{});
+                if (nb == 3) issue_w_piece(IC<3>{});
+                if (nb == 4) issue_w_piece(IC<4>{});
+                if (nb == 5) issue_w_piece(IC<5>{});
+            }
+            if constexpr (do_a) {
+                if (nb == 6) issue_a_piece(IC<2 * (j & 1)>{});
+                if (nb == 7) issue_a_piece(IC<2 * (j & 1) + 1>{});
             }
             if (nb >= 9 && has_next)   // W fragments 0..2 of the next stage, into ring slots the MFMAs above released
                 wf[(nb - 9) & 3] = *reinterpret_cast<const bf16x8*>(nxt + w_off + (nb - 9) * 1024);
         }
-        if constexpr (do_issue) advance_issue();
+        if constexpr (do_w) advance_w();
+        if constexpr (do_a && j == 1) advance_a();
+        if constexpr (j == 3) a_cur = a_nxt;
         c_off = n_off;
     };
-    // stages 0 .. nkt-5 in pairs (the A fragments ping-pong between two NAMED sets), then the four-stage tail in which the
-    // issue stops and the counted waits shrink
-    for (int kt = 0; kt + 6 <= nkt; kt += 2) {
-        stage(IC<1>{}, IC<1>{}, IC<2>{}, a0, a1);
-        stage(IC<1>{}, IC<1>{}, IC<2>{}, a1, a0);
+    // all slabs but the last: every stage issues W stage t+3, the first two also half of the next slab each (per stage
+    // 8, 8, 6, 6 loads per wave: the waits leave 14, 16, 14, 12 in flight); then the last slab, in which the issue stops
+    for (int sl = 0; sl + 1 < nslab; ++sl) {
+        stage(IC<0>{}, IC<1>{}, IC<1>{}, IC<1>{}, IC<14>{}, a0, a1);
+        stage(IC<1>{}, IC<1>{}, IC<1>{}, IC<1>{}, IC<16>{}, a1, a0);
+        stage(IC<2>{}, IC<1>{}, IC<1>{}, IC<1>{}, IC<14>{}, a0, a1);
+        stage(IC<3>{}, IC<1>{}, IC<1>{}, IC<1>{}, IC<12>{}, a1, a0);
     }
-    stage(IC<1>{}, IC<1>{}, IC<2>{}, a0, a1);   // stage nkt-4: issues stage nkt-1
-    stage(IC<0>{}, IC<1>{}, IC<1>{}, a1, a0);   // stage nkt-3
-    stage(IC<0>{}, IC<1>{}, IC<0>{}, a0, a1);   // stage nkt-2
-    stage(IC<0>{}, IC<0>{}, IC<0>{}, a1, a0);   // stage nkt-1
+    stage(IC<0>{}, IC<1>{}, IC<0>{}, IC<1>{}, IC<12>{}, a0, a1);   // stage nkt-4: issues W stage nkt-1
+    stage(IC<1>{}, IC<0>{}, IC<0>{}, IC<1>{}, IC<6>{}, a1, a0);    // stage nkt-3
+    stage(IC<2>{}, IC<0>{}, IC<0>{}, IC<1>{}, IC<0>{}, a0, a1);    // stage nkt-2
+    stage(IC<3>{}, IC<0>{}, IC<0>{}, IC<0>{}, IC<0>{}, a1, a0);    // stage nkt-1
 
     // ---------------- epilogue: the accumulators hold h = residual + bias + A W^T; they are only READ from here on ----------------
     // MFMA results -> any other reader need wait states hipcc does not insert for asm producers
@@ -303,6 +394,13 @@ __global__ __launch_bounds__(256, 1) void gemm_fr_kernel(FrParams fp) {
             if (hh == 0) red[wn * FM + wm * 64 + mb * 32 + r32] = t;
         }
         __syncthreads();
+        // every wave is out of the main loop: gamma and beta rows -> the idle A ring (3 pieces of 1 KiB each), landed by
+        // the second exchange below
+        if (wid < 2) {
+            const float* src = wid == 0 ? fp.gamma : fp.beta;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) glds16(src + i * 256 + lane * 4, lds_base + (unsigned)(F_GB + wid * FN * 4 + i * 1024));
+        }
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
             const int r = wm * 64 + mb * 32 + r32;
@@ -331,6 +429,7 @@ __global__ __launch_bounds__(256, 1) void gemm_fr_kernel(FrParams fp) {
             t += __shfl_xor(t, 32, 64);
             if (hh == 0) red2[wn * FM + wm * 64 + mb * 32 + r32] = t;
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
@@ -396,7 +495,7 @@ __global__ __launch_bounds__(256, 1) void gemm_fr_kernel(FrParams fp) {
             for (int i = 4 * half; i < 4 * half + 4; ++i) {
                 const int row = srow + 8 * i;
                 const u32x4 hv = *reinterpret_cast<const u32x4*>(hst + row * 128 + ((sq ^ (row & 7)) << 4));
-                if (grow0 + 8 * i < p.M) store16<true, true>(hrow + (size_t)(8 * i) * p.ldo + nb * 32, hv, 0);
+                if (grow0 + 8 * i < FR_DIAG_M) store16<true, true>(hrow + (size_t)(8 * i) * p.ldo + nb * 32, hv, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -407,7 +506,7 @@ __global__ __launch_bounds__(256, 1) void gemm_fr_kernel(FrParams fp) {
                 for (int i = 4 * half; i < 4 * half + 4; ++i) {
                     const int row = srow + 8 * i;
                     const u32x4 uv = *reinterpret_cast<const u32x4*>(ust + row * 128 + ((sq ^ (row & 7)) << 4));
-                    if (grow0 + 8 * i < p.M) {
+                    if (grow0 + 8 * i < FR_DIAG_M) {
                         if (LN) *reinterpret_cast<u32x4*>(urow + (size_t)(8 * i) * fp.ldu + (nb - 1) * 32) = uv;
                         else if (orow) *reinterpret_cast<u32x4*>(orow + (size_t)(8 * i) * p.ldo2 + (nb - 1) * 32) = uv;
                     }
@@ -420,35 +519,38 @@ __global__ __launch_bounds__(256, 1) void gemm_fr_kernel(FrParams fp) {
     }
 }
 
-template <bool LN>
+template <bool LN, bool RES>
 hipError_t launch_fr_t(const FrParams& fp, int grid, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fr_kernel<LN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fr_kernel<LN, RES>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_fr_kernel<LN>), dim3(grid), dim3(256), F_LDS, s, fp);
+    hipLaunchKernelGGL((gemm_fr_kernel<LN, RES>), dim3(grid), dim3(256), F_LDS, s, fp);
     return hipGetLastError();
 }
 
 }  // namespace
 
 bool gemm_fr_supports(int M, int N, int K, size_t lda, size_t ldw) {
-    if (N != FN || K % 32 || K < 64 || M < FM) return false;
+    if (N != FN || K % 64 || K < 64 || M < FM) return false;
     if ((size_t)M * lda * 2 >= (1ull << 32) || (size_t)N * ldw * 2 >= (1ull << 32)) return false;
     return true;
 }
 
 hipError_t launch_gemm_fr(const GemmParams& p_in, const float* gamma, const float* beta, void* u_bf16, int ldu,
-                          hipStream_t s) {
+                          int rot_period, hipStream_t s) {
     FrParams fp;
     fp.g = p_in;
     fp.g.tiles_m = (p_in.M + FM - 1) / FM;
     fp.g.tiles_n = 1;
     fp.gamma = gamma; fp.beta = beta; fp.u = (bf16*)u_bf16; fp.ldu = ldu;
-    return (gamma && u_bf16) ? launch_fr_t<true>(fp, fp.g.tiles_m, s) : launch_fr_t<false>(fp, fp.g.tiles_m, s);
+    fp.rot_period = g_fr_rot ? rot_period : 0;
+    const bool ln = gamma && u_bf16, res = p_in.residual != nullptr;
+    if (ln) return res ? launch_fr_t<true, true>(fp, fp.g.tiles_m, s) : launch_fr_t<true, false>(fp, fp.g.tiles_m, s);
+    return res ? launch_fr_t<false, true>(fp, fp.g.tiles_m, s) : launch_fr_t<false, false>(fp, fp.g.tiles_m, s);
 }
 
 }  // namespace ditto

@@ -51,6 +51,7 @@ hipError_t launch_pack_bf16(const float* src, void* dst_bf16, int rows, int cols
 hipError_t launch_scale_vec(float* v, int n, float f, hipStream_t s);
 // fp32 [N, K] -> bf16 stage-major [K/16][N][16] (the full-row GEMM's weight layout, gemm_fr.hip)
 hipError_t launch_pack_bf16_stage_major(const float* src, void* dst, int N, int K, hipStream_t s);
+extern int g_fr_rot;     // gemm.hip: full-row kernel's K-loop rotation: 0 off, 1 on in the model (period = tiles per utterance), > 1 = period for ditto_gemm_ln_bf16 too
 extern int g_fr_mask;    // gemm.hip: 1 = cross out-proj + LayerNorm3, 2 = fc2 + next block's LayerNorm1 on the full-row kernel
 // same row map for an fp32 vector (bias)
 hipError_t launch_pack_vec(const float* src, float* dst, int rows, int blk, int mult, int row_off, hipStream_t s);

@@ -228,7 +228,7 @@ size_t ditto_attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh);
 /* Full-row GEMM with the residual add and the FOLLOWING LayerNorm fused (N = 768 only; csrc/gemm_fr.hip):
  *   out fp32 [M,768] = residual + A[M,K] W[768,K]^T + bias   (residual may alias out: the in-place stream update of
  *   src/components/DiT.py:148 / :155),   u bf16 [M,ldu] = LayerNorm(out) * gamma + beta  (eps 1e-5; the norm of :152 / the
- *   next block's :105).  gamma = beta = u = NULL: no LayerNorm output.  K % 32 == 0, K >= 64, M >= 128.
+ *   next block's :105).  gamma = beta = u = NULL: no LayerNorm output.  K % 64 == 0, M >= 128.
  *   W is NOT the nn.Linear image: it is packed stage-major, Wp[K/16][768][16] (Wp[s][n][j] = W[n][16 s + j]), so that
  *   each K-step's 24 KiB are contiguous (the kernel moves them by LDS-DMA in whole cache lines). */
 int ditto_gemm_ln_bf16(const void* A, int lda, const void* W, const float* bias, const float* residual, float* out,
@@ -242,6 +242,10 @@ int ditto_gemm_ln_bf16(const void* A, int lda, const void* W, const float* bias,
  * 3 fc2, 4 QKV + RoPE, 5 gated MLP; -1 = the built-in rule).
  * "fr_mask": N = d = 768 projections on the full-row kernel with the residual add and the following LayerNorm fused
  * (csrc/gemm_fr.hip): bit 0 = cross out-proj + norm3, bit 1 = fc2 + the next block's norm1.
+ * "fr_rot": that kernel's K-loop rotation (tiles start their k sum at different places so that the workgroups of an XCD do
+ * not all ask the L2 for the same weight lines at once): 0 = off, 1 = on in the model path with period = row tiles per
+ * utterance (an utterance's bits do not depend on its place in the batch), > 1 = ditto_gemm_ln_bf16 rotates too, with that
+ * period in 128-row tiles.
  * "pp_nb": tile width of the ping-pong kernel's plain epilogues: 0 = rule, 3 = 128x192, 4 = 128x256.
  * "pp_stagger": phase offset between the two workgroups of a CU in the ping-pong GEMM, 10 ns ticks (-1 = built-in rule).
  * "gemm_flags": bit mask for kernel experiments (bit 0 = relaxed tile-start wait, default on; bits 1, 2 are

@@ -352,13 +352,16 @@ def test_fp8_gemm_gated(lib):
     assert max_abs(_deq(out), want.clamp(-448, 448)) < 0.07 * (1 + float(want.abs().max()))
 
 
-@pytest.mark.parametrize("M,K,ln", [(128, 768, True), (300, 256, True), (1024, 3072, True), (257, 64, False)])
-def test_full_row_gemm_with_fused_layernorm(lib, M, K, ln):
+@pytest.mark.parametrize("M,K,ln", [(128, 768, True), (300, 256, True), (1024, 3072, True), (257, 64, False), (1000, 128, True),
+                                      (515, 192, True), (2048, 768, True)])
+@pytest.mark.parametrize("rot", [0, 8, 3])
+def test_full_row_gemm_with_fused_layernorm(lib, M, K, ln, rot):
     """ditto_gemm_ln_bf16 (csrc/gemm_fr.hip): out = residual + A W^T + bias in place, u = LayerNorm(out) * gamma + beta, in ONE
-    kernel whose workgroups own whole rows — against the fp32 ops.  Experimental (not on the model path: measured slower
-    than GEMM + LayerNorm), kept correct.  Ragged M (row clamp / masks), short and long K, repeated for
-    run-to-run determinism."""
+    kernel whose workgroups own whole rows — against the fp32 ops.  The model's cross out-projection + norm3 and fc2 + next
+    norm1 (fr_mask).  Ragged M (row clamp / masks), one to 48 K slabs, with and without the K-loop rotation (period in
+    tiles; 2048 rows = 16 tiles takes the XCD tile remap), repeated for run-to-run determinism."""
     N = 768
+    hip.check(lib.ditto_set_option(b"fr_rot", rot))
     A = bf16(asym((M, K), 4).to(DEV))
     W = bf16((asym((N, K), 5) / math.sqrt(K)).to(DEV))
     Wp = W.view(N, K // 16, 16).permute(1, 0, 2).contiguous()      # the kernel's stage-major weight layout [K/16][N][16]
@@ -382,5 +385,6 @@ def test_full_row_gemm_with_fused_layernorm(lib, M, K, ln):
             first = (h.clone(), u.clone())
         else:
             assert torch.equal(h, first[0]) and torch.equal(u, first[1])
+    hip.check(lib.ditto_set_option(b"fr_rot", 1))
     assert lib.ditto_gemm_ln_bf16(A.data_ptr(), K, Wp.data_ptr(), None, None, h.data_ptr(), 512, None, None, None, 0, M, 512,
                                   K, stream()) == hip.ERR_SHAPE

@@ -7,8 +7,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ditto_tts_amd import hip
 ap = argparse.ArgumentParser(); ap.add_argument("--m", type=int, default=32768); ap.add_argument("--iters", type=int, default=15)
+ap.add_argument("--nores", action="store_true", help="new kernel without the residual (timing of the accumulator init)")
+ap.add_argument("--noln", action="store_true", help="new kernel without the LayerNorm output")
+ap.add_argument("--rot", type=int, default=8, help="fr_rot option: K-loop rotation period in tiles (0 = off)")
 a = ap.parse_args()
-lib = hip.lib(); st = torch.cuda.current_stream().cuda_stream
+lib = hip.lib(); hip.check(lib.ditto_set_option(b"fr_rot", a.rot)); st = torch.cuda.current_stream().cuda_stream
 M, N = a.m, 768
 torch.manual_seed(0)
 for K in (768, 3072):
@@ -28,8 +31,9 @@ for K in (768, 3072):
     def new():
         h = res.clone(); u = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
         def run():
-            hip.check(lib.ditto_gemm_ln_bf16(A.data_ptr(), K, Wp.data_ptr(), bias.data_ptr(), h.data_ptr(), h.data_ptr(), N,
-                                             g.data_ptr(), b.data_ptr(), u.data_ptr(), N, M, N, K, st))
+            hip.check(lib.ditto_gemm_ln_bf16(A.data_ptr(), K, Wp.data_ptr(), bias.data_ptr(), None if a.nores else h.data_ptr(),
+                                             h.data_ptr(), N, None if a.noln else g.data_ptr(), None if a.noln else b.data_ptr(),
+                                             None if a.noln else u.data_ptr(), N, M, N, K, st))
         return h, u, run
     h0, u0, r0 = old(); r0(); h1, u1, r1 = new(); r1(); torch.cuda.synchronize()
     want = res + A.float() @ W.float().T + bias

@@ -44,6 +44,8 @@ wall = {v: [] for v in variants}
 
 
 def select(v):
+    v, _, fr = v.partition("&")          # ...&fr_rot (full-row GEMM K-loop rotation: default 1 = on)
+    hip.check(lib.ditto_set_option(b"fr_rot", int(fr) if fr else 1))
     v, _, fm = v.partition("~")          # ...~fr_mask (full-row GEMM + fused LayerNorm: 1 out-proj, 2 fc2)
     hip.check(lib.ditto_set_option(b"fr_mask", int(fm) if fm else 0))
     v, _, nb = v.partition("!")          # ...!pp_nb (ping-pong tile width: 3 = 192, 4 = 256; default 0 = rule)
