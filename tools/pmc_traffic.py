@@ -9,9 +9,12 @@ import csv
 import json
 import sys
 
-CLASSES = [("gemm_gated_mlp", "gemm256_kernel<3"), ("gemm_qkv_rope", "gemm256_kernel<2"), ("gemm_fc2", "gemm192_kernel<1"),
-           ("gemm_q_proj", "gemm192_kernel<0"), ("gemm_out_proj", "gemm_pp_kernel<1"), ("gemm_final", "gemm192_kernel<4"),
-           ("attn_self", "attn64v2_kernel<true"), ("attn_cross", "attn64v2_kernel<false"), ("layernorm", "ln_kernel<3, 0>")]
+CLASSES = [("gemm_gated_mlp", "gemm256_kernel<3"), ("gemm_qkv_rope", "gemm256_kernel<2"), ("gemm_q_proj", "gemm192_kernel<0"),
+           ("gemm_final", "gemm192_kernel<4"), ("attn_self", "attn64v2_kernel<true"), ("attn_cross", "attn64v2_kernel<false"),
+           ("layernorm", "ln_kernel<3, 0>")]
+# the cross out-projection (+ norm3) and fc2 (+ next norm1) are the SAME kernel (gemm_fr_kernel<true, true>) at K = d and
+# K = 4d: its launches are told apart by their own read traffic (fc2 reads a 4x wider A), position by position in both passes
+FR = "gemm_fr_kernel<true, true>"
 
 
 def avg(path, counter):
@@ -20,6 +23,12 @@ def avg(path, counter):
         if r["Counter_Name"] == counter:
             acc[r["Kernel_Name"].replace("(anonymous namespace)::", "")].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+def series(path, counter, pat):
+    rows = [(int(r["Dispatch_Id"]), float(r["Counter_Value"])) for r in csv.DictReader(open(path))
+            if r["Counter_Name"] == counter and pat in r["Kernel_Name"]]
+    return [v for _, v in sorted(rows)]
 
 
 fetch, write = avg(sys.argv[1], "FETCH_SIZE"), avg(sys.argv[2], "WRITE_SIZE")
@@ -33,5 +42,14 @@ for cls, pat in CLASSES:
     k = ks[0]
     f, w = fetch[k], write.get(k, 0.0)
     out[cls] = {"kernel": k[:90], "fetch_kb": round(f, 1), "write_kb": round(w, 1), "traffic_bytes": int(2 * f * 1024 + w * 1024)}
+fs, ws = series(sys.argv[1], "FETCH_SIZE", FR), series(sys.argv[2], "WRITE_SIZE", FR)
+if fs and len(fs) == len(ws):
+    mid = (min(fs) + max(fs)) / 2
+    for cls, sel in (("gemm_out_proj", lambda v: v < mid), ("gemm_fc2", lambda v: v >= mid)):
+        idx = [i for i, v in enumerate(fs) if sel(v)]
+        if idx:
+            f, w = sum(fs[i] for i in idx) / len(idx), sum(ws[i] for i in idx) / len(idx)
+            out[cls] = {"kernel": FR + (" K=d" if cls == "gemm_out_proj" else " K=4d"), "launches": len(idx), "fetch_kb": round(f, 1),
+                        "write_kb": round(w, 1), "traffic_bytes": int(2 * f * 1024 + w * 1024)}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
