@@ -34,7 +34,8 @@ namespace ditto {
 // (needs bit 0); bit 4 (16): ditto_attention_bf16's q is pre-scaled
 // (unit tests of attn64v2); bit 5 (32): run the kernels above on pre-scaled q instead of attn64v2 (A/B); bit 6 (64):
 // attn64v2 at 2 waves per SIMD with the V prefetch instead of 3 without; bit 7 (128): no deep-prefetch instantiation
-// on small grids.  ditto_set_option("attn_flags")
+// on small grids; bit 8 (256): never attn64v3 (the software-pipelined kernel), bit 9 (512): attn64v3 wherever Skv % 128 == 0.
+// ditto_set_option("attn_flags")
 int g_attn_flags = 3;
 
 namespace {
@@ -57,6 +58,9 @@ struct AttnParams {
 };
 
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+
+template <int V>
+struct IC1 { static constexpr int value = V; };
 
 DITTO_DEV bf16x8 cat4(bf16x4 a, bf16x4 b) {
     bf16x8 r;
@@ -467,7 +471,9 @@ __global__ __launch_bounds__(256, WPS) void attn64v2_kernel(AttnParams p) {
         for (int r = 1; r < 16; ++r) dm = fmaxf(dm, fmaxf(st[0][r], st[1][r]));
         dm = fmaxf(dm, __shfl_xor(dm, 32, 64));
         if (kt == 0 || !__all(dm <= RESCALE_THR_LOG2)) {
-            const float up = kt == 0 ? dm : fmaxf(dm, 0.f);   // first tile: the running maximum IS this tile's
+            // first tile: the running maximum IS this tile's.  Whole octaves: the rescale factors are powers of two, which is
+            // what lets attn64v3 rescale a bf16 P exactly and stay BITWISE equal to this kernel
+            const float up = ceilf(kt == 0 ? dm : fmaxf(dm, 0.f));
             const float alpha = __builtin_amdgcn_exp2f(-up);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -506,6 +512,310 @@ __global__ __launch_bounds__(256, WPS) void attn64v2_kernel(AttnParams p) {
     const int nfull = ragged ? nkt - 1 : nkt;
     for (int kt = 0; kt < nfull; ++kt) tile_body(kt, std::false_type{});
     if (ragged) tile_body(nkt - 1, std::true_type{});
+
+    const float inv = 1.0f / lsum[0];
+    if (!qvalid) return;
+    const size_t grow = (size_t)b * p.Sq + qrow;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int col = h * DH + 32 * db + 8 * g + 4 * hh;
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = ot[db][4 * g + e] * inv;
+            if constexpr (RESID) {
+                float* rp = p.resid + grow * p.ldr + col;
+                f32x4 r = *reinterpret_cast<const f32x4*>(p.resid_in + grow * p.ldr + col);
+                r += o;
+                *reinterpret_cast<f32x4*>(rp) = r;
+            } else {
+                u32x2 st2;
+                st2[0] = pack_bf16x2(o[0], o[1]);
+                st2[1] = pack_bf16x2(o[2], o[3]);
+                *reinterpret_cast<u32x2*>(p.out + grow * p.ldo + col) = st2;
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// attn64v3: attn64v2's arithmetic as a THREE-tile software pipeline whose MFMAs and softmax VALU work are interleaved BY
+// HAND inside every wave.  Why: in attn64v2 a wave's instruction stream alternates between an MFMA burst (S = K Q^T), a
+// VALU burst (max, 32 exp2, 16 converts) and a second MFMA burst (O += V P), and the cycle count per 64-key tile of a SIMD
+// is the SUM of its waves' VALU and MFMA times (measured: 1476 cycles per wave and tile = 776 VALU + 640 MFMA; the SQ
+// counters read VALU 53 % + MFMA 43 %): three waves per SIMD do not overlap the two pipes for it.  One wave does, when an
+// independent VALU chunk follows every MFMA: measured on the full-row GEMM's loop (tools/build_diag.sh -DDITTO_DIAG_FR_VALU),
+// two transcendentals + three plain fp32 operations (44 VALU cycles) behind each 32-cycle 32x32x16 MFMA cost 10 cycles, one
+// transcendental 3.5, four plain FMAs 6.5 — while two PACKED fp32 FMAs cost 22 (they block the matrix pipe: none here).
+//   iteration t of a wave (20 slots, one MFMA + one VALU chunk each, a scheduling barrier behind every slot):
+//     slots 0..7    S'(t+1) = K(t+1) Q^T - m   (two chains of four MFMAs, alternating)  |  exp2 of S'(t) -> P(t), 2 per slot
+//     slots 8..19   O += V(t-1) P(t-1), l += 1 P(t-1)   (4 x {2 + 1} MFMAs)             |  the other 16 exp2 of S'(t), then
+//                                                                                          the row maximum of S'(t+1)
+//   so tile t's probabilities are computed while the matrix pipe works on tile t+1's scores and tile t-1's output.
+//   A raise of the running maximum (rare: deferred until a row exceeds it by 2^8, as in attn64v2) happens at the END of an
+//   iteration, by a whole number of octaves: S'(t+1), -m, O, l and the not yet accumulated P(t) are rescaled together (P in
+//   bf16 by a power of two: exact).
+//   K tiles live in a ring of 4, V tiles in a ring of 5 (tile t+3 is in flight while V(t-1) is still read): 72 KiB per
+//   workgroup, TWO workgroups per CU (256 registers per wave: S' twice, P twice, O, l, -m, Q).
+// Contract: as attn64v2 (pre-scaled q) and Skv % 128 == 0 (an even number of whole tiles: the two register sets of S'
+// and P swap roles every iteration and the loop is unrolled by two); other shapes take attn64v2.
+// ------------------------------------------------------------------------------------------------
+constexpr int V3_KSLOTS = 4, V3_VSLOTS = 5;
+constexpr int V3_LDS = (V3_KSLOTS + V3_VSLOTS) * KV_TILE_BYTES;   // 72 KiB
+
+template <bool RESID>
+__global__ __launch_bounds__(256, 2) void attn64v3_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];    // [4 K tiles][5 V tiles]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwg = p.nqb * p.H * p.B;
+    const int id = xcd_remap(blockIdx.x, nwg);
+    const int qb = id % p.nqb, bh = id / p.nqb;
+    const int h = bh % p.H, b = bh / p.H;
+    const int ql = lane & 31, hh = lane >> 5;
+    int qrow = qb * QBLK + wid * 32 + ql;
+    const bool qvalid = qrow < p.Sq;
+    qrow = qvalid ? qrow : p.Sq - 1;
+
+    bf16x8 qf[4];
+    {
+        const bf16* qp = p.q + ((size_t)b * p.Sq + qrow) * p.ldq + h * DH + 8 * hh;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+    }
+    const int nkt = p.Skv / KBLK;                                  // even, >= 2
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+    // this lane's two (row, chunk) DMA sources of tile 0; tile kt is + kt * 64 rows (LDS swizzles applied on the source)
+    const bf16 *ksrc[2], *vsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wid * 2 + i) * 8 + (lane >> 3), cpos = lane & 7;
+        ksrc[i] = p.k + ((size_t)b * p.Skv + row) * p.ldk + h * DH + (cpos ^ ((row >> 1) & 7)) * 8;
+        vsrc[i] = p.v + ((size_t)b * p.Skv + row) * p.ldv + h * DH + (cpos ^ (((row >> 1) & 1) << 2)) * 8;
+    }
+    const size_t kstep = (size_t)KBLK * p.ldk, vstep = (size_t)KBLK * p.ldv;
+    int issued = 0;                                               // tiles whose DMA has been issued
+    unsigned ik = 0, iv = 0;                                      // ring slots of the next tile to issue
+    auto dma_next = [&]() {                                       // 4 loads per wave: 2 K pieces, 2 V pieces
+        if (issued < nkt) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int piece = wid * 2 + i;
+#ifndef DITTO_DIAG_ATTN_NODMA   // tools/build_diag.sh: attn64v3 without its K/V tile traffic (timing only)
+                glds16(ksrc[i], lds_base + (unsigned)(ik * KV_TILE_BYTES + piece * 1024));
+                glds16(vsrc[i], lds_base + (unsigned)((V3_KSLOTS + iv) * KV_TILE_BYTES + piece * 1024));
+#endif
+                ksrc[i] += kstep; vsrc[i] += vstep;
+            }
+            ++issued;
+            ik = ik + 1 == V3_KSLOTS ? 0 : ik + 1;
+            iv = iv + 1 == V3_VSLOTS ? 0 : iv + 1;
+        }
+    };
+    // tile `need` has landed for this wave once only the tiles issued after it are in flight; then for everyone
+    auto wait_tile = [&](int need) {
+        const int younger = issued - 1 - need;
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef DITTO_DIAG_ATTN_NOBAR   // racy: timing only
+        __syncthreads();
+#endif
+    };
+
+    const int k_row_off = ql * 128, k_swz = (ql >> 1) & 7;
+    const int tr_q = (lane & 15) >> 2, tr_p = lane & 3;
+    const int tr_colbyte = (16 * ((lane >> 4) & 1) + 4 * tr_p) * 2;
+    const int tr_row0 = 4 * hh + tr_q;
+    const int tr_swz = ((tr_q >> 1) & 1) << 6;
+
+    f32x16 ot[2], lsum, cneg;    // cneg: every register = -m_run (the score chains' initial accumulator)
+    f32x16 sX[2], sY[2];         // S' of two tiles in flight
+    u32x4 pP[4], pQ[4];          // P (bf16 pairs) of two tiles in flight
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (bf16)1.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { ot[0][i] = 0.f; ot[1][i] = 0.f; lsum[i] = 0.f; cneg[i] = 0.f; }
+    float dm = 0.f;              // row maximum of the newest S' (relative to the running maximum)
+
+    // One iteration.  QK: scores of tile t+1 into stn; EX: probabilities of tile t from stc into pfc; PV: tile t-1's
+    // probabilities pfp into O and l.  kq / vq: ring slots of K(t+1) and V(t-1).
+    auto body = [&](auto QK_, auto EX_, auto PV_, unsigned kq, unsigned vq, f32x16 (&stc)[2], f32x16 (&stn)[2],
+                    u32x4 (&pfp)[4], u32x4 (&pfc)[4]) {
+        constexpr bool QK = decltype(QK_)::value != 0, EX = decltype(EX_)::value != 0, PV = decltype(PV_)::value != 0;
+        const char* kb = smem + kq * KV_TILE_BYTES;
+        const char* vb = smem + (V3_KSLOTS + vq) * KV_TILE_BYTES;
+        auto kfrag = [&](int j) {                                   // operand of score MFMA j: chain j & 1, k-step j >> 1
+#ifdef DITTO_DIAG_ATTN_NOKV
+            return qf[j & 3];
+#endif
+            return *reinterpret_cast<const bf16x8*>(kb + (j & 1) * 32 * 128 + k_row_off + (((2 * (j >> 1) + hh) ^ k_swz) << 4));
+        };
+        auto vfrag = [&](int s2, int db) {
+            const int colb = (tr_colbyte + 64 * db) ^ tr_swz;
+            const char* a0 = vb + (16 * s2 + tr_row0) * 128 + colb;
+#ifdef DITTO_DIAG_ATTN_NOTR     // V fragments by ONE plain 16-byte read (wrong data: timing of the transposed reads)
+            return *reinterpret_cast<const bf16x8*>(vb + (16 * s2) * 128 + db * 2048 + k_row_off + (((hh) ^ k_swz) << 4));
+#endif
+#ifdef DITTO_DIAG_ATTN_NOKV     // no LDS fragment reads at all
+            return qf[(s2 + db) & 3];
+#endif
+            return cat4(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0)),
+                        __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0 + 8 * 128)));
+        };
+        // the exponentials of a pair are ISSUED behind a slot's MFMA and PACKED in front of the next slot's: a convert right
+        // behind its own v_exp waits out the transcendental latency, and the in-order wave cannot issue its next MFMA meanwhile
+        float eh0 = 0.f, eh1 = 0.f;
+        auto exp_issue = [&](int q) {                               // P elements 2q, 2q+1 of the tile
+            if constexpr (EX) {
+                const int n = 2 * q;
+#ifdef DITTO_DIAG_ATTN_NOEXP    // tools/build_diag.sh: attn64v3 without its transcendentals (timing only)
+                eh0 = stc[n >> 4][n & 15]; eh1 = stc[n >> 4][(n & 15) + 1];
+#else
+                eh0 = __builtin_amdgcn_exp2f(stc[n >> 4][n & 15]);
+                eh1 = __builtin_amdgcn_exp2f(stc[n >> 4][(n & 15) + 1]);
+#endif
+            }
+        };
+        auto exp_pack = [&](int q) {
+            if constexpr (EX) {
+                if (q >= 0) pfc[q >> 2][q & 3] = pack_bf16x2(eh0, eh1);
+            }
+        };
+        auto max8 = [&](int g) {                                    // fold S'(t+1) elements 8g .. 8g+7 into dm
+            if constexpr (QK) {
+                float a = g == 0 ? stn[0][0] : dm;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) a = fmaxf(a, stn[g >> 1][8 * (g & 1) + r]);
+                dm = a;
+            }
+        };
+        // operand queue: the iteration's LDS fragments in the order the MFMAs consume them — K fragments 0..7 of the score
+        // chains, then V fragments 0..7 (2 s2 + db) — read QD fragments ahead of their MFMA (an LDS read issued two MFMAs
+        // ahead stalled every MFMA on its operand: 3 400 cycles per iteration for 1 400 of work)
+        constexpr int QD = 5, QN = QD + 1;
+        constexpr int NK = QK ? 8 : 0, NF = NK + (PV ? 8 : 0);
+        bf16x8 opq[QN];
+        auto fetch = [&](int f) {                                   // fragment f of the iteration's list -> its queue slot
+            if (f < NF) opq[f % QN] = f < NK ? kfrag(f) : vfrag((f - NK) >> 1, (f - NK) & 1);
+        };
+#pragma unroll
+        for (int f = 0; f < QD; ++f) fetch(f);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- slots 0..7: the score chains of tile t+1 | 16 of tile t's exponentials ----
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if constexpr (QK) {
+                fetch(j + QD);
+#ifdef DITTO_DIAG_ATTN_NOMFMA   // attn64v3 without its MFMAs (operands still fetched): timing only
+                asm volatile("" :: "v"(opq[j % QN]));
+                if ((j >> 1) == 0) stn[j & 1] = cneg;
+#else
+                stn[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(opq[j % QN], qf[j >> 1], (j >> 1) == 0 ? cneg : stn[j & 1], 0, 0, 0);
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            exp_pack(j - 1);
+            exp_issue(j);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- slots 8..19: O += V P, l += 1 P of tile t-1 | the other 16 exponentials, then the row maximum of S'(t+1) ----
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+                if constexpr (PV) {
+                    if (w < 2) {
+                        const int f = NK + 2 * s2 + w;
+                        fetch(f + QD);
+#ifdef DITTO_DIAG_ATTN_NOMFMA
+                        asm volatile("" :: "v"(opq[f % QN]), "v"(pfp[s2]));
+#else
+                        ot[w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(opq[f % QN], __builtin_bit_cast(bf16x8, pfp[s2]), ot[w], 0, 0, 0);
+#endif
+                    } else {
+#ifndef DITTO_DIAG_ATTN_NOMFMA
+                        lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, __builtin_bit_cast(bf16x8, pfp[s2]), lsum, 0, 0, 0);
+#endif
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (w == 0) exp_pack(s2 == 0 ? 7 : 8 + 2 * s2 - 1);   // the pair issued in the last exponential slot
+                if (w == 1) exp_pack(8 + 2 * s2);
+                if (w < 2) exp_issue(8 + 2 * s2 + w);
+                else max8(s2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        exp_pack(15);
+#ifndef DITTO_DIAG_ATTN_NORAISE
+        if constexpr (QK) dm = fmaxf(dm, __shfl_xor(dm, 32, 64));
+#endif
+    };
+    // Raise the running maximum by `up` octaves (a whole number per row): everything not yet summed is rescaled.
+    auto raise = [&](auto FIRST_, f32x16 (&stn)[2], u32x4 (&pfc)[4]) {
+        constexpr bool FIRST = decltype(FIRST_)::value != 0;
+#ifdef DITTO_DIAG_ATTN_NORAISE   // tools/build_diag.sh: no running-maximum check after the first tile (timing only)
+        if (FIRST) {
+#else
+        if (FIRST || !__all(dm <= RESCALE_THR_LOG2)) {
+#endif
+            const float up = FIRST ? ceilf(dm) : ceilf(fmaxf(dm, 0.f));   // first tile: the running maximum IS this tile's
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { stn[0][i] -= up; stn[1][i] -= up; cneg[i] -= up; }
+            if constexpr (!FIRST) {
+                const float alpha = __builtin_amdgcn_exp2f(-up);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { ot[0][i] *= alpha; ot[1][i] *= alpha; lsum[i] *= alpha; }
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned w = pfc[s2][j];
+                        pfc[s2][j] = pack_bf16x2(__uint_as_float(w << 16) * alpha, __uint_as_float(w & 0xFFFF0000u) * alpha);
+                    }
+            }
+        }
+    };
+
+    // ---- prologue: tiles 0, 1 in flight; scores of tile 0; its maximum becomes the running maximum ----
+    using T = IC1<1>; using F = IC1<0>;
+    dma_next(); dma_next();
+    wait_tile(0);
+    dma_next();                                                     // tile 2
+    unsigned kq = 0, vq = 0;                                        // ring slots of K(t+1), V(t-1) for the next iteration
+    auto kadv = [&]() { kq = kq + 1 == V3_KSLOTS ? 0 : kq + 1; };
+    auto vadv = [&]() { vq = vq + 1 == V3_VSLOTS ? 0 : vq + 1; };
+    body(T{}, F{}, F{}, kq, vq, sY, sX, pQ, pP);                     // S'(0) -> sX
+    raise(T{}, sX, pP);
+    kadv();
+    wait_tile(1);
+    dma_next();                                                     // tile 3
+    // ---- t = 0: scores of tile 1 -> sY, probabilities of tile 0 (sX) -> pP ----
+    body(T{}, T{}, F{}, kq, vq, sX, sY, pQ, pP);
+    raise(F{}, sY, pP);
+    kadv();
+    // ---- t = 1 .. nkt-2 in pairs ----
+    for (int t = 1; t + 1 < nkt; t += 2) {
+        wait_tile(t + 1);
+        dma_next();                                                 // tile t + 3
+        body(T{}, T{}, T{}, kq, vq, sY, sX, pP, pQ);                 // t odd: S'(t+1) -> sX, P(t) from sY -> pQ, O += V(t-1) pP
+        raise(F{}, sX, pQ);
+        kadv(); vadv();
+        wait_tile(t + 2);
+        dma_next();
+        body(T{}, T{}, T{}, kq, vq, sX, sY, pQ, pP);                 // t+1 even: S'(t+2) -> sY, P(t+1) from sX -> pP, O += V(t) pQ
+        raise(F{}, sY, pP);
+        kadv(); vadv();
+    }
+    // ---- t = nkt-1 (odd): no scores left; probabilities of the last tile from sY -> pQ, O += V(nkt-2) pP ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    body(F{}, T{}, T{}, kq, vq, sY, sX, pP, pQ);
+    vadv();
+    // ---- O += V(nkt-1) pQ ----
+    body(F{}, F{}, T{}, kq, vq, sY, sX, pQ, pP);
 
     const float inv = 1.0f / lsum[0];
     if (!qvalid) return;
@@ -660,7 +970,29 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
         }
         if (a.q_prescaled && !(g_attn_flags & 32)) {   // q already carries scale * log2(e): the reduced-VALU kernel
             const dim3 gridv(p.nqb * a.H * a.B);
-            // default: 3 waves per SIMD (<= 168 registers, no V-fragment prefetch).  Measured in-model (C2, B=32,
+            // whole pairs of key tiles: the software-pipelined, hand-interleaved kernel where it measures faster — small grids
+            // (batch-1 serving, 96 workgroups: 13.6 us against 15.6 for attn64v2's deep-prefetch instantiation) and long key
+            // sequences (Sq = Skv = 4096, B = 8: 445 against 457 us).  At C2 (N = T = 1024, B = 32) it ties in isolation
+            // (142.1 / 141.7 us) and loses in the model (148.9 / 141.3 us self, 133.9 / 132.1 cross): attn64v2 stays there.
+            // attn_flags 256 = never, 512 = wherever the shape allows.
+            const bool v3_shape = a.Skv % (2 * KBLK) == 0;
+            const bool v3_pays = (int)gridv.x <= 320 || a.Skv >= 2048;
+            if (v3_shape && !(g_attn_flags & 256) && (v3_pays || (g_attn_flags & 512))) {
+                static bool attr_set = false;
+                if (!attr_set) {
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn64v3_kernel<true>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
+                    if (e == hipSuccess)
+                        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn64v3_kernel<false>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
+                    if (e != hipSuccess) return e;
+                    attr_set = true;
+                }
+                if (a.resid_f32) hipLaunchKernelGGL((attn64v3_kernel<true>), gridv, dim3(256), V3_LDS, s, p);
+                else hipLaunchKernelGGL((attn64v3_kernel<false>), gridv, dim3(256), V3_LDS, s, p);
+                return hipGetLastError();
+            }
+            // 3 waves per SIMD (<= 168 registers, no V-fragment prefetch).  Measured in-model (C2, B=32,
             // tools/step_ab.py): 138 / 127 us (self / cross) against 159 / 141 us at 2 waves per SIMD with the
             // prefetch, and 150 / 140 us for attn64 — the kernel is latency-bound (SQ counters: VALU issue 53 %,
             // MFMA 28 %, both idle 34 % of the time at 2 waves), so occupancy pays more than the prefetch.

@@ -289,6 +289,11 @@ __global__ __launch_bounds__(256, 1) void gemm_fr_kernel(FrParams fp) {
     unsigned c_off = 0;          // W ring byte offset of the stage being multiplied
     unsigned a_cur = F_ARING;    // byte offset of the A slab being multiplied
     bf16x8 a0[2], a1[2], wf[4];
+#ifdef DITTO_DIAG_FR_VALU
+    float dz0 = 1.f; f32x2 dz1 = {1.f, 1.f}, dz2 = {1.f, 1.f};
+    float dy0 = 1.f; f32x2 dy1 = {1.f, 1.f}, dy2 = {1.f, 1.f};
+    float dw0 = 1.f, dw1 = 1.f, dw2 = 1.f, dw3 = 1.f, dw4 = 1.f, dw5 = 1.f;
+#endif
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) a0[mb] = *reinterpret_cast<const bf16x8*>(smem + a_cur + a_row + mb * 4096 + a_x);
 #pragma unroll
@@ -331,11 +336,40 @@ __global__ __launch_bounds__(256, 1) void gemm_fr_kernel(FrParams fp) {
             for (int mb = 0; mb < 2; ++mb) {
                 if (nb < NA) mfma_a(acca[nb < NA ? nb : 0][mb], wf[nb & 3], ACUR[mb]);
                 else mfma_v(accv[nb < NA ? 0 : nb - NA][mb], wf[nb & 3], ACUR[mb]);
+#if defined(DITTO_DIAG_FR_VALU) && DITTO_DIAG_FR_VALU == 7   // VALU-bound mix behind every MFMA: 2 transcendentals + 3 plain ops (44 cycles)
+                if (mb == 0) asm volatile("v_exp_f32 %0, %0\n\tv_fma_f32 %3, %3, %3, %3\n\tv_max_f32 %4, %4, %3\n\tv_exp_f32 %5, %5\n\tv_fma_f32 %3, %3, %3, %3" : "+v"(dz0), "+v"(dz1), "+v"(dz2), "+v"(dy0), "+v"(dw0), "+v"(dw1));
+                else asm volatile("v_exp_f32 %0, %0\n\tv_fma_f32 %3, %3, %3, %3\n\tv_max_f32 %4, %4, %3\n\tv_exp_f32 %5, %5\n\tv_fma_f32 %3, %3, %3, %3" : "+v"(dw2), "+v"(dy1), "+v"(dy2), "+v"(dw3), "+v"(dw4), "+v"(dw5));
+#endif
+#if defined(DITTO_DIAG_FR_VALU) && DITTO_DIAG_FR_VALU == 4   // 2 packed fp32 FMAs behind every MFMA
+                if (mb == 0) asm volatile("v_pk_fma_f32 %1, %1, %1, %1\n\tv_pk_fma_f32 %2, %2, %2, %2" : "+v"(dz0), "+v"(dz1), "+v"(dz2));
+                else asm volatile("v_pk_fma_f32 %1, %1, %1, %1\n\tv_pk_fma_f32 %2, %2, %2, %2" : "+v"(dy0), "+v"(dy1), "+v"(dy2));
+#endif
+#if defined(DITTO_DIAG_FR_VALU) && DITTO_DIAG_FR_VALU == 5   // 1 transcendental behind every MFMA
+                if (mb == 0) asm volatile("v_exp_f32 %0, %0" : "+v"(dz0), "+v"(dz1), "+v"(dz2));
+                else asm volatile("v_rcp_f32 %0, %0" : "+v"(dy0), "+v"(dy1), "+v"(dy2));
+#endif
+#if defined(DITTO_DIAG_FR_VALU) && DITTO_DIAG_FR_VALU == 6   // 4 plain fp32 FMAs behind every MFMA
+                if (mb == 0) asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %3, %3, %3, %3\n\tv_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %3, %3, %3, %3" : "+v"(dz0), "+v"(dz1), "+v"(dz2), "+v"(dy0));
+                else asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %3, %3, %3, %3\n\tv_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %3, %3, %3, %3" : "+v"(dy0), "+v"(dy1), "+v"(dy2), "+v"(dz0));
+#endif
+#if defined(DITTO_DIAG_FR_VALU) && DITTO_DIAG_FR_VALU == 3   // 24 cycles of independent VALU work behind EVERY MFMA
+                if (mb == 0) asm volatile("v_exp_f32 %0, %0\n\tv_pk_fma_f32 %1, %1, %1, %1\n\tv_pk_fma_f32 %2, %2, %2, %2" : "+v"(dz0), "+v"(dz1), "+v"(dz2));
+                else asm volatile("v_rcp_f32 %0, %0\n\tv_pk_fma_f32 %1, %1, %1, %1\n\tv_pk_fma_f32 %2, %2, %2, %2" : "+v"(dy0), "+v"(dy1), "+v"(dy2));
+#endif
             }
             // LAST stage: these are the final writes of the block's accumulators, and hipcc may read them right behind the
             // asm (it spilled a just-written AGPR block with scratch_store two instructions later: garbage in some lanes
             // of some launches).  An MFMA's result needs its wait states before ANY reader but the next MFMA of its chain.
             if constexpr (!has_next) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
+#if defined(DITTO_DIAG_FR_VALU) && DITTO_DIAG_FR_VALU < 3   // tools/build_diag.sh: dummy VALU work behind every MFMA pair (does it hide under the matrix pipe?)
+            asm volatile("v_exp_f32 %0, %0\n\tv_pk_fma_f32 %1, %1, %1, %1\n\tv_pk_fma_f32 %2, %2, %2, %2\n\t"
+                         "v_rcp_f32 %0, %0\n\tv_pk_mul_f32 %1, %1, %2\n\tv_pk_fma_f32 %2, %2, %1, %1\n\t"
+#if DITTO_DIAG_FR_VALU > 1
+                         "v_exp_f32 %0, %0\n\tv_pk_fma_f32 %1, %1, %1, %1\n\tv_pk_fma_f32 %2, %2, %2, %2\n\t"
+                         "v_rcp_f32 %0, %0\n\tv_pk_mul_f32 %1, %1, %2\n\tv_pk_fma_f32 %2, %2, %1, %1\n\t"
+#endif
+                         : "+v"(dz0), "+v"(dz1), "+v"(dz2));
+#endif
             if constexpr (do_w) {
                 if (nb == 0) issue_w_piece(IC<0>{});
                 if (nb == 1) issue_w_piece(IC<1>{});

@@ -163,10 +163,12 @@ def _attn_ref(q, k, v, B, H, Sq, Skv, dh, scale):
 @pytest.mark.parametrize("B,H,Sq,Skv,dh", [(1, 1, 32, 64, 64), (2, 3, 200, 96, 64), (1, 2, 128, 128, 64),
                                            (2, 2, 300, 200, 64), (1, 3, 1024, 1024, 64),
                                            (1, 4, 64, 1, 64), (2, 12, 256, 320, 64), (1, 1, 40, 50, 128),
-                                           (1, 2, 70, 33, 192)])
-@pytest.mark.parametrize("attn_flags", [0, 1, 3, 16, 16 + 64, 16 + 128, 16 + 32 + 3])
+                                           (1, 2, 70, 33, 192), (2, 3, 200, 256, 64), (1, 2, 70, 384, 64),
+                                           (1, 2, 333, 2048, 64)])
+@pytest.mark.parametrize("attn_flags", [0, 1, 3, 16, 16 + 64, 16 + 128, 16 + 32 + 3, 16 + 256, 16 + 512])
 def test_attention(lib, B, H, Sq, Skv, dh, attn_flags):
-    hip.check(lib.ditto_set_option(b"attn_flags", attn_flags))   # 1: K/V tiles by LDS-DMA
+    hip.check(lib.ditto_set_option(b"attn_flags", attn_flags))   # 1: K/V tiles by LDS-DMA; 16: pre-scaled q (attn64v3 when Skv % 128 == 0,
+                                                                  # and the rule says so, else attn64v2); 256: never attn64v3; 512: attn64v3 wherever Skv % 128 == 0
     d = H * dh
     q = bf16(asym((B * Sq, d), 8).to(DEV))
     if attn_flags & 16 and dh == 64:
@@ -191,7 +193,32 @@ def test_attention(lib, B, H, Sq, Skv, dh, attn_flags):
     assert max_abs(out.float(), want) < 6e-2
 
 
-@pytest.mark.parametrize("attn_flags", [3, 16, 16 + 64, 16 + 128])
+@pytest.mark.parametrize("B,H,Sq,Skv", [(1, 2, 128, 128), (2, 3, 200, 256), (1, 12, 1024, 1024), (1, 2, 333, 2048)])
+def test_attention_pipelined_kernel_is_bitwise_the_tile_loop_kernel(lib, B, H, Sq, Skv):
+    """attn64v3 (software-pipelined, attn_flags 512) and attn64v2 (256) are chosen by shape AND grid size, so an utterance's
+    bits may not depend on which one ran: same products in the same order, running-maximum raises by whole octaves in both.
+    Rows with forced raises included."""
+    dh, d = 64, H * 64
+    q = asym((B * Sq, d), 21) * 0.7
+    k = asym((B * Skv, d), 22) * 0.7
+    v = asym((B * Skv, d), 23)
+    k[Skv - 3, :dh] = q[5, :dh] * 40.0      # a late dominating key for one row: forced raise in the last tile
+    k[70, :dh] = q[9, :dh] * 30.0           # and one in tile 1
+    q = bf16((q * (1.4426950408889634 / math.sqrt(dh))).to(DEV))
+    k, v = bf16(k.to(DEV)), bf16(v.to(DEV))
+    outs = []
+    for flags in (16 + 256, 16 + 512):
+        hip.check(lib.ditto_set_option(b"attn_flags", flags))
+        out = torch.empty(B * Sq, d, dtype=torch.bfloat16, device=DEV)
+        hip.check(lib.ditto_attention_bf16(q.data_ptr(), d, k.data_ptr(), d, v.data_ptr(), d, out.data_ptr(), d, B, H, Sq,
+                                           Skv, dh, 1.0 / math.sqrt(dh), None, 0, stream()))
+        outs.append(out)
+    hip.check(lib.ditto_set_option(b"attn_flags", 3))
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("attn_flags", [3, 16, 16 + 64, 16 + 128, 16 + 256, 16 + 512])
 def test_attention_forced_rescale(lib, attn_flags):
     """Rule 26: force the online-softmax rescale branch — one key in the LAST tile dominates one query row."""
     hip.check(lib.ditto_set_option(b"attn_flags", attn_flags))

@@ -448,7 +448,10 @@ def test_low_latency_split_k_mode():
     try:
         got1 = m(xd[:1], td[:1], tt[:1])
         assert not torch.equal(got1, base1), "split-K path did not run"
-        assert rel_l2(got1, base1) < 1e-4
+        # a different fp32 summation order in fc2 flips a few bf16 roundings of the next layer's operands, and attention
+        # spreads every flip over all rows: three layers deep the two paths differ by 1e-4 .. 1e-3 depending on the data
+        # (layer-wise: 8e-8 after layer 0, 7e-5 .. 2e-4 after layer 1, 9e-4 after layer 2)
+        assert rel_l2(got1, base1) < 3e-3
         close(got1, O.ditto_forward(sd, 3, 4, x[:1], text[:1], t[:1]))
         assert torch.equal(m(xd[:1], td[:1], tt[:1]), got1)
         # the C2 shape at B = 1: fc2 in 5 splits, the final K = 1536 projection in 5 as well
