@@ -178,6 +178,14 @@ struct ProfScope {
 }  // namespace
 
 // One DiT block (reference src/components/DiT.py:100-157) on the fp32 residual stream `h`, in place.
+// The full-row kernel runs ONE 128-row tile per workgroup, so it needs enough rows to fill the chip: measured in the
+// model (tools/step_ab.py --batch b, C2 shapes, fr_mask 3 against 0) it loses below 160 tiles (B = 1: 2.92 vs 1.84 ms per
+// step, B = 8: 4.73 vs 4.02, B = 16: 7.00 vs 6.65) and wins from there on (B = 20: 8.37 vs 8.43, B = 24: 9.49 vs 10.17,
+// B = 32: 12.1 vs 13.0).  Like the choice of GEMM tile structure this rule depends on the number of rows in the launch: an
+// utterance's bits are independent of its batch neighbours WITHIN a class of batch sizes (equal shards of a sharded
+// batch are in the same class), not across (fr_mask 0 gives one class).
+static bool fr_pays(int M) { return (M + 127) / 128 >= 160; }
+
 static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* act, char* xcat_or_null,
                      void* attn_ws, size_t attn_ws_bytes, float* splitk_ws, size_t splitk_bytes, const char* kv, int kv_layer, int kv_ld,
                      const float* rope_cos, const float* rope_sin, int B, int N, int T, hipStream_t s,
@@ -191,8 +199,7 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
     const LayerPack& lp = m->layers[l];
     // full-row GEMM with the residual add and the FOLLOWING LayerNorm fused (gemm_fr.hip): bit 0 = cross out-proj + norm3,
     // bit 1 = fc2 + the next block's norm1 (ln1_done tells that block its norm1 output is already in u)
-    // (N >= 128, not M: the choice of kernel must not depend on the batch size, or an utterance's bits would)
-    const bool fr_ok = !fp8 && lp.WcoP && N >= 128 && gemm_fr_supports(M, d, d, (size_t)d, (size_t)d);
+    const bool fr_ok = !fp8 && lp.WcoP && fr_pays(M) && gemm_fr_supports(M, d, d, (size_t)d, (size_t)d);
     const bool fr_out = fr_ok && (g_fr_mask & 1), fr_fc2 = fr_ok && (g_fr_mask & 2);
     const int fr_rot = N % 128 == 0 ? N / 128 : 0;   // tiles per utterance: the K-loop rotation period (gemm_fr.hip)
         // ---- self-attention (src/components/DiT.py:103-139) ----
@@ -512,7 +519,7 @@ int ditto_forward(ditto_model_t m, const float* x, const void* cond, const int64
         HIP_TRY(launch_adaln(x, m->ttab, tmod, t, c.diffusion_steps, h, xcat, 2 * d, B, N, d, s));
     }
     // fc2 on the full-row kernel also emits the NEXT block's norm1 (fr_mask bit 1): that block then skips its LayerNorm
-    const bool chain_ln1 = (g_fr_mask & 2) && !(c.flags & DITTO_CFG_FP8_LINEAR) && m->layers[0].WcoP && N >= 128 &&
+    const bool chain_ln1 = (g_fr_mask & 2) && !(c.flags & DITTO_CFG_FP8_LINEAR) && m->layers[0].WcoP && fr_pays(M) &&
                            gemm_fr_supports(M, d, d, (size_t)d, (size_t)d);
     for (int l = 0; l < L; ++l)
         if (int rc = run_block(m, l, h, u, qkv, act, l == L - 1 ? xcat : nullptr, attn_ws, w.attn_bytes,

@@ -238,6 +238,37 @@ def test_full_size_c2_properties():
 
 
 @torch.no_grad()
+def test_full_size_c2_large_batch_takes_the_full_row_path():
+    """From 160 row tiles on (B >= 20 at N = 1024) the cross out-projection + norm3 and fc2 + the next block's norm1 run on the
+    full-row kernel (csrc/gemm_fr.hip, fr_mask).  At B = 20: parity of one utterance with the oracle; the fused path against
+    the unfused one (fr_mask 0) within bf16-path noise; bitwise independence of an utterance from its place in the batch (the
+    K-loop rotation is a function of the tile's position inside its utterance) and from the batch size within the class."""
+    from ditto_tts_amd import hip
+    from oracle import ditto_oracle as O
+    p = PRESETS["C2"]
+    cfg = p["cfg"]
+    m = build(cfg, 2)
+    B, N, T = 20, p["N"], p["T"]
+    x, text, t = synthetic_inputs(cfg, B, N, T, seed=5)
+    xd, td, tt = x.to(DEV), text.to(DEV), t.to(DEV)
+    out = m(xd, td, tt)
+    assert torch.isfinite(out).all()
+    close(out[:1], O.ditto_forward(synthetic_state_dict(cfg, 2), 12, 12, x[:1], text[:1], t[:1]))
+    hip.set_option("fr_mask", 0)
+    try:
+        plain = m(xd, td, tt)
+    finally:
+        hip.set_option("fr_mask", 3)
+    assert not torch.equal(plain, out), "the full-row path did not run"
+    assert rel_l2(out, plain) < 4e-3
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(1)).to(DEV)
+    assert torch.equal(m(xd[perm].contiguous(), td[perm].contiguous(), tt[perm].contiguous()), out[perm])
+    x2, text2, t2 = synthetic_inputs(cfg, 4, N, T, seed=9)
+    big = m(torch.cat([xd, x2.to(DEV)]), torch.cat([td, text2.to(DEV)]), torch.cat([tt, t2.to(DEV)]))
+    assert torch.equal(big[:B], out), "utterance result depends on the batch size inside the full-row class"
+
+
+@torch.no_grad()
 def test_full_size_c2_sampling_loop_properties():
     """The 50-step loop at BASELINE configs[1]'s full size (12L, d=768, N=T=1024), which only bench.py ran before:
     finite; ditto_denoise_steps (one library call) == the per-step loop, bitwise; sharding the batch [3] -> [2] + [1]
