@@ -178,14 +178,6 @@ struct ProfScope {
 }  // namespace
 
 // One DiT block (reference src/components/DiT.py:100-157) on the fp32 residual stream `h`, in place.
-// The full-row kernel runs ONE 128-row tile per workgroup, so it needs enough rows to fill the chip: measured in the
-// model (tools/step_ab.py --batch b, C2 shapes, fr_mask 3 against 0) it loses below 160 tiles (B = 1: 2.92 vs 1.84 ms per
-// step, B = 8: 4.73 vs 4.02, B = 16: 7.00 vs 6.65) and wins from there on (B = 20: 8.37 vs 8.43, B = 24: 9.49 vs 10.17,
-// B = 32: 12.1 vs 13.0).  Like the choice of GEMM tile structure this rule depends on the number of rows in the launch: an
-// utterance's bits are independent of its batch neighbours WITHIN a class of batch sizes (equal shards of a sharded
-// batch are in the same class), not across (fr_mask 0 gives one class).
-static bool fr_pays(int M) { return (M + 127) / 128 >= 160; }
-
 static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* act, char* xcat_or_null,
                      void* attn_ws, size_t attn_ws_bytes, float* splitk_ws, size_t splitk_bytes, const char* kv, int kv_layer, int kv_ld,
                      const float* rope_cos, const float* rope_sin, int B, int N, int T, hipStream_t s,

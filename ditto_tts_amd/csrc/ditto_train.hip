@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstring>
 
+#include "gemm_common.h"
 #include "model.h"
 
 using namespace ditto;
@@ -225,6 +226,12 @@ int ditto_train_forward(ditto_model_t m, const float* x, const float* text, cons
     HIP_TRY(launch_text_mod(text, m->wx, m->bx, pooled, tmod, B, T, c.text_dim, d, s));
     HIP_TRY(launch_adaln(x, m->ttab, tmod, t, c.diffusion_steps, hs(0), xcat, 2 * d, B, N, d, s));
 
+    // As in the inference forward (ditto_api.hip run_block): from 160 row tiles on, the cross out-projection + norm3 and
+    // fc2 + the next block's norm1 run on the full-row kernel (fr_mask); the LayerNorm outputs land in the tape slots the
+    // backward reads (u3, the next block's u1).
+    const bool fr_ok = m->layers[0].WcoP && fr_pays(M) && gemm_fr_supports(M, d, d, (size_t)d, (size_t)d);
+    const bool fr_out = fr_ok && (g_fr_mask & 1), fr_fc2 = fr_ok && (g_fr_mask & 2);
+    const int fr_rot = N % 128 == 0 ? N / 128 : 0;
     for (int l = 0; l < L; ++l) {
         const LayerPack& lp = m->layers[l];
         const LayerPackT& lt = m->layersT[l];
@@ -232,7 +239,7 @@ int ditto_train_forward(ditto_model_t m, const float* x, const float* text, cons
         float *h0 = hs(3 * l), *h1 = hs(3 * l + 1), *h2 = hs(3 * l + 2), *h3 = hs(3 * l + 3);
         char* qkv = tb + q.qkv;
         // ---- self-attention ----
-        HIP_TRY(launch_layernorm(h0, lp.g1, lp.be1, tb + q.u1, d, M, d, s));
+        if (!(fr_fc2 && l > 0)) HIP_TRY(launch_layernorm(h0, lp.g1, lp.be1, tb + q.u1, d, M, d, s));
         {
             GemmArgs g{};
             g.A = tb + q.u1; g.lda = d; g.W = lt.Wqkv_u; g.bias = lt.bqkv_u; g.out = qkv; g.ldo = 3 * d;
@@ -267,14 +274,19 @@ int ditto_train_forward(ditto_model_t m, const float* x, const float* text, cons
             if (dh == 64) a.lse_out = (float*)(tb + q.lse_c);
             HIP_TRY(launch_attention(a, s));
         }
-        {
+        if (fr_out) {
+            GemmParams gp{};
+            gp.A = (const bf16*)(tb + q.oc); gp.lda = d; gp.W = (const bf16*)lp.WcoP; gp.ldw = d; gp.w_rows = d; gp.bias = lp.bco;
+            gp.residual = h1; gp.ldr = d; gp.out = h2; gp.ldo = d; gp.M = M; gp.N = d; gp.K = d;
+            HIP_TRY(launch_gemm_fr(gp, lp.g3, lp.be3, tb + q.u3, d, fr_rot, s));
+        } else {
             GemmArgs g{};
             g.A = tb + q.oc; g.lda = d; g.W = lp.Wco; g.bias = lp.bco; g.residual = h1; g.ldr = d; g.out = h2; g.ldo = d;
             g.M = M; g.N = d; g.K = d;
             HIP_TRY(launch_gemm(g, EPI_BIAS_RES_F32, s));
+            // ---- gated MLP: product and pre-activations (for the backward) from one epilogue ----
+            HIP_TRY(launch_layernorm(h2, lp.g3, lp.be3, tb + q.u3, d, M, d, s));
         }
-        // ---- gated MLP: product and pre-activations (for the backward) from one epilogue ----
-        HIP_TRY(launch_layernorm(h2, lp.g3, lp.be3, tb + q.u3, d, M, d, s));
         {
             GemmArgs g{};
             g.A = tb + q.u3; g.lda = d; g.W = lp.W1g; g.bias = lp.b1g; g.out = tb + q.act; g.ldo = 4 * d;
@@ -282,7 +294,17 @@ int ditto_train_forward(ditto_model_t m, const float* x, const float* text, cons
             g.M = M; g.N = 8 * d; g.K = d;
             HIP_TRY(launch_gemm(g, EPI_GATED, s));
         }
-        {
+        if (fr_fc2) {
+            GemmParams gp{};
+            gp.A = (const bf16*)(tb + q.act); gp.lda = 4 * d; gp.W = (const bf16*)lp.W2P; gp.ldw = 4 * d; gp.w_rows = d;
+            gp.bias = lp.b2; gp.residual = h2; gp.ldr = d; gp.out = h3; gp.ldo = d; gp.M = M; gp.N = d; gp.K = 4 * d;
+            if (l == L - 1) {
+                gp.out2 = (bf16*)(xcat + (size_t)d * 2); gp.ldo2 = 2 * d;
+                HIP_TRY(launch_gemm_fr(gp, nullptr, nullptr, nullptr, d, fr_rot, s));
+            } else {
+                HIP_TRY(launch_gemm_fr(gp, m->layers[l + 1].g1, m->layers[l + 1].be1, tb + tp.layers[l + 1].u1, d, fr_rot, s));
+            }
+        } else {
             GemmArgs g{};
             g.A = tb + q.act; g.lda = 4 * d; g.W = lp.W2; g.bias = lp.b2; g.residual = h2; g.ldr = d; g.out = h3;
             g.ldo = d; g.M = M; g.N = d; g.K = 4 * d;
@@ -356,10 +378,10 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
         HIP_TRY(launch_gemm(g, f32 ? EPI_BIAS_F32 : EPI_BIAS_BF16, s));
         return DITTO_OK;
     };
-    auto ln_back = [&](const float* xin, const float* gamma, float* gw, float* gb) -> int {
-        HIP_TRY(launch_ln_bwd(du, xin, gamma, dh, vtmp, red, M, 1, d, s));
-        HIP_TRY(hipMemcpyAsync(gw, vtmp, (size_t)d * 4, hipMemcpyDeviceToDevice, s));
-        HIP_TRY(hipMemcpyAsync(gb, vtmp + d, (size_t)d * 4, hipMemcpyDeviceToDevice, s));
+    // LayerNorm backward into the stream gradient dh, which also leaves bf16(dh) in dyb (the dY operand of the segment below)
+    // and, when asked, the column sums of dh = the bias gradient of the Linear that closes that segment
+    auto ln_back = [&](const float* xin, const float* gamma, float* gw, float* gb, float* next_bias) -> int {
+        HIP_TRY(launch_ln_bwd_stream(du, xin, gamma, dh, dyb, gw, gb, next_bias, red, M, d, s));
         return DITTO_OK;
     };
 #define TRY_RC(expr) do { if (int _rc = (expr)) return _rc; } while (0)
@@ -380,23 +402,22 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
         const float *h0 = hs(3 * l), *h1 = hs(3 * l + 1), *h2 = hs(3 * l + 2);
 
         // ---- gated MLP: h3 = h2 + act W2^T + b2,  act = gelu(a) sigmoid(g),  [a|g] = u3 W1g^T + b1g ----
-        HIP_TRY(launch_cast_bf16(dh, dyb, (size_t)M * d, s));
-        HIP_TRY(launch_colsum_f32(dh, d, M, d, G.mlp_fc2_bias, red, s));
+        if (l == L - 1) {   // below the top layer the block above's last LayerNorm backward left both
+            HIP_TRY(launch_cast_bf16(dh, dyb, (size_t)M * d, s));
+            HIP_TRY(launch_colsum_f32(dh, d, M, d, G.mlp_fc2_bias, red, s));
+        }
         TRY_RC(wgrad(dyb, d, d, tb + q.act, 4 * d, 4 * d, M, G.mlp_fc2_weight));
         TRY_RC(dgrad(dyb, d, lt.W2T, 4 * d, big2, false));
-        HIP_TRY(launch_gated_bwd(big2, tb + q.pre, big1, M, 4 * d, s));
-        HIP_TRY(launch_colsum_bf16(big1, 8 * d, M, 8 * d, vtmp, red, s));
+        HIP_TRY(launch_gated_bwd(big2, tb + q.pre, big1, M, 4 * d, s, vtmp, red));   // + the packed fc1 | gate bias gradients
         HIP_TRY(launch_unpack_vec(vtmp, G.mlp_fc1_bias, 4 * d, 16, 2, 0, s));
         HIP_TRY(launch_unpack_vec(vtmp, G.gate_bias, 4 * d, 16, 2, 16, s));
         TRY_RC(wgrad(big1, 8 * d, 8 * d, tb + q.u3, d, d, M, wtmp));
         HIP_TRY(launch_unpack_rows(wtmp, G.mlp_fc1_weight, 4 * d, d, 16, 2, 0, s));
         HIP_TRY(launch_unpack_rows(wtmp, G.gate_weight, 4 * d, d, 16, 2, 16, s));
         TRY_RC(dgrad(big1, 8 * d, lt.W1gT, d, du, true));
-        TRY_RC(ln_back(h2, lp.g3, G.norm3_weight, G.norm3_bias));
+        TRY_RC(ln_back(h2, lp.g3, G.norm3_weight, G.norm3_bias, G.cross_out_proj_bias));
 
         // ---- cross-attention: h2 = h1 + oc Wo^T + bo,  oc = attn(qc, Kc, Vc),  qc = u2 Wq^T + bq ----
-        HIP_TRY(launch_cast_bf16(dh, dyb, (size_t)M * d, s));
-        HIP_TRY(launch_colsum_f32(dh, d, M, d, G.cross_out_proj_bias, red, s));
         TRY_RC(wgrad(dyb, d, d, tb + q.oc, d, d, M, G.cross_out_proj_weight));
         TRY_RC(dgrad(dyb, d, lt.WcoT, d, big2, false));
         {
@@ -414,10 +435,9 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
         TRY_RC(wgrad(big1, d, d, tb + q.u2, d, d, M, G.cross_in_proj_weight));
         TRY_RC(wgrad(dkv, 2 * d, 2 * d, tb + tp.text, c.text_dim, d, Mt, G.cross_in_proj_weight + (size_t)d * d));
         TRY_RC(dgrad(big1, d, lt.WcqT, d, du, true));
-        TRY_RC(ln_back(h1, lp.g2, G.norm2_weight, G.norm2_bias));
+        TRY_RC(ln_back(h1, lp.g2, G.norm2_weight, G.norm2_bias, nullptr));
 
         // ---- self-attention: h1 = h0 + attn(rope(q), rope(k), v), NO out-proj (src/components/DiT.py:134-139) ----
-        HIP_TRY(launch_cast_bf16(dh, dyb, (size_t)M * d, s));
         {
             const char* qkv = tb + q.qkv;
             AttnBwdArgs a{};
@@ -433,7 +453,7 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
         HIP_TRY(launch_colsum_bf16(big1, 3 * d, M, 3 * d, G.attn_in_proj_bias, red, s));
         TRY_RC(wgrad(big1, 3 * d, 3 * d, tb + q.u1, d, d, M, G.attn_in_proj_weight));
         TRY_RC(dgrad(big1, 3 * d, lt.WqkvT, d, du, true));
-        TRY_RC(ln_back(h0, lp.g1, G.norm1_weight, G.norm1_bias));
+        TRY_RC(ln_back(h0, lp.g1, G.norm1_weight, G.norm1_bias, l > 0 ? grads->layers[l - 1].mlp_fc2_bias : nullptr));
     }
 
     // ---- GlobalAdaLN (src/components/DiT.py:25-40): h0 = xhat (1 + s_t + s_x) + (b_t + b_x) ----

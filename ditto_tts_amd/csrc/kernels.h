@@ -51,6 +51,14 @@ hipError_t launch_pack_bf16(const float* src, void* dst_bf16, int rows, int cols
 hipError_t launch_scale_vec(float* v, int n, float f, hipStream_t s);
 // fp32 [N, K] -> bf16 stage-major [K/16][N][16] (the full-row GEMM's weight layout, gemm_fr.hip)
 hipError_t launch_pack_bf16_stage_major(const float* src, void* dst, int N, int K, hipStream_t s);
+// The full-row kernel runs ONE 128-row tile per workgroup, so it needs enough rows to fill the chip: measured in the
+// model (tools/step_ab.py --batch b, C2 shapes, fr_mask 3 against 0) it loses below 160 tiles (B = 1: 2.92 vs 1.84 ms per
+// step, B = 8: 4.73 vs 4.02, B = 16: 7.00 vs 6.65) and wins from there on (B = 20: 8.37 vs 8.43, B = 24: 9.49 vs 10.17,
+// B = 32: 12.1 vs 13.0).  Like the choice of GEMM tile structure this rule depends on the number of rows in the launch: an
+// utterance's bits are independent of its batch neighbours WITHIN a class of batch sizes (equal shards of a sharded
+// batch are in the same class), not across (fr_mask 0 gives one class).
+inline bool fr_pays(int M) { return (M + 127) / 128 >= 160; }
+
 extern int g_fr_rot;     // gemm.hip: full-row kernel's K-loop rotation: 0 off, 1 on in the model (period = tiles per utterance), > 1 = period for ditto_gemm_ln_bf16 too
 extern int g_fr_mask;    // gemm.hip: 1 = cross out-proj + LayerNorm3, 2 = fc2 + next block's LayerNorm1 on the full-row kernel
 // same row map for an fp32 vector (bias)
@@ -175,9 +183,13 @@ hipError_t launch_reduce_partials(const float* partial, int chunks, size_t n, fl
 hipError_t launch_colsum_f32(const float* x, int ld, int M, int n, float* out, float* scratch, hipStream_t s);
 hipError_t launch_colsum_bf16(const void* x, int ld, int M, int n, float* out, float* scratch, hipStream_t s);
 size_t ln_bwd_scratch_bytes(int rows_per_group, int groups, int d);
+hipError_t launch_ln_bwd_stream(const float* dy, const float* x, const float* gamma, float* dx_accum, void* dx_bf16,
+                                float* dgamma, float* dbeta, float* colsum_or_null, float* scratch, int rows, int d,
+                                hipStream_t s);
 hipError_t launch_ln_bwd(const float* dy, const float* x, const float* gamma, float* dx_accum, float* dgb_out,
                          float* scratch, int rows_per_group, int groups, int d, hipStream_t s);
-hipError_t launch_gated_bwd(const void* dact, const void* pre, void* dpre, int M, int F, hipStream_t s);
+hipError_t launch_gated_bwd(const void* dact, const void* pre, void* dpre, int M, int F, hipStream_t s,
+                            float* colsum_out = nullptr, float* scratch = nullptr);
 hipError_t launch_unpack_rows(const float* src, float* dst, int rows, int cols, int blk, int mult, int row_off,
                               hipStream_t s);
 hipError_t launch_unpack_vec(const float* src, float* dst, int rows, int blk, int mult, int row_off, hipStream_t s);

@@ -176,22 +176,27 @@ hipError_t launch_colsum_bf16(const void* x, int ld, int M, int n, float* out, f
 // partial[(group * chunks + chunk)][2d]; reduce_partials_kernel finishes.  dx is ADDED into dx_accum (the gradient
 // of the residual stream) when dx_accum != nullptr; gamma == nullptr means gamma = 1 (dx then is the no-affine LN).
 // ---------------------------------------------------------------------------------------------------------
-template <int CH>
+// EXT (the residual-stream uses of the model's backward): also writes bf16(dx_accum) — the dY operand of the next dgrad /
+// wgrad GEMMs — to dx_bf16, and a third partial row sum_rows dx_accum (the bias gradient of the Linear whose output was
+// added to the stream there), so that the separate cast and column-sum passes over the 100 MB stream disappear.
+template <int CH, bool EXT = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, float* __restrict__ dx_accum,
                                                      float* __restrict__ partial, int d, int rows_per_group,
-                                                     int rows_per_chunk, int chunks) {
-    __shared__ f32x4 red[4][2 * CH * 64];
+                                                     int rows_per_chunk, int chunks, bf16* __restrict__ dx_bf16 = nullptr) {
+    constexpr int NP = EXT ? 3 : 2;
+    __shared__ f32x4 red[4][NP * CH * 64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int chunk = blockIdx.x, group = blockIdx.y;
     const int nv = d >> 2;
     const int rbeg = chunk * rows_per_chunk;
     const int rend = rbeg + rows_per_chunk < rows_per_group ? rbeg + rows_per_chunk : rows_per_group;
-    f32x4 dg[CH], db[CH], gm[CH];
+    f32x4 dg[CH], db[CH], gm[CH], dc[EXT ? CH : 1];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         dg[c] = f32x4{0.f, 0.f, 0.f, 0.f};
         db[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (EXT) dc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int i = lane + 64 * c;
         gm[c] = (gamma && i < nv) ? reinterpret_cast<const f32x4*>(gamma)[i] : f32x4{1.f, 1.f, 1.f, 1.f};
     }
@@ -256,6 +261,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 #pragma unroll
                     for (int e = 0; e < 4; ++e) a[e] += rstd * (gy[c][e] - m1 - v[c][e] * m2);
                     ar[i] = a;
+                    if constexpr (EXT) {
+                        dc[c] += a;
+                        u32x2 pk;
+                        pk[0] = pack_bf16x2(a[0], a[1]); pk[1] = pack_bf16x2(a[2], a[3]);
+                        reinterpret_cast<u32x2*>(dx_bf16 + row * d)[i] = pk;
+                    }
                 }
             }
         }
@@ -265,15 +276,43 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     for (int c = 0; c < CH; ++c) {
         red[wv][c * 64 + lane] = dg[c];
         red[wv][(CH + c) * 64 + lane] = db[c];
+        if constexpr (EXT) red[wv][(2 * CH + c) * 64 + lane] = dc[c];
     }
     __syncthreads();
-    float* prow = partial + ((size_t)group * chunks + chunk) * 2 * d;
-    for (int idx = threadIdx.x; idx < 2 * CH * 64; idx += 256) {
+    float* prow = partial + ((size_t)group * chunks + chunk) * NP * d;
+    for (int idx = threadIdx.x; idx < NP * CH * 64; idx += 256) {
         const int c = (idx / 64) % CH, half = idx / (64 * CH), i = (idx & 63) + 64 * c;
         if (i < nv) {
             const f32x4 r = (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]);
             *reinterpret_cast<f32x4*>(prow + (size_t)half * d + 4 * i) = r;
         }
+    }
+}
+// finish of the extended form: partial [chunks][3d] -> dgamma, dbeta, colsum written straight to their destinations
+__global__ __launch_bounds__(256) void ln_bwd_finish3_kernel(const float* __restrict__ partial, int chunks, int d,
+                                                             float* __restrict__ o0, float* __restrict__ o1,
+                                                             float* __restrict__ o2) {
+    __shared__ float red[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int j = blockIdx.x * 16 + tx, n = 3 * d;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (j < n) {
+        const float* p = partial + j;
+        int c = ty;
+        for (; c + 48 < chunks; c += 64) {
+            a0 += p[(size_t)c * n]; a1 += p[(size_t)(c + 16) * n]; a2 += p[(size_t)(c + 32) * n];
+            a3 += p[(size_t)(c + 48) * n];
+        }
+        for (; c < chunks; c += 16) a0 += p[(size_t)c * n];
+    }
+    red[ty][tx] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (ty == 0 && j < n) {
+        float r = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) r += red[i][tx];
+        float* o = j < d ? o0 : (j < 2 * d ? o1 : o2);
+        if (o) o[j % d] = r;
     }
 }
 static int ln_bwd_chunks(int rows_per_group, int groups) {
@@ -285,6 +324,30 @@ static int ln_bwd_chunks(int rows_per_group, int groups) {
 }
 size_t ln_bwd_scratch_bytes(int rows_per_group, int groups, int d) {
     return (size_t)groups * ln_bwd_chunks(rows_per_group, groups) * 2 * d * 4;
+}
+// The residual-stream form (one group): dx_accum += dx; dx_bf16 = bf16(dx_accum); dgamma / dbeta / colsum(dx_accum)
+// (the last may be null) written to their own destinations.  scratch: ln_bwd_scratch_bytes(rows, 1, d) * 3 / 2.
+hipError_t launch_ln_bwd_stream(const float* dy, const float* x, const float* gamma, float* dx_accum, void* dx_bf16,
+                                float* dgamma, float* dbeta, float* colsum_or_null, float* scratch, int rows, int d,
+                                hipStream_t s) {
+    if (d % 4 || d > 2048 || !dx_accum || !dx_bf16 || !scratch) return hipErrorInvalidValue;
+    const int ch = (d / 4 + 63) / 64;
+    const int chunks = ln_bwd_chunks(rows, 1);
+    const int rpc = (rows + chunks - 1) / chunks;
+    dim3 grid(chunks, 1), block(256);
+#define LNB_CASE(C)                                                                                              \
+    case C:                                                                                                      \
+        hipLaunchKernelGGL((ln_bwd_kernel<C, true>), grid, block, 0, s, dy, x, gamma, dx_accum, scratch, d, rows, rpc,  \
+                           chunks, (bf16*)dx_bf16);                                                               \
+        break;
+    switch (ch) {
+        LNB_CASE(1) LNB_CASE(2) LNB_CASE(3) LNB_CASE(4) LNB_CASE(5) LNB_CASE(6) LNB_CASE(7) LNB_CASE(8)
+        default: return hipErrorInvalidValue;
+    }
+#undef LNB_CASE
+    hipLaunchKernelGGL(ln_bwd_finish3_kernel, dim3((3 * d + 15) / 16), dim3(256), 0, s, scratch, chunks, d, dgamma, dbeta,
+                       colsum_or_null);
+    return hipGetLastError();
 }
 // dgb_out fp32 [groups, 2d] = [dgamma | dbeta] per group (may be null together with scratch: dx only)
 hipError_t launch_ln_bwd(const float* dy, const float* x, const float* gamma, float* dx_accum, float* dgb_out,
@@ -352,14 +415,79 @@ __global__ __launch_bounds__(256) void gated_bwd_kernel(const bf16* __restrict__
         *reinterpret_cast<u32x4*>(dpre + off + 16) = pack8(dgt);
     }
 }
+// The same with the column sums of dpre (= the fc1 | gate bias gradients, packed order) as per-chunk partial rows:
+// block = 64 column groups x 4 row lanes, blockIdx.y = row chunk; partial[chunk][2F] is finished by reduce_partials_kernel.
+__global__ __launch_bounds__(256) void gated_bwd_colsum_kernel(const bf16* __restrict__ dact, const bf16* __restrict__ pre,
+                                                               bf16* __restrict__ dpre, float* __restrict__ partial, int M,
+                                                               int F, int rows_per_chunk) {
+    __shared__ float red[3][64][17];
+    const int jl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + jl;
+    const int q = j >> 1, e = j & 1;
+    const int rbeg = blockIdx.y * rows_per_chunk;
+    const int rend = rbeg + rows_per_chunk < M ? rbeg + rows_per_chunk : M;
+    float sa[8], sg8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sa[k] = 0.f; sg8[k] = 0.f; }
+    for (int m = rbeg + rl; m < rend; m += 4) {
+        const size_t off = (size_t)m * 2 * F + 32 * q + 8 * e;
+        float a[8], g[8], dy[8], da[8], dgt[8];
+        unpack8(*reinterpret_cast<const u32x4*>(pre + off), a);
+        unpack8(*reinterpret_cast<const u32x4*>(pre + off + 16), g);
+        unpack8(*reinterpret_cast<const u32x4*>(dact + (size_t)m * F + 8 * j), dy);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float sg = sigmoid_f(g[k]);
+            const float cdf = 0.5f * (1.0f + erff(a[k] * 0.70710678118654752440f));
+            const float pdf = 0.39894228040143267794f * __expf(-0.5f * a[k] * a[k]);
+            da[k] = dy[k] * sg * (cdf + a[k] * pdf);
+            dgt[k] = dy[k] * (a[k] * cdf) * sg * (1.0f - sg);
+        }
+        const u32x4 pa = pack8(da), pg = pack8(dgt);
+        *reinterpret_cast<u32x4*>(dpre + off) = pa;
+        *reinterpret_cast<u32x4*>(dpre + off + 16) = pg;
+        float ra[8], rg[8];                              // sum what the wgrad GEMM will read: the bf16-rounded values
+        unpack8(pa, ra); unpack8(pg, rg);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { sa[k] += ra[k]; sg8[k] += rg[k]; }
+    }
+    if (rl > 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { red[rl - 1][jl][k] = sa[k]; red[rl - 1][jl][8 + k] = sg8[k]; }
+    }
+    __syncthreads();
+    if (rl == 0) {
+        float* prow = partial + (size_t)blockIdx.y * 2 * F + 32 * q + 8 * e;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            prow[k] = (sa[k] + red[0][jl][k]) + (red[1][jl][k] + red[2][jl][k]);
+            prow[16 + k] = (sg8[k] + red[0][jl][8 + k]) + (red[1][jl][8 + k] + red[2][jl][8 + k]);
+        }
+    }
+}
 static int ew_grid(size_t n) {
     size_t g = (n + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
 }
-hipError_t launch_gated_bwd(const void* dact, const void* pre, void* dpre, int M, int F, hipStream_t s) {
+// colsum_out fp32 [2F] (packed column order) with scratch >= 256 * 2F floats: the fused form; null: elementwise only
+hipError_t launch_gated_bwd(const void* dact, const void* pre, void* dpre, int M, int F, hipStream_t s,
+                            float* colsum_out, float* scratch) {
     if (F % 16) return hipErrorInvalidValue;
+    if (colsum_out && scratch && (F / 8) % 64 == 0) {
+        int chunks = 1536 / (F / 8 / 64);
+        chunks = chunks > 256 ? 256 : chunks;
+        const int maxc = (M + 15) / 16;
+        chunks = chunks > maxc ? maxc : (chunks < 1 ? 1 : chunks);
+        const int rpc = (M + chunks - 1) / chunks;
+        hipLaunchKernelGGL(gated_bwd_colsum_kernel, dim3(F / 8 / 64, chunks), dim3(256), 0, s, (const bf16*)dact,
+                           (const bf16*)pre, (bf16*)dpre, scratch, M, F, rpc);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * F + 15) / 16, 1), dim3(256), 0, s, scratch, chunks,
+                           (size_t)(2 * F), colsum_out);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(gated_bwd_kernel, dim3(ew_grid((size_t)M * F / 8)), dim3(256), 0, s, (const bf16*)dact,
                        (const bf16*)pre, (bf16*)dpre, M, F);
+    if (colsum_out && scratch) return launch_colsum_bf16(dpre, 2 * F, M, 2 * F, colsum_out, scratch, s);
     return hipGetLastError();
 }
 

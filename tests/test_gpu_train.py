@@ -233,6 +233,37 @@ def test_gradients_are_bit_reproducible():
         assert torch.equal(grads[0][n], grads[1][n]), n
 
 
+def test_large_batch_training_step_takes_the_full_row_forward():
+    """From 160 row tiles on (B >= 20 at N = 1024) the training forward runs the cross out-projection + norm3 and fc2 + the
+    next block's norm1 on the full-row kernel (csrc/gemm_fr.hip), its LayerNorm outputs landing in the tape slots the
+    backward reads.  C2 (12 layers, d = 768) at B = 20: loss and every parameter gradient of the fused step against the
+    unfused one (fr_mask 0) within bf16-path noise — the small-shape tests above pin the unfused step to the oracle."""
+    from ditto_tts_amd.config import PRESETS
+    cfg = PRESETS["C2"]["cfg"]
+    x, text, t = (z.to(DEV) for z in synthetic_inputs(cfg, 20, 1024, 1024, seed=3))
+    target = hash_normal((20, 1024, cfg.hidden_dim), "noise", 4).to(DEV)
+    res = []
+    for mask in (3, 0):
+        hip.set_option("fr_mask", mask)
+        try:
+            m = _build(cfg, 9).eval()                    # eval: no dropout, both runs see the same function
+            loss = F.mse_loss(m(x, text, t), target)
+            loss.backward()
+            res.append((float(loss), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+            del m, loss
+        finally:
+            hip.set_option("fr_mask", 3)
+    (la, ga), (lb, gb) = res
+    assert abs(la - lb) < 2e-3 * abs(lb), (la, lb)
+    assert ga.keys() == gb.keys() and len(ga) > 200
+    differs = 0
+    for n in ga:
+        assert torch.isfinite(ga[n]).all(), n
+        assert rel_l2(ga[n], gb[n]) < 3e-2, (n, rel_l2(ga[n], gb[n]))
+        differs += int(not torch.equal(ga[n], gb[n]))
+    assert differs > 100, "the full-row forward did not run"
+
+
 def test_training_surface_contract():
     cfg = DiTTOConfig(128, 1, 2, 64, 128, 20)
     m = _build(cfg, 1).train()
