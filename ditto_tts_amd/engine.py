@@ -365,13 +365,9 @@ class DenoiseEngine:
         w, keep = self._weights_struct(state)
         keys = [f"blocks.{l}.{k}" for l in range(self.cfg.num_layers) for k in hip.LAYER_KEY.values()] + \
                [k for f, k in hip.GLOBAL_KEY.items() if f != "rotary_inv_freq"]
-        sizes = [state[k].numel() for k in keys]
-        offs, total = [], 0
-        for n in sizes:
-            offs.append(total)
-            total += (n + 63) // 64 * 64          # 256-byte aligned slices
-        flat = torch.empty(total, dtype=torch.float32, device=self.device)
-        grads = {k: flat[o:o + n].view(state[k].shape) for k, o, n in zip(keys, offs, sizes)}
+        # one tensor of its own per parameter (the allocator aligns to 512 B): autograd's AccumulateGrad takes such a
+        # gradient over as .grad without a copy; views of one flat buffer cost a copy kernel per parameter per step
+        grads = {k: torch.empty(state[k].shape, dtype=torch.float32, device=self.device) for k in keys}
         L = self.cfg.num_layers
         layers = (hip.LayerGrads * L)()
         for l in range(L):
