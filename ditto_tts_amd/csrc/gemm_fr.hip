@@ -225,6 +225,15 @@ __global__ __launch_bounds__(256, 1) void gemm_fr_kernel(FrParams fp) {
             constexpr int nb = decltype(NB)::value;
             if constexpr (RES) {
 #pragma unroll
+#ifdef DITTO_DIAG_FR_RESLINE   // tools/build_diag.sh: the residual read as whole 128-B lines per 8 lanes (WRONG mapping: timing)
+                for (int k = 0; k < 8; ++k) {
+                    int gr = m0 + wm * 64 + k * 8 + (lane >> 3);
+                    gr = gr < p.M ? gr : p.M - 1;
+                    const float* ptr = p.residual + (size_t)gr * p.ldr + wn * 384 + (lane & 7) * 4;
+                    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(t[k]) : "v"(ptr), "n"(nb * 128) : "memory");
+                }
+                if (false)
+#endif
                 for (int mb = 0; mb < 2; ++mb) {
                     const float* ptr = rp[mb];
                     asm volatile("global_load_dwordx4 %0, %4, off offset:%5\n\t"
