@@ -709,6 +709,28 @@ int ditto_gemm_bf16(const void* A, int lda, const void* W, const float* bias, co
     return DITTO_OK;
 }
 
+int ditto_gemm_tn_bf16(const void* X, int ldx, const void* Y, int ldy, float* out, int ldo, int Mo, int No, int K,
+                       int k_splits, int tile, void* workspace, size_t workspace_bytes, ditto_stream_t stream) {
+    if (!X || !Y || !out || !workspace || Mo < 8 || No < 8 || K <= 0 || (Mo | No | ldx | ldy) % 8 || ldo < No)
+        return fail(DITTO_ERR_ARG, "bad argument to ditto_gemm_tn_bf16");
+    if (tile != 128 && tile != 256) return fail(DITTO_ERR_ARG, "tile must be 128 or 256");
+    if ((uintptr_t)workspace % 256) return fail(DITTO_ERR_ARG, "workspace must be 256-byte aligned");
+    const int S = k_splits > 1 ? k_splits : 1;
+    const size_t need = 256 + (S > 1 ? (size_t)S * Mo * No * 4 : 0);
+    if (workspace_bytes < need) return fail(DITTO_ERR_SIZE, "workspace too small: %zu < %zu", workspace_bytes, need);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(workspace, 0, 256, s));
+    if (S > 1) {
+        if (ldo != No) return fail(DITTO_ERR_ARG, "split-K needs a contiguous output (ldo == No)");
+        float* part = (float*)((char*)workspace + 256);
+        HIP_TRY(launch_gemm_tn(X, ldx, Y, ldy, workspace, part, No, Mo, No, K, S, (size_t)Mo * No, s, tile == 256));
+        HIP_TRY(launch_reduce_partials(part, S, (size_t)Mo * No, out, s));
+    } else {
+        HIP_TRY(launch_gemm_tn(X, ldx, Y, ldy, workspace, out, ldo, Mo, No, K, 1, 0, s, tile == 256));
+    }
+    return DITTO_OK;
+}
+
 int ditto_gemm_ln_bf16(const void* A, int lda, const void* W, const float* bias, const float* residual, float* out,
                        int ldo, const float* gamma, const float* beta, void* u_bf16, int ldu, int M, int N, int K,
                        ditto_stream_t stream) {

@@ -98,6 +98,24 @@ inline int wgrad_splits(long tiles, long kt) {
     }
     return (int)best;
 }
+// The same for the 256 x 256 kernel (gemm_tn_wide_kernel: one workgroup per CU = 256 slots, ~1.6 us per K-tile of 64 of a
+// resident workgroup, 256 KiB per fp32 tile image).  Measured at C2, B = 32 (tools/tn_bench.py, best split in brackets,
+// against the 128 x 128 kernel's best): d x d 67.5 us [24] vs 85.9 [6]; 2d x d 105.7 [12] vs 137.8; QKV 144.0 [8] vs 184.8;
+// fc2 188.0 [6] vs 207.2; fc1|gate 348.0 [3] vs 446.6 — every shape is fastest at tiles * S ~ one round of 256.
+inline int wgrad_splits_wide(long tiles, long kt) {
+    const long smax = kt / 8 < 32 ? kt / 8 : 32;
+    if (smax <= 1) return 1;
+    const double slots = 256.0, unit = 1.6, tile_us = 256.0 * 256.0 * 4.0 / 3.0e6;
+    long best = 1;
+    double best_cost = 1e30;
+    for (long s = 1; s <= smax; ++s) {
+        const double rounds = (double)((tiles * s + (long)slots - 1) / (long)slots);
+        double cost = rounds * (double)((kt + s - 1) / s) * unit;
+        if (s > 1) cost += 5.0 + (double)(s + 1) * (double)tiles * tile_us;
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
+    }
+    return (int)best;
+}
 constexpr size_t WPART_BYTES = (size_t)(2048 + 320) * 128 * 128 * 4;   // S * tiles: up to ~4 rounds of 512 workgroups
 TrainWsPlan plan_train_ws(const ditto_config& c, int B, int N, int T) {
     TrainWsPlan w;
@@ -361,14 +379,17 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
     // dW[n1, n2] = dY[rows, n1]^T X[rows, n2]: the K-major GEMM (gemm_tn.hip: operands read transposed out of LDS, no
     // transpose passes), split along K when the output has few tiles, partial tiles summed in slice order
     auto wgrad = [&](const void* dY, int ld1, int n1, const void* X, int ld2, int n2, int rows, float* out) -> int {
-        const long tiles = (long)((n1 + 127) / 128) * ((n2 + 127) / 128);
-        const int S = wgrad_splits(tiles, (rows + 63) / 64);
+        // 256 x 256 tiles wherever the output has them (every weight of the d >= 256 configurations); gemm_flags bit 4096
+        // keeps the 128 x 128 kernel (A/B)
+        const bool wide = n1 >= 256 && n2 >= 256 && !(g_gemm_flags & GF_TN_NARROW);
+        const long tiles = wide ? (long)((n1 + 255) / 256) * ((n2 + 255) / 256) : (long)((n1 + 127) / 128) * ((n2 + 127) / 128);
+        const int S = wide ? wgrad_splits_wide(tiles, (rows + 63) / 64) : wgrad_splits(tiles, (rows + 63) / 64);
         if (S > 1 && (size_t)S * n1 * n2 * 4 <= WPART_BYTES) {
-            HIP_TRY(launch_gemm_tn(dY, ld1, X, ld2, zero256, wpart, n2, n1, n2, rows, S, (size_t)n1 * n2, s));
+            HIP_TRY(launch_gemm_tn(dY, ld1, X, ld2, zero256, wpart, n2, n1, n2, rows, S, (size_t)n1 * n2, s, wide));
             HIP_TRY(launch_reduce_partials(wpart, S, (size_t)n1 * n2, out, s));
             return DITTO_OK;
         }
-        HIP_TRY(launch_gemm_tn(dY, ld1, X, ld2, zero256, out, n2, n1, n2, rows, 1, 0, s));
+        HIP_TRY(launch_gemm_tn(dY, ld1, X, ld2, zero256, out, n2, n1, n2, rows, 1, 0, s, wide));
         return DITTO_OK;
     };
     // dX[M, n_in] = dY[M, n_out] * W, with Wt = W^T bf16 [n_in, n_out]

@@ -286,11 +286,153 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_ring_kernel(TnParams p) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// gemm_tn_wide_kernel: the ring kernel on a 256 (m) x 256 (n) tile — 512 threads = 8 waves in 2 (m) x 4 (n), each wave
+// 128 x 64 = 4 x 2 accumulators of v_mfma_f32_32x32x16_bf16 (128 registers), ONE workgroup per CU (4-stage ring of
+// 32 KiB = 128 KiB).  Why: the 128 x 128 kernel is bound by its LDS READS — per 16 k-rows a wave fetches 2 + 2 fragments
+// (8 ds_read_b64_tr_b16 of 512 B) for 4 MFMAs, so the 8 waves of a CU ask for 32 KiB per 256 MFMA cycles = 128 B/clk, all
+// the LDS has (its ~860 TFLOP/s) — and moves 64 KiB of L2 -> LDS traffic per 1 024 MFMA cycles of a CU, three times what
+// the chip sustains (~20 B/clk/CU).  Here: 4 + 2 fragments per 8 MFMAs (96 B/clk) and 32 KiB per 1 024 cycles, the bytes
+// per FLOP of the forward 256 x 256 kernel.  Same LDS image (k-rows of 512 B, 16-B chunk c of row r at c ^ ((r & 3) << 2),
+// which permutes the 64-B quarters inside each 256-B half-row), same software pipeline across the tile boundary, same
+// counted waits (4 loads per wave per stage), same split-K contract.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int WM = 256, WN = 256;
+constexpr int W_TILE = RK * WM * 2;        // 16 KiB per operand per stage
+constexpr int W_STAGE = 2 * W_TILE;        // X | Y
+constexpr int W_LDS = R_NST * W_STAGE;     // 128 KiB
+
+__global__ __launch_bounds__(512, 1) void gemm_tn_wide_kernel(TnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;                 // wave rows [128 wr, +128), columns [64 wc, +64)
+    const int tm = blockIdx.x / p.tiles_n, tn = blockIdx.x % p.tiles_n;
+    const int m0 = tm * WM, n0 = tn * WN;
+    const int split = blockIdx.y;
+
+    int nkt = (p.K + RK - 1) / RK, kbase = 0;
+    if (p.k_splits > 1) {
+        const int per = (nkt + p.k_splits - 1) / p.k_splits;
+        kbase = split * per;
+        nkt = nkt - kbase < per ? nkt - kbase : per;
+        if (nkt < 0) nkt = 0;
+    }
+    float* out = p.out + (size_t)split * p.split_stride;
+
+    // DMA: a stage = 16 pieces of 1 KiB (2 k-rows x 512 B) per operand; this wave moves pieces 2*wid, 2*wid+1 of X and Y
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+    const int prow = lane >> 5, cpos = lane & 31;          // row inside the piece, 16-B chunk position
+    auto stage = [&](int kt) {
+        const int st = kt & (R_NST - 1);
+        const int k0 = (kbase + kt) * RK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int piece = wid * 2 + i;
+            const int r = piece * 2 + prow;                 // k-row inside the stage
+            const int c = cpos ^ ((r & 3) << 2);            // source chunk for this LDS position
+            const int k = k0 + r;
+            // columns past the matrix are clamped (their products land in rows / columns that are never stored)
+            int cx = m0 + c * 8; cx = cx + 8 <= p.Mo ? cx : (p.Mo >= 8 ? p.Mo - 8 : 0);
+            int cy = n0 + c * 8; cy = cy + 8 <= p.No ? cy : (p.No >= 8 ? p.No - 8 : 0);
+            const bf16* sx = k < p.K ? p.X + (size_t)k * p.ldx + cx : p.zero + (c & 15) * 8;
+            const bf16* sy = k < p.K ? p.Y + (size_t)k * p.ldy + cy : p.zero + (c & 15) * 8;
+            glds16(sx, lds_base + (unsigned)(st * W_STAGE + piece * 1024));
+            glds16(sy, lds_base + (unsigned)(st * W_STAGE + W_TILE + piece * 1024));
+        }
+    };
+
+    const int hh = lane >> 5;
+    const int tr_q = (lane & 15) >> 2, tr_p = lane & 3;
+    const int tr_row0 = 4 * hh + tr_q;
+    const int tr_colbyte = 32 * ((lane >> 4) & 1) + 8 * tr_p;
+    const int tr_swz = (tr_q & 3) << 6;
+    int colx[4], coly[2];
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) colx[blk] = ((wr * 4 + blk) * 64 + tr_colbyte) ^ tr_swz;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) coly[blk] = ((wc * 2 + blk) * 64 + tr_colbyte) ^ tr_swz;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc[mb][0][i] = 0.f; acc[mb][1][i] = 0.f; }
+
+    auto read_frags = [&](const char* xb, int s2, bf16x8 (&fx)[4], bf16x8 (&fy)[2]) {
+        const char* yb = xb + W_TILE;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            const char* ax = xb + (16 * s2 + tr_row0) * 512 + colx[blk];
+            fx[blk] = cat4t(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(ax)),
+                            __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(ax + 8 * 512)));
+        }
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const char* ay = yb + (16 * s2 + tr_row0) * 512 + coly[blk];
+            fy[blk] = cat4t(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(ay)),
+                            __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(ay + 8 * 512)));
+        }
+    };
+    auto mma = [&](const bf16x8 (&fx)[4], const bf16x8 (&fy)[2]) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx[mb], fy[nb], acc[mb][nb], 0, 0, 0);
+    };
+    auto wait_behind = [&](int later) {
+        if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
+    bf16x8 f0x[4], f0y[2], f1x[4], f1y[2];
+    if (nkt > 0) {
+        for (int t = 0; t < R_NST - 1 && t < nkt; ++t) stage(t);           // tiles 0, 1, 2
+        wait_behind(nkt - 1 < R_NST - 2 ? nkt - 1 : R_NST - 2);
+        asm volatile("s_barrier" ::: "memory");
+        read_frags(smem, 0, f0x, f0y);
+        for (int kt = 0; kt + 1 < nkt; ++kt) {                             // the last tile is peeled: one path per body
+            read_frags(smem + (kt & (R_NST - 1)) * W_STAGE, 1, f1x, f1y);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(f0x, f0y);
+            __builtin_amdgcn_sched_barrier(0);
+            wait_behind(kt + 2 < nkt ? 1 : 0);
+            asm volatile("s_barrier" ::: "memory");
+            if (kt + R_NST - 1 < nkt) stage(kt + R_NST - 1);
+            read_frags(smem + ((kt + 1) & (R_NST - 1)) * W_STAGE, 0, f0x, f0y);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(f1x, f1y);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        read_frags(smem + ((nkt - 1) & (R_NST - 1)) * W_STAGE, 1, f1x, f1y);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(f0x, f0y);
+        mma(f1x, f1y);
+    }
+
+    const int ncol = lane & 31;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int col = n0 + (wc * 2 + nb) * 32 + ncol;
+            if (col >= p.No) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + (wr * 4 + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (row < p.Mo) out[(size_t)row * p.ldo + col] = acc[mb][nb][r];
+            }
+        }
+}
+
 }  // namespace
 
 // out fp32 [Mo, No] (ld = ldo) = X[K, Mo]^T Y[K, No]; k_splits > 1: partial sums to out + s * split_stride
+// wide: the 256 x 256 tile kernel (one workgroup per CU) instead of the 128 x 128 ring kernel
 hipError_t launch_gemm_tn(const void* X, int ldx, const void* Y, int ldy, const void* zero256, float* out, int ldo,
-                          int Mo, int No, int K, int k_splits, size_t split_stride, hipStream_t s) {
+                          int Mo, int No, int K, int k_splits, size_t split_stride, hipStream_t s, bool wide) {
     if (!X || !Y || !zero256 || !out || Mo < 8 || No < 8 || K <= 0 || (ldx | ldy) % 8 || (Mo | No) % 8)
         return hipErrorInvalidValue;
     static bool attr_set = false;
@@ -301,6 +443,9 @@ hipError_t launch_gemm_tn(const void* X, int ldx, const void* Y, int ldy, const 
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_ring_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS);
         if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_wide_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS);
+        if (e != hipSuccess) return e;
         attr_set = true;
     }
     TnParams p;
@@ -308,6 +453,11 @@ hipError_t launch_gemm_tn(const void* X, int ldx, const void* Y, int ldy, const 
     p.out = out; p.ldo = ldo; p.Mo = Mo; p.No = No; p.K = K;
     p.tiles_m = (Mo + TM - 1) / TM; p.tiles_n = (No + TN - 1) / TN;
     p.k_splits = k_splits > 1 ? k_splits : 1; p.split_stride = split_stride;
+    if (wide) {
+        p.tiles_m = (Mo + WM - 1) / WM; p.tiles_n = (No + WN - 1) / WN;
+        hipLaunchKernelGGL(gemm_tn_wide_kernel, dim3(p.tiles_m * p.tiles_n, p.k_splits), dim3(512), W_LDS, s, p);
+        return hipGetLastError();
+    }
     if (g_gemm_flags & 2048)
         hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tiles_m * p.tiles_n, p.k_splits), dim3(256), T_LDS, s, p);
     else

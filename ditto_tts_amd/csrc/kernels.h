@@ -173,7 +173,7 @@ size_t attention_train_workspace_bytes(int B, int H, int Sq, int Skv, int dh);  
 
 // ---------------- gemm_tn.hip : out fp32 [Mo, No] = X[K, Mo]^T Y[K, No], both operands K-major (wgrad) ----------------
 hipError_t launch_gemm_tn(const void* X, int ldx, const void* Y, int ldy, const void* zero256, float* out, int ldo,
-                          int Mo, int No, int K, int k_splits, size_t split_stride, hipStream_t s);
+                          int Mo, int No, int K, int k_splits, size_t split_stride, hipStream_t s, bool wide = false);
 
 // ---------------- train.hip : backward-pass row / elementwise kernels ----------------
 // optionally batched: nz_o * nz_i matrices, src of matrix (zo, zi) at + zo * s_o + zi * s_i, dst at + z * d_z (elements)

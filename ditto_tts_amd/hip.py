@@ -127,6 +127,7 @@ SYMBOLS = {
     "ditto_layernorm_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "ditto_gemm_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ditto_gemm_ln_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ditto_gemm_tn_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "ditto_attention_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
     "ditto_attention_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "ditto_vq_argmin": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
@@ -184,7 +185,7 @@ def lib() -> C.CDLL:
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = res, args
-        if l.ditto_abi_version() != 5:
+        if l.ditto_abi_version() != 6:
             raise RuntimeError("libditto_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DITTO_ABI_VERSION 5
+#define DITTO_ABI_VERSION 6
 
 typedef enum ditto_status {
     DITTO_OK = 0,
@@ -234,6 +234,15 @@ size_t ditto_attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh);
 int ditto_gemm_ln_bf16(const void* A, int lda, const void* W, const float* bias, const float* residual, float* out,
                        int ldo, const float* gamma, const float* beta, void* u_bf16, int ldu, int M, int N, int K,
                        ditto_stream_t stream);
+
+/* Weight-gradient GEMM of the backward pass (csrc/gemm_tn.hip): out fp32 [Mo, No] = X[K, Mo]^T Y[K, No], both operands
+ * K-major bf16 (rows = the contraction index, as activations and their gradients lie in memory), i.e. dW = dY^T X of
+ * nn.Linear (what autograd computes for reference src/TrainDiTTO.py:90).  tile = 128 (128x128, two workgroups per CU) or
+ * 256 (256x256, one per CU); k_splits > 1: the contraction is split, fp32 partial tiles are summed in slice order
+ * (deterministic).  workspace: 256 + k_splits * Mo * No * 4 bytes (256 alone when k_splits <= 1), 256-byte aligned.
+ * Mo, No, ldx, ldy multiples of 8. */
+int ditto_gemm_tn_bf16(const void* X, int ldx, const void* Y, int ldy, float* out, int ldo, int Mo, int No, int K,
+                       int k_splits, int tile, void* workspace, size_t workspace_bytes, ditto_stream_t stream);
 
 /* Process-wide tuning switches (tests / experiments).  "gemm_tile": 0 = automatic choice between the three GEMM
  * tile structures, 128 (128x128) / 129 (persistent 256x128 ring) / 131 (128x256 ping-pong, two workgroups per CU) /

@@ -193,6 +193,33 @@ def test_attention(lib, B, H, Sq, Skv, dh, attn_flags):
     assert max_abs(out.float(), want) < 6e-2
 
 
+@pytest.mark.parametrize("Mo,No,K", [(128, 128, 64), (256, 256, 96), (768, 768, 1000), (200, 328, 517), (2304, 768, 4096),
+                                     (8, 16, 33), (520, 264, 2050)])
+@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("splits", [1, 5])
+def test_weight_gradient_gemm_tn(lib, Mo, No, K, tile, splits):
+    """ditto_gemm_tn_bf16 (csrc/gemm_tn.hip): out = X^T Y with both operands K-major — dW = dY^T X of nn.Linear, what the
+    backward of reference src/TrainDiTTO.py:90 computes — on both tile structures (128x128 two workgroups per CU, 256x256
+    one per CU), plain and split-K with the ordered reduce; ragged Mo / No / K (zero rows past K, clamped columns);
+    repeated for run-to-run determinism.  Against the fp32 product of the bf16 operands."""
+    X = bf16(asym((K, Mo), 31).to(DEV))
+    Y = bf16(asym((K, No), 32).to(DEV))
+    want = X.float().T @ Y.float()
+    ws = torch.empty(256 + splits * Mo * No * 4, dtype=torch.uint8, device=DEV)
+    first = None
+    for rep in range(2):
+        out = torch.full((Mo, No), float("nan"), device=DEV)
+        hip.check(lib.ditto_gemm_tn_bf16(X.data_ptr(), Mo, Y.data_ptr(), No, out.data_ptr(), No, Mo, No, K, splits, tile,
+                                         ws.data_ptr(), ws.numel(), stream()))
+        assert rel_l2(out, want) < 1e-5 and max_abs(out, want) < 1e-3 * (1 + float(want.abs().max()))
+        if first is None:
+            first = out.clone()
+        else:
+            assert torch.equal(out, first)
+    assert lib.ditto_gemm_tn_bf16(X.data_ptr(), Mo, Y.data_ptr(), No, out.data_ptr(), No, Mo, No, K, 1, 64, ws.data_ptr(),
+                                  ws.numel(), stream()) == hip.ERR_ARG
+
+
 @pytest.mark.parametrize("B,H,Sq,Skv", [(1, 2, 128, 128), (2, 3, 200, 256), (1, 12, 1024, 1024), (1, 2, 333, 2048)])
 def test_attention_pipelined_kernel_is_bitwise_the_tile_loop_kernel(lib, B, H, Sq, Skv):
     """attn64v3 (software-pipelined, attn_flags 512) and attn64v2 (256) are chosen by shape AND grid size, so an utterance's
