@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
 // MODE 1 = dkdv kernel (block = keys;    tiles = queries: images Q_row, dO_row, Q_tr, dO_tr  + L / delta)
 // ------------------------------------------------------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void attn64_bwd_kernel(BwdParams p) {
+__global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void attn64_bwd_kernel(BwdParams p) {
     constexpr int NIMG = MODE == 0 ? 3 : 4;
     constexpr int BUF = NIMG * IMG + (MODE == 1 ? 512 : 0);   // + L[64] | delta[64] floats
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * BUF (MODE 1: 65 KiB, above the static limit)
