@@ -877,6 +877,11 @@ int ditto_set_option(const char* name, int value) {
         g_fr_mask = value;
         return DITTO_OK;
     }
+    if (!strcmp(name, "fr_dgrad")) {
+        if (value < 0 || value > 3) return fail(DITTO_ERR_ARG, "fr_dgrad must be in [0, 3]");
+        g_fr_dgrad = value;
+        return DITTO_OK;
+    }
     if (!strcmp(name, "fr_rot")) {
         if (value < 0 || value > 4096) return fail(DITTO_ERR_ARG, "fr_rot must be in [0, 4096]");
         g_fr_rot = value;

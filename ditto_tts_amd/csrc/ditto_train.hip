@@ -49,7 +49,7 @@ TapePlan plan_tape(const ditto_config& c, int B, int N, int T) {
 }
 
 struct TrainArenaPlan {
-    struct L { size_t WqkvT, WcqT, WcoT, W1gT, W2T, Wqkv_u, Wcq_u, bqkv_u, bcq_u; };
+    struct L { size_t WqkvT, WcqT, WcoT, W1gT, W2T, Wqkv_u, Wcq_u, bqkv_u, bcq_u, W1gTP, WqkvTP; };
     std::vector<L> layers;
     size_t WoutT, total;
 };
@@ -63,6 +63,8 @@ TrainArenaPlan plan_train_arena(const ditto_config& c) {
         q.WqkvT = take(3 * d * d * 2); q.WcqT = take(d * d * 2); q.WcoT = take(d * d * 2); q.W1gT = take(8 * d * d * 2);
         q.W2T = take(4 * d * d * 2);
         q.Wqkv_u = take(3 * d * d * 2); q.Wcq_u = take(d * d * 2); q.bqkv_u = take(3 * d * 4); q.bcq_u = take(d * 4);
+        q.W1gTP = q.WqkvTP = 0;
+        if (d == 768) { q.W1gTP = take(8 * d * d * 2); q.WqkvTP = take(3 * d * d * 2); }   // full-row kernel's layout (gemm_fr.hip)
     }
     p.WoutT = take(d * d * 2);
     p.total = off;
@@ -197,8 +199,15 @@ int ditto_train_attach(ditto_model_t m, const ditto_weights* w, void* train_aren
         HIP_TRY(launch_pack_bf16(lw.cross_in_proj_weight, A + q.Wcq_u, d, d, d, 0, BIG, 1, 0, s));
         HIP_TRY(hipMemcpyAsync(A + q.bqkv_u, lw.attn_in_proj_bias, (size_t)3 * d * 4, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(A + q.bcq_u, lw.cross_in_proj_bias, (size_t)d * 4, hipMemcpyDeviceToDevice, s));
+        const void *w1gtp = nullptr, *wqkvtp = nullptr;
+        if (d == 768) {
+            HIP_TRY(launch_repack_bf16_stage_major(A + q.W1gT, A + q.W1gTP, d, 8 * d, s));
+            HIP_TRY(launch_repack_bf16_stage_major(A + q.WqkvT, A + q.WqkvTP, d, 3 * d, s));
+            w1gtp = A + q.W1gTP; wqkvtp = A + q.WqkvTP;
+        }
         m->layersT[l] = LayerPackT{A + q.WqkvT, A + q.WcqT, A + q.WcoT, A + q.W1gT, A + q.W2T,
-                                   A + q.Wqkv_u, A + q.Wcq_u, (const float*)(A + q.bqkv_u), (const float*)(A + q.bcq_u)};
+                                   A + q.Wqkv_u, A + q.Wcq_u, (const float*)(A + q.bqkv_u), (const float*)(A + q.bcq_u),
+                                   w1gtp, wqkvtp};
     }
     HIP_TRY(launch_pack_bf16_t(w->proj_out_weight, A + p.WoutT, d, d, d, BIG, 1, 0, s));
     m->WoutT = A + p.WoutT;
@@ -356,6 +365,7 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
     hipStream_t s = (hipStream_t)stream;
     const int d = c.hidden_dim, L = c.num_layers, H = c.num_heads, dhd = d / H, M = B * N, Mt = B * T, td = c.time_dim;
     const float scale = 1.0f / sqrtf((float)dhd);
+    const bool lt0_has_fr = m->layersT[0].W1gTP != nullptr;
     const char* tb = (const char*)tape;
     char* ws = (char*)workspace;
     const char* kv = tb + tp.kv;
@@ -401,6 +411,17 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
     };
     // LayerNorm backward into the stream gradient dh, which also leaves bf16(dh) in dyb (the dY operand of the segment below)
     // and, when asked, the column sums of dh = the bias gradient of the Linear that closes that segment
+    // the same on the full-row kernel (N = d = 768 outputs, fp32, no bias / residual / LayerNorm), for the long-K dgrads: its
+    // tile reads each dY row once (the 256 x 192 kernel re-reads the dY panel per column tile); WtP = Wt stage-major.
+    // Option "fr_dgrad": bit 0 = the fc1|gate dgrad (K = 8d), bit 1 = the QKV dgrad (K = 3d).
+    const bool fr_dgrad = lt0_has_fr && fr_pays(M) && gemm_fr_supports(M, d, 8 * d, (size_t)8 * d, (size_t)8 * d);
+    auto dgrad_fr = [&](const void* dY, int n_out, const void* WtP, float* out) -> int {
+        GemmParams gp{};
+        gp.A = (const bf16*)dY; gp.lda = n_out; gp.W = (const bf16*)WtP; gp.ldw = n_out; gp.w_rows = d;
+        gp.out = out; gp.ldo = d; gp.M = M; gp.N = d; gp.K = n_out;
+        HIP_TRY(launch_gemm_fr(gp, nullptr, nullptr, nullptr, d, N % 128 == 0 ? N / 128 : 0, s));
+        return DITTO_OK;
+    };
     auto ln_back = [&](const float* xin, const float* gamma, float* gw, float* gb, float* next_bias) -> int {
         HIP_TRY(launch_ln_bwd_stream(du, xin, gamma, dh, dyb, gw, gb, next_bias, red, M, d, s));
         return DITTO_OK;
@@ -435,7 +456,8 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
         TRY_RC(wgrad(big1, 8 * d, 8 * d, tb + q.u3, d, d, M, wtmp));
         HIP_TRY(launch_unpack_rows(wtmp, G.mlp_fc1_weight, 4 * d, d, 16, 2, 0, s));
         HIP_TRY(launch_unpack_rows(wtmp, G.gate_weight, 4 * d, d, 16, 2, 16, s));
-        TRY_RC(dgrad(big1, 8 * d, lt.W1gT, d, du, true));
+        if (fr_dgrad && (g_fr_dgrad & 1)) TRY_RC(dgrad_fr(big1, 8 * d, lt.W1gTP, du));
+        else TRY_RC(dgrad(big1, 8 * d, lt.W1gT, d, du, true));
         TRY_RC(ln_back(h2, lp.g3, G.norm3_weight, G.norm3_bias, G.cross_out_proj_bias));
 
         // ---- cross-attention: h2 = h1 + oc Wo^T + bo,  oc = attn(qc, Kc, Vc),  qc = u2 Wq^T + bq ----
@@ -473,7 +495,8 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
         HIP_TRY(launch_rope_inplace(big1, 3 * d, rope_cos, rope_sin, M, N, 2 * d, dhd, s, -1.0f));
         HIP_TRY(launch_colsum_bf16(big1, 3 * d, M, 3 * d, G.attn_in_proj_bias, red, s));
         TRY_RC(wgrad(big1, 3 * d, 3 * d, tb + q.u1, d, d, M, G.attn_in_proj_weight));
-        TRY_RC(dgrad(big1, 3 * d, lt.WqkvT, d, du, true));
+        if (fr_dgrad && (g_fr_dgrad & 2)) TRY_RC(dgrad_fr(big1, 3 * d, lt.WqkvTP, du));
+        else TRY_RC(dgrad(big1, 3 * d, lt.WqkvT, d, du, true));
         TRY_RC(ln_back(h0, lp.g1, G.norm1_weight, G.norm1_bias, l > 0 ? grads->layers[l - 1].mlp_fc2_bias : nullptr));
     }
 

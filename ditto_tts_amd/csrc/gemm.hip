@@ -38,6 +38,7 @@ int g_pp_stagger = -1;
 int g_pp_nb = 0;
 // default 3: measured in-model at C2, B = 32 (tools/step_ab.py ~mask): 13.02 -> 12.73 (1) / 12.77 (2) / 12.40 ms (3)
 int g_fr_mask = [] { const char* e = getenv("DITTO_FR_MASK"); return e ? atoi(e) : 3; }();
+int g_fr_dgrad = [] { const char* e = getenv("DITTO_FR_DGRAD"); return e ? atoi(e) : 3; }();
 int g_fr_rot = [] { const char* e = getenv("DITTO_FR_ROT"); return e ? atoi(e) : 1; }();
 int g_pp_mask = [] { const char* e = getenv("DITTO_PP_MASK"); return e ? atoi(e) : -1; }();   // -1 = built-in rule
 int g_gemm_tile = [] { const char* e = getenv("DITTO_GEMM"); return e ? atoi(e) : 0; }();

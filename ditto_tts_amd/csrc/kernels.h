@@ -51,6 +51,7 @@ hipError_t launch_pack_bf16(const float* src, void* dst_bf16, int rows, int cols
 hipError_t launch_scale_vec(float* v, int n, float f, hipStream_t s);
 // fp32 [N, K] -> bf16 stage-major [K/16][N][16] (the full-row GEMM's weight layout, gemm_fr.hip)
 hipError_t launch_pack_bf16_stage_major(const float* src, void* dst, int N, int K, hipStream_t s);
+hipError_t launch_repack_bf16_stage_major(const void* src_bf16, void* dst, int N, int K, hipStream_t s);
 // The full-row kernel runs ONE 128-row tile per workgroup, so it needs enough rows to fill the chip: measured in the
 // model (tools/step_ab.py --batch b, C2 shapes, fr_mask 3 against 0) it loses below 160 tiles (B = 1: 2.92 vs 1.84 ms per
 // step, B = 8: 4.73 vs 4.02, B = 16: 7.00 vs 6.65) and wins from there on (B = 20: 8.37 vs 8.43, B = 24: 9.49 vs 10.17,
@@ -59,6 +60,7 @@ hipError_t launch_pack_bf16_stage_major(const float* src, void* dst, int N, int 
 // batch are in the same class), not across (fr_mask 0 gives one class).
 inline bool fr_pays(int M) { return (M + 127) / 128 >= 160; }
 
+extern int g_fr_dgrad;   // gemm.hip: training backward, long-K dgrads on the full-row kernel: bit 0 fc1|gate (K = 8d), bit 1 QKV (K = 3d)
 extern int g_fr_rot;     // gemm.hip: full-row kernel's K-loop rotation: 0 off, 1 on in the model (period = tiles per utterance), > 1 = period for ditto_gemm_ln_bf16 too
 extern int g_fr_mask;    // gemm.hip: 1 = cross out-proj + LayerNorm3, 2 = fc2 + next block's LayerNorm1 on the full-row kernel
 // same row map for an fp32 vector (bias)

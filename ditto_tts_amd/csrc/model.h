@@ -30,6 +30,7 @@ struct LayerPack {
 struct LayerPackT {
     const void *WqkvT, *WcqT, *WcoT, *W1gT, *W2T;
     const void *Wqkv_u, *Wcq_u; const float *bqkv_u, *bcq_u;
+    const void *W1gTP, *WqkvTP;   // stage-major copies of W1gT / WqkvT for the full-row kernel (d == 768 only, else null)
 };
 
 struct ArenaPlan {

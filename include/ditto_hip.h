@@ -251,6 +251,7 @@ int ditto_gemm_tn_bf16(const void* X, int ldx, const void* Y, int ldy, float* ou
  * 3 fc2, 4 QKV + RoPE, 5 gated MLP; -1 = the built-in rule).
  * "fr_mask": N = d = 768 projections on the full-row kernel with the residual add and the following LayerNorm fused
  * (csrc/gemm_fr.hip): bit 0 = cross out-proj + norm3, bit 1 = fc2 + the next block's norm1.
+ * "fr_dgrad": training backward, the long-K dgrads (N = d = 768) on the same kernel: bit 0 = fc1|gate (K = 8d), bit 1 = QKV.
  * "fr_rot": that kernel's K-loop rotation (tiles start their k sum at different places so that the workgroups of an XCD do
  * not all ask the L2 for the same weight lines at once): 0 = off, 1 = on in the model path with period = row tiles per
  * utterance (an utterance's bits do not depend on its place in the batch), > 1 = ditto_gemm_ln_bf16 rotates too, with that

@@ -236,7 +236,7 @@ def test_gradients_are_bit_reproducible():
 def test_large_batch_training_step_takes_the_full_row_forward():
     """From 160 row tiles on (B >= 20 at N = 1024) the training forward runs the cross out-projection + norm3 and fc2 + the
     next block's norm1 on the full-row kernel (csrc/gemm_fr.hip), its LayerNorm outputs landing in the tape slots the
-    backward reads.  C2 (12 layers, d = 768) at B = 20: loss and every parameter gradient of the fused step against the
+    backward reads, and the backward its two long-K dgrads (fc1|gate, QKV) on the same kernel.  C2 (12 layers, d = 768) at B = 20: loss and every parameter gradient of the fused step against the
     unfused one (fr_mask 0) within bf16-path noise — the small-shape tests above pin the unfused step to the oracle."""
     from ditto_tts_amd.config import PRESETS
     cfg = PRESETS["C2"]["cfg"]
@@ -245,6 +245,7 @@ def test_large_batch_training_step_takes_the_full_row_forward():
     res = []
     for mask in (3, 0):
         hip.set_option("fr_mask", mask)
+        hip.set_option("fr_dgrad", 3 if mask else 0)     # ... and the long-K dgrads of the backward on the same kernel
         try:
             m = _build(cfg, 9).eval()                    # eval: no dropout, both runs see the same function
             loss = F.mse_loss(m(x, text, t), target)
@@ -253,6 +254,7 @@ def test_large_batch_training_step_takes_the_full_row_forward():
             del m, loss
         finally:
             hip.set_option("fr_mask", 3)
+            hip.set_option("fr_dgrad", 3)
     (la, ga), (lb, gb) = res
     assert abs(la - lb) < 2e-3 * abs(lb), (la, lb)
     assert ga.keys() == gb.keys() and len(ga) > 200
