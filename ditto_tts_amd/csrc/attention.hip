@@ -34,7 +34,8 @@ namespace ditto {
 // (needs bit 0); bit 4 (16): ditto_attention_bf16's q is pre-scaled
 // (unit tests of attn64v2); bit 5 (32): run the kernels above on pre-scaled q instead of attn64v2 (A/B); bit 6 (64):
 // attn64v2 at 2 waves per SIMD with the V prefetch instead of 3 without; bit 7 (128): no deep-prefetch instantiation
-// on small grids; bit 8 (256): never attn64v3 (the software-pipelined kernel), bit 9 (512): attn64v3 wherever Skv % 128 == 0.
+// on small grids; bit 8 (256): never attn64v3 (the software-pipelined kernel), bit 9 (512): attn64v3 wherever Skv % 128 == 0; bit 10 (1024): its 8-wave (256 queries per
+// workgroup) form always, bit 11 (2048): never.
 // ditto_set_option("attn_flags")
 int g_attn_flags = 3;
 
@@ -563,8 +564,11 @@ __global__ __launch_bounds__(256, WPS) void attn64v2_kernel(AttnParams p) {
 constexpr int V3_KSLOTS = 4, V3_VSLOTS = 5;
 constexpr int V3_LDS = (V3_KSLOTS + V3_VSLOTS) * KV_TILE_BYTES;   // 72 KiB
 
-template <bool RESID>
-__global__ __launch_bounds__(256, 2) void attn64v3_kernel(AttnParams p) {
+// NW = waves per workgroup = 32-query blocks sharing the K/V tiles: 4 (128 queries, two workgroups per CU) or 8 (256
+// queries, one workgroup per CU: half the K/V LDS-DMA bytes and ring writes per FLOP; p.nqb counts blocks of 32 NW).
+template <bool RESID, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 2) void attn64v3_kernel(AttnParams p) {
+    constexpr int PW = 8 / NW;                                      // 1-KiB DMA pieces per wave per tile image (2 or 1)
     extern __shared__ __attribute__((aligned(16))) char smem[];    // [4 K tiles][5 V tiles]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -573,7 +577,7 @@ __global__ __launch_bounds__(256, 2) void attn64v3_kernel(AttnParams p) {
     const int qb = id % p.nqb, bh = id / p.nqb;
     const int h = bh % p.H, b = bh / p.H;
     const int ql = lane & 31, hh = lane >> 5;
-    int qrow = qb * QBLK + wid * 32 + ql;
+    int qrow = qb * (32 * NW) + wid * 32 + ql;
     const bool qvalid = qrow < p.Sq;
     qrow = qvalid ? qrow : p.Sq - 1;
 
@@ -588,19 +592,19 @@ __global__ __launch_bounds__(256, 2) void attn64v3_kernel(AttnParams p) {
     // this lane's two (row, chunk) DMA sources of tile 0; tile kt is + kt * 64 rows (LDS swizzles applied on the source)
     const bf16 *ksrc[2], *vsrc[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (wid * 2 + i) * 8 + (lane >> 3), cpos = lane & 7;
+    for (int i = 0; i < PW; ++i) {
+        const int row = (wid * PW + i) * 8 + (lane >> 3), cpos = lane & 7;
         ksrc[i] = p.k + ((size_t)b * p.Skv + row) * p.ldk + h * DH + (cpos ^ ((row >> 1) & 7)) * 8;
         vsrc[i] = p.v + ((size_t)b * p.Skv + row) * p.ldv + h * DH + (cpos ^ (((row >> 1) & 1) << 2)) * 8;
     }
     const size_t kstep = (size_t)KBLK * p.ldk, vstep = (size_t)KBLK * p.ldv;
     int issued = 0;                                               // tiles whose DMA has been issued
     unsigned ik = 0, iv = 0;                                      // ring slots of the next tile to issue
-    auto dma_next = [&]() {                                       // 4 loads per wave: 2 K pieces, 2 V pieces
+    auto dma_next = [&]() {                                       // 2 PW loads per wave: PW K pieces, PW V pieces
         if (issued < nkt) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int piece = wid * 2 + i;
+            for (int i = 0; i < PW; ++i) {
+                const int piece = wid * PW + i;
 #ifndef DITTO_DIAG_ATTN_NODMA   // tools/build_diag.sh: attn64v3 without its K/V tile traffic (timing only)
                 glds16(ksrc[i], lds_base + (unsigned)(ik * KV_TILE_BYTES + piece * 1024));
                 glds16(vsrc[i], lds_base + (unsigned)((V3_KSLOTS + iv) * KV_TILE_BYTES + piece * 1024));
@@ -615,9 +619,15 @@ __global__ __launch_bounds__(256, 2) void attn64v3_kernel(AttnParams p) {
     // tile `need` has landed for this wave once only the tiles issued after it are in flight; then for everyone
     auto wait_tile = [&](int need) {
         const int younger = issued - 1 - need;
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (PW == 2) {
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
 #ifndef DITTO_DIAG_ATTN_NOBAR   // racy: timing only
         __syncthreads();
 #endif
@@ -987,6 +997,25 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
                     if (e != hipSuccess) return e;
                     attr_set = true;
+                }
+                // 256 queries per workgroup (8 waves share the K/V tiles) where the key sequence is long: Sq = Skv = 4096, B = 8:
+                // 427.6 against 441.2 us; at 1024 keys it ties (140.6 / 141.3).  attn_flags 1024 forces it, 2048 forbids it.
+                if (((g_attn_flags & 1024) || (a.Skv >= 2048 && a.Sq >= 256)) && !(g_attn_flags & 2048)) {
+                    static bool attr8 = false;
+                    if (!attr8) {
+                        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn64v3_kernel<true, 8>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
+                        if (e == hipSuccess)
+                            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn64v3_kernel<false, 8>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
+                        if (e != hipSuccess) return e;
+                        attr8 = true;
+                    }
+                    p.nqb = (a.Sq + 255) / 256;
+                    const dim3 grid8(p.nqb * a.H * a.B);
+                    if (a.resid_f32) hipLaunchKernelGGL((attn64v3_kernel<true, 8>), grid8, dim3(512), V3_LDS, s, p);
+                    else hipLaunchKernelGGL((attn64v3_kernel<false, 8>), grid8, dim3(512), V3_LDS, s, p);
+                    return hipGetLastError();
                 }
                 if (a.resid_f32) hipLaunchKernelGGL((attn64v3_kernel<true>), gridv, dim3(256), V3_LDS, s, p);
                 else hipLaunchKernelGGL((attn64v3_kernel<false>), gridv, dim3(256), V3_LDS, s, p);

@@ -220,7 +220,8 @@ def test_weight_gradient_gemm_tn(lib, Mo, No, K, tile, splits):
                                   ws.numel(), stream()) == hip.ERR_ARG
 
 
-@pytest.mark.parametrize("B,H,Sq,Skv", [(1, 2, 128, 128), (2, 3, 200, 256), (1, 12, 1024, 1024), (1, 2, 333, 2048)])
+@pytest.mark.parametrize("B,H,Sq,Skv", [(1, 2, 128, 128), (2, 3, 200, 256), (1, 12, 1024, 1024), (1, 2, 333, 2048),
+                                        (2, 2, 4096, 4096)])
 def test_attention_pipelined_kernel_is_bitwise_the_tile_loop_kernel(lib, B, H, Sq, Skv):
     """attn64v3 (software-pipelined, attn_flags 512) and attn64v2 (256) are chosen by shape AND grid size, so an utterance's
     bits may not depend on which one ran: same products in the same order, running-maximum raises by whole octaves in both.
@@ -234,7 +235,7 @@ def test_attention_pipelined_kernel_is_bitwise_the_tile_loop_kernel(lib, B, H, S
     q = bf16((q * (1.4426950408889634 / math.sqrt(dh))).to(DEV))
     k, v = bf16(k.to(DEV)), bf16(v.to(DEV))
     outs = []
-    for flags in (16 + 256, 16 + 512):
+    for flags in (16 + 256, 16 + 512 + 2048, 16 + 512 + 1024):      # attn64v2; attn64v3 with 4 and with 8 waves per workgroup
         hip.check(lib.ditto_set_option(b"attn_flags", flags))
         out = torch.empty(B * Sq, d, dtype=torch.bfloat16, device=DEV)
         hip.check(lib.ditto_attention_bf16(q.data_ptr(), d, k.data_ptr(), d, v.data_ptr(), d, out.data_ptr(), d, B, H, Sq,
@@ -242,7 +243,7 @@ def test_attention_pipelined_kernel_is_bitwise_the_tile_loop_kernel(lib, B, H, S
         outs.append(out)
     hip.check(lib.ditto_set_option(b"attn_flags", 3))
     assert torch.isfinite(outs[0].float()).all()
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
 @pytest.mark.parametrize("attn_flags", [3, 16, 16 + 64, 16 + 128, 16 + 256, 16 + 512])
