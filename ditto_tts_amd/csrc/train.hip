@@ -315,15 +315,17 @@ __global__ __launch_bounds__(256) void ln_bwd_finish3_kernel(const float* __rest
         if (o) o[j % d] = r;
     }
 }
+// workgroups per group: enough to fill the chip at the kernel's 4 waves per SIMD (1 024 workgroups of 4 waves = every
+// wave slot of 256 CUs; at the former cap of 512 the d = 768 stream kernel ran at half occupancy: 102 us for 450 MB)
 static int ln_bwd_chunks(int rows_per_group, int groups) {
     int chunks = (1024 + groups - 1) / groups;
     const int maxc = (rows_per_group + 15) / 16;
     if (chunks > maxc) chunks = maxc;
-    if (chunks > 512) chunks = 512;
+    if (chunks > 1024) chunks = 1024;
     return chunks < 1 ? 1 : chunks;
 }
 size_t ln_bwd_scratch_bytes(int rows_per_group, int groups, int d) {
-    return (size_t)groups * ln_bwd_chunks(rows_per_group, groups) * 2 * d * 4;
+    return (size_t)groups * ln_bwd_chunks(rows_per_group, groups) * 3 * d * 4;   // 3: the stream form's extra column sum
 }
 // The residual-stream form (one group): dx_accum += dx; dx_bf16 = bf16(dx_accum); dgamma / dbeta / colsum(dx_accum)
 // (the last may be null) written to their own destinations.  scratch: ln_bwd_scratch_bytes(rows, 1, d) * 3 / 2.
