@@ -289,11 +289,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_ring_kernel(TnParams p) {
 // ---------------------------------------------------------------------------------------------------------
 // gemm_tn_wide_kernel: the ring kernel on a 256 (m) x 256 (n) tile — 512 threads = 8 waves in 2 (m) x 4 (n), each wave
 // 128 x 64 = 4 x 2 accumulators of v_mfma_f32_32x32x16_bf16 (128 registers), ONE workgroup per CU (4-stage ring of
-// 32 KiB = 128 KiB).  Why: the 128 x 128 kernel is bound by its LDS READS — per 16 k-rows a wave fetches 2 + 2 fragments
-// (8 ds_read_b64_tr_b16 of 512 B) for 4 MFMAs, so the 8 waves of a CU ask for 32 KiB per 256 MFMA cycles = 128 B/clk, all
-// the LDS has (its ~860 TFLOP/s) — and moves 64 KiB of L2 -> LDS traffic per 1 024 MFMA cycles of a CU, three times what
-// the chip sustains (~20 B/clk/CU).  Here: 4 + 2 fragments per 8 MFMAs (96 B/clk) and 32 KiB per 1 024 cycles, the bytes
-// per FLOP of the forward 256 x 256 kernel.  Same LDS image (k-rows of 512 B, 16-B chunk c of row r at c ^ ((r & 3) << 2),
+// 32 KiB = 128 KiB).  Why: the 128 x 128 kernel moves 64 KiB of L2 -> LDS traffic per 1 024 MFMA cycles of a CU, three
+// times what the chip sustains (~20 B/clk/CU), and per 16 k-rows a wave fetches 2 + 2 fragments (8 ds_read_b64_tr_b16 of
+// 512 B) for 4 MFMAs: 128 B/clk for the 8 waves of a CU, half the LDS array (~860 TFLOP/s).  Here: 32 KiB per 1 024
+// cycles — the bytes per FLOP of the forward 256 x 256 kernel — and 4 + 2 fragments per 8 MFMAs (96 B/clk).  Same LDS image (k-rows of 512 B, 16-B chunk c of row r at c ^ ((r & 3) << 2),
 // which permutes the 64-B quarters inside each 256-B half-row), same software pipeline across the tile boundary, same
 // counted waits (4 loads per wave per stage), same split-K contract.
 // ---------------------------------------------------------------------------------------------------------
