@@ -273,6 +273,28 @@ def test_full_size_c2_large_batch_takes_the_full_row_path():
 
 
 @torch.no_grad()
+def test_full_row_path_on_ragged_rows():
+    """The fused full-row path where nothing is aligned: N = 1000 latent frames (not a multiple of the 128-row tile: tiles
+    straddle utterances, no K-loop rotation, a partial last tile at M = 21 x 1000), T = 96: fused against unfused within
+    bf16-path noise, finite, repeatable."""
+    from ditto_tts_amd import hip
+    cfg = PRESETS["C2"]["cfg"]
+    m = build(cfg, 2)
+    x, text, t = synthetic_inputs(cfg, 21, 1000, 96, seed=7)
+    xd, td, tt = x.to(DEV), text.to(DEV), t.to(DEV)
+    out = m(xd, td, tt)
+    assert torch.isfinite(out).all()
+    assert torch.equal(m(xd, td, tt), out)
+    hip.set_option("fr_mask", 0)
+    try:
+        plain = m(xd, td, tt)
+    finally:
+        hip.set_option("fr_mask", 3)
+    assert not torch.equal(plain, out), "the full-row path did not run"
+    assert rel_l2(out, plain) < 4e-3
+
+
+@torch.no_grad()
 def test_full_size_c2_sampling_loop_properties():
     """The 50-step loop at BASELINE configs[1]'s full size (12L, d=768, N=T=1024), which only bench.py ran before:
     finite; ditto_denoise_steps (one library call) == the per-step loop, bitwise; sharding the batch [3] -> [2] + [1]
