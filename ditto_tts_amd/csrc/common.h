@@ -73,7 +73,39 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 // 29; the gated epilogue is issue-bound at 1 750 instructions per wave per tile):
 //     gelu(x) sigmoid(g) = (x + |x| erf(|x|/sqrt2)) * 1 / (2 + 2 e^-g)
 //     erf(|z|) = 1 - poly(t) e^(-x^2/2),   t = 1 / (1 + (p/sqrt2) |x|)          (A&S 7.1.26, as fast_gelu_erf)
+// Third form (default): erf as a RATIONAL function, z P(z^2) / Q(z^2) on |z| <= 4 (P of degree 6, Q of degree 4 with
+// Q >= 1; least-squares + Lawson-reweighted fit against scipy's erf: 5.4e-8 in fp64, 4.3e-7 evaluated in fp32 — the level
+// of the A&S form above), so that the two divisions of the product share ONE reciprocal and the Gaussian factor's
+// exponential disappears:
+//     gelu(x) sigmoid(g) = (x/2) (Q + z P) / (Q (1 + e^-g)),    z = clamp(x / sqrt2, -4, 4)
+// 2 transcendentals per output instead of 4: the gated epilogue runs with the matrix pipe idle and its transcendentals
+// (16 cycles each, quarter rate) were 62 % of its arithmetic time.  Q (1 + e^-g) = inf for
+// g < -88 gives 0, the limit; beyond |z| = 4 erf is +-1 to 1.5e-8.  The constants are pinned by tests/test_gated_math.py.
 DITTO_DEV f32x2 fast_gelu_sigmoid2(f32x2 x, f32x2 g) {
+    f32x2 z = x * 0.70710678118654752440f;
+    z[0] = __builtin_amdgcn_fmed3f(z[0], -4.0f, 4.0f); z[1] = __builtin_amdgcn_fmed3f(z[1], -4.0f, 4.0f);
+    const f32x2 u = z * z;
+    f32x2 pn = u * 1.9217200275534196e-08f + (-1.990321152334218e-06f);
+    pn = pn * u + 0.00015553680714219809f;
+    pn = pn * u + 0.0042930529452860355f;
+    pn = pn * u + 0.05243346840143204f;
+    pn = pn * u + 0.2139447033405304f;
+    pn = pn * u + 1.1283786296844482f;
+    f32x2 qd = u * 0.0010980380466207862f + 0.01555109117180109f;
+    qd = qd * u + 0.12079962342977524f;
+    qd = qd * u + 0.5229312181472778f;
+    qd = qd * u + 1.0f;
+    const f32x2 num = (x * 0.5f) * (z * pn + qd);             // x Q Phi(x)
+    const f32x2 eg = g * (-1.4426950408889634f);
+    f32x2 e;
+    e[0] = __builtin_amdgcn_exp2f(eg[0]); e[1] = __builtin_amdgcn_exp2f(eg[1]);
+    const f32x2 den = qd * e + qd;                            // Q (1 + e^-g)
+    f32x2 r;
+    r[0] = fast_rcp(den[0]); r[1] = fast_rcp(den[1]);
+    return num * r;
+}
+// second packed form (A/B: -DDITTO_GATED_AS): A&S erf, scalings folded, sign by |x| source modifiers
+DITTO_DEV f32x2 fast_gelu_sigmoid2_as(f32x2 x, f32x2 g) {
     f32x2 t;
     t[0] = fast_rcp(fmaf(fabsf(x[0]), 0.3275911f * 0.70710678118654752440f, 1.0f));
     t[1] = fast_rcp(fmaf(fabsf(x[1]), 0.3275911f * 0.70710678118654752440f, 1.0f));
