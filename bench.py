@@ -30,6 +30,15 @@ Besides the contract's line the JSON carries:
                launch duration; peak = 2.5 PFLOP/s dense bf16 (5 PFLOP/s for the fp8 GEMM classes of C5)
   cpu_baseline the fp32 oracle (proved equal to the reference, tests/test_oracle_*) on the host cores, rank 0, N = 1
                only, bounded samples at B = 1 and B = 4
+  parity       the line validates itself: after the timed region the GPU model runs ONE forward at the timed batch size
+               (so on the timed kernels: full-row path at B = 32) whose utterance 0 is the oracle's input
+               (synthetic_inputs(cfg, 1, N, T, seed = 7), the seed-1234 weights); rel-L2 / max-abs of that utterance
+               against the fp32 oracle, tolerance 2e-2 (6e-2 for the fp8 linear path).  Above tolerance the process
+               exits non-zero AFTER printing the line.
+  other_configs (N = 1 runs) the claims that used to live only in profiles/: C4 (N = 4096, B = 8), C5 fp8 and C5 bf16
+               (24L, d = 1024, B = 16) as short timed loops with their own dominant-kernel roofline, and train_step =
+               forward + backward + AdamW of C2 at B = 32 (reference src/TrainDiTTO.py:85-91), all witnessed by the
+               same run
 """
 import argparse
 import json
@@ -63,6 +72,10 @@ def parse():
     ap.add_argument("--no-sweep", action="store_true", help="skip the B in {1, 8, 32} sweep (N = 1 only)")
     ap.add_argument("--global-batch", type=int, default=256, help="C3 strong-scaling point: utterances held by rank 0")
     ap.add_argument("--no-c3", action="store_true", help="skip the C3 strong-scaling point")
+    ap.add_argument("--no-parity", action="store_true", help="skip the in-run oracle parity check of the timed shape")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the C4 / C5 / training-step side measurements (N = 1 runs of the default config only)")
+    ap.add_argument("--side-steps", type=int, default=10, help="timed steps of each side configuration")
     ap.add_argument("--noise", choices=["seeded", "torch"], default="seeded",
                     help="the step's N(0,1) draw: 'seeded' = the library's per-utterance counter-based generator inside the "
                          "update kernel (ditto_p_sample_seeded: what batch-sharded sampling uses, independent of the world "
@@ -110,13 +123,14 @@ def kernel_flops(cfg, B, N, T):
     }
 
 
-def kernel_bytes(cfg, B, N, T):
+def kernel_bytes(cfg, B, N, T, seeded=True):
     """Algorithmic HBM bytes of ONE launch of the memory-bound classes."""
     d, M = cfg.hidden_dim, B * N
     return {
         "layernorm": M * d * (4 + 2.0),                 # fp32 in, bf16 out
         "adaln": M * d * (4 + 4 + 2.0),                 # fp32 in, fp32 out + bf16 raw copy
-        "p_sample_update": M * d * 4 * 4.0,             # x, eps, z in; x out
+        # seeded kernel: x and eps in, x out (the noise is generated in registers); noise-tensor kernel: + z in
+        "p_sample_update": M * d * 4 * (3.0 if seeded else 4.0),
     }
 
 
@@ -138,24 +152,25 @@ def step_min_seconds(cfg, B, N, T, one_off_per_step):
 
 
 def pmc_traffic(kernel_class, B, N, T, cfg):
-    """HBM bytes per launch of `kernel_class` from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json,
-    tools/pmc_traffic.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 x2 correction on the
-    read side).  bench.py cannot run under the counter collector itself, so the figure is the offline one; it is only
-    reported when the workload is the one those passes measured (C2, B=32), else null."""
+    """(HBM bytes per launch of `kernel_class`, where the figure comes from): the committed rocprofv3 PMC passes
+    (profiles/*_pmc_traffic.json, tools/pmc_traffic.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command,
+    gfx950 x2 correction on the read side).  bench.py cannot run under the counter collector itself, so the figure is an
+    OFFLINE one — not a measurement of this run — and is labelled so in the line ("traffic_source"); it is only reported
+    when the workload is the one those passes measured (C2, B=32), else null."""
     if not (B == 32 and N == 1024 and T == 1024 and cfg.hidden_dim == 768 and cfg.num_layers == 12):
-        return None
+        return None, None
     pdir = os.path.join(ROOT, "profiles")
     try:
         names = sorted((f for f in os.listdir(pdir) if f.endswith("pmc_traffic.json")), reverse=True)  # newest first
     except OSError:
-        return None
+        return None, None
     for name in names:
         try:
             d = json.load(open(os.path.join(pdir, name)))
-            return d[kernel_class]["traffic_bytes"]
+            return d[kernel_class]["traffic_bytes"], f"offline PMC pass profiles/{name} (not this run)"
         except (OSError, KeyError, ValueError, TypeError):
             continue
-    return None
+    return None, None
 
 
 def usable_cores():
@@ -267,6 +282,162 @@ class StepRunner:
             self.step(i)
 
 
+def profile_classes(eng, runner, cfg, B, N, T, profile_steps):
+    """Per-kernel-class HIP-event timing (libditto_hip's profiler, events on the launch stream) of `profile_steps` pure
+    denoise steps of `runner`, eager.  Returns (roofline of the dominant class, every class)."""
+    dev = runner.dev
+    eng.profile_enable(True)
+    for i in range(profile_steps):
+        runner.step(1 + i, eager=True)     # k != 0: pure denoise steps, eager so events bracket launches
+    torch.cuda.synchronize(dev)
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+    kf, kb = kernel_flops(cfg, B, N, T), kernel_bytes(cfg, B, N, T, runner.seeded)
+    classes = {}
+    tot_ms = sum(ms for _, ms in prof.values()) or 1.0
+    for name, (n, ms) in prof.items():
+        if n == 0:
+            continue
+        avg = ms / n
+        ent = {"launches_per_step": n / profile_steps, "avg_ms": avg, "share": ms / tot_ms}
+        if name in kf:
+            ent["tflops"] = kf[name] / (avg * 1e-3) / 1e12
+            ent["peak_tflops"] = class_peak(cfg, name)
+            ent["frac_mfma"] = ent["tflops"] / ent["peak_tflops"]
+        if name in kb:
+            ent["gbs"] = kb[name] / (avg * 1e-3) / 1e9
+            ent["frac_hbm"] = ent["gbs"] / PEAK_HBM_GBS
+        classes[name] = ent
+    dom = max(classes, key=lambda k: classes[k]["share"])
+    e = classes[dom]
+    traffic, source = pmc_traffic(dom, B, N, T, cfg)
+    if "tflops" in e:
+        roof = {"bound": "mfma", "kernel": dom, "achieved": e["tflops"], "peak": e["peak_tflops"],
+                "unit": "TFLOP/s", "frac": e["frac_mfma"], "traffic": traffic, "traffic_source": source,
+                "avg_launch_ms": e["avg_ms"], "flops_per_launch": kf[dom]}
+    else:
+        roof = {"bound": "hbm", "kernel": dom, "achieved": e["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": e["frac_hbm"], "traffic": traffic, "traffic_source": source, "avg_launch_ms": e["avg_ms"],
+                "bytes_per_launch": kb[dom]}
+    return roof, classes
+
+
+def parity_check(model, cfg, B, N, T, dev):
+    """One GPU forward at the TIMED batch size (so on the timed kernels) whose utterance 0 is the oracle's input, against
+    the fp32 oracle on the host cores.  Tolerance: SURVEY.md 8c (bf16 operands / fp32 accumulate: rel-L2 <= 2e-2; the
+    fp8 linear path of C5: 6e-2)."""
+    from ditto_tts_amd.synth import synthetic_inputs, synthetic_state_dict
+    from oracle import ditto_oracle as O
+    torch.set_num_threads(usable_cores())
+    x0, text0, t0 = synthetic_inputs(cfg, 1, N, T, seed=7)
+    with torch.no_grad():
+        want = O.ditto_forward(synthetic_state_dict(cfg, seed=1234), cfg.num_layers, cfg.num_heads, x0, text0, t0)
+        if B > 1:
+            x1, text1, t1 = synthetic_inputs(cfg, B - 1, N, T, seed=8)
+            x, text, t = torch.cat([x0, x1]), torch.cat([text0, text1]), torch.cat([t0, t1])
+        else:
+            x, text, t = x0, text0, t0
+        got = model(x.to(dev), text.to(dev), t.to(dev))[:1].float().cpu()
+    dlt = (got.double() - want.double())
+    rel = float(torch.linalg.norm(dlt) / torch.linalg.norm(want.double()))
+    tol = 6e-2 if cfg.fp8_linear else 2e-2
+    return {"rel_l2": rel, "max_abs": float(dlt.abs().max()), "tol": tol, "ok": bool(rel <= tol and torch.isfinite(got).all()),
+            "ref_std": float(want.std()),
+            "what": f"utterance 0 of one GPU forward at B={B} (the timed kernels) vs the fp32 CPU oracle on "
+                    f"synthetic_inputs(cfg, 1, N={N}, T={T}, seed=7), weights synthetic_state_dict(seed=1234)"}
+
+
+def side_config(name, dev, steps, profile_steps, state_cache):
+    """A short timed loop of another BASELINE configuration in this same process (N = 1 runs): ms/step from HIP events on
+    the compute stream over `steps` steps after 3 warm-up steps (the text work of a new utterance batch is in step 0 of
+    the loop, as in the headline), the step's executed TFLOP/s, and the dominant kernel's roofline."""
+    from ditto_tts_amd.config import PRESETS
+    from ditto_tts_amd.modules import DiTTO
+    from ditto_tts_amd.sampler import SpeechGenerator
+    from ditto_tts_amd.synth import synthetic_state_dict
+    p = PRESETS[name]
+    cfg, N, T, B = p["cfg"], p["N"], p["T"], p["B"]
+    S = cfg.diffusion_steps
+    key = (cfg.hidden_dim, cfg.num_layers, cfg.num_heads)
+    if key not in state_cache:
+        state_cache[key] = synthetic_state_dict(cfg, seed=1234)
+    model = DiTTO(cfg.hidden_dim, cfg.num_layers, cfg.num_heads, cfg.time_dim, cfg.text_dim, S, fp8_linear=cfg.fp8_linear)
+    model.load_state_dict(state_cache[key])
+    model = model.to(dev).eval()
+    sg = SpeechGenerator(ditto_model=model, device=dev, diffusion_steps=S)
+    eng = model.engine(dev)
+    with torch.no_grad():
+        r = StepRunner(eng, sg, cfg, B, N, T, dev, 3000, False, True)
+        r.run(0, 3)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r.run(0, steps)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / steps
+        roof, classes = profile_classes(eng, r, cfg, B, N, T, profile_steps)
+    one_off = cfg.flops_text_kv(T) * ((steps + S - 1) // S) / steps
+    fl = B * (cfg.flops_per_utt_step(N, T, cached_kv=True) + one_off)
+    out = {"config": name, "workload": f"{cfg.num_layers}L d={cfg.hidden_dim} h={cfg.num_heads} N={N} T={T} B={B}",
+           "dtype": "fp8(e4m3) linear + bf16 attention" if cfg.fp8_linear else "bf16", "steps": steps,
+           "ms_per_step": ms, "value": B / (ms * 1e-3), "unit": "utterance-steps/s",
+           "step_tflops": fl / (ms * 1e-3) / 1e12,
+           "step_frac_of_mfma_peak": step_min_seconds(cfg, B, N, T, one_off) / (ms * 1e-3),
+           "roofline": roof,
+           "kernel_classes": {k: {kk: v[kk] for kk in ("avg_ms", "share", "frac_mfma", "frac_hbm") if kk in v}
+                              for k, v in classes.items()}}
+    del r, eng, sg, model
+    torch.cuda.empty_cache()
+    return out
+
+
+def train_step_line(dev, state_cache, steps=3):
+    """forward + backward + AdamW of DiTTO-S (C2 shape, B = 32 utterances, N = T = 1024) through the reference's training
+    closure shape (src/TrainDiTTO.py:85-91: model.train(), MSE against the noise, loss.backward(), optimizer step);
+    medians over `steps` steps after 1 warm-up, wall clock around synchronised phases."""
+    import torch.nn.functional as F
+    from ditto_tts_amd.config import PRESETS
+    from ditto_tts_amd.modules import DiTTO
+    p = PRESETS["C2"]
+    cfg, N, T, B = p["cfg"], p["N"], p["T"], p["B"]
+    key = (cfg.hidden_dim, cfg.num_layers, cfg.num_heads)
+    m = DiTTO(cfg.hidden_dim, cfg.num_layers, cfg.num_heads, cfg.time_dim, cfg.text_dim, cfg.diffusion_steps)
+    m.load_state_dict(state_cache[key])
+    m = m.to(dev).train()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, fused=True)
+    g = torch.Generator(device=dev).manual_seed(1)
+    d = cfg.hidden_dim
+    x = torch.randn(B, N, d, device=dev, generator=g)
+    text = torch.randn(B, T, d, device=dev, generator=g)
+    noise = torch.randn(B, N, d, device=dev, generator=g)
+    t = torch.randint(0, cfg.diffusion_steps, (B,), device=dev, generator=g)
+    times = {"fwd": [], "bwd": [], "opt": []}
+    loss = None
+    for i in range(steps + 1):
+        torch.cuda.synchronize(dev); t0 = time.perf_counter()
+        loss = F.mse_loss(m(x, text, t), noise)
+        torch.cuda.synchronize(dev); t1 = time.perf_counter()
+        opt.zero_grad(); loss.backward()
+        torch.cuda.synchronize(dev); t2 = time.perf_counter()
+        opt.step()
+        torch.cuda.synchronize(dev); t3 = time.perf_counter()
+        if i:
+            times["fwd"].append(t1 - t0); times["bwd"].append(t2 - t1); times["opt"].append(t3 - t2)
+    med = {k: sorted(v)[len(v) // 2] * 1e3 for k, v in times.items()}
+    tot = sum(med.values())
+    fl = 3 * cfg.flops_per_utt_step(N, T, cached_kv=False) * B
+    out = {"config": "C2 training step", "workload": f"12L d=768 h=12 N={N} T={T} B={B}: forward (tape) + backward + fused AdamW",
+           "dtype": "bf16 operands, fp32 accumulate / gradients / master weights", "steps": steps,
+           "fwd_ms": med["fwd"], "bwd_ms": med["bwd"], "optimizer_ms": med["opt"], "ms_per_step": tot,
+           "value": B / tot * 1e3, "unit": "utterances/s", "tflops_3x_forward": fl / (tot * 1e-3) / 1e12,
+           "frac_of_mfma_peak": fl / (tot * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "loss_finite": bool(torch.isfinite(loss).item()),
+           "peak_mem_gib": torch.cuda.max_memory_allocated(dev) / 2**30}
+    del m, opt, x, text, noise, loss
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
     env_world = os.environ.get("WORLD_SIZE")
@@ -315,6 +486,7 @@ def main():
 
     use_graph = args.graph == "on" or (args.graph == "auto" and B * N <= 8192)
     main_run = StepRunner(eng, sg, cfg, B, N, T, dev, 1000 + rank, use_graph, args.noise == "seeded")
+    seeded_noise = main_run.seeded
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -350,37 +522,11 @@ def main():
         # ---- roofline pass (rank 0): per-kernel-class HIP-event timing of the same steps, eager ----
         roof, classes = None, {}
         if rank == 0 and args.profile_steps > 0:
-            eng.profile_enable(True)
-            for i in range(args.profile_steps):
-                main_run.step(1 + i, eager=True)     # k != 0: pure denoise steps, eager so events bracket launches
-            torch.cuda.synchronize(dev)
-            prof = eng.profile_read()
-            eng.profile_enable(False)
-            kf, kb = kernel_flops(cfg, B, N, T), kernel_bytes(cfg, B, N, T)
-            tot_ms = sum(ms for _, ms in prof.values()) or 1.0
-            for name, (n, ms) in prof.items():
-                if n == 0:
-                    continue
-                avg = ms / n
-                ent = {"launches_per_step": n / args.profile_steps, "avg_ms": avg, "share": ms / tot_ms}
-                if name in kf:
-                    ent["tflops"] = kf[name] / (avg * 1e-3) / 1e12
-                    ent["peak_tflops"] = class_peak(cfg, name)
-                    ent["frac_mfma"] = ent["tflops"] / ent["peak_tflops"]
-                if name in kb:
-                    ent["gbs"] = kb[name] / (avg * 1e-3) / 1e9
-                    ent["frac_hbm"] = ent["gbs"] / PEAK_HBM_GBS
-                classes[name] = ent
-            dom = max(classes, key=lambda k: classes[k]["share"])
-            e = classes[dom]
-            if "tflops" in e:
-                roof = {"bound": "mfma", "kernel": dom, "achieved": e["tflops"], "peak": e["peak_tflops"],
-                        "unit": "TFLOP/s", "frac": e["frac_mfma"], "traffic": pmc_traffic(dom, B, N, T, cfg),
-                        "avg_launch_ms": e["avg_ms"], "flops_per_launch": kf[dom]}
-            else:
-                roof = {"bound": "hbm", "kernel": dom, "achieved": e["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": e["frac_hbm"], "traffic": pmc_traffic(dom, B, N, T, cfg), "avg_launch_ms": e["avg_ms"],
-                        "bytes_per_launch": kb[dom]}
+            roof, classes = profile_classes(eng, main_run, cfg, B, N, T, args.profile_steps)
+        # ---- in-run parity of the timed shape against the oracle (rank 0; every world size) ----
+        parity = None
+        if rank == 0 and not args.no_parity:
+            parity = parity_check(model, cfg, B, N, T, dev)
         dist.barrier()
 
         # ---- B sweep (N = 1 runs): the same step at B in {1, 8, 32} per GPU ----
@@ -450,11 +596,22 @@ def main():
                 digest = int(lat.view(torch.int32).to(torch.int64).sum().item() & 0x7FFFFFFFFFFFFFFF)
             c3 = {"global_batch": G, "micro_batch": mb, "steps": S, "scaling": "strong", "n_gpus": world,
                   "value": G * S / total, "unit": "utterance-steps/s", "total_s": total, **ph,
-                  "comm_bytes_per_peer": (G // world) * (T * cfg.text_dim + 2 * N * cfg.hidden_dim) * 4 if world > 1 else 0,
+                  "comm_bytes_per_peer": (G // world) * (T * cfg.text_dim * 2 + 2 * N * cfg.hidden_dim * 4) if world > 1 else 0,
                   "latents_finite_and_complete": ok, "latents_digest": digest,
-                  "note": "scatter (text fp32 + x_T fp32, grouped RCCL send/recv) and gather (latents fp32) are inside "
+                  "note": "scatter (text bf16 + x_T fp32, grouped RCCL send/recv) and gather (latents fp32) are inside "
                           "total_s; phase figures are the max over ranks"}
             del text_full, xT_full, lat
+
+    # ---- the other configurations and the training step, witnessed by this same run (N = 1, default config) ----
+    other = None
+    if world == 1 and args.config == "C2" and not args.no_other_configs:
+        del main_run
+        torch.cuda.empty_cache()
+        cache = {(cfg.hidden_dim, cfg.num_layers, cfg.num_heads): model.state_dict()}
+        other = []
+        for name in ("C4", "C5", "C5_bf16"):
+            other.append(side_config(name, dev, args.side_steps, min(args.profile_steps, 3) or 1, cache))
+        other.append(train_step_line(dev, cache))
 
     ms_per_step = elapsed / args.steps * 1e3
     value = B * world * args.steps / elapsed
@@ -478,7 +635,7 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "latent_len": N, "text_len": T,
                        "parallelism": f"batch-parallel x{world}, weights replicated, no data-path collective",
                        "hip_graph": bool(use_graph),
-                       "noise": "per-utterance Philox4x32-10 inside the update kernel" if main_run.seeded else "torch generator -> noise tensor"},
+                       "noise": "per-utterance Philox4x32-10 inside the update kernel" if seeded_noise else "torch generator -> noise tensor"},
             "step_tflops_per_gpu": step_tflops, "step_frac_of_mfma_peak": step_frac,
             "loops": {"n": len(loop_ms), "timer": "HIP events on the compute stream, max over ranks",
                       "ms_per_step": loop_ms,
@@ -487,6 +644,8 @@ def main():
             "sweep": sweep or None,
             "c3_strong": c3,
             "roofline": roof,
+            "parity": parity,
+            "other_configs": other,
             "kernel_classes": classes,
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -494,6 +653,9 @@ def main():
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     dist.barrier()
     dist.destroy_process_group()
+    if rank == 0 and parity is not None and not parity["ok"]:
+        raise SystemExit(f"bench.py: parity of the timed shape against the oracle FAILED: rel-L2 {parity['rel_l2']:.3e} > "
+                         f"{parity['tol']:.0e}")
 
 
 if __name__ == "__main__":

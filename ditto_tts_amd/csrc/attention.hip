@@ -988,29 +988,17 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
             const bool v3_shape = a.Skv % (2 * KBLK) == 0;
             const bool v3_pays = (int)gridv.x <= 320 || a.Skv >= 2048;
             if (v3_shape && !(g_attn_flags & 256) && (v3_pays || (g_attn_flags & 512))) {
-                static bool attr_set = false;
-                if (!attr_set) {
-                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn64v3_kernel<true>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
-                    if (e == hipSuccess)
-                        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn64v3_kernel<false>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
-                    if (e != hipSuccess) return e;
-                    attr_set = true;
-                }
+                static DevOnce lds_once;
+                if (hipError_t e = set_max_lds_once(lds_once, {reinterpret_cast<const void*>(&attn64v3_kernel<true>),
+                                                               reinterpret_cast<const void*>(&attn64v3_kernel<false>)}, V3_LDS))
+                    return e;
                 // 256 queries per workgroup (8 waves share the K/V tiles) where the key sequence is long: Sq = Skv = 4096, B = 8:
                 // 427.6 against 441.2 us; at 1024 keys it ties (140.6 / 141.3).  attn_flags 1024 forces it, 2048 forbids it.
                 if (((g_attn_flags & 1024) || (a.Skv >= 2048 && a.Sq >= 256)) && !(g_attn_flags & 2048)) {
-                    static bool attr8 = false;
-                    if (!attr8) {
-                        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn64v3_kernel<true, 8>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
-                        if (e == hipSuccess)
-                            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn64v3_kernel<false, 8>),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS);
-                        if (e != hipSuccess) return e;
-                        attr8 = true;
-                    }
+                    static DevOnce lds_once8;
+                    if (hipError_t e = set_max_lds_once(lds_once8, {reinterpret_cast<const void*>(&attn64v3_kernel<true, 8>),
+                                                                    reinterpret_cast<const void*>(&attn64v3_kernel<false, 8>)}, V3_LDS))
+                        return e;
                     p.nqb = (a.Sq + 255) / 256;
                     const dim3 grid8(p.nqb * a.H * a.B);
                     if (a.resid_f32) hipLaunchKernelGGL((attn64v3_kernel<true, 8>), grid8, dim3(512), V3_LDS, s, p);

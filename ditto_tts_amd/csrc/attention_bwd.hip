@@ -314,13 +314,8 @@ hipError_t launch_attention_bwd64(const AttnBwdArgs& a, const float* lse, const 
     p.keep_scale = p.drop_thr ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
     p.seed_lo = (unsigned)(a.seed & 0xFFFFFFFFu); p.seed_hi = (unsigned)(a.seed >> 32); p.layer = a.layer;
     constexpr int LDS0 = 2 * 3 * IMG, LDS1 = 2 * (4 * IMG + 512);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn64_bwd_kernel<1>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS1);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static DevOnce lds_once;
+    if (hipError_t e = set_max_lds_once(lds_once, {reinterpret_cast<const void*>(&attn64_bwd_kernel<1>)}, LDS1)) return e;
     p.nblk = (a.Sq + BLK - 1) / BLK;
     hipLaunchKernelGGL((attn64_bwd_kernel<0>), dim3(p.nblk * a.H * a.B), dim3(256), LDS0, s, p);
     p.nblk = (a.Skv + BLK - 1) / BLK;

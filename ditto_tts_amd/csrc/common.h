@@ -3,7 +3,28 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <initializer_list>
+
 namespace ditto {
+
+// Raise the dynamic-LDS limit of kernels ONCE PER DEVICE.  hipFuncAttributeMaxDynamicSharedMemorySize is a property of the
+// (function, device) pair: a process that runs the model on a second GPU must set it there too, or the first launch of a
+// kernel that asks for more than 64 KiB fails on that device.  One DevOnce per call site; bit d = done on device d.  Two
+// threads racing on the first call both set the (same) value: benign.  Devices >= 64 set it on every call.
+struct DevOnce { std::atomic<unsigned long long> done{0}; };
+inline hipError_t set_max_lds_once(DevOnce& once, std::initializer_list<const void*> kernels, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && ((once.done.load(std::memory_order_acquire) >> dev) & 1ull)) return hipSuccess;
+    for (const void* k : kernels) {
+        e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+    }
+    if (dev >= 0 && dev < 64) once.done.fetch_or(1ull << dev, std::memory_order_release);
+    return hipSuccess;
+}
 
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;

@@ -191,8 +191,9 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
     const LayerPack& lp = m->layers[l];
     // full-row GEMM with the residual add and the FOLLOWING LayerNorm fused (gemm_fr.hip): bit 0 = cross out-proj + norm3,
     // bit 1 = fc2 + the next block's norm1 (ln1_done tells that block its norm1 output is already in u)
-    const bool fr_ok = !fp8 && lp.WcoP && fr_pays(M) && gemm_fr_supports(M, d, d, (size_t)d, (size_t)d);
-    const bool fr_out = fr_ok && (g_fr_mask & 1), fr_fc2 = fr_ok && (g_fr_mask & 2);
+    const bool fr_have = !fp8 && lp.WcoP;
+    const bool fr_out = fr_have && (g_fr_mask & 1) && fr_outproj_ok(M, d);
+    const bool fr_fc2 = fr_have && (g_fr_mask & 2) && fr_fc2_ok(M, d);
     const int fr_rot = N % 128 == 0 ? N / 128 : 0;   // tiles per utterance: the K-loop rotation period (gemm_fr.hip)
         // ---- self-attention (src/components/DiT.py:103-139) ----
         if (!ln1_done) {
@@ -511,8 +512,7 @@ int ditto_forward(ditto_model_t m, const float* x, const void* cond, const int64
         HIP_TRY(launch_adaln(x, m->ttab, tmod, t, c.diffusion_steps, h, xcat, 2 * d, B, N, d, s));
     }
     // fc2 on the full-row kernel also emits the NEXT block's norm1 (fr_mask bit 1): that block then skips its LayerNorm
-    const bool chain_ln1 = (g_fr_mask & 2) && !(c.flags & DITTO_CFG_FP8_LINEAR) && m->layers[0].WcoP && fr_pays(M) &&
-                           gemm_fr_supports(M, d, d, (size_t)d, (size_t)d);
+    const bool chain_ln1 = (g_fr_mask & 2) && !(c.flags & DITTO_CFG_FP8_LINEAR) && m->layers[0].WcoP && fr_fc2_ok(M, d);
     for (int l = 0; l < L; ++l)
         if (int rc = run_block(m, l, h, u, qkv, act, l == L - 1 ? xcat : nullptr, attn_ws, w.attn_bytes,
                                (float*)(ws + w.splitk), w.splitk_bytes, kv, l,
@@ -877,6 +877,11 @@ int ditto_set_option(const char* name, int value) {
         g_fr_mask = value;
         return DITTO_OK;
     }
+    if (!strcmp(name, "fr_class_rows")) {
+        if (value < 0) return fail(DITTO_ERR_ARG, "fr_class_rows must be >= 0 (0 = every launch decides on its own rows)");
+        g_fr_class_rows = value;
+        return DITTO_OK;
+    }
     if (!strcmp(name, "fr_dgrad")) {
         if (value < 0 || value > 3) return fail(DITTO_ERR_ARG, "fr_dgrad must be in [0, 3]");
         g_fr_dgrad = value;
@@ -903,6 +908,17 @@ int ditto_set_option(const char* name, int value) {
         return DITTO_OK;
     }
     return fail(DITTO_ERR_ARG, "unknown option '%s'", name);
+}
+
+int ditto_full_row_plan(const ditto_config* cfg, int B, int N, int* outproj, int* fc2) {
+    if (int rc = check_cfg(cfg)) return rc;
+    if (!outproj || !fc2 || B <= 0 || N <= 0) return fail(DITTO_ERR_ARG, "bad argument to ditto_full_row_plan");
+    if ((long long)B * N > 0x7fffffffLL) return fail(DITTO_ERR_SHAPE, "B * N exceeds 2^31 - 1 rows");
+    const int d = cfg->hidden_dim, M = B * N;
+    const bool have = d == 768 && !(cfg->flags & DITTO_CFG_FP8_LINEAR);   // plan_arena packs the stage-major copies for these
+    *outproj = have && (g_fr_mask & 1) && fr_outproj_ok(M, d);
+    *fc2 = have && (g_fr_mask & 2) && fr_fc2_ok(M, d);
+    return DITTO_OK;
 }
 
 int ditto_profile_enable(ditto_model_t m, int enable) {

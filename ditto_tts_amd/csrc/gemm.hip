@@ -40,6 +40,7 @@ int g_pp_nb = 0;
 int g_fr_mask = [] { const char* e = getenv("DITTO_FR_MASK"); return e ? atoi(e) : 3; }();
 int g_fr_dgrad = [] { const char* e = getenv("DITTO_FR_DGRAD"); return e ? atoi(e) : 3; }();
 int g_fr_rot = [] { const char* e = getenv("DITTO_FR_ROT"); return e ? atoi(e) : 1; }();
+int g_fr_class_rows = 0;   // kernels.h fr_pays: rows of the unsplit batch whose kernel class every launch takes (0 = its own)
 int g_pp_mask = [] { const char* e = getenv("DITTO_PP_MASK"); return e ? atoi(e) : -1; }();   // -1 = built-in rule
 int g_gemm_tile = [] { const char* e = getenv("DITTO_GEMM"); return e ? atoi(e) : 0; }();
 
@@ -253,13 +254,8 @@ __global__ __launch_bounds__(256, 1) void gemm128_deep_kernel(GemmParams p) {
 
 template <int EPI>
 hipError_t launch_deep_t(const GemmParams& p, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm128_deep_kernel<EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, DEEP_LDS);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static DevOnce lds_once;
+    if (hipError_t e = set_max_lds_once(lds_once, {reinterpret_cast<const void*>(&gemm128_deep_kernel<EPI>)}, DEEP_LDS)) return e;
     hipLaunchKernelGGL((gemm128_deep_kernel<EPI>),
                        dim3(p.tiles_m * p.tiles_n * (p.k_splits > 1 ? p.k_splits : 1), g_batch_y),
                        dim3(256), DEEP_LDS, s, p);
@@ -268,13 +264,8 @@ hipError_t launch_deep_t(const GemmParams& p, hipStream_t s) {
 
 template <int EPI>
 hipError_t launch_t(const GemmParams& p, hipStream_t s) {
-    static bool attr_set = false;  // idempotent; races are benign (same value)
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm128_kernel<EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static DevOnce lds_once;
+    if (hipError_t e = set_max_lds_once(lds_once, {reinterpret_cast<const void*>(&gemm128_kernel<EPI>)}, GEMM_LDS)) return e;
     hipLaunchKernelGGL((gemm128_kernel<EPI>), dim3(p.tiles_m * p.tiles_n * (p.k_splits > 1 ? p.k_splits : 1), g_batch_y),
                        dim3(256), GEMM_LDS, s, p);
     return hipGetLastError();

@@ -247,13 +247,8 @@ __global__ __launch_bounds__(512, 2) void gemm192_kernel(GemmParams p) {
 
 template <int EPI>
 hipError_t launch192_t(const GemmParams& p, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm192_kernel<EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS192);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static DevOnce lds_once;
+    if (hipError_t e = set_max_lds_once(lds_once, {reinterpret_cast<const void*>(&gemm192_kernel<EPI>)}, LDS192)) return e;
     hipLaunchKernelGGL((gemm192_kernel<EPI>), dim3(p.tile_stride), dim3(512), LDS192, s, p);
     return hipGetLastError();
 }

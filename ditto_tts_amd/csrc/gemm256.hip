@@ -445,13 +445,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 
 template <int EPI, bool WIDE, bool FP8>
 hipError_t launch256_tw(const GemmParams& p, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<EPI, WIDE, FP8>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_ALLOC);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static DevOnce lds_once;
+    if (hipError_t e = set_max_lds_once(lds_once, {reinterpret_cast<const void*>(&gemm256_kernel<EPI, WIDE, FP8>)}, LDS256_ALLOC)) return e;
     hipLaunchKernelGGL((gemm256_kernel<EPI, WIDE, FP8>), dim3(p.tile_stride), dim3(512), LDS256_ALLOC, s, p);
     return hipGetLastError();
 }

@@ -361,6 +361,11 @@ hipError_t launch_gemm_o3(const GemmParams& p, GemmEpilogue epi, hipStream_t s);
 bool gemm_fr_supports(int M, int N, int K, size_t lda, size_t ldw);
 hipError_t launch_gemm_fr(const GemmParams& p, const float* gamma, const float* beta, void* u_bf16, int ldu, int rot_period,
                           hipStream_t s);
+// The two full-row launches of a DiT block over M rows of width d, each judged on the operand strides IT runs with (the
+// kernel builds 32-bit byte offsets from M * lda: fc2 reads A at lda = 4d).  One predicate for the inference forward, the
+// LayerNorm chaining decision and the training forward, so that the three cannot disagree.
+inline bool fr_outproj_ok(int M, int d) { return fr_pays(M) && gemm_fr_supports(M, d, d, (size_t)d, (size_t)d); }
+inline bool fr_fc2_ok(int M, int d) { return fr_pays(M) && gemm_fr_supports(M, d, 4 * d, (size_t)4 * d, (size_t)4 * d); }
 // gemm_pp.hip
 bool gemm_pp_supports(const GemmParams& p, GemmEpilogue epi);
 hipError_t launch_gemm_pp(const GemmParams& p, GemmEpilogue epi, hipStream_t s);

@@ -564,13 +564,8 @@ __global__ __launch_bounds__(256, 1) void gemm_fr_kernel(FrParams fp) {
 
 template <bool LN, bool RES>
 hipError_t launch_fr_t(const FrParams& fp, int grid, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fr_kernel<LN, RES>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static DevOnce lds_once;
+    if (hipError_t e = set_max_lds_once(lds_once, {reinterpret_cast<const void*>(&gemm_fr_kernel<LN, RES>)}, F_LDS)) return e;
     hipLaunchKernelGGL((gemm_fr_kernel<LN, RES>), dim3(grid), dim3(256), F_LDS, s, fp);
     return hipGetLastError();
 }

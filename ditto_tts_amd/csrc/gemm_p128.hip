@@ -201,13 +201,8 @@ __global__ __launch_bounds__(512, 2) void gemm_p128_kernel(GemmParams p) {
 
 template <int EPI>
 hipError_t launch_p128_t(const GemmParams& p, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p128_kernel<EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_P128);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static DevOnce lds_once;
+    if (hipError_t e = set_max_lds_once(lds_once, {reinterpret_cast<const void*>(&gemm_p128_kernel<EPI>)}, LDS_P128)) return e;
     hipLaunchKernelGGL((gemm_p128_kernel<EPI>), dim3(p.tile_stride), dim3(512), LDS_P128, s, p);
     return hipGetLastError();
 }

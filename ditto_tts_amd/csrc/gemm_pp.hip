@@ -269,13 +269,8 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(GemmParams p) {
 
 template <int EPI, int NB>
 hipError_t launch_pp_t(const GemmParams& p, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<EPI, NB>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, PP<NB>::LDS);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static DevOnce lds_once;
+    if (hipError_t e = set_max_lds_once(lds_once, {reinterpret_cast<const void*>(&gemm_pp_kernel<EPI, NB>)}, PP<NB>::LDS)) return e;
     hipLaunchKernelGGL((gemm_pp_kernel<EPI, NB>), dim3(p.tile_stride), dim3(256), PP<NB>::LDS, s, p);
     return hipGetLastError();
 }

@@ -434,19 +434,10 @@ hipError_t launch_gemm_tn(const void* X, int ldx, const void* Y, int ldy, const 
                           int Mo, int No, int K, int k_splits, size_t split_stride, hipStream_t s, bool wide) {
     if (!X || !Y || !zero256 || !out || Mo < 8 || No < 8 || K <= 0 || (ldx | ldy) % 8 || (Mo | No) % 8)
         return hipErrorInvalidValue;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_ring_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_wide_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static DevOnce once_t, once_r, once_w;
+    if (hipError_t e = set_max_lds_once(once_t, {reinterpret_cast<const void*>(&gemm_tn_kernel)}, T_LDS)) return e;
+    if (hipError_t e = set_max_lds_once(once_r, {reinterpret_cast<const void*>(&gemm_tn_ring_kernel)}, R_LDS)) return e;
+    if (hipError_t e = set_max_lds_once(once_w, {reinterpret_cast<const void*>(&gemm_tn_wide_kernel)}, W_LDS)) return e;
     TnParams p;
     p.X = (const bf16*)X; p.ldx = ldx; p.Y = (const bf16*)Y; p.ldy = ldy; p.zero = (const bf16*)zero256;
     p.out = out; p.ldo = ldo; p.Mo = Mo; p.No = No; p.K = K;

@@ -56,9 +56,16 @@ hipError_t launch_repack_bf16_stage_major(const void* src_bf16, void* dst, int N
 // model (tools/step_ab.py --batch b, C2 shapes, fr_mask 3 against 0) it loses below 160 tiles (B = 1: 2.92 vs 1.84 ms per
 // step, B = 8: 4.73 vs 4.02, B = 16: 7.00 vs 6.65) and wins from there on (B = 20: 8.37 vs 8.43, B = 24: 9.49 vs 10.17,
 // B = 32: 12.1 vs 13.0).  Like the choice of GEMM tile structure this rule depends on the number of rows in the launch: an
-// utterance's bits are independent of its batch neighbours WITHIN a class of batch sizes (equal shards of a sharded
-// batch are in the same class), not across (fr_mask 0 gives one class).
-inline bool fr_pays(int M) { return (M + 127) / 128 >= 160; }
+// utterance's bits are independent of its batch neighbours WITHIN a class of batch sizes, not across (the full-row kernel
+// sums over k in a rotated order and in 32x32x16 steps).  A caller that splits one batch over launches or GPUs pins the
+// class of the WHOLE batch for all of them: ditto_set_option("fr_class_rows", rows of the unsplit batch) makes every
+// launch decide as that batch would (dist.sample_sharded and SpeechGenerator's seeds= path do it), so that sharding
+// changes no bit; 0 (default) = decide on the launch's own rows.  fr_mask 0 gives one class outright.
+extern int g_fr_class_rows;   // gemm.hip
+inline bool fr_pays(int M) {
+    const int rows = g_fr_class_rows > 0 ? g_fr_class_rows : M;
+    return (rows + 127) / 128 >= 160;
+}
 
 extern int g_fr_dgrad;   // gemm.hip: training backward, long-K dgrads on the full-row kernel: bit 0 fc1|gate (K = 8d), bit 1 QKV (K = 3d)
 extern int g_fr_rot;     // gemm.hip: full-row kernel's K-loop rotation: 0 off, 1 on in the model (period = tiles per utterance), > 1 = period for ditto_gemm_ln_bf16 too

@@ -280,7 +280,8 @@ DITTO_DEV void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3,
     }
     o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
 }
-// four N(0,1) of (seed, step, quad index): u = (word + 0.5) 2^-32 in (0,1); r = sqrt(-2 ln u1); angle = 2 pi u2
+// four N(0,1) of (seed, step, quad index): u = ((word >> 8) + 0.5) 2^-24 in (0,1) (the top 24 bits of a Philox word);
+// r = sqrt(-2 ln u1); angle = 2 pi u2
 DITTO_DEV f32x4 normal4(unsigned long long seed, unsigned step, unsigned long long quad) {
     unsigned w[4];
     philox4x32_10((unsigned)quad, (unsigned)(quad >> 32), step, 0x44695454u /* "DiTT" */, (unsigned)seed,
@@ -539,6 +540,7 @@ __global__ __launch_bounds__(256) void pack_bf16_stage_major_kernel(const float*
     }
 }
 hipError_t launch_pack_bf16_stage_major(const float* src, void* dst, int N, int K, hipStream_t s) {
+    if (K % 16) return hipErrorInvalidValue;   // a ragged last stage would be written past the N * K image
     const size_t n = (size_t)N * K;
     size_t g = (n + 255) / 256;
     if (g > 4096) g = 4096;

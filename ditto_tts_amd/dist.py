@@ -85,9 +85,17 @@ def gather_batch(shard: torch.Tensor, total: int, root: int = 0, group=None) -> 
 def sample_sharded(sample_fn: Callable[[torch.Tensor, torch.Tensor, int], torch.Tensor],
                    text_full: Optional[torch.Tensor], xT_full: Optional[torch.Tensor], text_tail, x_tail,
                    device, root: int = 0, group=None, phases: Optional[dict] = None,
-                   sync: Optional[Callable[[], None]] = None) -> Optional[torch.Tensor]:
+                   sync: Optional[Callable[[], None]] = None, pin_class: bool = True) -> Optional[torch.Tensor]:
     """Scatter (text_emb, x_T) from root, run `sample_fn(text_shard, xT_shard, first_global_index)` on every
     rank (the whole denoise loop — no communication inside), gather the final latents on root.
+
+    The text conditioning travels as bf16 (it is the operand of bf16 GEMMs and of an fp32 mean only, and
+    every rank — root included — computes on the bf16-rounded values, so the world size changes no bit); x_T and the
+    latents travel as fp32.
+
+    `pin_class` (GPU shards only): run `sample_fn` under `hip.batch_class(rows of the GLOBAL batch)`, so that every
+    shard's launches pick the kernel class the unsplit batch would pick (the full-row GEMM sums in another order than
+    the tiled one) and the gathered latents are bit-identical at every world size.
 
     `phases` (optional dict) receives this rank's wall seconds of the three phases, {"scatter_s", "loop_s",
     "gather_s"}; `sync` (e.g. `torch.cuda.synchronize`) is called at each phase boundary so the figures are device
@@ -96,7 +104,9 @@ def sample_sharded(sample_fn: Callable[[torch.Tensor, torch.Tensor, int], torch.
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     tick = (lambda: (sync() if sync else None, time.perf_counter())[1]) if phases is not None else (lambda: 0.0)
     t0 = tick()
-    text = scatter_batch(text_full, text_tail, torch.float32, device, root, group)
+    text16 = text_full.to(torch.bfloat16) if rank == root else None
+    text = scatter_batch(text16, text_tail, torch.bfloat16, device, root, group).to(torch.float32)
+    del text16
     xT = scatter_batch(xT_full, x_tail, torch.float32, device, root, group)
     meta = torch.zeros(1, dtype=torch.int64, device=device)
     if rank == root:
@@ -105,7 +115,14 @@ def sample_sharded(sample_fn: Callable[[torch.Tensor, torch.Tensor, int], torch.
     total = int(meta.item())
     lo, _ = shard_bounds(total, world, rank)
     t1 = tick()
-    out = sample_fn(text, xT, lo) if text.shape[0] > 0 else xT
+    if text.shape[0] == 0:
+        out = xT
+    elif pin_class and xT.is_cuda:
+        from .hip import batch_class
+        with batch_class(total * int(x_tail[0])):
+            out = sample_fn(text, xT, lo)
+    else:
+        out = sample_fn(text, xT, lo)
     t2 = tick()
     full = gather_batch(out, total, root, group)
     t3 = tick()

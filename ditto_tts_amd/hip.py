@@ -161,6 +161,7 @@ SYMBOLS = {
     "ditto_attention_causal_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
     "ditto_layernorm_dual": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "ditto_set_option": (_i, [C.c_char_p, _i]),
+    "ditto_full_row_plan": (_i, [C.POINTER(Config), _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ditto_profile_enable": (_i, [_vp, _i]),
     "ditto_profile_read": (_i, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     "ditto_kernel_class_name": (C.c_char_p, [_i]),
@@ -185,7 +186,7 @@ def lib() -> C.CDLL:
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = res, args
-        if l.ditto_abi_version() != 6:
+        if l.ditto_abi_version() != 7:
             raise RuntimeError("libditto_hip.so ABI version mismatch")
         _lib = l
     return _lib
@@ -199,6 +200,35 @@ def check(rc: int):
 def set_option(name: str, value: int):
     """ditto_set_option: process-wide tuning switches of libditto_hip.so (include/ditto_hip.h)."""
     check(lib().ditto_set_option(name.encode(), int(value)))
+
+
+class batch_class:
+    """Context manager: every forward inside decides its kernel class (tiled GEMM + LayerNorm, or the full-row GEMM
+    with the LayerNorm fused: different summation orders, so different last bits) as a batch of `rows` = B x N rows
+    would.  A caller that splits one batch over several launches or GPUs wraps the pieces in
+    `batch_class(rows of the unsplit batch)`: an utterance's bits are then the same however the batch was split
+    (ditto_set_option("fr_class_rows"); dist.sample_sharded and SpeechGenerator's seeds= path use it).  Process-wide,
+    like every ditto_set_option switch; restores "decide per launch" (0) on exit."""
+
+    def __init__(self, rows: int):
+        self.rows = int(rows)
+
+    def __enter__(self):
+        set_option("fr_class_rows", min(self.rows, 0x7FFFFFFF))
+        return self
+
+    def __exit__(self, *exc):
+        set_option("fr_class_rows", 0)
+        return False
+
+
+def full_row_plan(cfg, B: int, N: int):
+    """(outproj, fc2): which of a block's two fused GEMM + LayerNorm launches a forward over B x N rows takes
+    (ditto_full_row_plan; host arithmetic, no GPU call)."""
+    a, b = C.c_int(0), C.c_int(0)
+    c = make_config(cfg)
+    check(lib().ditto_full_row_plan(C.byref(c), B, N, C.byref(a), C.byref(b)))
+    return bool(a.value), bool(b.value)
 
 
 def set_low_latency(on: bool = True):

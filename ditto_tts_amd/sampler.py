@@ -114,16 +114,21 @@ class SpeechGenerator:
 
     @torch.no_grad()
     def __sample_latents(self, text_emb, audio_emb, text_prompt=None, audio=None, is_slp=False, cond_by_audio=False,
-                         noises=None, keep=None, use_graph=None, seeds=None):
+                         noises=None, keep=None, use_graph=None, seeds=None, batch_class=None):
         """All reverse diffusion steps (reference :149-164).
 
         `noises` (optional): a sequence / callable giving the z of executed step i, for parity tests;
         `keep` (optional): dict filled with {i: state after step i} for the i it already has as keys;
         `seeds` (optional, int64 [B]): per-utterance seeds.  x_T and every step's z then come from the library's
         counter-based generator (Philox4x32-10 keyed by the utterance's seed, engine.noise_normal_), generated inside
-        the update kernel: an utterance's trajectory is a function of (seed, text, weights) only — the same bits
-        whatever batch or GPU it is sampled on (dist.sample_sharded).  Default None = the reference's behaviour,
-        torch.randn_like from the global generator;
+        the update kernel: an utterance's trajectory is a function of (seed, text, weights) and of the KERNEL CLASS its
+        launches take (batches of >= 160 row tiles run two GEMM + LayerNorm pairs per block on the full-row kernel,
+        which sums over k in another order).  Default None = the reference's behaviour, torch.randn_like from the global
+        generator;
+        `batch_class` (optional int): the number of utterances of the UNSPLIT batch this call is a piece of.  The loop
+        then runs under hip.batch_class(batch_class * N), every launch picks the class that batch would pick, and an
+        utterance's latents are the same bits whatever piece or GPU it is sampled on (dist.sample_sharded pins the
+        class itself: do not pass it there);
         `use_graph`: replay the step from a HIP graph (default off: measured no gain even at B = 1, the step is
         bound by per-kernel latency, not by its 122 launches; bit-identical to eager either way)."""
         if is_slp:
@@ -148,8 +153,15 @@ class SpeechGenerator:
         t_tensor = torch.empty(B, device=x.device, dtype=torch.long)
         use_graph = bool(use_graph)
         z = torch.empty_like(x)
-        graph = None
         n_loop = self._loop_steps()
+        if batch_class is not None:                 # capture and loop both under the unsplit batch's kernel class
+            from .hip import batch_class as _pin
+            with _pin(int(batch_class) * x.shape[1]):
+                return self.__loop(x, cond, t_tensor, z, use_graph, n_loop, seeds, noises, keep, eng)
+        return self.__loop(x, cond, t_tensor, z, use_graph, n_loop, seeds, noises, keep, eng)
+
+    def __loop(self, x, cond, t_tensor, z, use_graph, n_loop, seeds, noises, keep, eng):
+        graph = None
         if use_graph:
             t_tensor.fill_(n_loop - 1)
             keep_x = x.clone()                      # capture runs one warm-up step on x: restore it afterwards

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DITTO_ABI_VERSION 6
+#define DITTO_ABI_VERSION 7
 
 typedef enum ditto_status {
     DITTO_OK = 0,
@@ -251,6 +251,10 @@ int ditto_gemm_tn_bf16(const void* X, int ldx, const void* Y, int ldy, float* ou
  * 3 fc2, 4 QKV + RoPE, 5 gated MLP; -1 = the built-in rule).
  * "fr_mask": N = d = 768 projections on the full-row kernel with the residual add and the following LayerNorm fused
  * (csrc/gemm_fr.hip): bit 0 = cross out-proj + norm3, bit 1 = fc2 + the next block's norm1.
+ * "fr_class_rows": the full-row kernel sums over k in a different order than the tiled GEMMs, so an utterance's bits depend on
+ * whether its launch took it — a function of the launch's row count (>= 160 tiles of 128 rows).  A caller that splits ONE batch
+ * over several launches or GPUs sets this to the rows (B * N) of the unsplit batch: every launch then decides as that batch
+ * would and sharding changes no bit (ditto_tts_amd/dist.py sample_sharded does).  0 (default) = each launch on its own rows.
  * "fr_dgrad": training backward, the long-K dgrads (N = d = 768) on the same kernel: bit 0 = fc1|gate (K = 8d), bit 1 = QKV.
  * "fr_rot": that kernel's K-loop rotation (tiles start their k sum at different places so that the workgroups of an XCD do
  * not all ask the L2 for the same weight lines at once): 0 = off, 1 = on in the model path with period = row tiles per
@@ -266,6 +270,12 @@ int ditto_gemm_tn_bf16(const void* X, int ldx, const void* Y, int ldy, float* ou
  * are split over (K-splits with an ordered fp32 reduce; 256 is the measured choice: -10 % step time at B = 1).
  * Default 0 = never split, which keeps an utterance's result bit-identical whatever else is in its batch. */
 int ditto_set_option(const char* name, int value);
+
+/* Which launches of one DiT block (reference src/components/DiT.py:148+152, :155+:105) a forward over B utterances of N
+ * frames runs on the full-row kernel, under the current "fr_mask" / "fr_class_rows" options: *outproj, *fc2 = 0 / 1.  Host
+ * arithmetic only (no GPU call): the full-row kernel addresses its operands with 32-bit byte offsets, so each launch is
+ * admitted on the row stride IT reads with (fc2: 4 * hidden_dim). */
+int ditto_full_row_plan(const ditto_config* cfg, int B, int N, int* outproj, int* fc2);
 
 /* ---- either side of the loop -------------------------------------------------------
  * ditto_vq_argmin: VectorQuantizer.forward (src/components/VectorQuantizer.py:22-43): idx[r] = argmin_k

@@ -25,7 +25,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, n), f"{n} declared in ditto_hip.h but not exported by libditto_hip.so"
         assert n in hip.SYMBOLS, f"{n} has no ctypes prototype in ditto_tts_amd/hip.py"
     assert sorted(hip.SYMBOLS) == names
-    assert lib.ditto_abi_version() == 6
+    assert lib.ditto_abi_version() == 7
 
 
 def test_struct_layout_matches_header():
@@ -73,3 +73,36 @@ def test_config_rejects_what_the_reference_cannot_run():
         DiTTOConfig(768, 12, 12, 256, 512, 50)
     with pytest.raises(ValueError):
         DiTTOConfig(770, 12, 12, 256, 770, 50)
+
+
+def test_full_row_plan_is_judged_per_launch_and_pinnable():
+    """the full-row kernel addresses its A operand with 32-bit byte offsets, so each of a block's two fused
+    launches must be admitted on the stride IT reads with (fc2: lda = 4 d), and the class must be pinnable from the
+    unsplit batch so that shards of one batch agree (ditto_full_row_plan: host arithmetic, no GPU call)."""
+    cfg = PRESETS["C2"]["cfg"]
+    try:
+        assert hip.full_row_plan(cfg, 32, 1024) == (True, True)      # the headline shape: 256 row tiles
+        assert hip.full_row_plan(cfg, 20, 1024) == (True, True)      # 160 tiles: the threshold
+        assert hip.full_row_plan(cfg, 19, 1024) == (False, False)
+        assert hip.full_row_plan(cfg, 16, 1024) == (False, False)    # a shard of the 32 batch on its own...
+        with hip.batch_class(32 * 1024):                             # ...and pinned to the class of the unsplit batch
+            assert hip.full_row_plan(cfg, 16, 1024) == (True, True)
+            assert hip.full_row_plan(cfg, 1, 1024) == (True, True)
+            assert hip.full_row_plan(cfg, 1, 64) == (False, False)   # fewer rows than one 128-row tile: never
+        assert hip.full_row_plan(cfg, 16, 1024) == (False, False)    # the pin is gone
+        # M * lda * 2 >= 2^32 with lda = 4 d = 3072: M >= 699051 rows.  The out-projection (lda = d) still fits.
+        assert hip.full_row_plan(cfg, 682, 1024) == (True, True)     # 698368 rows
+        assert hip.full_row_plan(cfg, 683, 1024) == (True, False)    # 699392 rows: fc2's A offsets would wrap
+        assert hip.full_row_plan(cfg, 2731, 1024) == (False, False)  # M * d * 2 >= 2^32 as well
+        hip.set_option("fr_mask", 1)
+        assert hip.full_row_plan(cfg, 32, 1024) == (True, False)
+        hip.set_option("fr_mask", 2)
+        assert hip.full_row_plan(cfg, 32, 1024) == (False, True)
+        hip.set_option("fr_mask", 0)
+        assert hip.full_row_plan(cfg, 32, 1024) == (False, False)
+    finally:
+        hip.set_option("fr_mask", 3)
+        hip.set_option("fr_class_rows", 0)
+    assert hip.full_row_plan(PRESETS["C5"]["cfg"], 32, 1024) == (False, False)      # d = 1024 / fp8: no full-row weights
+    with pytest.raises(hip.DittoHipError):
+        hip.set_option("fr_class_rows", -1)

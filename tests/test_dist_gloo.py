@@ -67,7 +67,8 @@ def test_world2_equals_world1_bitwise():
     sd = synthetic_state_dict(CFG, seed=4)
     text, xT = hash_normal((B, T, 64), "text", 1), hash_normal((B, N, 64), "xT", 1)
     torch.set_num_threads(1)
-    want = _sample_fn(sd)(text, xT, 0)
+    # the conditioning travels (and is consumed, on root too) as bf16: SURVEY.md 8e, dist.sample_sharded
+    want = _sample_fn(sd)(text.to(torch.bfloat16).float(), xT, 0)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

@@ -45,7 +45,7 @@ def test_sharded_sampling_on_rccl_equals_direct(rccl_world1):
         return sg._SpeechGenerator__sample_latents(text_shard, x_shard, cond_by_audio=True,
                                                    noises=lambda i: noises[i][first:first + x_shard.shape[0]])
 
-    want = fn(text, xT, 0)
+    want = fn(text.to(torch.bfloat16).float(), xT, 0)     # the conditioning travels and is consumed as bf16
     got = sample_sharded(fn, text, xT, (T, 128), (N, 128), DEV)
     assert torch.equal(got, want)
     sh = scatter_batch(text, (T, 128), torch.float32, DEV)
@@ -101,7 +101,10 @@ def _rccl_worker(rank, world, port, q):
         assert set(phases) == {"scatter_s", "loop_s", "gather_s"}
         got2 = sample_sharded(fn_seeded, text, xT, (T, 256), (N, 256), dev)
         if rank == 0:
-            want, want2 = fn(text, xT, 0), fn_seeded(text, xT, 0)
+            t16 = text.to(torch.bfloat16).float()             # what every rank computed on (bf16 transport)
+            from ditto_tts_amd.hip import batch_class
+            with batch_class(B * N):                           # sample_sharded pins the unsplit batch's kernel class
+                want, want2 = fn(t16, xT, 0), fn_seeded(t16, xT, 0)
             q.put((bool(torch.equal(got, want)) and bool(torch.equal(got2, want2)), bool(torch.isfinite(got).all()),
                    tuple(got.shape)))
     finally:

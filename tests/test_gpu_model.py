@@ -273,6 +273,56 @@ def test_full_size_c2_large_batch_takes_the_full_row_path():
 
 
 @torch.no_grad()
+def test_headline_shape_b32_against_oracle():
+    """The shape the driver times (C2: 12L, d = 768, N = T = 1024, B = 32 per GPU, full-row path, seed-1234 weights):
+    utterance 0 is bench.py's own parity input (synthetic_inputs(cfg, 1, N, T, seed = 7)) and is compared with the fp32
+    oracle; the other 31 fill the batch.  Also: its bits are those it has in a batch of 20 (same kernel class)."""
+    from ditto_tts_amd import hip
+    from oracle import ditto_oracle as O
+    p = PRESETS["C2"]
+    cfg, N, T = p["cfg"], p["N"], p["T"]
+    m = build(cfg, 1234)
+    x0, text0, t0 = synthetic_inputs(cfg, 1, N, T, seed=7)
+    x1, text1, t1 = synthetic_inputs(cfg, 31, N, T, seed=8)
+    xd, td, tt = torch.cat([x0, x1]).to(DEV), torch.cat([text0, text1]).to(DEV), torch.cat([t0, t1]).to(DEV)
+    assert hip.full_row_plan(cfg, 32, N) == (True, True)
+    out = m(xd, td, tt)
+    assert torch.isfinite(out).all()
+    close(out[:1], O.ditto_forward(synthetic_state_dict(cfg, 1234), cfg.num_layers, cfg.num_heads, x0, text0, t0))
+    assert torch.equal(m(xd[:20].contiguous(), td[:20].contiguous(), tt[:20].contiguous())[0], out[0])
+
+
+@torch.no_grad()
+def test_shards_straddling_the_full_row_threshold_agree_when_the_class_is_pinned():
+    """ADVICE r2.  d = 768, N = 1024: a batch of 20 utterances (160 row tiles) takes the full-row kernel, its shards of 12
+    and 8 utterances on their own do not, and the two paths differ in the last bits.  dist.sample_sharded and the seeds=
+    path therefore pin every piece to the class of the UNSPLIT batch (hip.batch_class / "fr_class_rows"): pinned, the
+    shards reproduce the unsplit forward bit for bit, and so does the seeded sampling loop with batch_class=."""
+    from ditto_tts_amd import hip
+    cfg = DiTTOConfig(768, 2, 12, 256, 768, 4)
+    m = build(cfg, 6)
+    B, N, T = 20, 1024, 64
+    x, text, t = synthetic_inputs(cfg, B, N, T, seed=13)
+    xd, td, tt = x.to(DEV), text.to(DEV), t.to(DEV)
+    assert hip.full_row_plan(cfg, B, N) == (True, True) and hip.full_row_plan(cfg, 12, N) == (False, False)
+    whole = m(xd, td, tt)
+    parts = [(0, 12), (12, 20)]
+    free = torch.cat([m(xd[a:b].contiguous(), td[a:b].contiguous(), tt[a:b].contiguous()) for a, b in parts])
+    assert not torch.equal(free, whole), "the shards were expected to take the tiled path on their own"
+    assert rel_l2(free, whole) < 4e-3
+    with hip.batch_class(B * N):
+        pinned = torch.cat([m(xd[a:b].contiguous(), td[a:b].contiguous(), tt[a:b].contiguous()) for a, b in parts])
+    assert torch.equal(pinned, whole), "pinned to the unsplit batch's class, a shard must reproduce its bits"
+    assert hip.full_row_plan(cfg, 12, N) == (False, False)      # the pin ended with the block
+    sg = SpeechGenerator(ditto_model=m, device=DEV)
+    seeds = torch.arange(B, device=DEV) + 77
+    full = sg.sample_latents(td, xd, seeds=seeds)
+    got = torch.cat([sg.sample_latents(td[a:b].contiguous(), xd[a:b].contiguous(), seeds=seeds[a:b], batch_class=B)
+                     for a, b in parts])
+    assert torch.isfinite(full).all() and torch.equal(got, full)
+
+
+@torch.no_grad()
 def test_full_row_path_on_ragged_rows():
     """The fused full-row path where nothing is aligned: N = 1000 latent frames (not a multiple of the 128-row tile: tiles
     straddle utterances, no K-loop rotation, a partial last tile at M = 21 x 1000), T = 96: fused against unfused within
