@@ -18,7 +18,7 @@ LIB = os.path.join(HERE, "libditto_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # per-file extras.  attention.hip: without -fno-honor-nans hipcc canonicalises every MFMA output (v_max x,x)
 # before the row-max fmaxf chain (+32 VALU per KV tile); the softmax has no NaN semantics to preserve.
-EXTRA = {"attention.hip": ["-fno-honor-nans"]}
+EXTRA = {"attention.hip": ["-fno-honor-nans"], "attention_v4.hip": ["-fno-honor-nans"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC,
          "-Wall", "-Wno-unused-function"]
 

@@ -26,7 +26,7 @@
 //   * online softmax in the exp2 domain with fp32 running (max, sum); O^T rescale is a per-lane scalar.
 #include <type_traits>
 
-#include "gemm_common.h"
+#include "attn_common.h"
 
 namespace ditto {
 
@@ -35,45 +35,20 @@ namespace ditto {
 // (unit tests of attn64v2); bit 5 (32): run the kernels above on pre-scaled q instead of attn64v2 (A/B); bit 6 (64):
 // attn64v2 at 2 waves per SIMD with the V prefetch instead of 3 without; bit 7 (128): no deep-prefetch instantiation
 // on small grids; bit 8 (256): never attn64v3 (the software-pipelined kernel), bit 9 (512): attn64v3 wherever Skv % 128 == 0; bit 10 (1024): its 8-wave (256 queries per
-// workgroup) form always, bit 11 (2048): never.
+// workgroup) form always, bit 11 (2048): never; bit 12 (4096): attn64v4 (attention_v4.hip: one wave per SIMD, 64 queries per wave)
+// wherever Skv % 64 == 0.
 // ditto_set_option("attn_flags")
 int g_attn_flags = 3;
 
 namespace {
 
-constexpr int DH = 64, QBLK = 128, KBLK = 64;
-constexpr int KV_TILE_BYTES = KBLK * DH * 2;  // 8 KiB
-
-struct AttnParams {
-    const bf16* q; int ldq;
-    const bf16* k; int ldk;
-    const bf16* v; int ldv;
-    bf16* out; int ldo;
-    float* resid; int ldr;
-    const float* resid_in;
-    int B, H, Sq, Skv, nqb;
-    float scale_log2;  // scale * log2(e)
-    // training forward (TRAIN instantiations only)
-    float* lse;                    // [B, H, Sq] log2-domain log-sum-exp: m * scale_log2 + log2(l)
-    unsigned drop_thr; float keep_scale; unsigned seed_lo, seed_hi; int layer;
-};
-
-typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+constexpr int DH = ATT_DH, QBLK = 128, KBLK = ATT_KBLK;
+constexpr int KV_TILE_BYTES = ATT_KV_TILE_BYTES;  // 8 KiB
 
 template <int V>
 struct IC1 { static constexpr int value = V; };
 
-DITTO_DEV bf16x8 cat4(bf16x4 a, bf16x4 b) {
-    bf16x8 r;
-    r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
-    r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
-    return r;
-}
-
-// online-softmax rescale threshold (guide T13), in log2 units of the exp2 domain: the running max is only raised
-// (and O^T / l rescaled) when some row's new maximum exceeds it by more than this, so P stays <= 2^8 — exact in
-// bf16's exponent range, accumulated in fp32 — and the 32-register O^T rescale is skipped on most tiles.
-constexpr float RESCALE_THR_LOG2 = 8.0f;
+constexpr float RESCALE_THR_LOG2 = ATT_RESCALE_THR_LOG2;   // attn_common.h
 
 // __launch_bounds__(256, 2): 2 waves per SIMD => a 256-register budget, so the MFMA accumulators (S^T, O^T: 64
 // registers) stay in VGPRs.  With the default budget hipcc parks them in AGPRs and moves all 64 through
@@ -979,6 +954,8 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
             return hipGetLastError();
         }
         if (a.q_prescaled && !(g_attn_flags & 32)) {   // q already carries scale * log2(e): the reduced-VALU kernel
+            // one wave per SIMD, 64 queries per wave (attention_v4.hip): attn_flags 4096 = wherever the shape allows
+            if ((g_attn_flags & 4096) && attn64v4_supports(p)) return launch_attn64v4(p, a.resid_f32 != nullptr, s);
             const dim3 gridv(p.nqb * a.H * a.B);
             // whole pairs of key tiles: the software-pipelined, hand-interleaved kernel where it measures faster — small grids
             // (batch-1 serving, 96 workgroups: 13.6 us against 15.6 for attn64v2's deep-prefetch instantiation) and long key

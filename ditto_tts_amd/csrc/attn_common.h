@@ -1,0 +1,43 @@
+// attn_common.h — what the fused head_dim-64 attention kernels (attention.hip, attention_v4.hip) share: the kernel
+// parameter block, tile constants and two fragment helpers.
+#pragma once
+#include "gemm_common.h"
+
+namespace ditto {
+
+constexpr int ATT_DH = 64, ATT_KBLK = 64;
+constexpr int ATT_KV_TILE_BYTES = ATT_KBLK * ATT_DH * 2;  // 8 KiB: 64 keys x 64 head columns of bf16
+
+struct AttnParams {
+    const bf16* q; int ldq;
+    const bf16* k; int ldk;
+    const bf16* v; int ldv;
+    bf16* out; int ldo;
+    float* resid; int ldr;
+    const float* resid_in;
+    int B, H, Sq, Skv, nqb;
+    float scale_log2;  // scale * log2(e)
+    // training forward (TRAIN instantiations only)
+    float* lse;                    // [B, H, Sq] log2-domain log-sum-exp: m * scale_log2 + log2(l)
+    unsigned drop_thr; float keep_scale; unsigned seed_lo, seed_hi; int layer;
+};
+
+typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+
+DITTO_DEV bf16x8 cat4(bf16x4 a, bf16x4 b) {
+    bf16x8 r;
+    r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+    r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+    return r;
+}
+
+// online-softmax rescale threshold (guide T13), in log2 units of the exp2 domain: the running max is only raised
+// (and O^T / l rescaled) when some row's new maximum exceeds it by more than this, so P stays <= 2^8 — exact in
+// bf16's exponent range, accumulated in fp32 — and the 32-register O^T rescale is skipped on most tiles.
+constexpr float ATT_RESCALE_THR_LOG2 = 8.0f;
+
+// attention_v4.hip: one wave per SIMD, 64 queries per wave (pre-scaled q, Skv % 64 == 0, Skv >= 128)
+bool attn64v4_supports(const AttnParams& p);
+hipError_t launch_attn64v4(const AttnParams& p, bool resid, hipStream_t s);
+
+}  // namespace ditto

@@ -165,10 +165,11 @@ def _attn_ref(q, k, v, B, H, Sq, Skv, dh, scale):
                                            (1, 4, 64, 1, 64), (2, 12, 256, 320, 64), (1, 1, 40, 50, 128),
                                            (1, 2, 70, 33, 192), (2, 3, 200, 256, 64), (1, 2, 70, 384, 64),
                                            (1, 2, 333, 2048, 64)])
-@pytest.mark.parametrize("attn_flags", [0, 1, 3, 16, 16 + 64, 16 + 128, 16 + 32 + 3, 16 + 256, 16 + 512])
+@pytest.mark.parametrize("attn_flags", [0, 1, 3, 16, 16 + 64, 16 + 128, 16 + 32 + 3, 16 + 256, 16 + 512, 16 + 4096])
 def test_attention(lib, B, H, Sq, Skv, dh, attn_flags):
     hip.check(lib.ditto_set_option(b"attn_flags", attn_flags))   # 1: K/V tiles by LDS-DMA; 16: pre-scaled q (attn64v3 when Skv % 128 == 0,
-                                                                  # and the rule says so, else attn64v2); 256: never attn64v3; 512: attn64v3 wherever Skv % 128 == 0
+                                                                  # and the rule says so, else attn64v2); 256: never attn64v3; 512: attn64v3 wherever Skv % 128 == 0;
+                                                                  # 4096: attn64v4 (one wave per SIMD, 64 queries per wave) wherever Skv % 64 == 0
     d = H * dh
     q = bf16(asym((B * Sq, d), 8).to(DEV))
     if attn_flags & 16 and dh == 64:
@@ -235,7 +236,7 @@ def test_attention_pipelined_kernel_is_bitwise_the_tile_loop_kernel(lib, B, H, S
     q = bf16((q * (1.4426950408889634 / math.sqrt(dh))).to(DEV))
     k, v = bf16(k.to(DEV)), bf16(v.to(DEV))
     outs = []
-    for flags in (16 + 256, 16 + 512 + 2048, 16 + 512 + 1024):      # attn64v2; attn64v3 with 4 and with 8 waves per workgroup
+    for flags in (16 + 256, 16 + 512 + 2048, 16 + 512 + 1024, 16 + 4096):   # attn64v2; attn64v3 with 4 and with 8 waves per workgroup; attn64v4
         hip.check(lib.ditto_set_option(b"attn_flags", flags))
         out = torch.empty(B * Sq, d, dtype=torch.bfloat16, device=DEV)
         hip.check(lib.ditto_attention_bf16(q.data_ptr(), d, k.data_ptr(), d, v.data_ptr(), d, out.data_ptr(), d, B, H, Sq,
@@ -244,9 +245,10 @@ def test_attention_pipelined_kernel_is_bitwise_the_tile_loop_kernel(lib, B, H, S
     hip.check(lib.ditto_set_option(b"attn_flags", 3))
     assert torch.isfinite(outs[0].float()).all()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.equal(outs[0], outs[3]), "attn64v4 (one wave per SIMD, two query blocks per wave) differs from attn64v2"
 
 
-@pytest.mark.parametrize("attn_flags", [3, 16, 16 + 64, 16 + 128, 16 + 256, 16 + 512])
+@pytest.mark.parametrize("attn_flags", [3, 16, 16 + 64, 16 + 128, 16 + 256, 16 + 512, 16 + 4096])
 def test_attention_forced_rescale(lib, attn_flags):
     """Rule 26: force the online-softmax rescale branch — one key in the LAST tile dominates one query row."""
     hip.check(lib.ditto_set_option(b"attn_flags", attn_flags))

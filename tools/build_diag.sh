@@ -10,7 +10,7 @@ out=$1; shift
 cd "$(dirname "$0")/../ditto_tts_amd/csrc"
 mkdir -p /tmp/diag_objs
 for f in *.hip; do
-  extra=""; [ "$f" = attention.hip ] && extra="-fno-honor-nans"
+  extra=""; { [ "$f" = attention.hip ] || [ "$f" = attention_v4.hip ]; } && extra="-fno-honor-nans"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I ../../include -I . -Wno-unused-function $extra "$@" -c $f -o /tmp/diag_objs/${f%.hip}.o &
 done
 wait
