@@ -44,8 +44,10 @@ namespace ditto {
 
 namespace {
 
-constexpr int V4_KSLOTS = 3, V4_VSLOTS = 3;
-constexpr int V4_LDS = (V4_KSLOTS + V4_VSLOTS) * ATT_KV_TILE_BYTES;   // 48 KiB
+// K ring and V ring of NS tiles each (template parameter): NS = 8 -> 128 KiB, the one workgroup a CU holds anyway (512
+// registers per wave).  With 3 + 3 slots (the first version) a CU had two tiles = 32 KiB in flight and the kernel ran at the
+// LATENCY of its LDS-DMA (3 000 cycles per iteration for 1 500 of issue: 154 us against attn64v2's 133).
+constexpr int v4_lds_bytes(int ns) { return 2 * ns * ATT_KV_TILE_BYTES; }
 constexpr int V4_QWG = 256;                                            // queries per workgroup (4 waves x 2 blocks x 32)
 
 template <int V>
@@ -138,13 +140,71 @@ DITTO_DEV void scale_acc(float& acc, float f) {
 }
 #define V4_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-template <bool RESID>
+#ifdef DITTO_DIAG_V4_STAMP   // tools/build_diag.sh: where does an iteration spend its cycles?  (s_memtime stamps; timing build only)
+constexpr int V4_STAMP_WAVES = 8192;
+__device__ unsigned long long g_v4_stamps[V4_STAMP_WAVES * 16];   // one record per wave: plain stores (atomics on 16 words cost more than the kernel)   // summed over waves: prologue | slots 0..19 | slots 20..39 | wait + barrier | drain | epilogue | iterations | waves
+DITTO_DEV unsigned long long v4_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define V4_STAMP(var) const unsigned long long var = v4_now()
+#define V4_ACC(i, a, b) st_acc[i] += (b) - (a)
+#if DITTO_DIAG_V4_STAMP > 1      // also inside the tile loop (three stamps per iteration: they cost more than they show)
+#define V4_STAMP_IN(var) const unsigned long long var = v4_now()
+#define V4_ACC_IN(i, a, b) st_acc[i] += (b) - (a)
+#else
+#define V4_STAMP_IN(var)
+#define V4_ACC_IN(i, a, b)
+#endif
+#else
+#define V4_STAMP(var)
+#define V4_ACC(i, a, b)
+#define V4_STAMP_IN(var)
+#define V4_ACC_IN(i, a, b)
+#endif
+
+// s_waitcnt vmcnt takes an immediate: the (even) number of this wave's LDS-DMA pieces that may stay in flight
+DITTO_DEV void wait_vm_pieces(int y) {
+#define V4_VM(n) case n: asm volatile("s_waitcnt vmcnt(" #n ") lgkmcnt(0)" ::: "memory"); break;
+    switch (y) {
+        V4_VM(2) V4_VM(4) V4_VM(6) V4_VM(8) V4_VM(10) V4_VM(12) V4_VM(14) V4_VM(16) V4_VM(18) V4_VM(20) V4_VM(22) V4_VM(24)
+        V4_VM(26) V4_VM(28) V4_VM(30) V4_VM(32) V4_VM(34) V4_VM(36) V4_VM(38) V4_VM(40)
+        default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+    }
+#undef V4_VM
+}
+
+// LDS-DMA piece with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset; M0 (the LDS destination) is left
+// as set: nothing else in this kernel reads it, and with one wave per SIMD every scalar instruction is issue time.
+DITTO_DEV void v4_dma(unsigned voff, const void* sbase, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
+// NS: tiles per ring (K and V each).  G: iterations per barrier.  In iteration t the tiles K(t + D), V(t + D - 1) are issued,
+// D = NS - G, into the ring slots of K(t - G) / V(t - G - 1), which every wave left before the last barrier.
+template <bool RESID, int NS, int G>
 __global__ __launch_bounds__(256, 1) void attn64v4_kernel(AttnParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];    // [3 K tiles][3 V tiles]
+    constexpr int V4_KSLOTS = NS, V4_VSLOTS = NS, D = NS - G;
+    constexpr int Y_STEADY = 4 * (D - G - 1);      // pieces that may stay in flight at a barrier while both streams still issue
+    static_assert(G >= 1 && D >= G + 1 && Y_STEADY <= 40, "ring depth / barrier period");
+    extern __shared__ __attribute__((aligned(16))) char smem[];    // [NS K tiles][NS V tiles]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef DITTO_DIAG_V4_STAMP
+    unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     const int nwg = p.nqb * p.H * p.B;
-    const int id = xcd_remap(blockIdx.x, nwg);
+    // gridDim.x == nwg: one item per workgroup.  gridDim.x < nwg (attn_flags 32768: one workgroup per CU): a workgroup walks
+    // the items blockIdx.x, blockIdx.x + gridDim.x, ... one after the other (no re-dispatch between them); round r of the grid
+    // covers the ids [r gridDim.x, (r + 1) gridDim.x), XCD-contiguous inside the round.
+  for (int item = blockIdx.x; item < nwg; item += gridDim.x) {
+    const int round0 = (item / (int)gridDim.x) * (int)gridDim.x;
+    const int in_round = nwg - round0 < (int)gridDim.x ? nwg - round0 : (int)gridDim.x;
+    const int id = round0 + xcd_remap(item - round0, in_round);
+    V4_STAMP(t_begin);
     const int qb = id % p.nqb, bh = id / p.nqb;
     const int h = bh % p.H, b = bh / p.H;
     const int ql = lane & 31, hh = lane >> 5;
@@ -158,42 +218,43 @@ __global__ __launch_bounds__(256, 1) void attn64v4_kernel(AttnParams p) {
     {
         const bf16* pa = p.q + ((size_t)b * p.Sq + qrowA) * p.ldq + h * ATT_DH + 8 * hh;
         const bf16* pb = p.q + ((size_t)b * p.Sq + qrowB) * p.ldq + h * ATT_DH + 8 * hh;
+        // hand-written loads, straight into the AGPRs, the OLDEST vector-memory operations of the wave: the prologue's
+        // counted wait for the first K / V tiles retires them too.  (As compiler loads hipcc put its vmcnt waits in front of
+        // the loop's first MFMAs, where they drained the LDS-DMA in flight.)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            qA[ks] = *reinterpret_cast<const bf16x8*>(pa + 16 * ks);
-            qB[ks] = *reinterpret_cast<const bf16x8*>(pb + 16 * ks);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(qA[ks]) : "v"(pa + 16 * ks) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(qB[ks]) : "v"(pb + 16 * ks) : "memory");
         }
     }
-    // (pinned below, behind the prologue DMA: hipcc then waits for them THERE; left alone it loaded them straight into
-    //  AGPRs and put its vmcnt waits in front of the loop's first MFMAs, where they drained the LDS-DMA in flight)
     const int nkt = p.Skv / ATT_KBLK;                              // >= 1, whole tiles
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
 
     // ---- LDS-DMA: a tile image = 8 pieces of 1 KiB (8 rows x 128 B); wave w moves pieces 2w, 2w+1 of K and of V.
     //      LDS swizzles are applied on the SOURCE address (the DMA writes lane-linearly) ----
-    const bf16 *ksrc[2], *vsrc[2];
+    //      Source = scalar tile base (advances by 64 rows per tile) + per-lane byte offset (constant for the kernel).
+    unsigned kvo[2], vvo[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = (wid * 2 + i) * 8 + (lane >> 3), cpos = lane & 7;
-        ksrc[i] = p.k + ((size_t)b * p.Skv + row) * p.ldk + h * ATT_DH + (cpos ^ ((row >> 1) & 7)) * 8;
-        vsrc[i] = p.v + ((size_t)b * p.Skv + row) * p.ldv + h * ATT_DH + (cpos ^ (((row >> 1) & 1) << 2)) * 8;
+        kvo[i] = (unsigned)((row * p.ldk + (cpos ^ ((row >> 1) & 7)) * 8) * 2);
+        vvo[i] = (unsigned)((row * p.ldv + (cpos ^ (((row >> 1) & 1) << 2)) * 8) * 2);
     }
-    // BRANCH-FREE: every iteration issues its four pieces.  Past the last tile the source stops advancing (the last tile
-    // is fetched again, into a slot nobody reads any more): no out-of-bounds read, one vmcnt count for every iteration, no
-    // basic-block boundary inside the slot sequence.
-    const size_t kstep = (size_t)ATT_KBLK * p.ldk, vstep = (size_t)ATT_KBLK * p.ldv;
+    const char* kbase = reinterpret_cast<const char*>(p.k + (size_t)b * p.Skv * p.ldk + h * ATT_DH);
+    const char* vbase = reinterpret_cast<const char*>(p.v + (size_t)b * p.Skv * p.ldv + h * ATT_DH);
+    // Tiles are issued in the order K(0) | K(1), V(0) | K(2), V(1) | ...; past the last tile nothing is issued (wave-uniform
+    // branches around the asm statements: the slot sequence is asm volatile and keeps its order across them).
+    const size_t kstep = (size_t)ATT_KBLK * p.ldk * 2, vstep = (size_t)ATT_KBLK * p.ldv * 2;   // bytes per tile
     int k_issued = 0, v_issued = 0;                               // tiles whose DMA has been issued
     unsigned ik = 0, iv = 0;                                      // ring slots the next K / V tile goes to
     auto dma_k_piece = [&](int i) {
-        glds16(ksrc[i], lds_base + (unsigned)(ik * ATT_KV_TILE_BYTES + (wid * 2 + i) * 1024));
-        ksrc[i] += (k_issued + 1 < nkt) ? kstep : (size_t)0;
+        v4_dma(kvo[i], kbase, lds_base + (unsigned)(ik * ATT_KV_TILE_BYTES + (wid * 2 + i) * 1024));
     };
     auto dma_v_piece = [&](int i) {
-        glds16(vsrc[i], lds_base + (unsigned)((V4_KSLOTS + iv) * ATT_KV_TILE_BYTES + (wid * 2 + i) * 1024));
-        vsrc[i] += (v_issued + 1 < nkt) ? vstep : (size_t)0;
+        v4_dma(vvo[i], vbase, lds_base + (unsigned)((V4_KSLOTS + iv) * ATT_KV_TILE_BYTES + (wid * 2 + i) * 1024));
     };
-    auto k_advance = [&]() { ++k_issued; ik = ik + 1 == V4_KSLOTS ? 0 : ik + 1; };
-    auto v_advance = [&]() { ++v_issued; iv = iv + 1 == V4_VSLOTS ? 0 : iv + 1; };
+    auto k_advance = [&]() { ++k_issued; kbase += kstep; ik = ik + 1 == V4_KSLOTS ? 0 : ik + 1; };
+    auto v_advance = [&]() { ++v_issued; vbase += vstep; iv = iv + 1 == V4_VSLOTS ? 0 : iv + 1; };
 
     // ---- fragment addressing (byte offsets inside a tile image) ----
     // K: lane reads key row ql of a 32-key block, 16-B chunk (2 ks + hh) ^ ((ql >> 1) & 7)
@@ -301,6 +362,7 @@ __global__ __launch_bounds__(256, 1) void attn64v4_kernel(AttnParams p) {
         constexpr bool have_prev = decltype(HAVE_PREV_)::value != 0, have_cur = decltype(HAVE_CUR_)::value != 0;
         constexpr bool have_next_k = decltype(HAVE_NEXT_K_)::value != 0;   // K(t+1) exists: its fragments are read in slots 28..35
         using FT = decltype(FIRST_TILE_);
+        const bool do_k = k_issued < nkt, do_v = v_issued < nkt;           // does tile K(t+NS) / V(t+NS-1) exist?
         // slot s: `mfma(IC4<ek>, IC4<xk>, operands)` issues the slot's MFMA with the slot's chunk behind it in ONE statement
         // (HAS_MFMA_ = 0: the MFMA does not exist in this iteration; the chunk runs alone).  Exponential work: block A in
         // slots 17..34, block B in 37..39 and 0..14; maximum work: A in 10..15, B in 30..35 — at most one of each per slot.
@@ -326,12 +388,12 @@ __global__ __launch_bounds__(256, 1) void attn64v4_kernel(AttnParams p) {
             if constexpr (rB == 8) {
                 if constexpr (s >= 28) decide(FT{}, sB, cB, oB, lB, dmB); else decide(IC4<0>{}, sB, cB, oB, lB, dmB);
             }
-            // group g(t) = { K(t+3), V(t+2) }: one LDS-DMA piece behind each of the first four slots
+            // group g(t) = { K(t+NS), V(t+NS-1) }: one LDS-DMA piece behind each of the first four slots
             if constexpr (have_cur) {
-                if constexpr (s == 0) dma_k_piece(0);
-                if constexpr (s == 1) { dma_k_piece(1); k_advance(); }
-                if constexpr (s == 2) dma_v_piece(0);
-                if constexpr (s == 3) { dma_v_piece(1); v_advance(); }
+                if constexpr (s == 0) { if (do_k) dma_k_piece(0); }
+                if constexpr (s == 1) { if (do_k) { dma_k_piece(1); k_advance(); } }
+                if constexpr (s == 2) { if (do_v) dma_v_piece(0); }
+                if constexpr (s == 3) { if (do_v) { dma_v_piece(1); v_advance(); } }
             }
             V4_FENCE();
         };
@@ -344,6 +406,7 @@ __global__ __launch_bounds__(256, 1) void attn64v4_kernel(AttnParams p) {
                 else slot_s<ek, xk>(sA[j & 1], kf[j], qA[j >> 1], f);
             });
         };
+        V4_STAMP_IN(t_it0);
         sa(IC4<0>{}); sa(IC4<1>{}); sa(IC4<2>{}); sa(IC4<3>{}); sa(IC4<4>{}); sa(IC4<5>{}); sa(IC4<6>{}); sa(IC4<7>{});
         // ---- slots 8..19: O_B, l_B += V(t-1) P_B(t-1) ----
         // (iteration 0 has no MFMA here: the distance that lets the vector pipe read S'_A is then made of s_nops)
@@ -358,6 +421,7 @@ __global__ __launch_bounds__(256, 1) void attn64v4_kernel(AttnParams p) {
         };
         pvb(IC4<0>{}); pvb(IC4<1>{}); pvb(IC4<2>{}); pvb(IC4<3>{}); pvb(IC4<4>{}); pvb(IC4<5>{});
         pvb(IC4<6>{}); pvb(IC4<7>{}); pvb(IC4<8>{}); pvb(IC4<9>{}); pvb(IC4<10>{}); pvb(IC4<11>{});
+        V4_STAMP_IN(t_it1);
         // ---- slots 20..27: S'_B(t) = K(t) Q_B^T - m_B; V(t) fragments from LDS (their registers were released by slot 18) ----
         auto sb = [&](auto J_) {
             constexpr int j = decltype(J_)::value;
@@ -383,41 +447,59 @@ __global__ __launch_bounds__(256, 1) void attn64v4_kernel(AttnParams p) {
         pva(IC4<0>{}); pva(IC4<1>{}); pva(IC4<2>{}); pva(IC4<3>{}); pva(IC4<4>{}); pva(IC4<5>{});
         pva(IC4<6>{}); pva(IC4<7>{}); pva(IC4<8>{}); pva(IC4<9>{}); pva(IC4<10>{}); pva(IC4<11>{});
         if constexpr (have_cur && have_next_k) { kq = kq + 1 == V4_KSLOTS ? 0 : kq + 1; }
+        V4_STAMP_IN(t_it2);
+        if constexpr (have_cur && have_prev) { V4_ACC_IN(1, t_it0, t_it1); V4_ACC_IN(2, t_it1, t_it2); V4_ACC_IN(6, 0ull, 1ull); }
+        if constexpr (!have_cur) V4_ACC_IN(4, t_it0, t_it2);
     };
-    // End of iteration t: everything iteration t+1 reads from LDS — V(t+1) and K(t+2), i.e. group g(t-1) and older — has
-    // landed for this wave once only g(t)'s pieces are in flight; then for every wave.  The fragment reads of this
-    // iteration are retired first: the barrier also releases the slots of K(t+1) / V(t) to the next group's DMA.
-    auto end_of_iteration = [&]() {        // the four pieces of g(t) may stay in flight
-        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    // A barrier ends every G-th iteration.  At the barrier behind iteration t everything the next G iterations read from LDS —
+    // K(<= t+G+1) and V(<= t+G) — has landed for this wave once only the pieces issued after them are in flight (tiles go out
+    // in the order ... K(j+1), V(j), K(j+2), V(j+1) ...: 2 pieces per tile); then, by the barrier, for every wave.  The fragment
+    // reads of this iteration are retired first: the barrier also releases ring slots to the DMA of the next G iterations.
+    auto end_of_iteration = [&](int t) {
+        if (G > 1 && (t + 1) % G != 0) return;
+        V4_STAMP_IN(t_w0);
+        const int yk = k_issued - (t + G + 2), yv = v_issued - (t + G + 1);
+        const int y = 2 * (yk > 0 ? yk : 0) + 2 * (yv > 0 ? yv : 0);
+        if (y == Y_STEADY) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(Y_STEADY) : "memory");
+        else wait_vm_pieces(y);
         asm volatile("s_barrier" ::: "memory");
+        V4_STAMP_IN(t_w1);
+        if (t > 0) V4_ACC_IN(3, t_w0, t_w1);
     };
 
-    // ---- prologue: K(0) | K(1), V(0) | K(2), V(1) in flight; K(0) fragments ----
+    // ---- prologue: K(0) | K(1), V(0) | ... | K(D-1), V(D-2) in flight; K(0) fragments ----
     using T = IC4<1>; using F = IC4<0>;
+    V4_STAMP(t_p0);                    // [8] setup + Q loads issued
+    V4_ACC(8, t_begin, t_p0);
     dma_k_piece(0); dma_k_piece(1); k_advance();
-    dma_k_piece(0); dma_k_piece(1); k_advance();
-    dma_v_piece(0); dma_v_piece(1); v_advance();
-    dma_k_piece(0); dma_k_piece(1); k_advance();
-    dma_v_piece(0); dma_v_piece(1); v_advance();
-    // the Q fragments are the compiler's own (younger) loads: pinning them here makes hipcc wait for them — and, vmcnt
-    // retiring in order, for every DMA piece above — before the loop instead of inside it
-    asm volatile("" : "+a"(qA[0]), "+a"(qA[1]), "+a"(qA[2]), "+a"(qA[3]), "+a"(qB[0]), "+a"(qB[1]), "+a"(qB[2]), "+a"(qB[3]));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_barrier" ::: "memory");
 #pragma unroll
-    for (int f = 0; f < 8; ++f) read_k(f);
+    for (int j = 0; j + 1 < D; ++j) {
+        if (k_issued < nkt) { dma_k_piece(0); dma_k_piece(1); k_advance(); }
+        if (v_issued < nkt) { dma_v_piece(0); dma_v_piece(1); v_advance(); }
+    }
+    V4_STAMP(t_p1);                    // [9] prologue DMA issued
+    V4_ACC(9, t_p0, t_p1);
+    {                                  // Q (the oldest loads), K(<= G), V(<= G-1) have landed: what iterations 0 .. G-1 read
+        const int yk = k_issued - (G + 1), yv = v_issued - G;
+        wait_vm_pieces(2 * (yk > 0 ? yk : 0) + 2 * (yv > 0 ? yv : 0));
+        asm volatile("s_barrier" ::: "memory");
+    }
+    V4_STAMP(t_p2);                    // [10] first tiles landed + barrier
+    V4_ACC(10, t_p1, t_p2);
+    asm volatile("" : "+a"(qA[0]), "+a"(qA[1]), "+a"(qA[2]), "+a"(qA[3]), "+a"(qB[0]), "+a"(qB[1]), "+a"(qB[2]), "+a"(qB[3]));
+#pragma unroll
+    for (int f = 0; f < 8; ++f) read_k(f);     // (the DMA of iteration 0 goes to ring slot D != 0: K(0) may be read at leisure)
     kq = 1;
-    // every wave holds its K(0) fragments before anyone's g(0) overwrites that slot
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]), "+v"(kf[4]), "+v"(kf[5]), "+v"(kf[6]), "+v"(kf[7])::"memory");
-    asm volatile("s_barrier" ::: "memory");
 
+    V4_STAMP(t_loop);
+    V4_ACC(0, t_begin, t_loop);
     // ---- t = 0 ----
-    if (nkt > 1) { iteration(F{}, T{}, T{}, T{}); end_of_iteration(); }
+    if (nkt > 1) { iteration(F{}, T{}, T{}, T{}); end_of_iteration(0); }
     else iteration(F{}, T{}, T{}, F{});
     // ---- t = 1 .. nkt-2 ----
     for (int t = 1; t + 1 < nkt; ++t) {
         iteration(T{}, T{}, F{}, T{});
-        end_of_iteration();
+        end_of_iteration(t);
     }
     // ---- t = nkt-1 (no K(t+1) to fetch; the drain reads nothing from LDS: no barrier behind it) ----
     if (nkt > 1) iteration(T{}, T{}, F{}, F{});
@@ -427,6 +509,8 @@ __global__ __launch_bounds__(256, 1) void attn64v4_kernel(AttnParams p) {
     // landing later would write into LDS that already belongs to the next workgroup
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+    V4_STAMP(t_epi);
+    V4_ACC(12, t_loop, t_epi);        // [12] the whole tile loop
     // ---------------- epilogue ----------------
     // MFMA results (asm producers) -> vector readers: wait states hipcc does not insert
     asm volatile("s_nop 15\n\ts_nop 15" : "+a"(oA[0]), "+a"(oA[1]), "+a"(oB[0]), "+a"(oB[1]), "+a"(lA), "+a"(lB));
@@ -457,25 +541,64 @@ __global__ __launch_bounds__(256, 1) void attn64v4_kernel(AttnParams p) {
     };
     store_block(oA, lA, qrowA, validA);
     store_block(oB, lB, qrowB, validB);
+    if (item + (int)gridDim.x < nwg) asm volatile("s_barrier" ::: "memory");   // every wave is out of this item's LDS before the next item's DMA
+  }
+#ifdef DITTO_DIAG_V4_STAMP
+    V4_STAMP(t_st);                    // [11] epilogue arithmetic + store issue
+    V4_ACC(11, t_epi, t_st);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    V4_STAMP(t_end);
+    V4_ACC(5, t_epi, t_end);
+    if (lane == 0)
+        for (int i = 0; i < 16; ++i) g_v4_stamps[(size_t)((blockIdx.x * 4 + wid) % V4_STAMP_WAVES) * 16 + i] = st_acc[i];
+#endif
 }
 
 }  // namespace
+
+#ifdef DITTO_DIAG_V4_STAMP
+extern "C" int ditto_diag_v4_stamps(unsigned long long* out) {   // sum of the per-wave records of the LAST launches, then clear (diagnostic build only)
+    static unsigned long long host[V4_STAMP_WAVES * 16];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_v4_stamps), sizeof(host)) != hipSuccess) return 1;
+    for (int i = 0; i < 16; ++i) out[i] = 0;
+    for (int w = 0; w < V4_STAMP_WAVES; ++w)
+        for (int i = 0; i < 16; ++i) out[i] += host[(size_t)w * 16 + i];
+    for (size_t i = 0; i < sizeof(host) / sizeof(host[0]); ++i) host[i] = 0;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_v4_stamps), host, sizeof(host)) != hipSuccess;
+}
+#endif
 
 bool attn64v4_supports(const AttnParams& p) {
     return p.Skv >= ATT_KBLK && p.Skv % ATT_KBLK == 0 && p.Sq >= 1 && !p.lse && !p.drop_thr;
 }
 
-hipError_t launch_attn64v4(const AttnParams& p_in, bool resid, hipStream_t s) {
+namespace {
+template <int NS, int G>
+hipError_t launch_v4_t(const AttnParams& p, bool resid, hipStream_t s) {
     static DevOnce lds_once;
-    if (hipError_t e = set_max_lds_once(lds_once, {reinterpret_cast<const void*>(&attn64v4_kernel<true>),
-                                                   reinterpret_cast<const void*>(&attn64v4_kernel<false>)}, V4_LDS))
+    if (hipError_t e = set_max_lds_once(lds_once, {reinterpret_cast<const void*>(&attn64v4_kernel<true, NS, G>),
+                                                   reinterpret_cast<const void*>(&attn64v4_kernel<false, NS, G>)}, v4_lds_bytes(NS)))
         return e;
+    int nwg = p.nqb * p.H * p.B;
+    if ((g_attn_flags & 32768) && nwg > 256) nwg = 256;      // A/B: persistent workgroups, one per CU
+    const dim3 grid(nwg);
+    if (resid) hipLaunchKernelGGL((attn64v4_kernel<true, NS, G>), grid, dim3(256), v4_lds_bytes(NS), s, p);
+    else hipLaunchKernelGGL((attn64v4_kernel<false, NS, G>), grid, dim3(256), v4_lds_bytes(NS), s, p);
+    return hipGetLastError();
+}
+}  // namespace
+
+hipError_t launch_attn64v4(const AttnParams& p_in, bool resid, hipStream_t s) {
     AttnParams p = p_in;
     p.nqb = (p.Sq + V4_QWG - 1) / V4_QWG;
-    const dim3 grid(p.nqb * p.H * p.B);
-    if (resid) hipLaunchKernelGGL((attn64v4_kernel<true>), grid, dim3(256), V4_LDS, s, p);
-    else hipLaunchKernelGGL((attn64v4_kernel<false>), grid, dim3(256), V4_LDS, s, p);
-    return hipGetLastError();
+    // attn_flags bits 13-14 (A/B): ring depth / barrier period: 0 -> 8 tiles, a barrier per iteration; 1 -> 8 tiles, a barrier
+    // per 2 iterations; 2 -> 4 tiles, per iteration; 3 -> 10 tiles, per 3 iterations
+    switch ((g_attn_flags >> 13) & 3) {
+        case 1: return launch_v4_t<8, 2>(p, resid, s);
+        case 2: return launch_v4_t<4, 1>(p, resid, s);
+        case 3: return launch_v4_t<10, 3>(p, resid, s);
+        default: return launch_v4_t<8, 1>(p, resid, s);
+    }
 }
 
 }  // namespace ditto
