@@ -887,6 +887,21 @@ int ditto_set_option(const char* name, int value) {
         g_fr_dgrad = value;
         return DITTO_OK;
     }
+    if (!strcmp(name, "fr_tile")) {
+        if (value != 0 && value != 64 && value != 128) return fail(DITTO_ERR_ARG, "fr_tile must be 0 (rule), 64 or 128");
+        g_fr_tile = value;
+        return DITTO_OK;
+    }
+    if (!strcmp(name, "fr64_maxk")) {
+        if (value < 0) return fail(DITTO_ERR_ARG, "fr64_maxk must be >= 0");
+        g_fr64_maxk = value;
+        return DITTO_OK;
+    }
+    if (!strcmp(name, "fr_stagger")) {
+        if (value < 0 || value > 100000) return fail(DITTO_ERR_ARG, "fr_stagger must be in [0, 100000] (10 ns ticks)");
+        g_fr_stagger = value;
+        return DITTO_OK;
+    }
     if (!strcmp(name, "fr_rot")) {
         if (value < 0 || value > 4096) return fail(DITTO_ERR_ARG, "fr_rot must be in [0, 4096]");
         g_fr_rot = value;

@@ -357,13 +357,22 @@ bool gemm192_supports(GemmEpilogue epi);
 hipError_t launch_gemm192(const GemmParams& p, GemmEpilogue epi, hipStream_t s);
 // gemm_o3.hip
 hipError_t launch_gemm_o3(const GemmParams& p, GemmEpilogue epi, hipStream_t s);
-// gemm_fr.hip: full-row N = 768 GEMM, fp32 residual in place, fused LayerNorm -> u bf16 (gamma/u null: none)
+// gemm_fr.hip / gemm_fr64.hip: full-row N = 768 GEMM, fp32 residual in place, fused LayerNorm -> u bf16 (gamma/u null: none)
+struct FrParams {
+    GemmParams g;
+    const float* gamma; const float* beta;   // LayerNorm affine of the fused norm (null: no LayerNorm output)
+    bf16* u; int ldu;                         // LayerNorm output
+    int rot_period;                           // > 0: 128-row tiles t and t + rot_period start their K loop at the same place
+    int stagger_ticks;                        // gemm_fr64: start delay (10 ns ticks) of the workgroup holding its CU's second LDS allocation
+};
 bool gemm_fr_supports(int M, int N, int K, size_t lda, size_t ldw);
 hipError_t launch_gemm_fr(const GemmParams& p, const float* gamma, const float* beta, void* u_bf16, int ldu, int rot_period,
                           hipStream_t s);
 // The two full-row launches of a DiT block over M rows of width d, each judged on the operand strides IT runs with (the
 // kernel builds 32-bit byte offsets from M * lda: fc2 reads A at lda = 4d).  One predicate for the inference forward, the
 // LayerNorm chaining decision and the training forward, so that the three cannot disagree.
+// gemm_fr64.hip: the same contract and the SAME BITS on 64-row tiles, two workgroups per CU (called by launch_gemm_fr)
+hipError_t launch_gemm_fr64(const FrParams& fp, hipStream_t s);
 inline bool fr_outproj_ok(int M, int d) { return fr_pays(M) && gemm_fr_supports(M, d, d, (size_t)d, (size_t)d); }
 inline bool fr_fc2_ok(int M, int d) { return fr_pays(M) && gemm_fr_supports(M, d, 4 * d, (size_t)4 * d, (size_t)4 * d); }
 // gemm_pp.hip

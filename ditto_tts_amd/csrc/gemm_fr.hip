@@ -73,13 +73,6 @@ constexpr int NA = 7;                              // column blocks whose accumu
 #define PIN_A(x) asm volatile("" : "+a"(x))
 #define PIN_V(x) asm volatile("" : "+v"(x))
 
-struct FrParams {
-    GemmParams g;
-    const float* gamma; const float* beta;   // LayerNorm affine of the fused norm (null: no LayerNorm output)
-    bf16* u; int ldu;                         // LayerNorm output
-    int rot_period;                           // > 0: tiles t and t + rot_period start their K loop at the same place (below)
-};
-
 template <int V>
 struct IC { static constexpr int value = V; };
 
@@ -586,6 +579,12 @@ hipError_t launch_gemm_fr(const GemmParams& p_in, const float* gamma, const floa
     fp.g.tiles_n = 1;
     fp.gamma = gamma; fp.beta = beta; fp.u = (bf16*)u_bf16; fp.ldu = ldu;
     fp.rot_period = g_fr_rot ? rot_period : 0;
+    fp.stagger_ticks = 0;
+    // 64-row tiles, two workgroups per CU (gemm_fr64.hip): bit-identical results, so this is a speed rule only
+    if (fr_use_tile64(p_in.M, p_in.K)) {
+        fp.stagger_ticks = g_fr_stagger;
+        return launch_gemm_fr64(fp, s);
+    }
     const bool ln = gamma && u_bf16, res = p_in.residual != nullptr;
     if (ln) return res ? launch_fr_t<true, true>(fp, fp.g.tiles_m, s) : launch_fr_t<true, false>(fp, fp.g.tiles_m, s);
     return res ? launch_fr_t<false, true>(fp, fp.g.tiles_m, s) : launch_fr_t<false, false>(fp, fp.g.tiles_m, s);

@@ -69,6 +69,15 @@ inline bool fr_pays(int M) {
 
 extern int g_fr_dgrad;   // gemm.hip: training backward, long-K dgrads on the full-row kernel: bit 0 fc1|gate (K = 8d), bit 1 QKV (K = 3d)
 extern int g_fr_rot;     // gemm.hip: full-row kernel's K-loop rotation: 0 off, 1 on in the model (period = tiles per utterance), > 1 = period for ditto_gemm_ln_bf16 too
+extern int g_fr_tile;    // gemm.hip: full-row kernel's tile: 0 = rule, 64 = gemm_fr64.hip for every launch with K <= g_fr64_maxk, 128 = gemm_fr.hip
+extern int g_fr64_maxk;  // gemm.hip: longest K that takes the 64-row kernel when fr_tile = 64
+extern int g_fr_stagger; // gemm.hip: gemm_fr64's start delay of the second workgroup of a CU (10 ns ticks)
+// Which full-row kernel: same bits either way (tests/test_gpu_kernels.py), a speed rule only.
+inline bool fr_use_tile64(int M, int K) {
+    if (M < 64) return false;
+    if (g_fr_tile == 64) return K <= g_fr64_maxk;
+    return false;
+}
 extern int g_fr_mask;    // gemm.hip: 1 = cross out-proj + LayerNorm3, 2 = fc2 + next block's LayerNorm1 on the full-row kernel
 // same row map for an fp32 vector (bias)
 hipError_t launch_pack_vec(const float* src, float* dst, int rows, int blk, int mult, int row_off, hipStream_t s);

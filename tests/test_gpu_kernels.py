@@ -445,3 +445,47 @@ def test_full_row_gemm_with_fused_layernorm(lib, M, K, ln, rot):
     hip.check(lib.ditto_set_option(b"fr_rot", 1))
     assert lib.ditto_gemm_ln_bf16(A.data_ptr(), K, Wp.data_ptr(), None, None, h.data_ptr(), 512, None, None, None, 0, M, 512,
                                   K, stream()) == hip.ERR_SHAPE
+
+
+@pytest.mark.parametrize("M,K,ln,res", [(128, 768, True, True), (300, 256, True, True), (1024, 3072, True, True),
+                                          (257, 64, False, True), (1000, 128, True, False), (515, 192, True, True),
+                                          (4096, 768, True, True), (2048, 3072, False, True)])
+@pytest.mark.parametrize("rot", [0, 8, 3])
+def test_full_row_gemm_on_64_row_tiles_is_bitwise_the_128_row_kernel(lib, M, K, ln, res, rot):
+    """csrc/gemm_fr64.hip (64 x 768 tiles, two workgroups per CU, wave-private W ring) against csrc/gemm_fr.hip on the same
+    inputs: h and u must agree BIT FOR BIT (same K order incl. the rotation of the 128-row tile the rows belong to, same
+    accumulator init, same association of the LayerNorm statistics) — the choice between the two is a speed rule, not a
+    numerics class.  Ragged M, with / without residual, bias, LayerNorm, start delay of the second workgroup on and off."""
+    N = 768
+    hip.check(lib.ditto_set_option(b"fr_rot", rot))
+    A = bf16(asym((M, K), 14).to(DEV))
+    W = bf16((asym((N, K), 15) / math.sqrt(K)).to(DEV))
+    Wp = W.view(N, K // 16, 16).permute(1, 0, 2).contiguous()
+    bias = (0.1 * asym((N,), 16)).to(DEV)
+    r0 = asym((M, N), 17).to(DEV)
+    g = (1 + 0.1 * asym((N,), 18)).to(DEV)
+    b = (0.1 * asym((N,), 19)).to(DEV)
+    want = A.float() @ W.float().T + bias + (r0 if res else 0)
+    outs = {}
+    try:
+        for tile, stagger in ((128, 0), (64, 0), (64, 700)):
+            hip.check(lib.ditto_set_option(b"fr_tile", tile))
+            hip.check(lib.ditto_set_option(b"fr_stagger", stagger))
+            h = r0.clone() if res else torch.full((M, N), 7.0, device=DEV)
+            u = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+            hip.check(lib.ditto_gemm_ln_bf16(A.data_ptr(), K, Wp.data_ptr(), bias.data_ptr(), h.data_ptr() if res else None,
+                                             h.data_ptr(), N, g.data_ptr() if ln else None, b.data_ptr() if ln else None,
+                                             u.data_ptr() if ln else None, N, M, N, K, stream()))
+            torch.cuda.synchronize()
+            outs[(tile, stagger)] = (h, u)
+    finally:
+        hip.check(lib.ditto_set_option(b"fr_tile", 0))
+        hip.check(lib.ditto_set_option(b"fr_stagger", 1200))
+        hip.check(lib.ditto_set_option(b"fr_rot", 1))
+    h128, u128 = outs[(128, 0)]
+    assert rel_l2(h128, want) < 1e-5
+    for key in ((64, 0), (64, 700)):
+        h64, u64 = outs[key]
+        assert rel_l2(h64, want) < 1e-5 and max_abs(h64, want) < 2e-4, key
+        assert torch.equal(h64, h128), (key, float((h64 - h128).abs().max()))
+        assert torch.equal(u64, u128), (key, float((u64.float() - u128.float()).abs().max()))

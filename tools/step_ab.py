@@ -2,7 +2,7 @@
 """In-model A/B of GEMM variants: per-kernel-class average launch time of the real denoise step (C2, B=32),
 variants interleaved round-robin in ONE process on ONE device (cross-run numbers differ by >10 % between boxes).
     python tools/step_ab.py --variants 128/73,256/73,0/73 [--rounds 4] [--steps 3]
-variant = gemm_tile/gemm_flags[@attn_flags][#splitk_wgs][%gemm_group][^pp_mask]"""
+variant = gemm_tile/gemm_flags[@attn_flags][#splitk_wgs][%gemm_group][^pp_mask][!pp_nb][~fr_mask][&fr_rot][+fr_tile.fr64_maxk.fr_stagger]"""
 import argparse
 import os
 import sys
@@ -44,6 +44,11 @@ wall = {v: [] for v in variants}
 
 
 def select(v):
+    v, _, ft = v.partition("+")          # ...+fr_tile.fr64_maxk.fr_stagger (64-row full-row kernel: gemm_fr64.hip; default: the rule)
+    ftv = [int(x) for x in ft.split(".")] if ft else []
+    hip.check(lib.ditto_set_option(b"fr_tile", ftv[0] if len(ftv) > 0 else 0))
+    hip.check(lib.ditto_set_option(b"fr64_maxk", ftv[1] if len(ftv) > 1 else 1 << 30))
+    hip.check(lib.ditto_set_option(b"fr_stagger", ftv[2] if len(ftv) > 2 else 1200))
     v, _, fr = v.partition("&")          # ...&fr_rot (full-row GEMM K-loop rotation: default 1 = on)
     hip.check(lib.ditto_set_option(b"fr_rot", int(fr) if fr else 1))
     v, _, fm = v.partition("~")          # ...~fr_mask (full-row GEMM + fused LayerNorm: 1 out-proj, 2 fc2)
