@@ -67,10 +67,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     const int srow = lane >> 3;   // row inside a piece
     const int scpos = lane & 7;   // chunk position inside the 128-B row
     int m0 = 0, n0 = 0;           // origin of the tile whose DMA is being issued
+    // FLAT K loop (GF_FLAT_K, even K-tile counts): K-tiles nkt and nkt + 1 of a tile ARE K-tiles 0 and 1 of the workgroup's
+    // next tile, so the DMA slots of the last iteration (empty otherwise) carry the next tile's first six half-tiles, the
+    // matrix pipe covers their issue (a 1-KiB LDS-DMA piece holds its wave for 60-180 cycles, twelve of them per wave sat
+    // between main loop and epilogue), and K-tile 0 of the next tile is resident before this tile's epilogue starts.
+    int nm0 = 0, nn0 = 0;         // origin of the workgroup's next tile
+    bool flat_next = false;       // flat mode and a next tile exists (wave-uniform)
     unsigned bias_slot = 0;       // which of the two 1 KiB bias rows (after the K-tile buffers) the last prologue filled
     auto stage = [&](int buf, auto HALF, int kt) {
         constexpr int half = decltype(HALF)::value;
-        if (kt >= nkt) return;    // wave-uniform; the waits below account for it
+        int om = m0, on = n0;
+        if (kt >= nkt) {          // wave-uniform; the waits below account for it
+            if (!flat_next) return;
+            kt -= nkt; om = nm0; on = nn0;
+        }
 #ifdef DITTO_DIAG_NODMA
         if (kt > 0) return;       // timing experiment: the main loop without its global->LDS traffic (WRONG results)
 #endif
@@ -82,11 +92,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             const int c = scpos ^ ((row >> 1) & 7);
             const char* src;
             if constexpr (half < 2) {
-                int gr = m0 + half * 128 + row;
+                int gr = om + half * 128 + row;
                 gr = gr < p.M ? gr : p.M - 1;
                 src = (const char*)p.A + (size_t)gr * p.lda * ESZ + k0b + c * 16;
             } else {
-                int gr = n0 + (half - 2) * 128 + row;
+                int gr = on + (half - 2) * 128 + row;
                 gr = gr < p.w_rows ? gr : p.w_rows - 1;
                 src = (const char*)p.W + (size_t)gr * p.ldw * ESZ + k0b + c * 16;
             }
@@ -94,24 +104,27 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         }
     };
     // tile 0 -> buffer 0 (all four halves), tile 1's B halves -> buffer 1: the state the loop's P1 expects
-    auto prologue = [&](int tile) {
-        int tm, tn;
-        tile_to_mn(xcd_remap(tile, ntiles), p.tiles_m, p.tiles_n, p.group_n, tm, tn);
-        m0 = tm * 256;
-        n0 = tn * 256;
+    auto stage_bias = [&](int tn0) {   // the bias row (fp8: + weight scales) of the tile at column origin tn0 -> the other LDS slot
         bias_slot ^= 1u;
-        if (wid == 0 && p.bias) {   // this tile's bias row -> LDS (read by its FAST epilogue); columns past N are clamped, unused
-            int c = n0 + lane * 4;
+        if (wid == 0 && p.bias) {   // read by the tile's FAST epilogue; columns past N are clamped, unused
+            int c = tn0 + lane * 4;
             c = c + 4 <= p.N ? c : 0;
             glds16(p.bias + c, lds_base + (unsigned)(LDS256 + bias_slot * 2048));
         }
         if constexpr (FP8) {
             if (wid == 1 && p.wscale) {   // fp8: the per-output-column weight scales of the tile, same route
-                int c = n0 + lane * 4;
+                int c = tn0 + lane * 4;
                 c = c + 4 <= p.N ? c : 0;
                 glds16(p.wscale + c, lds_base + (unsigned)(LDS256 + bias_slot * 2048 + 1024));
             }
         }
+    };
+    auto prologue = [&](int tile) {
+        int tm, tn;
+        tile_to_mn(xcd_remap(tile, ntiles), p.tiles_m, p.tiles_n, p.group_n, tm, tn);
+        m0 = tm * 256;
+        n0 = tn * 256;
+        stage_bias(n0);
         stage(0, IC<2>{}, 0);
         stage(0, IC<3>{}, 0);
         stage(0, IC<0>{}, 0);
@@ -235,22 +248,38 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
     }
 
+    const bool flat = WIDE && (p.flags & GF_FLAT_K) && nkt >= 2 && (nkt & 1) == 0;
+    bool first_tile = true;
     for (; tile < ntiles; tile += p.tile_stride) {
         const int cur_m0 = m0, cur_n0 = n0;
+        const int next = tile + p.tile_stride;
+        if (flat) {
+            flat_next = next < ntiles;
+            if (flat_next) {
+                int tm, tn;
+                tile_to_mn(xcd_remap(next, ntiles), p.tiles_m, p.tiles_n, p.group_n, tm, tn);
+                nm0 = tm * 256;
+                nn0 = tn * 256;
+            }
+        }
 #pragma unroll
         for (int m = 0; m < 8; ++m)
 #pragma unroll
             for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        // buffer 0 complete (everything older than the newest 4 loads: tile 1's B halves, or the previous
-        // tile's epilogue stores, which were issued AFTER this tile's prologue DMA)
-        if (prev_interior && nkt > 1 && (p.flags & GF_RELAXED_WAIT)) {
-            if constexpr (EPI_STORES == 8) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else if constexpr (EPI_STORES == 16) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
-        } else {
-            wait_dma(nkt > 1);
-        }
+        if (!flat || first_tile) {
+            // buffer 0 complete (everything older than the newest 4 loads: tile 1's B halves, or the previous
+            // tile's epilogue stores, which were issued AFTER this tile's prologue DMA)
+            if (prev_interior && nkt > 1 && (p.flags & GF_RELAXED_WAIT)) {
+                if constexpr (EPI_STORES == 8) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else if constexpr (EPI_STORES == 16) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+            } else {
+                wait_dma(nkt > 1);
+            }
+        }   // flat, later tiles: K-tile 0 landed behind the counted wait of the previous tile's last phase; its B halves of K-tile
+            // 1 (the newest four loads before the epilogue's stores) are covered by the first iteration's own counted wait
+        first_tile = false;
         DITTO_BAR();
         if (wm == 1) DITTO_BAR();  // stagger the second wave group by one barrier
 
@@ -277,7 +306,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
                 read_A(0, IC<1>{});
                 stage(0, IC<2>{}, te + 2);
                 stage(0, IC<3>{}, te + 2);
-                wait_dma(te + 2 < nkt);
+                wait_dma(te + 2 < nkt || flat_next);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 DITTO_BAR();
                 mma(IC<1>{}, IC<1>{});
@@ -300,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
                 read_A(1, IC<1>{});
                 stage(1, IC<2>{}, to + 2);
                 stage(1, IC<3>{}, to + 2);
-                wait_dma(to + 2 < nkt);
+                wait_dma(to + 2 < nkt || flat_next);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 DITTO_BAR();
                 if (odd_valid) {
@@ -368,8 +397,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         }
         if (wm == 0) DITTO_BAR();  // balance the stagger barrier: every LDS read of this tile has retired
 
-        // next tile's first K-tiles start streaming in now, under this tile's epilogue
-        const int next = tile + p.tile_stride;
+        // next tile's first K-tiles start streaming in now, under this tile's epilogue (flat mode: they are in already)
         // FAST epilogue: the tile's 256 bias values came in by LDS-DMA with ITS OWN prologue (one 1 KiB piece, wave 0,
         // the oldest load of the prologue), so the epilogue reads them with ds_read and contains no global load at all.
         // (As compiler-visible global loads issued after the next tile's prologue DMA they made hipcc open every
@@ -377,7 +405,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         const bool fast_epi = epilogue_fast_ok<EPI>(p, cur_m0, cur_n0, 256, 256) && !(p.flags & GF_DIAG_NO_EPILOGUE) &&
                               (!FP8 || p.wscale);
         const unsigned cur_bias_slot = bias_slot;
-        if (next < ntiles) prologue(next);
+        if (flat) {
+            if (flat_next) { stage_bias(nn0); m0 = nm0; n0 = nn0; }
+        } else if (next < ntiles) {
+            prologue(next);
+        }
         // ---------------- epilogue ----------------
         prev_interior = (cur_m0 + 256 <= p.M) && (cur_n0 + 256 <= p.N) && !p.out2 &&
                         !(p.flags & (GF_DIAG_NO_STORE | GF_DIAG_NO_EPILOGUE));

@@ -46,7 +46,8 @@ enum { GF_RELAXED_WAIT = 1,        // tile-start wait skips over the previous ti
        GF_SLOW_EPILOGUE = 1024,    // A/B: never take the specialised straight-line epilogue (was: RoPE table loads A/B, retired)
        GF_TN_TWO_BUFFER = 2048,    // gemm_tn.hip A/B: the first (two-buffer) weight-gradient kernel
        GF_TN_NARROW = 4096,        // ditto_train.hip A/B: weight gradients on the 128 x 128 kernel only (no 256 x 256 tiles)
-       GF_PP_PARITY = 8192 };      // gemm_pp with pp_stagger > 0: the late-starting workgroups are the odd blockIdx (default: second LDS allocation of the CU)
+       GF_PP_PARITY = 8192,
+       GF_FLAT_K = 16384 };        // gemm256 wide-phase: the K loop runs flat over the tile switch (the next tile's first half-tiles ride the last iteration's empty DMA slots)      // gemm_pp with pp_stagger > 0: the late-starting workgroups are the odd blockIdx (default: second LDS allocation of the CU)
 
 // Tile order.  An XCD (private 4 MiB L2) receives a contiguous range of the linear tile index (xcd_remap); within it
 // the tiles run down M inside a SUPER-COLUMN of `G` column tiles, so the tiles an XCD works on at one time are a

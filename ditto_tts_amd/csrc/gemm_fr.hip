@@ -82,6 +82,22 @@ DITTO_DEV void mfma_a(f32x16& c, const bf16x8& w, const bf16x8& a) {
 DITTO_DEV void mfma_v(f32x16& c, const bf16x8& w, const bf16x8& a) {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(w), "v"(a));
 }
+// Hazard argument for the asm MFMAs.  hipcc inserts the wait states an MFMA result needs before a NON-MFMA reader only for
+// MFMAs it emitted itself; behind an asm statement it pads nothing.  (a) Inside an accumulator chain the only reader of a
+// result is the next MFMA of the same chain (same vdst = srcC): back-to-back dependent MFMAs of one shape need no software
+// wait states (the hardware interlocks srcC).  (b) Operand registers (wf / a fragments) are only READ by the MFMA and
+// rewritten by ds_reads, whose data returns long after the MFMA has fetched its operands.  (c) The LAST MFMA of each chain
+// is followed by arbitrary compiler-scheduled readers (v_accvgpr_read, a spill's scratch_store, the LayerNorm adds): an
+// 8-pass 32x32x16 MFMA needs 11 wait states before any of them.  A separate `s_nop` STATEMENT is not enough: in
+// gemm_fr64.hip hipcc placed a spill of the just-written block BETWEEN the MFMA statement and the s_nop statement that
+// followed the pair (wrong lanes in u, caught by the bitwise test).  So the last-stage MFMAs carry `s_nop 15` (16 wait
+// states) inside their own asm statement; the nop is hidden under the 32 cycles the matrix pipe is busy anyway.
+DITTO_DEV void mfma_a_last(f32x16& c, const bf16x8& w, const bf16x8& a) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 15" : "+a"(c) : "v"(w), "v"(a));
+}
+DITTO_DEV void mfma_v_last(f32x16& c, const bf16x8& w, const bf16x8& a) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 15" : "+v"(c) : "v"(w), "v"(a));
+}
 
 template <bool LN, bool RES>
 __global__ __launch_bounds__(256, 1) void gemm_fr_kernel(FrParams fp) {
@@ -336,8 +352,13 @@ __global__ __launch_bounds__(256, 1) void gemm_fr_kernel(FrParams fp) {
             }
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
-                if (nb < NA) mfma_a(acca[nb < NA ? nb : 0][mb], wf[nb & 3], ACUR[mb]);
-                else mfma_v(accv[nb < NA ? 0 : nb - NA][mb], wf[nb & 3], ACUR[mb]);
+                if constexpr (has_next) {
+                    if (nb < NA) mfma_a(acca[nb < NA ? nb : 0][mb], wf[nb & 3], ACUR[mb]);
+                    else mfma_v(accv[nb < NA ? 0 : nb - NA][mb], wf[nb & 3], ACUR[mb]);
+                } else {   // last stage: each MFMA carries its own wait states (hazard argument above)
+                    if (nb < NA) mfma_a_last(acca[nb < NA ? nb : 0][mb], wf[nb & 3], ACUR[mb]);
+                    else mfma_v_last(accv[nb < NA ? 0 : nb - NA][mb], wf[nb & 3], ACUR[mb]);
+                }
 #if defined(DITTO_DIAG_FR_VALU) && DITTO_DIAG_FR_VALU == 7   // VALU-bound mix behind every MFMA: 2 transcendentals + 3 plain ops (44 cycles)
                 if (mb == 0) asm volatile("v_exp_f32 %0, %0\n\tv_fma_f32 %3, %3, %3, %3\n\tv_max_f32 %4, %4, %3\n\tv_exp_f32 %5, %5\n\tv_fma_f32 %3, %3, %3, %3" : "+v"(dz0), "+v"(dz1), "+v"(dz2), "+v"(dy0), "+v"(dw0), "+v"(dw1));
                 else asm volatile("v_exp_f32 %0, %0\n\tv_fma_f32 %3, %3, %3, %3\n\tv_max_f32 %4, %4, %3\n\tv_exp_f32 %5, %5\n\tv_fma_f32 %3, %3, %3, %3" : "+v"(dw2), "+v"(dy1), "+v"(dy2), "+v"(dw3), "+v"(dw4), "+v"(dw5));
@@ -359,10 +380,6 @@ __global__ __launch_bounds__(256, 1) void gemm_fr_kernel(FrParams fp) {
                 else asm volatile("v_rcp_f32 %0, %0\n\tv_pk_fma_f32 %1, %1, %1, %1\n\tv_pk_fma_f32 %2, %2, %2, %2" : "+v"(dy0), "+v"(dy1), "+v"(dy2));
 #endif
             }
-            // LAST stage: these are the final writes of the block's accumulators, and hipcc may read them right behind the
-            // asm (it spilled a just-written AGPR block with scratch_store two instructions later: garbage in some lanes
-            // of some launches).  An MFMA's result needs its wait states before ANY reader but the next MFMA of its chain.
-            if constexpr (!has_next) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
 #if defined(DITTO_DIAG_FR_VALU) && DITTO_DIAG_FR_VALU < 3   // tools/build_diag.sh: dummy VALU work behind every MFMA pair (does it hide under the matrix pipe?)
             asm volatile("v_exp_f32 %0, %0\n\tv_pk_fma_f32 %1, %1, %1, %1\n\tv_pk_fma_f32 %2, %2, %2, %2\n\t"
                          "v_rcp_f32 %0, %0\n\tv_pk_mul_f32 %1, %1, %2\n\tv_pk_fma_f32 %2, %2, %1, %1\n\t"

@@ -133,6 +133,39 @@ def test_every_epilogue_on_every_structure(lib, tile, flags):
         hip.check(lib.ditto_set_option(b"gemm_flags", 321))
 
 
+@pytest.mark.parametrize("shape", [(4096, 6144, 768), (5000, 2304, 768), (8192, 768, 3072), (4096, 2304, 192)])
+def test_flat_k_loop_across_the_tile_switch_is_bitwise(lib, shape):
+    """gemm256 with GF_FLAT_K (16384): the next tile's first six half-tiles ride the empty DMA slots of the last K
+    iteration, no prologue between main loop and epilogue.  More tiles than CUs (384 / 180 / 96 / 144 tiles; the second and
+    fourth shapes have ragged last row tiles, the fourth an ODD K-tile count that must fall back), every C-ABI epilogue:
+    the arithmetic is unchanged, so the outputs must equal the default build's BIT FOR BIT."""
+    M, N, K = shape
+    A = bf16(asym((M, K), 24).to(DEV))
+    W = bf16((asym((N, K), 25) / math.sqrt(K)).to(DEV))
+    bias = (0.1 * asym((N,), 26)).to(DEV)
+    res = asym((M, N), 27).to(DEV)
+    try:
+        hip.check(lib.ditto_set_option(b"gemm_tile", 256))
+        for epi in (0, 1, 3, 4):
+            outs = []
+            for fl in (321, 321 + 16384):
+                hip.check(lib.ditto_set_option(b"gemm_flags", fl))
+                ldo = N // 2 if epi == 3 else N
+                out = res.clone() if epi == 1 else torch.zeros(M, ldo, device=DEV,
+                                                               dtype=torch.bfloat16 if epi in (0, 3) else torch.float32)
+                hip.check(lib.ditto_gemm_bf16(A.data_ptr(), K, W.data_ptr(), bias.data_ptr(),
+                                              out.data_ptr() if epi == 1 else None, out.data_ptr(), ldo, M, N, K, epi, stream()))
+                torch.cuda.synchronize()
+                outs.append(out)
+            assert torch.equal(outs[0], outs[1]), (shape, epi, float((outs[0].float() - outs[1].float()).abs().max()))
+            if epi == 4:
+                want = A.float() @ W.float().T + bias
+                assert rel_l2(outs[1], want) < 1e-5
+    finally:
+        hip.check(lib.ditto_set_option(b"gemm_tile", 0))
+        hip.check(lib.ditto_set_option(b"gemm_flags", 321))
+
+
 def test_gemm_identity_asymmetric_256(lib, tile256):
     K = N = 256
     A = bf16(torch.eye(K, device=DEV))

@@ -29,7 +29,7 @@ for (M, N, K) in [(256, 2304, 768), (512, 6144, 768), (1024, 768, 3072), (384, 7
             return out
         ref = run(128, 321)
         for t in [int(x) for x in a.tiles.split(",")]:
-            for fl in (321, 1345):
+            for fl in (321, 1345, 16705, 17729):
                 o = run(t, fl)
                 d = (o.float() - ref.float()).abs().max().item()
                 scale = ref.float().abs().max().item()
