@@ -50,6 +50,23 @@ struct IC { static constexpr int value = V; };
 
 #define DITTO_BAR() asm volatile("s_barrier" ::: "memory")
 
+#ifdef DITTO_DIAG_G256_STAMP   // tools/build_diag.sh: where does a tile spend its cycles?  (s_memtime stamps; timing build only)
+constexpr int G256_STAMP_WAVES = 4096;
+__device__ unsigned long long g_g256_stamps[G256_STAMP_WAVES * 8];   // per wave: tile start | main loop | end barrier + prologue | epilogue | tiles | 1
+DITTO_DEV unsigned long long g256_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define G256_STAMP(var) const unsigned long long var = g256_now()
+#define G256_ACC(i, a, b) st_acc[i] += (b) - (a)
+#else
+#define G256_STAMP(var)
+#define G256_ACC(i, a, b)
+#endif
+
 template <int EPI, bool WIDE, bool FP8>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -250,7 +267,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 
     const bool flat = WIDE && (p.flags & GF_FLAT_K) && nkt >= 2 && (nkt & 1) == 0;
     bool first_tile = true;
+#ifdef DITTO_DIAG_G256_STAMP
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 1, 0, 0}, lb_acc = 0;
+#endif
     for (; tile < ntiles; tile += p.tile_stride) {
+        G256_STAMP(t_top);
+#ifdef DITTO_DIAG_G256_STAMP
+        if (st_acc[6]) lb_acc += t_top - st_acc[6];        // loop back: the previous tile's last stamp -> this top
+#endif
         const int cur_m0 = m0, cur_n0 = n0;
         const int next = tile + p.tile_stride;
         if (flat) {
@@ -282,6 +306,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         first_tile = false;
         DITTO_BAR();
         if (wm == 1) DITTO_BAR();  // stagger the second wave group by one barrier
+        G256_STAMP(t_loop);
 
         if constexpr (WIDE) {
             // Wide-phase schedule: 2 phases of 32 MFMAs per K-tile (half the barriers).  The phase's ds_reads are
@@ -395,6 +420,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
                 DITTO_BAR();
             }
         }
+        G256_STAMP(t_end);
         if (wm == 0) DITTO_BAR();  // balance the stagger barrier: every LDS read of this tile has retired
 
         // next tile's first K-tiles start streaming in now, under this tile's epilogue (flat mode: they are in already)
@@ -411,6 +437,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             prologue(next);
         }
         // ---------------- epilogue ----------------
+        G256_STAMP(t_epi);
+#ifdef DITTO_DIAG_G256_STAMP
+        if (!first_tile || true) { G256_ACC(0, t_top, t_loop); G256_ACC(1, t_loop, t_end); G256_ACC(2, t_end, t_epi); st_acc[4] += 1; st_acc[6] = t_epi; }
+#endif
         prev_interior = (cur_m0 + 256 <= p.M) && (cur_n0 + 256 <= p.N) && !p.out2 &&
                         !(p.flags & (GF_DIAG_NO_STORE | GF_DIAG_NO_EPILOGUE));
         if (p.flags & GF_DIAG_NO_EPILOGUE) {
@@ -428,6 +458,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         } else {
             load_bias(p, cur_n0 + wn * 64, fq, bias4);
         }
+        G256_STAMP(t_bias);
+#ifdef DITTO_DIAG_G256_STAMP
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        { const unsigned long long t_b2 = g256_now(); st_acc[7] += t_b2 - t_epi; (void)t_bias; }
+#endif
         if constexpr (FP8) {   // per-output-column weight scale of the fp8 quantisation
             f32x4 ws4[4];
 #pragma unroll
@@ -472,7 +507,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
                     epilogue_row<EPI>(p, (p.flags & GF_DIAG_SMALL_OUT) ? (row & 255) : row, cur_n0 + wn * 64, acc[m], bias4, fq);
             }
         }
+#ifdef DITTO_DIAG_G256_STAMP
+        { const unsigned long long t_e1 = g256_now(); st_acc[3] += t_e1 - t_epi; st_acc[6] = t_e1; }
+#endif
     }
+#ifdef DITTO_DIAG_G256_STAMP
+    {
+        const unsigned long long t_fin = g256_now();
+        (void)t_fin;
+        st_acc[6] = lb_acc;
+        const int w = blockIdx.x * 8 + wid;
+        if (lane == 0 && w < G256_STAMP_WAVES)
+            for (int i = 0; i < 8; ++i) g_g256_stamps[w * 8 + i] = st_acc[i];
+    }
+#endif
 }
 
 template <int EPI, bool WIDE, bool FP8>
@@ -488,6 +536,18 @@ hipError_t launch256_t(const GemmParams& p, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef DITTO_DIAG_G256_STAMP
+extern "C" int ditto_diag_g256_stamps(unsigned long long* out) {   // sums of the per-wave records of the LAST launch (diagnostic build only)
+    static unsigned long long host[G256_STAMP_WAVES * 8];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_g256_stamps), sizeof(host)) != hipSuccess) return 1;
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    for (int w = 0; w < G256_STAMP_WAVES; ++w)
+        for (int i = 0; i < 8; ++i) out[i] += host[(size_t)w * 8 + i];
+    for (size_t i = 0; i < sizeof(host) / sizeof(host[0]); ++i) host[i] = 0;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_g256_stamps), host, sizeof(host)) != hipSuccess;
+}
+#endif
 
 hipError_t launch_gemm256(const GemmParams& p_in, GemmEpilogue epi, hipStream_t s) {
     // persistent grid: one workgroup per CU (128 KiB LDS each), walking tiles b, b + grid, ...
