@@ -53,9 +53,11 @@ ArenaPlan plan_arena(const ditto_config& c) {
         q.bqkv = take(3 * d * 4); q.bcq = take(d * 4); q.bco = take(d * 4); q.b1g = take(8 * d * 4); q.b2 = take(d * 4);
         q.g1 = take(d * 4); q.be1 = take(d * 4); q.g2 = take(d * 4); q.be2 = take(d * 4); q.g3 = take(d * 4);
         q.be3 = take(d * 4);
-        // stage-major bf16 copies of the two N = d projections for the full-row kernel (gemm_fr.hip; d == 768, bf16 only)
-        const bool fr = d == 768 && !(c.flags & DITTO_CFG_FP8_LINEAR);
-        q.WcoP = fr ? take(d * d * 2) : 0; q.W2P = fr ? take(4 * d * d * 2) : 0;
+        // stage-major bf16 copies of the N = d projections for the full-row kernels (gemm_fr.hip: d == 768, bf16 linears;
+        // gemm_fr64.hip: d == 1024 — the cross out-projection is bf16 in the fp8 configuration too, fc2 only without it)
+        const bool fp8c = (c.flags & DITTO_CFG_FP8_LINEAR) != 0;
+        const bool fr_o = (d == 768 && !fp8c) || d == 1024, fr_2 = (d == 768 || d == 1024) && !fp8c;
+        q.WcoP = fr_o ? take(d * d * 2) : 0; q.W2P = fr_2 ? take(4 * d * d * 2) : 0;
     }
     p.Wkv = take(L * 2 * d * d * 2); p.bkv = take(L * 2 * d * 4);
     p.Wfin = take(d * 2 * d * 2); p.bfin = take(d * 4);
@@ -191,9 +193,10 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
     const LayerPack& lp = m->layers[l];
     // full-row GEMM with the residual add and the FOLLOWING LayerNorm fused (gemm_fr.hip): bit 0 = cross out-proj + norm3,
     // bit 1 = fc2 + the next block's norm1 (ln1_done tells that block its norm1 output is already in u)
-    const bool fr_have = !fp8 && lp.WcoP;
-    const bool fr_out = fr_have && (g_fr_mask & 1) && fr_outproj_ok(M, d);
-    const bool fr_fc2 = fr_have && (g_fr_mask & 2) && fr_fc2_ok(M, d);
+    // (the stage-major weight copies exist exactly where a kernel exists: d = 768 bf16, d = 1024 — there the out-projection
+    // also in the fp8 configuration, with the LayerNorm output written as fp8)
+    const bool fr_out = lp.WcoP && (g_fr_mask & 1) && fr_outproj_ok(M, d);
+    const bool fr_fc2 = !fp8 && lp.W2P && (g_fr_mask & 2) && fr_fc2_ok(M, d);
     const int fr_rot = N % 128 == 0 ? N / 128 : 0;   // tiles per utterance: the K-loop rotation period (gemm_fr.hip)
         // ---- self-attention (src/components/DiT.py:103-139) ----
         if (!ln1_done) {
@@ -245,7 +248,7 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
             GemmParams gp{};
             gp.A = (const bf16*)u; gp.lda = d; gp.W = (const bf16*)lp.WcoP; gp.ldw = d; gp.w_rows = d; gp.bias = lp.bco;
             gp.residual = h; gp.ldr = d; gp.out = h; gp.ldo = d; gp.M = M; gp.N = d; gp.K = d;
-            HIP_TRY(launch_gemm_fr(gp, lp.g3, lp.be3, qkv, d, fr_rot, s));
+            HIP_TRY(launch_gemm_fr(gp, lp.g3, lp.be3, qkv, d, fr_rot, s, fp8));
         } else {
             ProfScope ps(m, s, DITTO_KC_GEMM_OUTPROJ);
             GemmArgs g{};
@@ -383,10 +386,9 @@ int ditto_model_create(const ditto_config* cfg, const ditto_weights* w, void* ar
         HIP_TRY(hipMemcpyAsync(A + plan.bkv + (size_t)l * 2 * d * 4, lw.cross_in_proj_bias + d, 2 * d * 4,
                                hipMemcpyDeviceToDevice, s));
         HIP_TRY(launch_pack_bf16(lw.cross_out_proj_weight, A + q.Wco, d, d, d, 0, BIG, 1, 0, s));
-        if (d == 768 && !fp8) {
-            HIP_TRY(launch_pack_bf16_stage_major(lw.cross_out_proj_weight, A + q.WcoP, d, d, s));
-            HIP_TRY(launch_pack_bf16_stage_major(lw.mlp_fc2_weight, A + q.W2P, d, 4 * d, s));
-        }
+        const bool fr_o = (d == 768 && !fp8) || d == 1024, fr_2 = (d == 768 || d == 1024) && !fp8;   // as plan_arena
+        if (fr_o) HIP_TRY(launch_pack_bf16_stage_major(lw.cross_out_proj_weight, A + q.WcoP, d, d, s));
+        if (fr_2) HIP_TRY(launch_pack_bf16_stage_major(lw.mlp_fc2_weight, A + q.W2P, d, 4 * d, s));
         HIP_TRY(hipMemcpyAsync(A + q.bco, lw.cross_out_proj_bias, d * 4, hipMemcpyDeviceToDevice, s));
         // gated MLP: rows interleaved [16 x fc1 | 16 x gate] so both halves of a product meet in one lane
         HIP_TRY(launch_pack_vec(lw.mlp_fc1_bias, (float*)(A + q.b1g), 4 * d, 16, 2, 0, s));
@@ -402,7 +404,8 @@ int ditto_model_create(const ditto_config* cfg, const ditto_weights* w, void* ar
         lp.bqkv = (const float*)(A + q.bqkv); lp.bcq = (const float*)(A + q.bcq); lp.bco = (const float*)(A + q.bco);
         lp.b1g = (const float*)(A + q.b1g); lp.b2 = (const float*)(A + q.b2);
         lp.sqkv = (const float*)(A + q.sqkv); lp.s1g = (const float*)(A + q.s1g); lp.s2 = (const float*)(A + q.s2);
-        if (d == 768 && !fp8) { lp.WcoP = A + q.WcoP; lp.W2P = A + q.W2P; }
+        if (fr_o) lp.WcoP = A + q.WcoP;
+        if (fr_2) lp.W2P = A + q.W2P;
         lp.g1 = (const float*)(A + q.g1); lp.be1 = (const float*)(A + q.be1); lp.g2 = (const float*)(A + q.g2);
         lp.be2 = (const float*)(A + q.be2); lp.g3 = (const float*)(A + q.g3); lp.be3 = (const float*)(A + q.be3);
     }
@@ -512,7 +515,7 @@ int ditto_forward(ditto_model_t m, const float* x, const void* cond, const int64
         HIP_TRY(launch_adaln(x, m->ttab, tmod, t, c.diffusion_steps, h, xcat, 2 * d, B, N, d, s));
     }
     // fc2 on the full-row kernel also emits the NEXT block's norm1 (fr_mask bit 1): that block then skips its LayerNorm
-    const bool chain_ln1 = (g_fr_mask & 2) && !(c.flags & DITTO_CFG_FP8_LINEAR) && m->layers[0].WcoP && fr_fc2_ok(M, d);
+    const bool chain_ln1 = (g_fr_mask & 2) && !(c.flags & DITTO_CFG_FP8_LINEAR) && m->layers[0].W2P && fr_fc2_ok(M, d);
     for (int l = 0; l < L; ++l)
         if (int rc = run_block(m, l, h, u, qkv, act, l == L - 1 ? xcat : nullptr, attn_ws, w.attn_bytes,
                                (float*)(ws + w.splitk), w.splitk_bytes, kv, l,
@@ -736,12 +739,14 @@ int ditto_gemm_ln_bf16(const void* A, int lda, const void* W, const float* bias,
                        ditto_stream_t stream) {
     if (!A || !W || !out || (gamma == nullptr) != (beta == nullptr) || (gamma == nullptr) != (u_bf16 == nullptr))
         return fail(DITTO_ERR_ARG, "bad argument to ditto_gemm_ln_bf16");
-    if (!gemm_fr_supports(M, N, K, (size_t)lda, (size_t)K) || lda % 8)
-        return fail(DITTO_ERR_SHAPE, "ditto_gemm_ln_bf16 needs N == 768, K %% 64 == 0, M >= 128, lda %% 8 == 0");
+    const bool ok = N == 1024 ? gemm_fr64_supports(M, N, K, (size_t)lda, (size_t)K) : gemm_fr_supports(M, N, K, (size_t)lda, (size_t)K);
+    if (!ok || lda % 8)
+        return fail(DITTO_ERR_SHAPE, "ditto_gemm_ln_bf16 needs N == 768 (M >= 128) or N == 1024 (M >= 64), K %% 64 == 0, lda %% 8 == 0");
     GemmParams p{};
     p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)W; p.ldw = K; p.w_rows = N; p.bias = bias;
     p.residual = residual; p.ldr = ldo; p.out = out; p.ldo = ldo; p.M = M; p.N = N; p.K = K;
-    HIP_TRY(launch_gemm_fr(p, gamma, beta, u_bf16, ldu, g_fr_rot > 1 ? g_fr_rot : 0, (hipStream_t)stream));
+    if (g_fr_u_fp8 && (N != 1024 || !gamma)) return fail(DITTO_ERR_SHAPE, "fr_u_fp8 (test hook) needs N == 1024 and a LayerNorm output");
+    HIP_TRY(launch_gemm_fr(p, gamma, beta, u_bf16, ldu, g_fr_rot > 1 ? g_fr_rot : 0, (hipStream_t)stream, g_fr_u_fp8 != 0));
     return DITTO_OK;
 }
 
@@ -887,6 +892,10 @@ int ditto_set_option(const char* name, int value) {
         g_fr_dgrad = value;
         return DITTO_OK;
     }
+    if (!strcmp(name, "fr_u_fp8")) {   // test hook: ditto_gemm_ln_bf16 writes u as fp8 e4m3 bytes ([M, ldu] bytes; N = 1024)
+        g_fr_u_fp8 = value != 0;
+        return DITTO_OK;
+    }
     if (!strcmp(name, "fr_tile")) {
         if (value != 0 && value != 64 && value != 128) return fail(DITTO_ERR_ARG, "fr_tile must be 0 (rule), 64 or 128");
         g_fr_tile = value;
@@ -930,9 +939,10 @@ int ditto_full_row_plan(const ditto_config* cfg, int B, int N, int* outproj, int
     if (!outproj || !fc2 || B <= 0 || N <= 0) return fail(DITTO_ERR_ARG, "bad argument to ditto_full_row_plan");
     if ((long long)B * N > 0x7fffffffLL) return fail(DITTO_ERR_SHAPE, "B * N exceeds 2^31 - 1 rows");
     const int d = cfg->hidden_dim, M = B * N;
-    const bool have = d == 768 && !(cfg->flags & DITTO_CFG_FP8_LINEAR);   // plan_arena packs the stage-major copies for these
-    *outproj = have && (g_fr_mask & 1) && fr_outproj_ok(M, d);
-    *fc2 = have && (g_fr_mask & 2) && fr_fc2_ok(M, d);
+    const bool fp8c = (cfg->flags & DITTO_CFG_FP8_LINEAR) != 0;          // plan_arena packs the stage-major copies for these:
+    const bool have_o = (d == 768 && !fp8c) || d == 1024, have_2 = (d == 768 || d == 1024) && !fp8c;
+    *outproj = have_o && (g_fr_mask & 1) && fr_outproj_ok(M, d);
+    *fc2 = have_2 && (g_fr_mask & 2) && fr_fc2_ok(M, d);
     return DITTO_OK;
 }
 

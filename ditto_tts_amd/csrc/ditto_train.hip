@@ -256,7 +256,7 @@ int ditto_train_forward(ditto_model_t m, const float* x, const float* text, cons
     // As in the inference forward (ditto_api.hip run_block): from 160 row tiles on, the cross out-projection + norm3 and
     // fc2 + the next block's norm1 run on the full-row kernel (fr_mask); the LayerNorm outputs land in the tape slots the
     // backward reads (u3, the next block's u1).
-    const bool fr_have = m->layers[0].WcoP != nullptr;
+    const bool fr_have = d == 768 && m->layers[0].WcoP != nullptr && m->layers[0].W2P != nullptr;
     const bool fr_out = fr_have && (g_fr_mask & 1) && fr_outproj_ok(M, d);
     const bool fr_fc2 = fr_have && (g_fr_mask & 2) && fr_fc2_ok(M, d);
     const int fr_rot = N % 128 == 0 ? N / 128 : 0;

@@ -43,6 +43,7 @@ int g_fr_rot = [] { const char* e = getenv("DITTO_FR_ROT"); return e ? atoi(e) :
 int g_fr_tile = [] { const char* e = getenv("DITTO_FR_TILE"); return e ? atoi(e) : 0; }();
 int g_fr64_maxk = [] { const char* e = getenv("DITTO_FR64_MAXK"); return e ? atoi(e) : 1 << 30; }();
 int g_fr_stagger = [] { const char* e = getenv("DITTO_FR_STAGGER"); return e ? atoi(e) : 1200; }();
+int g_fr_u_fp8 = 0;
 int g_fr_class_rows = 0;   // kernels.h fr_pays: rows of the unsplit batch whose kernel class every launch takes (0 = its own)
 int g_pp_mask = [] { const char* e = getenv("DITTO_PP_MASK"); return e ? atoi(e) : -1; }();   // -1 = built-in rule
 int g_gemm_tile = [] { const char* e = getenv("DITTO_GEMM"); return e ? atoi(e) : 0; }();

@@ -365,17 +365,26 @@ struct FrParams {
     bf16* u; int ldu;                         // LayerNorm output
     int rot_period;                           // > 0: 128-row tiles t and t + rot_period start their K loop at the same place
     int stagger_ticks;                        // gemm_fr64: start delay (10 ns ticks) of the workgroup holding its CU's second LDS allocation
+    bool u_fp8;                               // gemm_fr64, N = 1024: u is fp8 e4m3 bytes ([M, ldu] bytes) for the fp8 linear path
 };
 bool gemm_fr_supports(int M, int N, int K, size_t lda, size_t ldw);
 hipError_t launch_gemm_fr(const GemmParams& p, const float* gamma, const float* beta, void* u_bf16, int ldu, int rot_period,
-                          hipStream_t s);
+                          hipStream_t s, bool u_fp8 = false);   // u_fp8 (N = 1024 only): u is fp8 e4m3 bytes
 // The two full-row launches of a DiT block over M rows of width d, each judged on the operand strides IT runs with (the
 // kernel builds 32-bit byte offsets from M * lda: fc2 reads A at lda = 4d).  One predicate for the inference forward, the
 // LayerNorm chaining decision and the training forward, so that the three cannot disagree.
 // gemm_fr64.hip: the same contract and the SAME BITS on 64-row tiles, two workgroups per CU (called by launch_gemm_fr)
 hipError_t launch_gemm_fr64(const FrParams& fp, hipStream_t s);
-inline bool fr_outproj_ok(int M, int d) { return fr_pays(M) && gemm_fr_supports(M, d, d, (size_t)d, (size_t)d); }
-inline bool fr_fc2_ok(int M, int d) { return fr_pays(M) && gemm_fr_supports(M, d, 4 * d, (size_t)4 * d, (size_t)4 * d); }
+bool gemm_fr64_supports(int M, int N, int K, size_t lda, size_t ldw);   // N = 768 or 1024
+// d = 768: gemm_fr.hip (or its bit-identical 64-row twin); d = 1024: gemm_fr64.hip only.
+inline bool fr_outproj_ok(int M, int d) {
+    if (d == 1024) return fr_pays_64(M) && gemm_fr64_supports(M, d, d, (size_t)d, (size_t)d);
+    return fr_pays(M) && gemm_fr_supports(M, d, d, (size_t)d, (size_t)d);
+}
+inline bool fr_fc2_ok(int M, int d) {
+    if (d == 1024) return fr_pays_64(M) && gemm_fr64_supports(M, d, 4 * d, (size_t)4 * d, (size_t)4 * d);
+    return fr_pays(M) && gemm_fr_supports(M, d, 4 * d, (size_t)4 * d, (size_t)4 * d);
+}
 // gemm_pp.hip
 bool gemm_pp_supports(const GemmParams& p, GemmEpilogue epi);
 hipError_t launch_gemm_pp(const GemmParams& p, GemmEpilogue epi, hipStream_t s);

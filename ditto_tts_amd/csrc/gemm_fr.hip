@@ -548,7 +548,11 @@ __global__ __launch_bounds__(256, 1) void gemm_fr_kernel(FrParams fp) {
             for (int i = 4 * half; i < 4 * half + 4; ++i) {
                 const int row = srow + 8 * i;
                 const u32x4 hv = *reinterpret_cast<const u32x4*>(hst + row * 128 + ((sq ^ (row & 7)) << 4));
-                if (grow0 + 8 * i < FR_DIAG_M) store16<true, true>(hrow + (size_t)(8 * i) * p.ldo + nb * 32, hv, 0);
+                if (grow0 + 8 * i < FR_DIAG_M) {
+                    // nt: h is not re-read before the next segment's GEMM has streamed its operands through the caches (A/B: gemm_flags bit 64 off = plain stores)
+                    if (p.flags & GF_STORE_NT) store16<true, true>(hrow + (size_t)(8 * i) * p.ldo + nb * 32, hv, 0);
+                    else *reinterpret_cast<u32x4*>(hrow + (size_t)(8 * i) * p.ldo + nb * 32) = hv;
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -589,14 +593,18 @@ bool gemm_fr_supports(int M, int N, int K, size_t lda, size_t ldw) {
 }
 
 hipError_t launch_gemm_fr(const GemmParams& p_in, const float* gamma, const float* beta, void* u_bf16, int ldu,
-                          int rot_period, hipStream_t s) {
+                          int rot_period, hipStream_t s, bool u_fp8) {
     FrParams fp;
     fp.g = p_in;
+    fp.g.flags = g_gemm_flags;
     fp.g.tiles_m = (p_in.M + FM - 1) / FM;
     fp.g.tiles_n = 1;
     fp.gamma = gamma; fp.beta = beta; fp.u = (bf16*)u_bf16; fp.ldu = ldu;
     fp.rot_period = g_fr_rot ? rot_period : 0;
     fp.stagger_ticks = 0;
+    fp.u_fp8 = u_fp8;
+    if (p_in.N == 1024) return launch_gemm_fr64(fp, s);          // d = 1024: 64 x 1024 tiles, one workgroup per CU
+    if (u_fp8) return hipErrorInvalidValue;
     // 64-row tiles, two workgroups per CU (gemm_fr64.hip): bit-identical results, so this is a speed rule only
     if (fr_use_tile64(p_in.M, p_in.K)) {
         fp.stagger_ticks = g_fr_stagger;

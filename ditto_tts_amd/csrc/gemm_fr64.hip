@@ -37,24 +37,41 @@
 //             (per lane ONE chain over a half row — the odd wave of a pair continues the even wave's partial —, + lane ^ 32,
 //             half 0 + half 1): h and u are bit-identical to
 //             gemm_fr.hip's (tests/test_gpu_kernels.py), so the choice between the two kernels is not a numerics class.
+//
+// d = 1024 (BASELINE config C5): the same kernel with NBW = 8 column blocks per wave — a 64 x 1024 tile, 256 accumulators per
+// lane (all in AGPRs), ONE workgroup per CU with the whole register file, a W ring of FOUR 32-KiB stages (136 KiB of LDS),
+// DMA four stages ahead.  M = 16 x 1024 rows make exactly one tile per CU.  There is no 128-row kernel at this width, so
+// nothing pins its bits; U8 = the LayerNorm output as fp8 e4m3 (saturating) for the fp8 linear path's next GEMM.
 #include "gemm_common.h"
 
 namespace ditto {
 
 namespace {
 
-constexpr int HM = 64, HN = 768, HK = 16, HNS = 3;
-constexpr int H_W_BYTES = HN * HK * 2;            // 24 KiB: one K = 16 stage of W
-constexpr int H_WRING = HNS * H_W_BYTES;          // 72 KiB
+constexpr int HM = 64, HK = 16;
 constexpr int H_ASLAB = HM * 32 * 2;              // 4 KiB: 64 rows x 32 k
-constexpr int H_ARING = H_WRING;
-constexpr int H_LDS = H_ARING + 2 * H_ASLAB;      // 80 KiB
-constexpr int H_BIAS = 2 * H_W_BYTES;             // bias row: ring slot 2, until the accumulators are initialised
-constexpr int H_STAGE = 4 * 16384;                // epilogue: 4 x 16 KiB of store staging, then ...
-constexpr int H_GB = H_STAGE;                     // ... gamma | beta rows (6 KiB) ...
-constexpr int H_RED = H_GB + 2 * HN * 4;          // ... row statistics: per-lane partials [2 pairs][2][64] + row sums [2 halves][64] fp32 (<= 2 KiB)
-static_assert(H_RED + 2 * 4 * HM * 4 <= H_WRING, "epilogue overlays fit the idle W ring");
-constexpr int HNA = 4;                            // column blocks (of 6) whose accumulators live in AGPRs
+constexpr int H_STAGE = 4 * 16384;                // epilogue: 4 x 16 KiB of store staging, then gamma | beta rows, then row statistics
+// NBW = 32-column blocks per wave: 6 -> N = 768 (two workgroups per CU), 8 -> N = 1024 (one)
+template <int NBW> struct FH {
+    static constexpr int HN = 128 * NBW;
+    static constexpr int HNS = NBW == 6 ? 3 : 4;                // W ring slots
+    static constexpr int W_BYTES = HN * HK * 2;                 // 24 / 32 KiB: one K = 16 stage of W
+    static constexpr int WRING = HNS * W_BYTES;                 // 72 / 128 KiB
+    static constexpr int ARING = WRING;
+    static constexpr int LDS = ARING + 2 * H_ASLAB;             // 80 / 136 KiB
+    static constexpr int BIAS = (HNS - 1) * W_BYTES;            // bias row: the last ring slot, until the accumulators are initialised
+    static constexpr int GB = H_STAGE;                          // gamma | beta rows (6 / 8 KiB)
+    static constexpr int RED = GB + 2 * HN * 4;                 // per-lane partials [2 pairs][2][64] + row sums [2 halves][64] fp32 (1.5 KiB)
+    static constexpr int HNA = NBW == 6 ? 4 : 8;                // column blocks whose accumulators live in AGPRs (hipcc splits 256 registers 128 / 128)
+    static constexpr int WD = NBW == 6 ? 2 : 4;                 // residual blocks (4 loads each) in flight per wave while the accumulators are initialised
+    static constexpr int WPE = NBW == 6 ? 2 : 1;                // waves per SIMD
+    // loads a wave may leave in flight at the wait of stage s (after NBW - 3 pieces of stage s + HNS went out), derived in
+    // the header for NBW = 6 and the same way for NBW = 8: steady state j = 0 / j = 1, then stages nkt-4, nkt-3
+    static constexpr int VM0 = NBW == 6 ? 10 : 22, VM1 = NBW == 6 ? 9 : 16;
+    static constexpr int VMT4 = NBW == 6 ? 10 : 17, VMT3 = NBW == 6 ? 6 : 3;
+    static constexpr int T4_ISSUES_W = NBW == 6 ? 1 : 0;        // stage nkt-4 still issues W stage nkt-1 with a 3-slot ring
+    static_assert(RED + 3 * 2 * HM * 4 <= WRING, "epilogue overlays fit the idle W ring");
+};
 
 #ifdef DITTO_DIAG_FR_NOSTORE
 #define FH_DIAG_M (p.M - (1 << 30))
@@ -84,8 +101,12 @@ DITTO_DEV void hmfma_v_last(f32x16& c, const bf16x8& w, const bf16x8& a) {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 15" : "+v"(c) : "v"(w), "v"(a));
 }
 
-template <bool LN, bool RES>
-__global__ __launch_bounds__(256, 2) void gemm_fr64_kernel(FrParams fp) {
+template <int NBW, bool LN, bool RES, bool U8>
+__global__ __launch_bounds__(256, FH<NBW>::WPE) void gemm_fr64_kernel(FrParams fp) {
+    constexpr int HN = FH<NBW>::HN, HNS = FH<NBW>::HNS, H_W_BYTES = FH<NBW>::W_BYTES, H_WRING = FH<NBW>::WRING;
+    constexpr int H_ARING = FH<NBW>::ARING, H_BIAS = FH<NBW>::BIAS, H_GB = FH<NBW>::GB, H_RED = FH<NBW>::RED, HNA = FH<NBW>::HNA;
+    constexpr int WCOLS = 32 * NBW, NBP = HN * 4 / 1024;             // a wave's columns; 1-KiB pieces of an fp32 row of N
+    static_assert(!U8 || (LN && NBW % 4 == 0), "fp8 LayerNorm output: four column blocks per 128-B line");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const GemmParams& p = fp.g;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -116,9 +137,9 @@ __global__ __launch_bounds__(256, 2) void gemm_fr64_kernel(FrParams fp) {
     const int pc = ppos ^ ((prow >> 3) & 1);                     // W: source chunk landing at position ppos of row prow
     unsigned vwk = (unsigned)(prow * 32 + pc * 16 + s0 * 4 * H_W_BYTES);
     int w_left = nkt - 4 * s0, a_left = nslab - 2 * s0;           // stages / slabs until the rotated K loop wraps to k = 0
-    const char* wbase[6];                                         // wave-uniform: this wave's own six 32-row pieces
+    const char* wbase[NBW];                                         // wave-uniform: this wave's own six 32-row pieces
 #pragma unroll
-    for (int i = 0; i < 6; ++i) wbase[i] = (const char*)p.W + (size_t)(wid * 6 + i) * 1024;
+    for (int i = 0; i < NBW; ++i) wbase[i] = (const char*)p.W + (size_t)(wid * NBW + i) * 1024;
     unsigned vak;                                                 // A: this wave's piece = rows [16 wid, +16) x 64 B
     {
         const int row = 16 * wid + (lane >> 2);
@@ -126,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fr64_kernel(FrParams fp) {
         ar = ar < p.M ? ar : p.M - 1;
         vak = (unsigned)(((size_t)ar * p.lda + ((lane & 3) ^ ((0 - (row >> 2)) & 3)) * 8) * 2) + (unsigned)(s0 * 128);
     }
-    unsigned w_slot = lds_base + (unsigned)(wid * 6 * 1024);      // LDS address of this wave's pieces in the slot the next stage goes to
+    unsigned w_slot = lds_base + (unsigned)(wid * NBW * 1024);      // LDS address of this wave's pieces in the slot the next stage goes to
     unsigned a_buf = lds_base + H_ARING + (unsigned)(wid * 1024); // ... and of this wave's piece in the buffer the next slab goes to
     auto dma = [&](unsigned voff, const char* base, unsigned dst) {
 #ifndef DITTO_DIAG_FR_NODMA
@@ -151,22 +172,23 @@ __global__ __launch_bounds__(256, 2) void gemm_fr64_kernel(FrParams fp) {
     auto issue_w_stage = [&]() {
         issue_w_piece(HC<0>{}); issue_w_piece(HC<1>{}); issue_w_piece(HC<2>{});
         issue_w_piece(HC<3>{}); issue_w_piece(HC<4>{}); issue_w_piece(HC<5>{});
+        if constexpr (NBW == 8) { issue_w_piece(HC<6>{}); issue_w_piece(HC<7>{}); }
         advance_w();
     };
 
-    // bias row -> ring slot 2 (3 pieces of 1 KiB = 768 fp32): the oldest loads of the kernel
+    // bias row -> the last ring slot (N fp32 = 3 / 4 pieces of 1 KiB): the oldest loads of the kernel
     if (wid == 0) {
         if (p.bias) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) glds16(p.bias + i * 256 + lane * 4, lds_base + (unsigned)(H_BIAS + i * 1024));
+            for (int i = 0; i < NBP; ++i) glds16(p.bias + i * 256 + lane * 4, lds_base + (unsigned)(H_BIAS + i * 1024));
         } else {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) *reinterpret_cast<f32x4*>(smem + H_BIAS + i * 1024 + lane * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < NBP; ++i) *reinterpret_cast<f32x4*>(smem + H_BIAS + i * 1024 + lane * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
     // ---- fragment addressing: lane reads row (lane & 31) of a 32-row block, 16-B half (lane >> 5) ----
     const int r32 = lane & 31, hh = lane >> 5;
-    const int w_off = (wid * 192 + r32) * 32 + ((hh ^ ((r32 >> 3) & 1)) << 4);    // in a W slot: + nb * 1024
+    const int w_off = (wid * WCOLS + r32) * 32 + ((hh ^ ((r32 >> 3) & 1)) << 4);    // in a W slot: + nb * 1024
     const int a_row = r32 * 64;                                                    // + mb * 2048
     const int a_x = (hh ^ ((0 - (r32 >> 2)) & 3)) << 4;                            // stage j of the slab: ^ (j << 5)
 
@@ -174,13 +196,14 @@ __global__ __launch_bounds__(256, 2) void gemm_fr64_kernel(FrParams fp) {
     issue_a_piece(); advance_a();
     issue_a_piece(); advance_a();
     issue_w_stage(); issue_w_stage();
+    if constexpr (HNS == 4) issue_w_stage();
 
     // ---- the accumulators START as bias + residual (gemm_fr.hip: the epilogue then only READS them).  48 hand-written
-    //      global_load_dwordx4 per lane in the accumulator layout, a window of 8 (two 32 x 32 blocks) in flight. ----
+    //      global_load_dwordx4 per lane in the accumulator layout, a window of two (N = 768) or four (N = 1024) 32 x 32 blocks in flight. ----
     const float* lbias = reinterpret_cast<const float*>(smem + H_BIAS);
     const float* lgamma = reinterpret_cast<const float*>(smem + H_GB);     // these two: valid in the epilogue only
     const float* lbeta = lgamma + HN;
-    f32x16 acca[HNA][2], accv[HNA < 6 ? 6 - HNA : 1][2];
+    f32x16 acca[HNA][2], accv[HNA < NBW ? NBW - HNA : 1][2];
     {
         const float* rp[2] = {nullptr, nullptr};
         if constexpr (RES) {
@@ -188,10 +211,11 @@ __global__ __launch_bounds__(256, 2) void gemm_fr64_kernel(FrParams fp) {
             for (int mb = 0; mb < 2; ++mb) {
                 int gr = m0 + mb * 32 + r32;
                 gr = gr < p.M ? gr : p.M - 1;
-                rp[mb] = p.residual + (size_t)gr * p.ldr + wid * 192 + 4 * hh;
+                rp[mb] = p.residual + (size_t)gr * p.ldr + wid * WCOLS + 4 * hh;
             }
         }
-        f32x4 T[2][4];                                               // [window slot][g]
+        constexpr int WD = FH<NBW>::WD, NG = 2 * NBW;                // window depth; groups = (nb, mb) blocks
+        f32x4 T[WD][4];                                              // [window slot][g]
         auto issue_group = [&](auto GI, f32x4 (&t)[4]) {             // the 4 loads of block (nb, mb) = (GI / 2, GI % 2)
             constexpr int nb = decltype(GI)::value >> 1, mb = decltype(GI)::value & 1;
             if constexpr (RES) {
@@ -208,20 +232,19 @@ __global__ __launch_bounds__(256, 2) void gemm_fr64_kernel(FrParams fp) {
                 for (int i = 0; i < 4; ++i) t[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         };
-        auto finish_group = [&](auto GI, auto INFLIGHT, f32x4 (&t)[4]) {
-            constexpr int nb = decltype(GI)::value >> 1, mb = decltype(GI)::value & 1, inflight = decltype(INFLIGHT)::value;
-            if constexpr (RES) {
-                if constexpr (inflight == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3])::"memory");
-                else asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3])::"memory");
-            }
-            if constexpr (nb == 0 && mb == 0) {
+        auto finish_group = [&](auto GI, f32x4 (&t)[4]) {
+            constexpr int gi = decltype(GI)::value, nb = gi >> 1, mb = gi & 1;
+            constexpr int younger = NG - 1 - gi < WD - 1 ? NG - 1 - gi : WD - 1;   // groups issued after this one and still in flight
+            if constexpr (RES)
+                asm volatile("s_waitcnt vmcnt(%4)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]) : "n"(4 * younger) : "memory");
+            if constexpr (gi == 0) {
                 if constexpr (!RES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 FH_BAR();      // every wave is past a wait that covers wave 0's bias row (the oldest load): visible to all
             }
             f32x16 v;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(lbias + wid * 192 + nb * 32 + 8 * g + 4 * hh);
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(lbias + wid * WCOLS + nb * 32 + 8 * g + 4 * hh);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[4 * g + e] = t[g][e] + b4[e];
             }
@@ -229,26 +252,23 @@ __global__ __launch_bounds__(256, 2) void gemm_fr64_kernel(FrParams fp) {
             else { accv[nb < HNA ? 0 : nb - HNA][mb] = v; FH_PIN_V(accv[nb < HNA ? 0 : nb - HNA][mb]); }
             __builtin_amdgcn_sched_barrier(0);
         };
+        auto init_step = [&](auto GI) {
+            constexpr int gi = decltype(GI)::value;
+            finish_group(GI, T[gi % WD]);
+            if constexpr (gi + WD < NG) issue_group(HC<gi + WD>{}, T[gi % WD]);
+        };
         issue_group(HC<0>{}, T[0]); issue_group(HC<1>{}, T[1]);
-        finish_group(HC<0>{}, HC<4>{}, T[0]); issue_group(HC<2>{}, T[0]);
-        finish_group(HC<1>{}, HC<4>{}, T[1]); issue_group(HC<3>{}, T[1]);
-        finish_group(HC<2>{}, HC<4>{}, T[0]); issue_group(HC<4>{}, T[0]);
-        finish_group(HC<3>{}, HC<4>{}, T[1]); issue_group(HC<5>{}, T[1]);
-        finish_group(HC<4>{}, HC<4>{}, T[0]); issue_group(HC<6>{}, T[0]);
-        finish_group(HC<5>{}, HC<4>{}, T[1]); issue_group(HC<7>{}, T[1]);
-        finish_group(HC<6>{}, HC<4>{}, T[0]); issue_group(HC<8>{}, T[0]);
-        finish_group(HC<7>{}, HC<4>{}, T[1]); issue_group(HC<9>{}, T[1]);
-        finish_group(HC<8>{}, HC<4>{}, T[0]); issue_group(HC<10>{}, T[0]);
-        finish_group(HC<9>{}, HC<4>{}, T[1]); issue_group(HC<11>{}, T[1]);
-        finish_group(HC<10>{}, HC<4>{}, T[0]);
-        finish_group(HC<11>{}, HC<0>{}, T[1]);
+        if constexpr (WD == 4) { issue_group(HC<2>{}, T[2]); issue_group(HC<3>{}, T[3]); }
+        init_step(HC<0>{}); init_step(HC<1>{}); init_step(HC<2>{}); init_step(HC<3>{}); init_step(HC<4>{}); init_step(HC<5>{});
+        init_step(HC<6>{}); init_step(HC<7>{}); init_step(HC<8>{}); init_step(HC<9>{}); init_step(HC<10>{}); init_step(HC<11>{});
+        if constexpr (NBW == 8) { init_step(HC<12>{}); init_step(HC<13>{}); init_step(HC<14>{}); init_step(HC<15>{}); }
     }
 
     // slabs 0, 1 and W stages 0, 1 have landed for this wave (older than the residual loads); for everyone, and everyone is
     // done with the bias row in slot 2:
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     FH_BAR();
-    issue_w_stage();             // W stage 2 (nkt >= 4)
+    issue_w_stage();             // the W stage whose slot held the bias row (nkt >= 4)
     unsigned c_off = 0;          // W ring byte offset of the stage being multiplied
     unsigned a_cur = H_ARING;    // byte offset of the A slab being multiplied
     bf16x8 a0[2], a1[2], wf[4];
@@ -271,14 +291,10 @@ __global__ __launch_bounds__(256, 2) void gemm_fr64_kernel(FrParams fp) {
         const char* nxt = smem + n_off;
         const unsigned a_nxt = j == 1 ? (unsigned)(2 * H_ARING + H_ASLAB) - a_cur : a_cur;
 #pragma unroll
-        for (int nb = 0; nb < 6; ++nb) {
-            const int G = 6 * j + nb;
-            if (nb == 3 && has_next) {
-                static_assert(vm == 10 || vm == 9 || vm == 6 || vm == 0, "");
-                if constexpr (vm == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-                else if constexpr (vm == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-                else if constexpr (vm == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int nb = 0; nb < NBW; ++nb) {
+            const int G = NBW * j + nb;
+            if (nb == NBW - 3 && has_next) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(vm) : "memory");
                 if constexpr (j == 1) {
 #ifndef DITTO_DIAG_FR_NOBAR
                     FH_BAR();
@@ -290,8 +306,8 @@ __global__ __launch_bounds__(256, 2) void gemm_fr64_kernel(FrParams fp) {
                     ANXT[mb] = *reinterpret_cast<const bf16x8*>(smem + a_nxt + a_row + mb * 2048 + (a_x ^ (((j + 1) & 1) << 5)));
             }
             // W fragment three ahead: this stage's while it has them, then the next stage's first three
-            if (nb + 3 < 6) wf[(G + 3) & 3] = *reinterpret_cast<const bf16x8*>(cur + w_off + (nb + 3) * 1024);
-            else if (has_next) wf[(G + 3) & 3] = *reinterpret_cast<const bf16x8*>(nxt + w_off + (nb + 3 - 6) * 1024);
+            if (nb + 3 < NBW) wf[(G + 3) & 3] = *reinterpret_cast<const bf16x8*>(cur + w_off + (nb + 3) * 1024);
+            else if (has_next) wf[(G + 3) & 3] = *reinterpret_cast<const bf16x8*>(nxt + w_off + (nb + 3 - NBW) * 1024);
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
                 if constexpr (has_next) {
@@ -309,6 +325,10 @@ __global__ __launch_bounds__(256, 2) void gemm_fr64_kernel(FrParams fp) {
                 if (nb == 3) issue_w_piece(HC<3>{});
                 if (nb == 4) issue_w_piece(HC<4>{});
                 if (nb == 5) issue_w_piece(HC<5>{});
+                if constexpr (NBW == 8) {
+                    if (nb == 6) issue_w_piece(HC<6>{});
+                    if (nb == 7) issue_w_piece(HC<7>{});
+                }
             }
         }
         if constexpr (do_w) advance_w();
@@ -318,11 +338,11 @@ __global__ __launch_bounds__(256, 2) void gemm_fr64_kernel(FrParams fp) {
     // all slabs but the last two: full issue (the waits leave 10 / 9 loads in flight); then the last four stages, in which
     // the issue stops
     for (int sl = 0; sl + 2 < nslab; ++sl) {
-        stage(HC<0>{}, HC<1>{}, HC<1>{}, HC<1>{}, HC<10>{}, a0, a1);
-        stage(HC<1>{}, HC<1>{}, HC<1>{}, HC<1>{}, HC<9>{}, a1, a0);
+        stage(HC<0>{}, HC<1>{}, HC<1>{}, HC<1>{}, HC<FH<NBW>::VM0>{}, a0, a1);
+        stage(HC<1>{}, HC<1>{}, HC<1>{}, HC<1>{}, HC<FH<NBW>::VM1>{}, a1, a0);
     }
-    stage(HC<0>{}, HC<1>{}, HC<0>{}, HC<1>{}, HC<10>{}, a0, a1);   // stage nkt-4: issues W stage nkt-1
-    stage(HC<1>{}, HC<0>{}, HC<0>{}, HC<1>{}, HC<6>{}, a1, a0);    // stage nkt-3
+    stage(HC<0>{}, HC<FH<NBW>::T4_ISSUES_W>{}, HC<0>{}, HC<1>{}, HC<FH<NBW>::VMT4>{}, a0, a1);   // stage nkt-4 (3-slot ring: issues W stage nkt-1)
+    stage(HC<1>{}, HC<0>{}, HC<0>{}, HC<1>{}, HC<FH<NBW>::VMT3>{}, a1, a0);                       // stage nkt-3
     stage(HC<0>{}, HC<0>{}, HC<0>{}, HC<1>{}, HC<0>{}, a0, a1);    // stage nkt-2
     stage(HC<1>{}, HC<0>{}, HC<0>{}, HC<0>{}, HC<0>{}, a1, a0);    // stage nkt-1
 
@@ -335,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fr64_kernel(FrParams fp) {
         if (wid < 2) {
             const float* src = wid == 0 ? fp.gamma : fp.beta;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) glds16(src + i * 256 + lane * 4, lds_base + (unsigned)(H_GB + wid * HN * 4 + i * 1024));
+            for (int i = 0; i < NBP; ++i) glds16(src + i * 256 + lane * 4, lds_base + (unsigned)(H_GB + wid * HN * 4 + i * 1024));
         }
         // Row statistics in gemm_fr.hip's association, bit for bit: there ONE lane sums the 12 column blocks of a half row in
         // one sequential chain; here a half row is split over waves 2 p (blocks 0..5) and 2 p + 1 (blocks 6..11), so the odd
@@ -349,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fr64_kernel(FrParams fp) {
         float* red = part + 2 * 2 * 64;                               // [half][64 rows]
         auto row_chain = [&](auto PASS, float (&c2)[2]) {
 #pragma unroll
-            for (int nb = 0; nb < 6; ++nb)
+            for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb) {
                     // re-pin the block in its home file: the copy below is then a NEW value that cannot be hoisted above this
@@ -404,18 +424,20 @@ __global__ __launch_bounds__(256, 2) void gemm_fr64_kernel(FrParams fp) {
     }
     // stores (gemm_fr.hip): every output row leaves through a wave-private LDS stage so that the stores are whole 128-B
     // lines: h fp32 (nt), u = LN(h) bf16, optional bf16 copy of h.
-    const int cl = wid * 192 + 4 * hh;                             // this lane's column origin; + nb * 32 + 8 g
+    const int cl = wid * WCOLS + 4 * hh;                             // this lane's column origin; + nb * 32 + 8 g
     const float* gl = lgamma + cl;
     const float* bl = lbeta + cl;
     char* hst = smem + wid * 16384;                                 // h stage: [64 rows][128 B]
     char* ust = hst + 8192;                                         // u stage: [64 rows][128 B] = 64 bf16 columns
     const int srow = lane >> 3, sq = lane & 7;                      // read-back: row srow (+ 8 i), 16-B chunk sq
     const int grow0 = m0 + srow;
-    float* hrow = (float*)p.out + (size_t)(grow0 < p.M ? grow0 : 0) * p.ldo + wid * 192 + sq * 4;
-    bf16* urow = fp.u ? fp.u + (size_t)(grow0 < p.M ? grow0 : 0) * fp.ldu + wid * 192 + sq * 8 : nullptr;
-    bf16* orow = p.out2 ? p.out2 + (size_t)(grow0 < p.M ? grow0 : 0) * p.ldo2 + wid * 192 + sq * 8 : nullptr;
+    float* hrow = (float*)p.out + (size_t)(grow0 < p.M ? grow0 : 0) * p.ldo + wid * WCOLS + sq * 4;
+    bf16* urow = fp.u ? fp.u + (size_t)(grow0 < p.M ? grow0 : 0) * fp.ldu + wid * WCOLS + sq * 8 : nullptr;
+    bf16* orow = p.out2 ? p.out2 + (size_t)(grow0 < p.M ? grow0 : 0) * p.ldo2 + wid * WCOLS + sq * 8 : nullptr;
+    // U8: u is fp8 e4m3, [M, ldu] BYTES; a staged 128-B line holds four column blocks
+    unsigned char* u8row = U8 && fp.u ? (unsigned char*)fp.u + (size_t)(grow0 < p.M ? grow0 : 0) * fp.ldu + wid * WCOLS + sq * 16 : nullptr;
 #pragma unroll
-    for (int nb = 0; nb < 6; ++nb) {
+    for (int nb = 0; nb < NBW; ++nb) {
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
             if (nb < HNA) FH_PIN_A(acca[nb < HNA ? nb : 0][mb]); else FH_PIN_V(accv[nb < HNA ? 0 : nb - HNA][mb]);
@@ -436,9 +458,15 @@ __global__ __launch_bounds__(256, 2) void gemm_fr64_kernel(FrParams fp) {
                 *reinterpret_cast<f32x4*>(hst + row * 128 + (((2 * g + hh) ^ (row & 7)) << 4)) = v4;
                 f32x4 y = v4;                                        // bf16 side: LayerNorm output, or the plain copy
                 if constexpr (LN) y = (v4 - mean[mb]) * rstd[mb] * g4 + b4;
-                u32x2 st;
-                st[0] = pack_bf16x2(y[0], y[1]); st[1] = pack_bf16x2(y[2], y[3]);
-                *reinterpret_cast<u32x2*>(ust + row * 128 + ((((nb & 1) * 4 + g) ^ (row & 7)) << 4) + hh * 8) = st;
+                if constexpr (U8) {
+                    // fp8: column 8 g + 4 hh of block nb is byte (nb & 3) * 32 + 8 g + 4 hh of the 128-column line
+                    *reinterpret_cast<unsigned*>(ust + row * 128 + ((((nb & 3) * 2 + (g >> 1)) ^ (row & 7)) << 4) + (g & 1) * 8 + hh * 4) =
+                        pack_fp8x4(y[0], y[1], y[2], y[3]);
+                } else {
+                    u32x2 st;
+                    st[0] = pack_bf16x2(y[0], y[1]); st[1] = pack_bf16x2(y[2], y[3]);
+                    *reinterpret_cast<u32x2*>(ust + row * 128 + ((((nb & 1) * 4 + g) ^ (row & 7)) << 4) + hh * 8) = st;
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -448,11 +476,15 @@ __global__ __launch_bounds__(256, 2) void gemm_fr64_kernel(FrParams fp) {
             for (int i = 4 * half; i < 4 * half + 4; ++i) {
                 const int row = srow + 8 * i;
                 const u32x4 hv = *reinterpret_cast<const u32x4*>(hst + row * 128 + ((sq ^ (row & 7)) << 4));
-                if (grow0 + 8 * i < FH_DIAG_M) store16<true, true>(hrow + (size_t)(8 * i) * p.ldo + nb * 32, hv, 0);
+                if (grow0 + 8 * i < FH_DIAG_M) {
+                    // nt: h is not re-read before the next segment's GEMM has streamed its operands through the caches (A/B: gemm_flags bit 64 off = plain stores)
+                    if (p.flags & GF_STORE_NT) store16<true, true>(hrow + (size_t)(8 * i) * p.ldo + nb * 32, hv, 0);
+                    else *reinterpret_cast<u32x4*>(hrow + (size_t)(8 * i) * p.ldo + nb * 32) = hv;
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (nb & 1) {
+        if (U8 ? (nb & 3) == 3 : (nb & 1)) {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -460,7 +492,8 @@ __global__ __launch_bounds__(256, 2) void gemm_fr64_kernel(FrParams fp) {
                     const int row = srow + 8 * i;
                     const u32x4 uv = *reinterpret_cast<const u32x4*>(ust + row * 128 + ((sq ^ (row & 7)) << 4));
                     if (grow0 + 8 * i < FH_DIAG_M) {
-                        if (LN) *reinterpret_cast<u32x4*>(urow + (size_t)(8 * i) * fp.ldu + (nb - 1) * 32) = uv;
+                        if constexpr (U8) *reinterpret_cast<u32x4*>(u8row + (size_t)(8 * i) * fp.ldu + (nb - 3) * 32) = uv;
+                        else if (LN) *reinterpret_cast<u32x4*>(urow + (size_t)(8 * i) * fp.ldu + (nb - 1) * 32) = uv;
                         else if (orow) *reinterpret_cast<u32x4*>(orow + (size_t)(8 * i) * p.ldo2 + (nb - 1) * 32) = uv;
                     }
                 }
@@ -472,23 +505,41 @@ __global__ __launch_bounds__(256, 2) void gemm_fr64_kernel(FrParams fp) {
     }
 }
 
-template <bool LN, bool RES>
+template <int NBW, bool LN, bool RES, bool U8>
 hipError_t launch_fr64_t(const FrParams& fp, int grid, hipStream_t s) {
     static DevOnce lds_once;
-    if (hipError_t e = set_max_lds_once(lds_once, {reinterpret_cast<const void*>(&gemm_fr64_kernel<LN, RES>)}, H_LDS)) return e;
-    hipLaunchKernelGGL((gemm_fr64_kernel<LN, RES>), dim3(grid), dim3(256), H_LDS, s, fp);
+    if (hipError_t e = set_max_lds_once(lds_once, {reinterpret_cast<const void*>(&gemm_fr64_kernel<NBW, LN, RES, U8>)}, FH<NBW>::LDS)) return e;
+    hipLaunchKernelGGL((gemm_fr64_kernel<NBW, LN, RES, U8>), dim3(grid), dim3(256), FH<NBW>::LDS, s, fp);
     return hipGetLastError();
 }
 
 }  // namespace
 
+bool gemm_fr64_supports(int M, int N, int K, size_t lda, size_t ldw) {
+    if ((N != 768 && N != 1024) || K % 64 || K < 64 || M < HM) return false;
+    if ((size_t)M * lda * 2 >= (1ull << 32) || (size_t)N * ldw * 2 >= (1ull << 32)) return false;
+    return true;
+}
+
+// fp.u_fp8: the LayerNorm output is fp8 e4m3 bytes (N = 1024 only)
 hipError_t launch_gemm_fr64(const FrParams& fp_in, hipStream_t s) {
     FrParams fp = fp_in;
     fp.g.tiles_m = (fp.g.M + HM - 1) / HM;
     fp.g.tiles_n = 1;
     const bool ln = fp.gamma && fp.u, res = fp.g.residual != nullptr;
-    if (ln) return res ? launch_fr64_t<true, true>(fp, fp.g.tiles_m, s) : launch_fr64_t<true, false>(fp, fp.g.tiles_m, s);
-    return res ? launch_fr64_t<false, true>(fp, fp.g.tiles_m, s) : launch_fr64_t<false, false>(fp, fp.g.tiles_m, s);
+    const int grid = fp.g.tiles_m;
+    if (fp.g.N == 1024) {
+        fp.stagger_ticks = 0;                // one workgroup per CU
+        if (fp.u_fp8) {
+            if (!ln) return hipErrorInvalidValue;
+            return res ? launch_fr64_t<8, true, true, true>(fp, grid, s) : launch_fr64_t<8, true, false, true>(fp, grid, s);
+        }
+        if (ln) return res ? launch_fr64_t<8, true, true, false>(fp, grid, s) : launch_fr64_t<8, true, false, false>(fp, grid, s);
+        return res ? launch_fr64_t<8, false, true, false>(fp, grid, s) : launch_fr64_t<8, false, false, false>(fp, grid, s);
+    }
+    if (fp.g.N != 768 || fp.u_fp8) return hipErrorInvalidValue;
+    if (ln) return res ? launch_fr64_t<6, true, true, false>(fp, grid, s) : launch_fr64_t<6, true, false, false>(fp, grid, s);
+    return res ? launch_fr64_t<6, false, true, false>(fp, grid, s) : launch_fr64_t<6, false, false, false>(fp, grid, s);
 }
 
 }  // namespace ditto

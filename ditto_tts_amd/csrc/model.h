@@ -20,7 +20,7 @@ inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct LayerPack {
     const void *Wqkv, *Wcq, *Wco, *W1g, *W2;
-    const void *WcoP = nullptr, *W2P = nullptr;   // stage-major copies for the full-row kernel (d == 768, bf16 path)
+    const void *WcoP = nullptr, *W2P = nullptr;   // stage-major copies for the full-row kernels (d == 768 bf16; d == 1024: WcoP always, W2P bf16)
     const float *sqkv, *s1g, *s2;   // fp8 weight scales (DITTO_CFG_FP8_LINEAR)
     const float *bqkv, *bcq, *bco, *b1g, *b2;
     const float *g1, *be1, *g2, *be2, *g3, *be3;

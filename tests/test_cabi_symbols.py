@@ -103,6 +103,13 @@ def test_full_row_plan_is_judged_per_launch_and_pinnable():
     finally:
         hip.set_option("fr_mask", 3)
         hip.set_option("fr_class_rows", 0)
-    assert hip.full_row_plan(PRESETS["C5"]["cfg"], 32, 1024) == (False, False)      # d = 1024 / fp8: no full-row weights
+    # d = 1024 (BASELINE config C5) runs the 64-row kernel (csrc/gemm_fr64.hip), judged on 64-row tiles (>= 192 of them).  Its
+    # cross out-projection is bf16 in the fp8 configuration too (LayerNorm output written as fp8); fc2 only in the bf16 one.
+    c5 = PRESETS["C5"]["cfg"]
+    assert hip.full_row_plan(c5, 16, 1024) == (True, False)
+    assert hip.full_row_plan(c5, 8, 1024) == (False, False)
+    c5b = PRESETS["C5_bf16"]["cfg"]
+    assert hip.full_row_plan(c5b, 16, 1024) == (True, True)
+    assert hip.full_row_plan(c5b, 11, 1024) == (False, False)
     with pytest.raises(hip.DittoHipError):
         hip.set_option("fr_class_rows", -1)

@@ -480,6 +480,60 @@ def test_full_row_gemm_with_fused_layernorm(lib, M, K, ln, rot):
                                   K, stream()) == hip.ERR_SHAPE
 
 
+@pytest.mark.parametrize("M,K,ln,res", [(64, 1024, True, True), (300, 256, True, True), (1024, 4096, True, True), (257, 64, False, True),
+                                          (1000, 128, True, False), (515, 192, True, True), (4096, 1024, True, True),
+                                          (2048, 4096, False, True)])
+@pytest.mark.parametrize("rot", [0, 8, 3])
+def test_full_row_gemm_at_width_1024(lib, M, K, ln, res, rot):
+    """csrc/gemm_fr64.hip at N = 1024 (BASELINE config C5: 64 x 1024 tiles, one workgroup per CU, W ring of four stages, all
+    accumulators in AGPRs): out = residual + A W^T + bias in place and u = LayerNorm(out) against the fp32 ops; ragged M,
+    one to 64 K slabs, K-loop rotation, with / without residual and LayerNorm, run-to-run determinism; the LayerNorm output
+    also as fp8 e4m3 (the fp8 linear path's next operand) against the bf16 one."""
+    N = 1024
+    hip.check(lib.ditto_set_option(b"fr_rot", rot))
+    A = bf16(asym((M, K), 34).to(DEV))
+    W = bf16((asym((N, K), 35) / math.sqrt(K)).to(DEV))
+    Wp = W.view(N, K // 16, 16).permute(1, 0, 2).contiguous()
+    bias = (0.1 * asym((N,), 36)).to(DEV)
+    r0 = asym((M, N), 37).to(DEV)
+    g = (1 + 0.1 * asym((N,), 38)).to(DEV)
+    b = (0.1 * asym((N,), 39)).to(DEV)
+    want = A.float() @ W.float().T + bias + (r0 if res else 0)
+    wu = torch.nn.functional.layer_norm(want, (N,), g, b, 1e-5)
+    first = None
+    try:
+        for rep in range(3):
+            h = r0.clone() if res else torch.full((M, N), 7.0, device=DEV)
+            u = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+            hip.check(lib.ditto_gemm_ln_bf16(A.data_ptr(), K, Wp.data_ptr(), bias.data_ptr(), h.data_ptr() if res else None,
+                                             h.data_ptr(), N, g.data_ptr() if ln else None, b.data_ptr() if ln else None,
+                                             u.data_ptr() if ln else None, N, M, N, K, stream()))
+            torch.cuda.synchronize()
+            assert rel_l2(h, want) < 1e-5 and max_abs(h, want) < 3e-4
+            if ln:
+                assert max_abs(u.float(), wu) < 4e-2 and rel_l2(u.float(), wu) < 4e-3      # bf16 output
+            if first is None:
+                first = (h.clone(), u.clone())
+            else:
+                assert torch.equal(h, first[0]) and torch.equal(u, first[1])
+        if ln:
+            hip.check(lib.ditto_set_option(b"fr_u_fp8", 1))
+            h8 = r0.clone() if res else torch.full((M, N), 7.0, device=DEV)
+            u8 = torch.zeros(M, N, dtype=torch.uint8, device=DEV)
+            hip.check(lib.ditto_gemm_ln_bf16(A.data_ptr(), K, Wp.data_ptr(), bias.data_ptr(), h8.data_ptr() if res else None,
+                                             h8.data_ptr(), N, g.data_ptr(), b.data_ptr(), u8.data_ptr(), N, M, N, K, stream()))
+            torch.cuda.synchronize()
+            assert torch.equal(h8, first[0])
+            got8 = u8.view(torch.float8_e4m3fn).float()
+            ref8 = wu.clamp(-448, 448).to(torch.float8_e4m3fn).float()       # one e4m3 rounding of the fp32 LayerNorm
+            # the kernel rounds ITS fp32 y (1e-6 from the reference's): a different e4m3 neighbour only at ties
+            assert float((got8 != ref8).float().mean()) < 2e-3
+            assert max_abs(got8, wu.clamp(-448, 448)) < 0.07 * (1 + float(wu.abs().max()))
+    finally:
+        hip.check(lib.ditto_set_option(b"fr_u_fp8", 0))
+        hip.check(lib.ditto_set_option(b"fr_rot", 1))
+
+
 @pytest.mark.parametrize("M,K,ln,res", [(128, 768, True, True), (300, 256, True, True), (1024, 3072, True, True),
                                           (257, 64, False, True), (1000, 128, True, False), (515, 192, True, True),
                                           (4096, 768, True, True), (2048, 3072, False, True)])

@@ -7,6 +7,7 @@ derived from the reference's own bf16-vs-fp32 spread of 9.5e-3 at 12 layers):
 import pytest
 import torch
 
+from ditto_tts_amd import hip
 from ditto_tts_amd.config import PRESETS, DiTTOConfig
 from ditto_tts_amd.modules import DiT, DiTTO
 from ditto_tts_amd.sampler import SpeechGenerator
@@ -510,6 +511,37 @@ def test_c5_fp8_linear_against_oracle():
     assert r16 < RTOL
     assert r8 < 6e-2
     assert r8 > r16          # the fp8 path really ran
+
+
+@torch.no_grad()
+def test_c5_width_takes_the_full_row_path_against_oracle():
+    """d = 1024 on the full-row kernel (csrc/gemm_fr64.hip at N = 1024): cross out-projection + residual + norm3 in both
+    configurations (fp8: norm3 written as fp8), fc2 + residual + the next block's norm1 in the bf16 one.  The kernel class is
+    pinned to C5's batch (16 x 1024 rows) so that a size the oracle finishes in seconds takes the path; same stated
+    tolerances as the unfused path (bf16 2e-2, fp8 6e-2), and fused vs unfused within bf16-path noise."""
+    from oracle import ditto_oracle as O
+    L = 4
+    cfg16 = DiTTOConfig(1024, L, 16, 256, 1024, 50)
+    sd = synthetic_state_dict(cfg16, 6)
+    x, text, t = synthetic_inputs(cfg16, 2, 256, 192, seed=4)
+    want = O.ditto_forward(sd, L, 16, x, text, t)
+    for fp8 in (False, True):
+        cfg = DiTTOConfig(1024, L, 16, 256, 1024, 50, fp8_linear=fp8)
+        m = DiTTO(1024, L, 16, 256, 1024, 50, fp8_linear=fp8)
+        m.load_state_dict(sd)
+        m = m.to(DEV).eval()
+        plain = m(x.to(DEV), text.to(DEV), t.to(DEV))
+        assert hip.full_row_plan(cfg, 2, 256) == (False, False)
+        with hip.batch_class(16 * 1024):
+            assert hip.full_row_plan(cfg, 2, 256) == (True, not fp8)
+            fused = m(x.to(DEV), text.to(DEV), t.to(DEV))
+            assert torch.equal(fused, m(x.to(DEV), text.to(DEV).clone(), t.to(DEV)))
+        r_plain, r_fused, r_pair = rel_l2(plain, want), rel_l2(fused, want), rel_l2(fused, plain)
+        print(f"d=1024 {L}L fp8={fp8}: unfused rel-L2 {r_plain:.3e}, full-row {r_fused:.3e}, fused vs unfused {r_pair:.3e}")
+        assert r_fused < (6e-2 if fp8 else RTOL)
+        assert r_pair < (4e-2 if fp8 else 6e-3)
+        assert not torch.equal(fused, plain)       # the other kernels really ran
+        del m
 
 
 def test_standalone_blocks_are_forward_only():
