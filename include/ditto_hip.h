@@ -225,12 +225,13 @@ int ditto_attention_bf16(const void* q, int ldq, const void* k, int ldk, const v
 /* scratch bytes ditto_attention_bf16 needs (0 for the fused dh = 64 kernel) */
 size_t ditto_attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh);
 
-/* Full-row GEMM with the residual add and the FOLLOWING LayerNorm fused (N = 768 only; csrc/gemm_fr.hip):
- *   out fp32 [M,768] = residual + A[M,K] W[768,K]^T + bias   (residual may alias out: the in-place stream update of
+/* Full-row GEMM with the residual add and the FOLLOWING LayerNorm fused (N = 768: csrc/gemm_fr.hip, M >= 128, or its
+ * bit-identical 64-row twin csrc/gemm_fr64.hip under "fr_tile" 64; N = 1024: csrc/gemm_fr64.hip, M >= 64):
+ *   out fp32 [M,N] = residual + A[M,K] W[N,K]^T + bias   (residual may alias out: the in-place stream update of
  *   src/components/DiT.py:148 / :155),   u bf16 [M,ldu] = LayerNorm(out) * gamma + beta  (eps 1e-5; the norm of :152 / the
- *   next block's :105).  gamma = beta = u = NULL: no LayerNorm output.  K % 64 == 0, M >= 128.
- *   W is NOT the nn.Linear image: it is packed stage-major, Wp[K/16][768][16] (Wp[s][n][j] = W[n][16 s + j]), so that
- *   each K-step's 24 KiB are contiguous (the kernel moves them by LDS-DMA in whole cache lines). */
+ *   next block's :105).  gamma = beta = u = NULL: no LayerNorm output.  K % 64 == 0.
+ *   W is NOT the nn.Linear image: it is packed stage-major, Wp[K/16][N][16] (Wp[s][n][j] = W[n][16 s + j]), so that
+ *   each K-step's 24 / 32 KiB are contiguous (the kernel moves them by LDS-DMA in whole cache lines). */
 int ditto_gemm_ln_bf16(const void* A, int lda, const void* W, const float* bias, const float* residual, float* out,
                        int ldo, const float* gamma, const float* beta, void* u_bf16, int ldu, int M, int N, int K,
                        ditto_stream_t stream);
@@ -255,6 +256,11 @@ int ditto_gemm_tn_bf16(const void* X, int ldx, const void* Y, int ldy, float* ou
  * whether its launch took it — a function of the launch's row count (>= 160 tiles of 128 rows).  A caller that splits ONE batch
  * over several launches or GPUs sets this to the rows (B * N) of the unsplit batch: every launch then decides as that batch
  * would and sharding changes no bit (ditto_tts_amd/dist.py sample_sharded does).  0 (default) = each launch on its own rows.
+ * "fr_tile": which N = 768 full-row kernel: 0 / 128 = 128-row tiles, one workgroup per CU (csrc/gemm_fr.hip); 64 = 64-row tiles,
+ * two workgroups per CU (csrc/gemm_fr64.hip) for launches with K <= "fr64_maxk"; the results are bit-identical.  "fr_stagger":
+ * start delay of a CU's second workgroup in that kernel, 10 ns ticks.  (N = 1024 always runs csrc/gemm_fr64.hip.)
+ * "fr_u_fp8": TEST HOOK: ditto_gemm_ln_bf16 at N = 1024 writes u as fp8 e4m3 bytes ([M, ldu] bytes), the form the fp8 linear
+ * path's model forward uses for norm3.
  * "fr_dgrad": training backward, the long-K dgrads (N = d = 768) on the same kernel: bit 0 = fc1|gate (K = 8d), bit 1 = QKV.
  * "fr_rot": that kernel's K-loop rotation (tiles start their k sum at different places so that the workgroups of an XCD do
  * not all ask the L2 for the same weight lines at once): 0 = off, 1 = on in the model path with period = row tiles per
@@ -263,7 +269,8 @@ int ditto_gemm_tn_bf16(const void* X, int ldx, const void* Y, int ldy, float* ou
  * "pp_nb": tile width of the ping-pong kernel's plain epilogues: 0 = rule, 3 = 128x192, 4 = 128x256.
  * "pp_stagger": phase offset between the two workgroups of a CU in the ping-pong GEMM, 10 ns ticks (-1 = built-in rule).
  * "gemm_flags": bit mask for kernel experiments (bit 0 = relaxed tile-start wait, default on; bits 1, 2 are
- * DIAGNOSTIC timing switches that skip stores / the epilogue and produce WRONG results — tools/ only).
+ * DIAGNOSTIC timing switches that skip stores / the epilogue and produce WRONG results — tools/ only; bit 14 = 16384: the
+ * persistent 256x256 kernel runs its K loop flat over the tile switch, bit-identical results).
  * "gemm_group": forced super-column width of the GEMM tile order (A/B tool; 0 = the built-in rule, which a sweep of
  * 3 / 4 / 6 / 12 / 24 at C2 B = 32 did not beat).
  * "splitk_wgs": low-latency mode for batches of 1-2 utterances: workgroups the long-K GEMMs (fc2, final projection)
