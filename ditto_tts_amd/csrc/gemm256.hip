@@ -67,8 +67,13 @@ DITTO_DEV unsigned long long g256_now() {
 #define G256_ACC(i, a, b)
 #endif
 
-template <int EPI, bool WIDE, bool FP8>
+// FLAT is a TEMPLATE parameter on purpose: as a run-time mode its three extra scalars (next tile origin, "a next tile
+// exists") cost the default kernel 15 % — the main loop is at the SGPR limit, and the spills (v_writelane / v_readlane) landed
+// inside it: same-box A/B gated GEMM 275 -> 318 us, QKV 127 -> 146 us, step 11.9 -> 12.6 ms, found only against the previous
+// round's library, because an A/B of the FLAG inside the new build compares two equally slowed kernels.
+template <int EPI, bool WIDE, bool FP8, bool FLAT = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
+    static_assert(!FLAT || WIDE, "the flat K loop exists for the wide-phase schedule");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -95,6 +100,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         constexpr int half = decltype(HALF)::value;
         int om = m0, on = n0;
         if (kt >= nkt) {          // wave-uniform; the waits below account for it
+            if constexpr (!FLAT) return;
             if (!flat_next) return;
             kt -= nkt; om = nm0; on = nn0;
         }
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
     }
 
-    const bool flat = WIDE && (p.flags & GF_FLAT_K) && nkt >= 2 && (nkt & 1) == 0;
+    constexpr bool flat = FLAT;   // the launcher picks the instantiation (GF_FLAT_K, even K-tile count)
     bool first_tile = true;
 #ifdef DITTO_DIAG_G256_STAMP
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 1, 0, 0}, lb_acc = 0;
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 #endif
         const int cur_m0 = m0, cur_n0 = n0;
         const int next = tile + p.tile_stride;
-        if (flat) {
+        if constexpr (flat) {
             flat_next = next < ntiles;
             if (flat_next) {
                 int tm, tn;
@@ -331,7 +337,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
                 read_A(0, IC<1>{});
                 stage(0, IC<2>{}, te + 2);
                 stage(0, IC<3>{}, te + 2);
-                wait_dma(te + 2 < nkt || flat_next);
+                wait_dma(te + 2 < nkt || (FLAT && flat_next));
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 DITTO_BAR();
                 mma(IC<1>{}, IC<1>{});
@@ -354,7 +360,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
                 read_A(1, IC<1>{});
                 stage(1, IC<2>{}, to + 2);
                 stage(1, IC<3>{}, to + 2);
-                wait_dma(to + 2 < nkt || flat_next);
+                wait_dma(to + 2 < nkt || (FLAT && flat_next));
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 DITTO_BAR();
                 if (odd_valid) {
@@ -431,7 +437,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         const bool fast_epi = epilogue_fast_ok<EPI>(p, cur_m0, cur_n0, 256, 256) && !(p.flags & GF_DIAG_NO_EPILOGUE) &&
                               (!FP8 || p.wscale);
         const unsigned cur_bias_slot = bias_slot;
-        if (flat) {
+        if constexpr (flat) {
             if (flat_next) { stage_bias(nn0); m0 = nm0; n0 = nn0; }
         } else if (next < ntiles) {
             prologue(next);
@@ -523,16 +529,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 #endif
 }
 
-template <int EPI, bool WIDE, bool FP8>
+template <int EPI, bool WIDE, bool FP8, bool FLAT = false>
 hipError_t launch256_tw(const GemmParams& p, hipStream_t s) {
     static DevOnce lds_once;
-    if (hipError_t e = set_max_lds_once(lds_once, {reinterpret_cast<const void*>(&gemm256_kernel<EPI, WIDE, FP8>)}, LDS256_ALLOC)) return e;
-    hipLaunchKernelGGL((gemm256_kernel<EPI, WIDE, FP8>), dim3(p.tile_stride), dim3(512), LDS256_ALLOC, s, p);
+    if (hipError_t e = set_max_lds_once(lds_once, {reinterpret_cast<const void*>(&gemm256_kernel<EPI, WIDE, FP8, FLAT>)}, LDS256_ALLOC)) return e;
+    hipLaunchKernelGGL((gemm256_kernel<EPI, WIDE, FP8, FLAT>), dim3(p.tile_stride), dim3(512), LDS256_ALLOC, s, p);
     return hipGetLastError();
 }
 template <int EPI>
 hipError_t launch256_t(const GemmParams& p, hipStream_t s) {
-    return (p.flags & GF_WIDE_PHASE) ? launch256_tw<EPI, true, false>(p, s) : launch256_tw<EPI, false, false>(p, s);
+    if (!(p.flags & GF_WIDE_PHASE)) return launch256_tw<EPI, false, false>(p, s);
+    const int nkt = p.K / 64;
+    if ((p.flags & GF_FLAT_K) && nkt >= 2 && (nkt & 1) == 0) return launch256_tw<EPI, true, false, true>(p, s);   // opt-in experiment
+    return launch256_tw<EPI, true, false>(p, s);
 }
 
 }  // namespace

@@ -548,11 +548,7 @@ __global__ __launch_bounds__(256, 1) void gemm_fr_kernel(FrParams fp) {
             for (int i = 4 * half; i < 4 * half + 4; ++i) {
                 const int row = srow + 8 * i;
                 const u32x4 hv = *reinterpret_cast<const u32x4*>(hst + row * 128 + ((sq ^ (row & 7)) << 4));
-                if (grow0 + 8 * i < FR_DIAG_M) {
-                    // nt: h is not re-read before the next segment's GEMM has streamed its operands through the caches (A/B: gemm_flags bit 64 off = plain stores)
-                    if (p.flags & GF_STORE_NT) store16<true, true>(hrow + (size_t)(8 * i) * p.ldo + nb * 32, hv, 0);
-                    else *reinterpret_cast<u32x4*>(hrow + (size_t)(8 * i) * p.ldo + nb * 32) = hv;
-                }
+                if (grow0 + 8 * i < FR_DIAG_M) store16<true, true>(hrow + (size_t)(8 * i) * p.ldo + nb * 32, hv, 0);   // nt (a run-time plain / nt switch here cost the K = 768 launch 5 us: the branch splits the store block; the A/B itself: no gain from plain stores)
             }
             __builtin_amdgcn_sched_barrier(0);
         }

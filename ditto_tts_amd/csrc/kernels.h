@@ -62,8 +62,10 @@ hipError_t launch_repack_bf16_stage_major(const void* src_bf16, void* dst, int N
 // launch decide as that batch would (dist.sample_sharded and SpeechGenerator's seeds= path do it), so that sharding
 // changes no bit; 0 (default) = decide on the launch's own rows.  fr_mask 0 gives one class outright.
 extern int g_fr_class_rows;   // gemm.hip
+extern int g_fr_tile;
 inline bool fr_pays(int M) {
     const int rows = g_fr_class_rows > 0 ? g_fr_class_rows : M;
+    if (g_fr_tile == 64) return (rows + 63) / 64 >= 160;   // EXPERIMENT (fr_tile 64): the 64-row kernel fills the chip from half the rows on
     return (rows + 127) / 128 >= 160;
 }
 
@@ -75,7 +77,7 @@ inline bool fr_pays_64(int M) {
 
 extern int g_fr_dgrad;   // gemm.hip: training backward, long-K dgrads on the full-row kernel: bit 0 fc1|gate (K = 8d), bit 1 QKV (K = 3d)
 extern int g_fr_rot;     // gemm.hip: full-row kernel's K-loop rotation: 0 off, 1 on in the model (period = tiles per utterance), > 1 = period for ditto_gemm_ln_bf16 too
-extern int g_fr_tile;    // gemm.hip: full-row kernel's tile: 0 = rule, 64 = gemm_fr64.hip for every launch with K <= g_fr64_maxk, 128 = gemm_fr.hip
+// g_fr_tile (declared above): gemm.hip: full-row kernel's tile: 0 = rule, 64 = gemm_fr64.hip for every launch with K <= g_fr64_maxk, 128 = gemm_fr.hip
 extern int g_fr64_maxk;  // gemm.hip: longest K that takes the 64-row kernel when fr_tile = 64
 extern int g_fr_u_fp8;   // gemm.hip: test hook (ditto_set_option("fr_u_fp8")): ditto_gemm_ln_bf16 writes the LayerNorm output as fp8
 extern int g_fr_stagger; // gemm.hip: gemm_fr64's start delay of the second workgroup of a CU (10 ns ticks)

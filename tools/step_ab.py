@@ -46,9 +46,10 @@ wall = {v: [] for v in variants}
 def select(v):
     v, _, ft = v.partition("+")          # ...+fr_tile.fr64_maxk.fr_stagger (64-row full-row kernel: gemm_fr64.hip; default: the rule)
     ftv = [int(x) for x in ft.split(".")] if ft else []
-    hip.check(lib.ditto_set_option(b"fr_tile", ftv[0] if len(ftv) > 0 else 0))
-    hip.check(lib.ditto_set_option(b"fr64_maxk", ftv[1] if len(ftv) > 1 else 1 << 30))
-    hip.check(lib.ditto_set_option(b"fr_stagger", ftv[2] if len(ftv) > 2 else 1200))
+    if ft or not os.environ.get("DITTO_HIP_LIB"):   # (an older library selected with DITTO_HIP_LIB does not know these)
+        hip.check(lib.ditto_set_option(b"fr_tile", ftv[0] if len(ftv) > 0 else 0))
+        hip.check(lib.ditto_set_option(b"fr64_maxk", ftv[1] if len(ftv) > 1 else 1 << 30))
+        hip.check(lib.ditto_set_option(b"fr_stagger", ftv[2] if len(ftv) > 2 else 1200))
     v, _, fr = v.partition("&")          # ...&fr_rot (full-row GEMM K-loop rotation: default 1 = on)
     hip.check(lib.ditto_set_option(b"fr_rot", int(fr) if fr else 1))
     v, _, fm = v.partition("~")          # ...~fr_mask (full-row GEMM + fused LayerNorm: 1 out-proj, 2 fc2)
