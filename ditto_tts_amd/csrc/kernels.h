@@ -62,10 +62,12 @@ hipError_t launch_repack_bf16_stage_major(const void* src_bf16, void* dst, int N
 // launch decide as that batch would (dist.sample_sharded and SpeechGenerator's seeds= path do it), so that sharding
 // changes no bit; 0 (default) = decide on the launch's own rows.  fr_mask 0 gives one class outright.
 extern int g_fr_class_rows;   // gemm.hip
+// (Measured with the 64-row kernel admitted from 160 64-row tiles on, tools/step_ab.py --batch: B = 12 5.78 -> 5.37 ms per step,
+// B = 16 6.43 -> 6.46: it helps where the 256 x 192 tiles of the unfused N = d GEMMs make a fractional round and not where they
+// make a whole one; not adopted — it would move the class boundary for batch sizes no benchmark of this repository runs.)
 extern int g_fr_tile;
 inline bool fr_pays(int M) {
     const int rows = g_fr_class_rows > 0 ? g_fr_class_rows : M;
-    if (g_fr_tile == 64) return (rows + 63) / 64 >= 160;   // EXPERIMENT (fr_tile 64): the 64-row kernel fills the chip from half the rows on
     return (rows + 127) / 128 >= 160;
 }
 
