@@ -897,7 +897,7 @@ int ditto_set_option(const char* name, int value) {
         return DITTO_OK;
     }
     if (!strcmp(name, "fr_tile")) {
-        if (value != 0 && value != 64 && value != 128) return fail(DITTO_ERR_ARG, "fr_tile must be 0 (rule), 64 or 128");
+        if (value != 0 && value != 64 && value != 128 && value != 130) return fail(DITTO_ERR_ARG, "fr_tile must be 0 (rule), 64, 128 or 130 (128 rows, W straight into registers)");
         g_fr_tile = value;
         return DITTO_OK;
     }

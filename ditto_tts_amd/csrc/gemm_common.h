@@ -375,6 +375,8 @@ hipError_t launch_gemm_fr(const GemmParams& p, const float* gamma, const float* 
 // LayerNorm chaining decision and the training forward, so that the three cannot disagree.
 // gemm_fr64.hip: the same contract and the SAME BITS on 64-row tiles, two workgroups per CU (called by launch_gemm_fr)
 hipError_t launch_gemm_fr64(const FrParams& fp, hipStream_t s);
+// gemm_frd.hip: the same contract at N = 768 with W fetched straight from L2 into registers (128-row tiles, wave-private W)
+hipError_t launch_gemm_frd(const FrParams& fp, hipStream_t s);
 bool gemm_fr64_supports(int M, int N, int K, size_t lda, size_t ldw);   // N = 768 or 1024
 // d = 768: gemm_fr.hip (or its bit-identical 64-row twin); d = 1024: gemm_fr64.hip only.
 inline bool fr_outproj_ok(int M, int d) {

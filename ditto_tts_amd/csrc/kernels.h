@@ -83,6 +83,13 @@ extern int g_fr_rot;     // gemm.hip: full-row kernel's K-loop rotation: 0 off, 
 extern int g_fr64_maxk;  // gemm.hip: longest K that takes the 64-row kernel when fr_tile = 64
 extern int g_fr_u_fp8;   // gemm.hip: test hook (ditto_set_option("fr_u_fp8")): ditto_gemm_ln_bf16 writes the LayerNorm output as fp8
 extern int g_fr_stagger; // gemm.hip: gemm_fr64's start delay of the second workgroup of a CU (10 ns ticks)
+// gemm_frd.hip (W straight into registers) is the N = 768 full-row kernel since round 3 (in-model, same process: out-proj +
+// norm3 78.1 -> 75.7 us, fc2 + norm1 158.7 -> 153.3 us); fr_tile 128 forces gemm_fr.hip, 64 the 64-row twin.  All three
+// produce the same h bits; u may differ in the last bf16 bit of a few elements between gemm_frd and the other two.
+inline bool fr_use_direct(int M, int K) {
+    (void)K;
+    return (g_fr_tile == 0 || g_fr_tile == 130) && M >= 128;
+}
 // Which full-row kernel: same bits either way (tests/test_gpu_kernels.py), a speed rule only.
 inline bool fr_use_tile64(int M, int K) {
     if (M < 64) return false;

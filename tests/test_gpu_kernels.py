@@ -480,6 +480,51 @@ def test_full_row_gemm_with_fused_layernorm(lib, M, K, ln, rot):
                                   K, stream()) == hip.ERR_SHAPE
 
 
+@pytest.mark.parametrize("M,K,ln,res", [(128, 768, True, True), (300, 256, True, True), (1024, 3072, True, True),
+                                          (257, 64, False, True), (1000, 128, True, False), (515, 192, True, True),
+                                          (4096, 768, True, True), (2048, 6144, False, True)])
+@pytest.mark.parametrize("rot", [0, 8, 3])
+def test_full_row_gemm_with_weights_straight_into_registers(lib, M, K, ln, res, rot):
+    """csrc/gemm_frd.hip (fr_tile 130: 128 x 768 tiles, a wave owns 128 rows x 192 columns and fetches ITS weight fragments
+    with global_load_dwordx4 two stages ahead into a register ring — no W in the LDS) against csrc/gemm_fr.hip: h must agree
+    BIT FOR BIT (same K order incl. rotation, same accumulator init); u = LayerNorm(h) sums its statistics per quarter row,
+    so it may differ from gemm_fr.hip's in the last bf16 bit of a few elements — checked against the fp32 op and counted.
+    Ragged M, one to 96 K slabs, with / without residual and LayerNorm, run-to-run determinism."""
+    N = 768
+    hip.check(lib.ditto_set_option(b"fr_rot", rot))
+    A = bf16(asym((M, K), 44).to(DEV))
+    W = bf16((asym((N, K), 45) / math.sqrt(K)).to(DEV))
+    Wp = W.view(N, K // 16, 16).permute(1, 0, 2).contiguous()
+    bias = (0.1 * asym((N,), 46)).to(DEV)
+    r0 = asym((M, N), 47).to(DEV)
+    g = (1 + 0.1 * asym((N,), 48)).to(DEV)
+    b = (0.1 * asym((N,), 49)).to(DEV)
+    want = A.float() @ W.float().T + bias + (r0 if res else 0)
+    wu = torch.nn.functional.layer_norm(want, (N,), g, b, 1e-5)
+    outs = {}
+    try:
+        for tile in (128, 130, 130):
+            hip.check(lib.ditto_set_option(b"fr_tile", tile))
+            h = r0.clone() if res else torch.full((M, N), 7.0, device=DEV)
+            u = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+            hip.check(lib.ditto_gemm_ln_bf16(A.data_ptr(), K, Wp.data_ptr(), bias.data_ptr(), h.data_ptr() if res else None,
+                                             h.data_ptr(), N, g.data_ptr() if ln else None, b.data_ptr() if ln else None,
+                                             u.data_ptr() if ln else None, N, M, N, K, stream()))
+            torch.cuda.synchronize()
+            if tile in outs:
+                assert torch.equal(h, outs[tile][0]) and torch.equal(u, outs[tile][1])      # run-to-run
+            outs[tile] = (h, u)
+    finally:
+        hip.check(lib.ditto_set_option(b"fr_tile", 0))
+        hip.check(lib.ditto_set_option(b"fr_rot", 1))
+    (h128, u128), (hd, ud) = outs[128], outs[130]
+    assert rel_l2(hd, want) < 1e-5 and max_abs(hd, want) < 3e-4
+    assert torch.equal(hd, h128), float((hd - h128).abs().max())
+    if ln:
+        assert max_abs(ud.float(), wu) < 4e-2 and rel_l2(ud.float(), wu) < 4e-3
+        assert float((ud != u128).float().mean()) < 1e-3          # a bf16 rounding tie here and there at most
+
+
 @pytest.mark.parametrize("M,K,ln,res", [(64, 1024, True, True), (300, 256, True, True), (1024, 4096, True, True), (257, 64, False, True),
                                           (1000, 128, True, False), (515, 192, True, True), (4096, 1024, True, True),
                                           (2048, 4096, False, True)])

@@ -10,7 +10,7 @@ ap = argparse.ArgumentParser(); ap.add_argument("--m", type=int, default=32768);
 ap.add_argument("--nores", action="store_true", help="new kernel without the residual (timing of the accumulator init)")
 ap.add_argument("--noln", action="store_true", help="new kernel without the LayerNorm output")
 ap.add_argument("--rot", type=int, default=8, help="fr_rot option: K-loop rotation period in tiles (0 = off)")
-ap.add_argument("--variants", default="128/0,64/0,64/600,64/1200,64/1800", help="new-kernel variants fr_tile/fr_stagger (10 ns ticks)")
+ap.add_argument("--variants", default="128/0,130/0,64/0,64/1800", help="new-kernel variants fr_tile/fr_stagger (10 ns ticks)")
 a = ap.parse_args()
 lib = hip.lib(); hip.check(lib.ditto_set_option(b"fr_rot", a.rot)); st = torch.cuda.current_stream().cuda_stream
 M, N = a.m, 768
