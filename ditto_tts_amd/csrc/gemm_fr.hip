@@ -145,6 +145,9 @@ __global__ __launch_bounds__(256, 1) void gemm_fr_kernel(FrParams fp) {
         const int row = 8 * (wid * 4 + j) + arow;                 // row inside the tile
         int ar = m0 + row;
         ar = ar < p.M ? ar : p.M - 1;
+#ifdef DITTO_DIAG_FR_AHOT      // tools/build_diag.sh: every tile reads the A rows of tile 0 (L2-resident, statistically the same data): what does A's HBM / Infinity Cache latency cost?
+        ar = row;
+#endif
         vak[j] = (unsigned)(((size_t)ar * p.lda + (apos ^ ((row >> 1) & 7)) * 8) * 2) + (unsigned)(s0 * 128);   // chunk c of row r sits at c ^ ((r >> 1) & 7)
     }
     unsigned w_slot = lds_base;                                   // LDS byte address of the W ring slot the next stage goes to
