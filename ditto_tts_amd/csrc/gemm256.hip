@@ -117,10 +117,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             if constexpr (half < 2) {
                 int gr = om + half * 128 + row;
                 gr = gr < p.M ? gr : p.M - 1;
+#ifdef DITTO_DIAG_G256_AHOT   // tools/build_diag.sh: every tile reads the A rows of row tile 0 (L2-resident, the same statistics): what does A's path cost?
+                gr = half * 128 + row;
+#endif
+#ifdef DITTO_DIAG_G256_WHOT   // ... and the W rows of column tile 0
+                (void)on;
+#endif
                 src = (const char*)p.A + (size_t)gr * p.lda * ESZ + k0b + c * 16;
             } else {
                 int gr = on + (half - 2) * 128 + row;
                 gr = gr < p.w_rows ? gr : p.w_rows - 1;
+#ifdef DITTO_DIAG_G256_WHOT
+                gr = (half - 2) * 128 + row;
+#endif
                 src = (const char*)p.W + (size_t)gr * p.ldw * ESZ + k0b + c * 16;
             }
             glds16(src, lds_base + (unsigned)(buf * KT_BYTES + half * HALF_BYTES + piece * 1024));
