@@ -14,7 +14,7 @@ CLASSES = [("gemm_gated_mlp", "gemm256_kernel<3"), ("gemm_qkv_rope", "gemm256_ke
            ("layernorm", "ln_kernel<3, 0>")]
 # the cross out-projection (+ norm3) and fc2 (+ next norm1) are the SAME kernel (gemm_fr_kernel<true, true>) at K = d and
 # K = 4d: its launches are told apart by their own read traffic (fc2 reads a 4x wider A), position by position in both passes
-FR = "gemm_fr_kernel<true, true>"
+FR = "gemm_frd_kernel<true, true>"      # round 3: the full-row kernel with W fetched straight into registers (gemm_frd.hip)
 
 
 def avg(path, counter):
@@ -43,6 +43,9 @@ for cls, pat in CLASSES:
     f, w = fetch[k], write.get(k, 0.0)
     out[cls] = {"kernel": k[:90], "fetch_kb": round(f, 1), "write_kb": round(w, 1), "traffic_bytes": int(2 * f * 1024 + w * 1024)}
 fs, ws = series(sys.argv[1], "FETCH_SIZE", FR), series(sys.argv[2], "WRITE_SIZE", FR)
+if not fs:
+    FR = "gemm_fr_kernel<true, true>"       # older builds / fr_tile 128
+    fs, ws = series(sys.argv[1], "FETCH_SIZE", FR), series(sys.argv[2], "WRITE_SIZE", FR)
 if fs and len(fs) == len(ws):
     mid = (min(fs) + max(fs)) / 2
     for cls, sel in (("gemm_out_proj", lambda v: v < mid), ("gemm_fc2", lambda v: v >= mid)):
