@@ -225,8 +225,8 @@ int ditto_attention_bf16(const void* q, int ldq, const void* k, int ldk, const v
 /* scratch bytes ditto_attention_bf16 needs (0 for the fused dh = 64 kernel) */
 size_t ditto_attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh);
 
-/* Full-row GEMM with the residual add and the FOLLOWING LayerNorm fused (N = 768: csrc/gemm_fr.hip, M >= 128, or its
- * bit-identical 64-row twin csrc/gemm_fr64.hip under "fr_tile" 64; N = 1024: csrc/gemm_fr64.hip, M >= 64):
+/* Full-row GEMM with the residual add and the FOLLOWING LayerNorm fused (N = 768: csrc/gemm_frd.hip, M >= 128, or
+ * csrc/gemm_fr.hip / its 64-row twin csrc/gemm_fr64.hip under "fr_tile" 128 / 64; N = 1024: csrc/gemm_fr64.hip, M >= 64):
  *   out fp32 [M,N] = residual + A[M,K] W[N,K]^T + bias   (residual may alias out: the in-place stream update of
  *   src/components/DiT.py:148 / :155),   u bf16 [M,ldu] = LayerNorm(out) * gamma + beta  (eps 1e-5; the norm of :152 / the
  *   next block's :105).  gamma = beta = u = NULL: no LayerNorm output.  K % 64 == 0.
@@ -256,9 +256,12 @@ int ditto_gemm_tn_bf16(const void* X, int ldx, const void* Y, int ldy, float* ou
  * whether its launch took it — a function of the launch's row count (>= 160 tiles of 128 rows).  A caller that splits ONE batch
  * over several launches or GPUs sets this to the rows (B * N) of the unsplit batch: every launch then decides as that batch
  * would and sharding changes no bit (ditto_tts_amd/dist.py sample_sharded does).  0 (default) = each launch on its own rows.
- * "fr_tile": which N = 768 full-row kernel: 0 / 128 = 128-row tiles, one workgroup per CU (csrc/gemm_fr.hip); 64 = 64-row tiles,
- * two workgroups per CU (csrc/gemm_fr64.hip) for launches with K <= "fr64_maxk"; the results are bit-identical.  "fr_stagger":
- * start delay of a CU's second workgroup in that kernel, 10 ns ticks.  (N = 1024 always runs csrc/gemm_fr64.hip.)
+ * "fr_tile": which N = 768 full-row kernel: 0 (default) / 130 = 128-row tiles with the weights fetched straight from L2 into
+ * registers (csrc/gemm_frd.hip); 128 = 128-row tiles with the weights through an LDS ring (csrc/gemm_fr.hip); 64 = 64-row tiles,
+ * two workgroups per CU (csrc/gemm_fr64.hip) for launches with K <= "fr64_maxk".  All three produce the same fp32 result bit
+ * for bit; the LayerNorm output of 128 and 64 is bit-identical, that of 0 / 130 may differ from it in the last bf16 bit of a few
+ * elements (other association of the row statistics).  "fr_stagger": start delay of a CU's second workgroup in the 64-row
+ * kernel, 10 ns ticks.  (N = 1024 always runs csrc/gemm_fr64.hip.)
  * "fr_u_fp8": TEST HOOK: ditto_gemm_ln_bf16 at N = 1024 writes u as fp8 e4m3 bytes ([M, ldu] bytes), the form the fp8 linear
  * path's model forward uses for norm3.
  * "fr_dgrad": training backward, the long-K dgrads (N = d = 768) on the same kernel: bit 0 = fc1|gate (K = 8d), bit 1 = QKV.

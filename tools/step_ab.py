@@ -44,6 +44,9 @@ wall = {v: [] for v in variants}
 
 
 def select(v):
+    v, _, cr = v.partition("=")          # ...=fr_class_rows (pin the full-row kernel class: rows of the batch to decide as)
+    if cr or not os.environ.get("DITTO_HIP_LIB"):
+        hip.check(lib.ditto_set_option(b"fr_class_rows", int(cr) if cr else 0))
     v, _, ft = v.partition("+")          # ...+fr_tile.fr64_maxk.fr_stagger (64-row full-row kernel: gemm_fr64.hip; default: the rule)
     ftv = [int(x) for x in ft.split(".")] if ft else []
     if ft or not os.environ.get("DITTO_HIP_LIB"):   # (an older library selected with DITTO_HIP_LIB does not know these)
