@@ -544,6 +544,35 @@ def test_c5_width_takes_the_full_row_path_against_oracle():
         del m
 
 
+@torch.no_grad()
+def test_c5_full_shape_against_oracle():
+    """BASELINE configs[4] at its FULL shape — 24 layers, d = 1024, h = 16, N = T = 1024 — one utterance against the fp32
+    oracle, kernel class pinned to C5's batch of 16 so that the launches are the ones bench.py times (full-row kernel for
+    the cross out-projection + norm3 in both configurations, for fc2 + the next norm1 in the bf16 one).  Stated tolerances:
+    bf16 2e-2, fp8 6e-2 (the N = 1024 shape had only ever run in the bench)."""
+    from oracle import ditto_oracle as O
+    p = PRESETS["C5"]
+    cfg8, N, T = p["cfg"], p["N"], p["T"]
+    cfg16 = PRESETS["C5_bf16"]["cfg"]
+    sd = synthetic_state_dict(cfg16, 6)
+    x, text, t = synthetic_inputs(cfg16, 1, N, T, seed=4)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    want = O.ditto_forward(sd, cfg16.num_layers, cfg16.num_heads, x, text, t)
+    res = {}
+    for cfg in (cfg16, cfg8):
+        m = DiTTO(cfg.hidden_dim, cfg.num_layers, cfg.num_heads, cfg.time_dim, cfg.text_dim, cfg.diffusion_steps,
+                  fp8_linear=cfg.fp8_linear)
+        m.load_state_dict(sd)
+        m = m.to(DEV).eval()
+        with hip.batch_class(p["B"] * N):
+            assert hip.full_row_plan(cfg, 1, N) == (True, not cfg.fp8_linear)
+            res[cfg.fp8_linear] = rel_l2(m(x.to(DEV), text.to(DEV), t.to(DEV)), want)
+        del m
+    print(f"C5 full shape 24L N=T=1024: bf16 rel-L2 {res[False]:.3e}, fp8 rel-L2 {res[True]:.3e}")
+    assert res[False] < RTOL
+    assert res[True] < 6e-2 and res[True] > res[False]
+
+
 def test_standalone_blocks_are_forward_only():
     """DiTTO trains (tests/test_gpu_train.py); the standalone DiT / GlobalAdaLN modules refuse autograd loudly."""
     from ditto_tts_amd.modules import DiT
