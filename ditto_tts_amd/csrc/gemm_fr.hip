@@ -604,10 +604,10 @@ hipError_t launch_gemm_fr(const GemmParams& p_in, const float* gamma, const floa
     fp.u_fp8 = u_fp8;
     if (p_in.N == 1024) return launch_gemm_fr64(fp, s);          // d = 1024: 64 x 1024 tiles, one workgroup per CU
     if (u_fp8) return hipErrorInvalidValue;
-    // W fetched straight into registers (gemm_frd.hip): same h bits, u within a bf16 ulp of this kernel's
-    if (fr_use_direct(p_in.M, p_in.K)) return launch_gemm_frd(fp, s);
-    // 64-row tiles, two workgroups per CU (gemm_fr64.hip): bit-identical results, so this is a speed rule only
-    if (fr_use_tile64(p_in.M, p_in.K)) {
+    // which N = 768 kernel (kernels.h fr_launch_kernel): all three produce the same h bits, a speed rule only
+    const int kern = fr_launch_kernel(p_in.M, p_in.K);
+    if (kern == 130) return launch_gemm_frd(fp, s);
+    if (kern == 64) {
         fp.stagger_ticks = g_fr_stagger;
         return launch_gemm_fr64(fp, s);
     }

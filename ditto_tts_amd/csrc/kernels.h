@@ -62,14 +62,23 @@ hipError_t launch_repack_bf16_stage_major(const void* src_bf16, void* dst, int N
 // launch decide as that batch would (dist.sample_sharded and SpeechGenerator's seeds= path do it), so that sharding
 // changes no bit; 0 (default) = decide on the launch's own rows.  fr_mask 0 gives one class outright.
 extern int g_fr_class_rows;   // gemm.hip
-// (Measured with the 64-row kernel admitted from 160 64-row tiles on, tools/step_ab.py --batch: B = 12 5.78 -> 5.37 ms per step,
-// B = 16 6.43 -> 6.46: it helps where the 256 x 192 tiles of the unfused N = d GEMMs make a fractional round and not where they
-// make a whole one; not adopted — it would move the class boundary for batch sizes no benchmark of this repository runs.)
+// Which N = 768 full-row kernel a batch of `rows` rows takes, 0 = none (the tiled GEMMs + LayerNorm launches).  Measured in the
+// model at C2 shapes, tools/step_ab.py --batch b with the class pinned (ms per step, unfused / 64-row / 128-row direct):
+//   b = 10: 4.68 / 4.85 / 5.18   11: 5.78 / 5.34 / 5.65   12: 5.78 / 5.37   13: 6.15 / 5.73 / 6.01   14: 6.73 / 6.19 / 6.55
+//   15: 6.99 / 6.52 / 6.85   16: 6.43 / 6.46   17: 7.73 / 8.12 / 7.47   18: 7.93 / 8.34 / 7.68   19: 8.30 / 8.75 / 8.16   >= 20: direct
+// i.e. the 128-row kernel (gemm_frd.hip) from 136 of its tiles on; below that the 64-row kernel (gemm_fr64.hip, two workgroups
+// per CU) from 176 of ITS tiles on — except where the unfused N = d GEMMs' 256 x 192 tiles make exactly one round of the 256
+// CUs (16 x 1024 rows), which is the one place in that range where they are not quantised away.  The two full-row kernels
+// produce the same h bits (u within a bf16 rounding tie), the unfused path differs in the last bits: the CLASS boundary that
+// callers pin (fr_class_rows) is "full-row or not".
 extern int g_fr_tile;
-inline bool fr_pays(int M) {
-    const int rows = g_fr_class_rows > 0 ? g_fr_class_rows : M;
-    return (rows + 127) / 128 >= 160;
+inline int fr_rule_rows(int rows) {
+    const int t128 = (rows + 127) / 128, t64 = (rows + 63) / 64;
+    if (t128 >= 136) return 130;
+    if (t64 >= 176 && ((rows + 255) / 256) * 4 != 256) return 64;
+    return 0;
 }
+inline bool fr_pays(int M) { return fr_rule_rows(g_fr_class_rows > 0 ? g_fr_class_rows : M) != 0; }
 
 // d = 1024 runs the 64-row kernel only (gemm_fr64.hip, one workgroup per CU): it needs three quarters of the CUs busy.
 inline bool fr_pays_64(int M) {
@@ -80,21 +89,24 @@ inline bool fr_pays_64(int M) {
 extern int g_fr_dgrad;   // gemm.hip: training backward, long-K dgrads on the full-row kernel: bit 0 fc1|gate (K = 8d), bit 1 QKV (K = 3d)
 extern int g_fr_rot;     // gemm.hip: full-row kernel's K-loop rotation: 0 off, 1 on in the model (period = tiles per utterance), > 1 = period for ditto_gemm_ln_bf16 too
 // g_fr_tile (declared above): gemm.hip: full-row kernel's tile: 0 = rule, 64 = gemm_fr64.hip for every launch with K <= g_fr64_maxk, 128 = gemm_fr.hip
-extern int g_fr64_maxk;  // gemm.hip: longest K that takes the 64-row kernel when fr_tile = 64
+// g_fr64_maxk (declared below): gemm.hip: longest K that takes the 64-row kernel when fr_tile = 64
 extern int g_fr_u_fp8;   // gemm.hip: test hook (ditto_set_option("fr_u_fp8")): ditto_gemm_ln_bf16 writes the LayerNorm output as fp8
 extern int g_fr_stagger; // gemm.hip: gemm_fr64's start delay of the second workgroup of a CU (10 ns ticks)
-// gemm_frd.hip (W straight into registers) is the N = 768 full-row kernel since round 3 (in-model, same process: out-proj +
-// norm3 78.1 -> 75.7 us, fc2 + norm1 158.7 -> 153.3 us); fr_tile 128 forces gemm_fr.hip, 64 the 64-row twin.  All three
-// produce the same h bits; u may differ in the last bf16 bit of a few elements between gemm_frd and the other two.
-inline bool fr_use_direct(int M, int K) {
-    (void)K;
-    return (g_fr_tile == 0 || g_fr_tile == 130) && M >= 128;
-}
-// Which full-row kernel: same bits either way (tests/test_gpu_kernels.py), a speed rule only.
-inline bool fr_use_tile64(int M, int K) {
-    if (M < 64) return false;
-    if (g_fr_tile == 64) return K <= g_fr64_maxk;
-    return false;
+extern int g_fr64_maxk;
+// The kernel a full-row LAUNCH of M rows and depth K runs on: 130 = gemm_frd.hip (W straight into registers: the N = 768
+// kernel since round 3; in-model fc2 + norm1 162.5 -> 157.0 us against gemm_fr.hip), 64 = gemm_fr64.hip, 128 = gemm_fr.hip.
+// fr_tile 0 = the rule of fr_rule_rows on the class rows (a launch outside the rule, e.g. ditto_gemm_ln_bf16 on a small M, takes
+// the direct kernel); fr_tile 64 / 128 / 130 force one (64 only up to K = fr64_maxk).  The 128-row kernels need M >= 128.
+inline int fr_launch_kernel(int M, int K) {
+    int k = g_fr_tile;
+    if (k == 0) {
+        k = fr_rule_rows(g_fr_class_rows > 0 ? g_fr_class_rows : M);
+        if (k == 0) k = 130;
+    } else if (k == 64 && K > g_fr64_maxk) {
+        k = 130;
+    }
+    if (k != 64 && M < 128) k = 64;
+    return k;
 }
 extern int g_fr_mask;    // gemm.hip: 1 = cross out-proj + LayerNorm3, 2 = fc2 + next block's LayerNorm1 on the full-row kernel
 // same row map for an fp32 vector (bias)

@@ -122,7 +122,7 @@ class SpeechGenerator:
         `seeds` (optional, int64 [B]): per-utterance seeds.  x_T and every step's z then come from the library's
         counter-based generator (Philox4x32-10 keyed by the utterance's seed, engine.noise_normal_), generated inside
         the update kernel: an utterance's trajectory is a function of (seed, text, weights) and of the KERNEL CLASS its
-        launches take (batches of >= 160 row tiles run two GEMM + LayerNorm pairs per block on the full-row kernel,
+        launches take (batches of 11 .. 15 and >= 17 utterances of 1024 frames — csrc/kernels.h fr_rule_rows — run two GEMM + LayerNorm pairs per block on a full-row kernel,
         which sums over k in another order).  Default None = the reference's behaviour, torch.randn_like from the global
         generator;
         `batch_class` (optional int): the number of utterances of the UNSPLIT batch this call is a piece of.  The loop

@@ -253,7 +253,8 @@ int ditto_gemm_tn_bf16(const void* X, int ldx, const void* Y, int ldy, float* ou
  * "fr_mask": N = d = 768 projections on the full-row kernel with the residual add and the following LayerNorm fused
  * (csrc/gemm_fr.hip): bit 0 = cross out-proj + norm3, bit 1 = fc2 + the next block's norm1.
  * "fr_class_rows": the full-row kernel sums over k in a different order than the tiled GEMMs, so an utterance's bits depend on
- * whether its launch took it — a function of the launch's row count (>= 160 tiles of 128 rows).  A caller that splits ONE batch
+ * whether its launch took it — a function of the launch's row count (>= 136 tiles of 128 rows, or 176 .. 271 tiles of 64 rows
+ * other than 16384 rows exactly: csrc/kernels.h fr_rule_rows, a measured rule).  A caller that splits ONE batch
  * over several launches or GPUs sets this to the rows (B * N) of the unsplit batch: every launch then decides as that batch
  * would and sharding changes no bit (ditto_tts_amd/dist.py sample_sharded does).  0 (default) = each launch on its own rows.
  * "fr_tile": which N = 768 full-row kernel: 0 (default) / 130 = 128-row tiles with the weights fetched straight from L2 into

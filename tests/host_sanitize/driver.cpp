@@ -84,7 +84,7 @@ static void size_queries() {
             EXPECT(ditto_full_row_plan(&c, B, N, &a, &b) == DITTO_OK && (a == 0 || a == 1) && (b == 0 || b == 1),
                    "full_row_plan B=%d N=%d", B, N);
             const bool f8 = (fl & DITTO_CFG_FP8_LINEAR) != 0;
-            if (d == 768) { if (f8 || M < 160 * 128 - 127) EXPECT(a == 0 && b == 0, "full-row plan where it cannot run (d = 768)"); }
+            if (d == 768) { if (f8 || M < 176 * 64 - 63) EXPECT(a == 0 && b == 0, "full-row plan where it cannot run (d = 768)"); }
             else if (d == 1024) {   // 64-row tiles, >= 192 of them; fc2 never under fp8
                 if (M < 192 * 64 - 63) EXPECT(a == 0 && b == 0, "full-row plan where it cannot run (d = 1024)");
                 if (f8) EXPECT(b == 0, "fp8 fc2 on the full-row kernel");

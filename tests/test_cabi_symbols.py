@@ -82,9 +82,12 @@ def test_full_row_plan_is_judged_per_launch_and_pinnable():
     cfg = PRESETS["C2"]["cfg"]
     try:
         assert hip.full_row_plan(cfg, 32, 1024) == (True, True)      # the headline shape: 256 row tiles
-        assert hip.full_row_plan(cfg, 20, 1024) == (True, True)      # 160 tiles: the threshold
-        assert hip.full_row_plan(cfg, 19, 1024) == (False, False)
-        assert hip.full_row_plan(cfg, 16, 1024) == (False, False)    # a shard of the 32 batch on its own...
+        assert hip.full_row_plan(cfg, 17, 1024) == (True, True)      # 136 tiles of 128 rows: the 128-row kernel's threshold
+        assert hip.full_row_plan(cfg, 15, 1024) == (True, True)      # below it the 64-row kernel, from 176 of its tiles on ...
+        assert hip.full_row_plan(cfg, 11, 1024) == (True, True)
+        assert hip.full_row_plan(cfg, 10, 1024) == (False, False)
+        assert hip.full_row_plan(cfg, 16, 1024) == (False, False)    # ... except where the tiled GEMMs make one exact round:
+                                                                     # a shard of the 32 batch on its own...
         with hip.batch_class(32 * 1024):                             # ...and pinned to the class of the unsplit batch
             assert hip.full_row_plan(cfg, 16, 1024) == (True, True)
             assert hip.full_row_plan(cfg, 1, 1024) == (True, True)

@@ -295,8 +295,9 @@ def test_headline_shape_b32_against_oracle():
 
 @torch.no_grad()
 def test_shards_straddling_the_full_row_threshold_agree_when_the_class_is_pinned():
-    """ADVICE r2.  d = 768, N = 1024: a batch of 20 utterances (160 row tiles) takes the full-row kernel, its shards of 12
-    and 8 utterances on their own do not, and the two paths differ in the last bits.  dist.sample_sharded and the seeds=
+    """ADVICE r2.  d = 768, N = 1024: a batch of 20 utterances (160 row tiles) takes the full-row kernel, its shards of 16
+    and 4 utterances on their own do not (16 x 1024 rows are one exact round of the tiled GEMMs: kernels.h fr_rule_rows), and
+    the two paths differ in the last bits.  dist.sample_sharded and the seeds=
     path therefore pin every piece to the class of the UNSPLIT batch (hip.batch_class / "fr_class_rows"): pinned, the
     shards reproduce the unsplit forward bit for bit, and so does the seeded sampling loop with batch_class=."""
     from ditto_tts_amd import hip
@@ -305,16 +306,17 @@ def test_shards_straddling_the_full_row_threshold_agree_when_the_class_is_pinned
     B, N, T = 20, 1024, 64
     x, text, t = synthetic_inputs(cfg, B, N, T, seed=13)
     xd, td, tt = x.to(DEV), text.to(DEV), t.to(DEV)
-    assert hip.full_row_plan(cfg, B, N) == (True, True) and hip.full_row_plan(cfg, 12, N) == (False, False)
+    assert hip.full_row_plan(cfg, B, N) == (True, True) and hip.full_row_plan(cfg, 16, N) == (False, False)
+    assert hip.full_row_plan(cfg, 4, N) == (False, False)
     whole = m(xd, td, tt)
-    parts = [(0, 12), (12, 20)]
+    parts = [(0, 16), (16, 20)]
     free = torch.cat([m(xd[a:b].contiguous(), td[a:b].contiguous(), tt[a:b].contiguous()) for a, b in parts])
     assert not torch.equal(free, whole), "the shards were expected to take the tiled path on their own"
     assert rel_l2(free, whole) < 4e-3
     with hip.batch_class(B * N):
         pinned = torch.cat([m(xd[a:b].contiguous(), td[a:b].contiguous(), tt[a:b].contiguous()) for a, b in parts])
     assert torch.equal(pinned, whole), "pinned to the unsplit batch's class, a shard must reproduce its bits"
-    assert hip.full_row_plan(cfg, 12, N) == (False, False)      # the pin ended with the block
+    assert hip.full_row_plan(cfg, 16, N) == (False, False)      # the pin ended with the block
     sg = SpeechGenerator(ditto_model=m, device=DEV)
     seeds = torch.arange(B, device=DEV) + 77
     full = sg.sample_latents(td, xd, seeds=seeds)
