@@ -42,7 +42,7 @@ int g_fr_dgrad = [] { const char* e = getenv("DITTO_FR_DGRAD"); return e ? atoi(
 int g_fr_rot = [] { const char* e = getenv("DITTO_FR_ROT"); return e ? atoi(e) : 1; }();
 int g_fr_tile = [] { const char* e = getenv("DITTO_FR_TILE"); return e ? atoi(e) : 0; }();
 int g_fr64_maxk = [] { const char* e = getenv("DITTO_FR64_MAXK"); return e ? atoi(e) : 1 << 30; }();
-int g_fr_stagger = [] { const char* e = getenv("DITTO_FR_STAGGER"); return e ? atoi(e) : 1200; }();
+int g_fr_stagger = [] { const char* e = getenv("DITTO_FR_STAGGER"); return e ? atoi(e) : 0; }();   // off: worth 6 us isolated at 512 tiles, nothing in the model, and a late second workgroup is pure tail when only a few CUs get one
 int g_fr_u_fp8 = 0;
 int g_fr_class_rows = 0;   // kernels.h fr_pays: rows of the unsplit batch whose kernel class every launch takes (0 = its own)
 int g_pp_mask = [] { const char* e = getenv("DITTO_PP_MASK"); return e ? atoi(e) : -1; }();   // -1 = built-in rule

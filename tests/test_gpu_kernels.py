@@ -612,7 +612,7 @@ def test_full_row_gemm_on_64_row_tiles_is_bitwise_the_128_row_kernel(lib, M, K, 
             outs[(tile, stagger)] = (h, u)
     finally:
         hip.check(lib.ditto_set_option(b"fr_tile", 0))
-        hip.check(lib.ditto_set_option(b"fr_stagger", 1200))
+        hip.check(lib.ditto_set_option(b"fr_stagger", 0))
         hip.check(lib.ditto_set_option(b"fr_rot", 1))
     h128, u128 = outs[(128, 0)]
     assert rel_l2(h128, want) < 1e-5

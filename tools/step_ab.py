@@ -52,7 +52,7 @@ def select(v):
     if ft or not os.environ.get("DITTO_HIP_LIB"):   # (an older library selected with DITTO_HIP_LIB does not know these)
         hip.check(lib.ditto_set_option(b"fr_tile", ftv[0] if len(ftv) > 0 else 0))
         hip.check(lib.ditto_set_option(b"fr64_maxk", ftv[1] if len(ftv) > 1 else 1 << 30))
-        hip.check(lib.ditto_set_option(b"fr_stagger", ftv[2] if len(ftv) > 2 else 1200))
+        hip.check(lib.ditto_set_option(b"fr_stagger", ftv[2] if len(ftv) > 2 else 0))
     v, _, fr = v.partition("&")          # ...&fr_rot (full-row GEMM K-loop rotation: default 1 = on)
     hip.check(lib.ditto_set_option(b"fr_rot", int(fr) if fr else 1))
     v, _, fm = v.partition("~")          # ...~fr_mask (full-row GEMM + fused LayerNorm: 1 out-proj, 2 fc2)
