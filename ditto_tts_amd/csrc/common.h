@@ -125,6 +125,30 @@ DITTO_DEV f32x2 fast_gelu_sigmoid2(f32x2 x, f32x2 g) {
     r[0] = fast_rcp(den[0]); r[1] = fast_rcp(den[1]);
     return num * r;
 }
+// Fourth form (A/B build -DDITTO_GATED_H): the whole activation in PACKED fp16, in the sigmoid form of the
+// Gaussian cdf,
+//     gelu(x) sigmoid(g) ~= x / ((1 + e^-p(x)) (1 + e^-g)),   p(x) = 2 sqrt(2/pi) x (1 + 0.044715 x^2)   (the "tanh" GELU),
+// 7 v_pk_*_f16 (one pass each, where v_pk_*_f32 takes two) + 4 v_exp_f16 + 2 v_rcp_f16 per PAIR of outputs, against 18 packed
+// fp32 operations + 4 transcendentals.  Accuracy (tests/test_gated_math.py; x, g ~ N(0, 1.5)): the form itself is 1.8e-4 rel-L2 from the
+// exact erf product (max 4.7e-4 absolute), the fp16 evaluation 4.9e-4 — against the 1.66e-3 of rounding the EXACT value to bf16,
+// which is what the epilogue does next: 1.73e-3 after rounding, +4 %.  Limits: e^-p overflows to +inf for x < -4.2 and the
+// reciprocal returns 0 (gelu -> 0); for x > 4 e^-p underflows and the product is x sigmoid(g); g < -11: 0; no 0 * inf arises
+// ((1 + e) >= 1).  x is kept in fp32 for the final multiply.
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+DITTO_DEV f32x2 fast_gelu_sigmoid2_h(f32x2 x, f32x2 g) {
+    const h16x2 xh = __builtin_bit_cast(h16x2, __builtin_amdgcn_cvt_pkrtz(x[0], x[1]));
+    const h16x2 gh = __builtin_bit_cast(h16x2, __builtin_amdgcn_cvt_pkrtz(g[0], g[1]));
+    // exponents in log2 units: -log2(e) * 2 sqrt(2/pi) (1 + 0.044715 x^2) x   and   -log2(e) g
+    const h16x2 inner = (xh * xh) * (_Float16)(-0.10294324f) + (_Float16)(-2.3022082f);
+    const h16x2 ea = xh * inner, eg = gh * (_Float16)(-1.4426950f);
+    h16x2 e1, e2;
+    e1[0] = __builtin_exp2f16(ea[0]); e1[1] = __builtin_exp2f16(ea[1]);
+    e2[0] = __builtin_exp2f16(eg[0]); e2[1] = __builtin_exp2f16(eg[1]);
+    const h16x2 den = (e1 + (_Float16)1.0f) * (e2 + (_Float16)1.0f);
+    h16x2 r;
+    r[0] = __builtin_amdgcn_rcph(den[0]); r[1] = __builtin_amdgcn_rcph(den[1]);
+    return x * f32x2{(float)r[0], (float)r[1]};
+}
 // second packed form (A/B: -DDITTO_GATED_AS): A&S erf, scalings folded, sign by |x| source modifiers
 DITTO_DEV f32x2 fast_gelu_sigmoid2_as(f32x2 x, f32x2 g) {
     f32x2 t;

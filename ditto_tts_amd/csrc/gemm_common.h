@@ -189,6 +189,9 @@ DITTO_DEV void store_bf16_pair(bf16* rowp, int col0 /* column of block nb */, u3
 DITTO_DEV f32x2 cheap_gate2(f32x2 x, f32x2 g) { return x * g; }
 #define fast_gelu_sigmoid2 cheap_gate2
 #endif
+#ifdef DITTO_GATED_H    // A/B build of the packed-fp16 sigmoid form (common.h)
+#define fast_gelu_sigmoid2 fast_gelu_sigmoid2_h
+#endif
 #ifdef DITTO_GATED_AS   // A/B build of the second packed form (A&S erf, 4 transcendentals per output)
 #define fast_gelu_sigmoid2 fast_gelu_sigmoid2_as
 #endif
