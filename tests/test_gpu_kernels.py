@@ -525,6 +525,51 @@ def test_full_row_gemm_with_weights_straight_into_registers(lib, M, K, ln, res, 
         assert float((ud != u128).float().mean()) < 1e-3          # a bf16 rounding tie here and there at most
 
 
+def test_full_row_kernels_on_seeded_random_shapes(lib):
+    """Twenty seeded (M, K, rotation, bias / residual / LayerNorm) draws — M anywhere in 128 .. 5000, K any multiple of 64 up to
+    6144 (the training dgrad's depth) — through all three N = 768 full-row kernels (fr_tile 130 / 128 / 64) and, at N = 1024,
+    the 64-row kernel: against the fp32 ops, h of the three N = 768 kernels bitwise equal, u of 128 and 64 bitwise equal."""
+    import random
+    rnd = random.Random(20261002)
+    try:
+        for case in range(20):
+            N = 768 if case % 4 else 1024
+            M = rnd.randint(128, 5000)
+            K = 64 * rnd.randint(1, 96 if case % 5 else 24)
+            rot = rnd.choice([0, 0, 3, 8])
+            ln, res, has_bias = rnd.random() < 0.7, rnd.random() < 0.8, rnd.random() < 0.8
+            hip.check(lib.ditto_set_option(b"fr_rot", rot))
+            A = bf16(asym((M, K), 100 + case).to(DEV))
+            W = bf16((asym((N, K), 200 + case) / math.sqrt(K)).to(DEV))
+            Wp = W.view(N, K // 16, 16).permute(1, 0, 2).contiguous()
+            bias = (0.1 * asym((N,), 300 + case)).to(DEV)
+            r0 = asym((M, N), 400 + case).to(DEV)
+            g = (1 + 0.1 * asym((N,), 500 + case)).to(DEV)
+            b = (0.1 * asym((N,), 600 + case)).to(DEV)
+            want = A.float() @ W.float().T + (bias if has_bias else 0) + (r0 if res else 0)
+            wu = torch.nn.functional.layer_norm(want, (N,), g, b, 1e-5)
+            outs = {}
+            for tile in ((130, 128, 64) if N == 768 else (0,)):
+                hip.check(lib.ditto_set_option(b"fr_tile", tile))
+                h = r0.clone() if res else torch.full((M, N), -3.0, device=DEV)
+                u = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+                hip.check(lib.ditto_gemm_ln_bf16(A.data_ptr(), K, Wp.data_ptr(), bias.data_ptr() if has_bias else None,
+                                                 h.data_ptr() if res else None, h.data_ptr(), N, g.data_ptr() if ln else None,
+                                                 b.data_ptr() if ln else None, u.data_ptr() if ln else None, N, M, N, K, stream()))
+                torch.cuda.synchronize()
+                tag = (case, N, M, K, rot, ln, res, has_bias, tile)
+                assert rel_l2(h, want) < 1e-5 and max_abs(h, want) < 5e-4, tag
+                if ln:
+                    assert max_abs(u.float(), wu) < 4e-2 and rel_l2(u.float(), wu) < 4e-3, tag
+                outs[tile] = (h, u)
+            if N == 768:
+                assert torch.equal(outs[130][0], outs[128][0]) and torch.equal(outs[64][0], outs[128][0]), (case, M, K)
+                assert torch.equal(outs[64][1], outs[128][1]), (case, M, K)
+    finally:
+        hip.check(lib.ditto_set_option(b"fr_tile", 0))
+        hip.check(lib.ditto_set_option(b"fr_rot", 1))
+
+
 @pytest.mark.parametrize("M,K,ln,res", [(64, 1024, True, True), (300, 256, True, True), (1024, 4096, True, True), (257, 64, False, True),
                                           (1000, 128, True, False), (515, 192, True, True), (4096, 1024, True, True),
                                           (2048, 4096, False, True)])
