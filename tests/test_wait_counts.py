@@ -175,3 +175,59 @@ def test_fr64_wait_table_matches_a_queue_simulation():
                 # exact in the steady state (stages that are neither among the first hns nor in the tail)
                 if hns <= s < nkt - 4:
                     assert vm == younger, (nbw, nslab, s, vm, younger)
+
+
+# ---------------------------------------------------------------- gemm_frd.hip: the asynchronous register ring in the ISA
+def test_frd_register_ring_is_never_copied_while_loads_are_in_flight():
+    """gemm_frd's W fragments are loaded by asm `global_load_dwordx4` statements into a register ring that hipcc believes is
+    written synchronously; the kernel's own counted waits make that true before each use.  What would break it silently is a
+    compiler-inserted COPY (v_mov / v_accvgpr_write) or a spill of a ring register between a load's issue and its wait.  This
+    test compiles the file to ISA (device pass only, a few seconds) and checks, for all four instantiations, that from the
+    first to the last MFMA no instruction reads a ring register except MFMAs and no scratch access exists at all."""
+    src = os.path.join(CSRC, "gemm_frd.hip")
+    inc = os.path.join(HERE, "..", "include")
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "frd.s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", inc, "-I", CSRC,
+                        "--cuda-device-only", "-S", src, "-o", out], check=True, capture_output=True)
+        text = open(out).read()
+    parts = re.split(r"\n(_ZN5ditto12_GLOBAL__N_115gemm_frd_kernel\w+): ; @", text)
+    assert len(parts) == 9, "four instantiations expected"
+    for i in range(1, len(parts), 2):
+        body = parts[i + 1].split("s_endpgm")[0].split("\n")
+        loads = [(n, re.match(r"\s*global_load_dwordx4 v\[(\d+):(\d+)\], v\d+, s\[", ln)) for n, ln in enumerate(body)]
+        loads = [(n, m) for n, m in loads if m]
+        assert len(loads) >= 24, parts[i]
+        ring = set()
+        for _, m in loads:
+            ring.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        assert len(ring) == 48, (parts[i], len(ring))                     # two stages x six fragments x four registers
+        assert not any("scratch_" in ln for ln in body), parts[i]
+        # walk the instruction stream: a register is IN FLIGHT from the W load that targets it to the first MFMA that reads it
+        # (the kernel's counted wait sits right in front of that MFMA); nothing else may touch it in between
+        inflight, nload, nuse = set(), 0, 0
+        for n, raw in enumerate(body):
+            ln = raw.split(";")[0].strip()
+            if not ln or ln.startswith(".") or ln.endswith(":"):
+                continue
+            m = re.match(r"(\S+)\s*(.*)", ln)
+            op, args = m.group(1), m.group(2)
+            regs = set()
+            for x, y in re.findall(r"v\[(\d+):(\d+)\]", args):
+                regs.update(range(int(x), int(y) + 1))
+            regs.update(int(x) for x in re.findall(r"\bv(\d+)\b", args))
+            wl = re.match(r"global_load_dwordx4 v\[(\d+):(\d+)\], v(\d+), s\[", ln)
+            if wl:
+                dst = set(range(int(wl.group(1)), int(wl.group(2)) + 1))
+                assert not (dst & inflight), (parts[i][-28:], n, ln, "loaded into a register whose previous load was never consumed")
+                assert int(wl.group(3)) not in inflight, (parts[i][-28:], n, ln, "address register is an in-flight destination")
+                inflight |= dst
+                nload += 1
+            elif op.startswith("v_mfma"):
+                hit = regs & inflight
+                if hit:
+                    nuse += 1
+                    inflight -= hit
+            else:
+                assert not (regs & inflight), (parts[i][-28:], n, ln, "touches a W fragment register while its load is in flight")
+        assert nload >= 24 and nuse >= 24 and not inflight, (parts[i][-28:], nload, nuse, sorted(inflight))
