@@ -102,9 +102,15 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 // 2 transcendentals per output instead of 4: the gated epilogue runs with the matrix pipe idle and its transcendentals
 // (16 cycles each, quarter rate) were 62 % of its arithmetic time.  Q (1 + e^-g) = inf for
 // g < -88 gives 0, the limit; beyond |z| = 4 erf is +-1 to 1.5e-8.  The constants are pinned by tests/test_gated_math.py.
+// The NEGATIVE tail: at z = -4 the factor Q + z P is not 0 but the fit's residual (+-4e-7 Q), so with the plain x / 2
+// in front the result grew like x * 2e-7 for x < -5.66 instead of decaying.  x / 2 is therefore taken from the LOWER-clamped z:
+// x / 2 = (x / sqrt2) / sqrt2, and zl = max(x / sqrt2, -4) bounds the tail by 2.8 * 4e-7 (pinned by the CPU test's sweep to
+// |x| = 1e4); for x > -5.66 it is x / 2 to 1 ulp.
 DITTO_DEV f32x2 fast_gelu_sigmoid2(f32x2 x, f32x2 g) {
-    f32x2 z = x * 0.70710678118654752440f;
-    z[0] = __builtin_amdgcn_fmed3f(z[0], -4.0f, 4.0f); z[1] = __builtin_amdgcn_fmed3f(z[1], -4.0f, 4.0f);
+    f32x2 zl = x * 0.70710678118654752440f, z;
+    // (v_med3_f32 rather than fmaxf / fminf: no NaN-canonicalising v_max x, x in front)
+    zl[0] = __builtin_amdgcn_fmed3f(zl[0], -4.0f, 3.0e38f); zl[1] = __builtin_amdgcn_fmed3f(zl[1], -4.0f, 3.0e38f);
+    z[0] = __builtin_amdgcn_fmed3f(zl[0], -4.0f, 4.0f); z[1] = __builtin_amdgcn_fmed3f(zl[1], -4.0f, 4.0f);
     const f32x2 u = z * z;
     f32x2 pn = u * 1.9217200275534196e-08f + (-1.990321152334218e-06f);
     pn = pn * u + 0.00015553680714219809f;
@@ -116,7 +122,7 @@ DITTO_DEV f32x2 fast_gelu_sigmoid2(f32x2 x, f32x2 g) {
     qd = qd * u + 0.12079962342977524f;
     qd = qd * u + 0.5229312181472778f;
     qd = qd * u + 1.0f;
-    const f32x2 num = (x * 0.5f) * (z * pn + qd);             // x Q Phi(x)
+    const f32x2 num = (zl * 0.70710678118654752440f) * (z * pn + qd);   // (x / 2) Q (1 + erf): x Q Phi(x)
     const f32x2 eg = g * (-1.4426950408889634f);
     f32x2 e;
     e[0] = __builtin_amdgcn_exp2f(eg[0]); e[1] = __builtin_amdgcn_exp2f(eg[1]);

@@ -48,10 +48,11 @@ def test_rational_erf_constants_and_product():
     xs = np.linspace(-12, 12, 2401).astype(np.float32)
     gs = np.linspace(-100, 30, 261).astype(np.float32)
     X, G = np.meshgrid(xs, gs)
-    zc = np.clip((X * f(0.70710678118654752440)).astype(np.float32), -4, 4).astype(np.float32)
+    zl = np.maximum((X * f(0.70710678118654752440)).astype(np.float32), f(-4)).astype(np.float32)
+    zc = np.minimum(zl, f(4)).astype(np.float32)
     u = (zc * zc).astype(np.float32)
     Pv, Qv = _horner(P, u), _horner(Q, u)
-    num = ((X * f(0.5)).astype(np.float32) * (zc * Pv + Qv).astype(np.float32)).astype(np.float32)
+    num = ((zl * f(0.70710678118654752440)).astype(np.float32) * (zc * Pv + Qv).astype(np.float32)).astype(np.float32)
     with np.errstate(over="ignore"):
         E = np.exp2((G * f(-1.4426950408889634)).astype(np.float32)).astype(np.float32)
         den = (Qv * E + Qv).astype(np.float32)
@@ -63,3 +64,20 @@ def test_rational_erf_constants_and_product():
     assert err.max() < 3e-6                                   # |x| <= 12: 4e-7 of erf times |x| / 2
     big = np.abs(want) > 1e-3
     assert (err[big] / np.abs(want[big])).max() < 5e-4        # an eighth of a bf16 rounding step, in the far negative tail
+    # the tails: far negative x must decay (the lower-clamped x / 2 bounds it by 2.8 * |residual of the fit|), far
+    # positive x must give x * sigmoid(g)
+    xt = np.concatenate([-np.logspace(math.log10(5.7), 4, 400), np.logspace(math.log10(5.7), 4, 400)]).astype(np.float32)
+    gt = np.array([-3.0, 0.0, 2.5], dtype=np.float32)
+    X, G = np.meshgrid(xt, gt)
+    zl = np.maximum((X * f(0.70710678118654752440)).astype(np.float32), f(-4)).astype(np.float32)
+    zc = np.minimum(zl, f(4)).astype(np.float32)
+    u = (zc * zc).astype(np.float32)
+    Pv, Qv = _horner(P, u), _horner(Q, u)
+    num = ((zl * f(0.70710678118654752440)).astype(np.float32) * (zc * Pv + Qv).astype(np.float32)).astype(np.float32)
+    E = np.exp2((G * f(-1.4426950408889634)).astype(np.float32)).astype(np.float32)
+    out = (num * (f(1) / (Qv * E + Qv).astype(np.float32))).astype(np.float32)
+    neg = X < 0
+    assert np.abs(out[neg]).max() < 2e-6
+    wantp = X[~neg].astype(np.float64) / (1 + np.exp(-G[~neg].astype(np.float64)))
+    assert (np.abs(out[~neg] - wantp) / wantp).max() < 2e-6
+
