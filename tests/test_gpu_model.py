@@ -274,6 +274,36 @@ def test_full_size_c2_large_batch_takes_the_full_row_path():
 
 
 @torch.no_grad()
+def test_mid_batch_takes_the_64_row_full_row_kernel():
+    """B = 12 at N = 1024 (192 tiles of 64 rows): kernels.h fr_rule_rows sends the two fused launches of a block to the 64-row
+    kernel (csrc/gemm_fr64.hip, two workgroups per CU).  One utterance against the oracle, fused against unfused within
+    bf16-path noise, batch-position invariance, run-to-run equality; against the same utterances inside a batch of 20 (another
+    batch-size class: the tiled GEMMs around the full-row launches pick other tile structures there) within that noise."""
+    from oracle import ditto_oracle as O
+    p = PRESETS["C2"]
+    cfg = p["cfg"]
+    m = build(cfg, 2)
+    B, N, T = 12, p["N"], p["T"]
+    x, text, t = synthetic_inputs(cfg, 20, N, T, seed=5)
+    xd, td, tt = x.to(DEV), text.to(DEV), t.to(DEV)
+    assert hip.full_row_plan(cfg, B, N) == (True, True)
+    out = m(xd[:B].contiguous(), td[:B].contiguous(), tt[:B].contiguous())
+    assert torch.isfinite(out).all()
+    close(out[:1], O.ditto_forward(synthetic_state_dict(cfg, 2), 12, 12, x[:1], text[:1], t[:1]))
+    hip.set_option("fr_mask", 0)
+    try:
+        plain = m(xd[:B].contiguous(), td[:B].contiguous(), tt[:B].contiguous())
+    finally:
+        hip.set_option("fr_mask", 3)
+    assert not torch.equal(plain, out) and rel_l2(out, plain) < 4e-3
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(3)).to(DEV)
+    assert torch.equal(m(xd[:B][perm].contiguous(), td[:B][perm].contiguous(), tt[:B][perm].contiguous()), out[perm])
+    assert torch.equal(m(xd[:B].contiguous(), td[:B].contiguous(), tt[:B].contiguous()), out)
+    big = m(xd, td, tt)                                  # 20 utterances: the 128-row kernel, other GEMM tile structures
+    assert rel_l2(big[:B], out) < 4e-3
+
+
+@torch.no_grad()
 def test_headline_shape_b32_against_oracle():
     """The shape the driver times (C2: 12L, d = 768, N = T = 1024, B = 32 per GPU, full-row path, seed-1234 weights):
     utterance 0 is bench.py's own parity input (synthetic_inputs(cfg, 1, N, T, seed = 7)) and is compared with the fp32
