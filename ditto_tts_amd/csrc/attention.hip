@@ -1129,8 +1129,11 @@ size_t attention_train_workspace_bytes(int B, int H, int Sq, int Skv, int dh) {
     return g > dl ? g : dl;
 }
 
+bool attention_bwd_fuses_rope(const AttnBwdArgs& a) { return a.dh == DH && a.lse && a.rope_cos && a.rope_sin && a.Sq == a.Skv; }
+
 hipError_t launch_attention_bwd(const AttnBwdArgs& a, hipStream_t s) {
     if (a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Skv <= 0 || a.dh % 64) return hipErrorInvalidValue;
+    if ((a.rope_cos || a.rope_sin) && !attention_bwd_fuses_rope(a)) return hipErrorInvalidValue;   // the caller asks first
     if (a.dh == DH && a.lse) {   // fused: delta = rowsum(dO * O) into the workspace, then the two kernels
         if (!a.workspace || a.workspace_bytes < (size_t)a.B * a.H * a.Sq * 4) return hipErrorInvalidValue;
         float* delta = (float*)a.workspace;

@@ -892,6 +892,11 @@ int ditto_set_option(const char* name, int value) {
         g_fr_dgrad = value;
         return DITTO_OK;
     }
+    if (!strcmp(name, "train_flags")) {
+        if (value < 0 || value > 1) return fail(DITTO_ERR_ARG, "train_flags must be in [0, 1]");
+        g_train_flags = value;
+        return DITTO_OK;
+    }
     if (!strcmp(name, "fr_u_fp8")) {   // test hook: ditto_gemm_ln_bf16 writes u as fp8 e4m3 bytes ([M, ldu] bytes; N = 1024)
         g_fr_u_fp8 = value != 0;
         return DITTO_OK;

@@ -491,9 +491,13 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
             a.lddv = 3 * d; a.B = B; a.H = H; a.Sq = N; a.Skv = N; a.dh = dhd; a.scale = scale;
             a.workspace = attn_ws; a.workspace_bytes = wp.attn_bytes;
             if (dhd == 64) { a.lse = (const float*)(tb + q.lse_s); a.h_after = h1; a.h_before = h0; a.ldh = d; }
+            // the rotation's backward: in the dq / dk epilogues where the kernel can (head_dim 64), else one pass in place
+            a.rope_cos = rope_cos; a.rope_sin = rope_sin;
+            const bool fused_rope_bwd = (g_train_flags & 1) == 0 && attention_bwd_fuses_rope(a);
+            if (!fused_rope_bwd) a.rope_cos = a.rope_sin = nullptr;
             HIP_TRY(launch_attention_bwd(a, s));
+            if (!fused_rope_bwd) HIP_TRY(launch_rope_inplace(big1, 3 * d, rope_cos, rope_sin, M, N, 2 * d, dhd, s, -1.0f));
         }
-        HIP_TRY(launch_rope_inplace(big1, 3 * d, rope_cos, rope_sin, M, N, 2 * d, dhd, s, -1.0f));
         HIP_TRY(launch_colsum_bf16(big1, 3 * d, M, 3 * d, G.attn_in_proj_bias, red, s));
         TRY_RC(wgrad(big1, 3 * d, 3 * d, tb + q.u1, d, d, M, G.attn_in_proj_weight));
         if (fr_dgrad && (g_fr_dgrad & 2)) TRY_RC(dgrad_fr(big1, 3 * d, lt.WqkvTP, du));

@@ -39,6 +39,7 @@ int g_pp_nb = 0;
 // default 3: measured in-model at C2, B = 32 (tools/step_ab.py ~mask): 13.02 -> 12.73 (1) / 12.77 (2) / 12.40 ms (3)
 int g_fr_mask = [] { const char* e = getenv("DITTO_FR_MASK"); return e ? atoi(e) : 3; }();
 int g_fr_dgrad = [] { const char* e = getenv("DITTO_FR_DGRAD"); return e ? atoi(e) : 3; }();
+int g_train_flags = [] { const char* e = getenv("DITTO_TRAIN_FLAGS"); return e ? atoi(e) : 0; }();
 int g_fr_rot = [] { const char* e = getenv("DITTO_FR_ROT"); return e ? atoi(e) : 1; }();
 int g_fr_tile = [] { const char* e = getenv("DITTO_FR_TILE"); return e ? atoi(e) : 0; }();
 int g_fr64_maxk = [] { const char* e = getenv("DITTO_FR64_MAXK"); return e ? atoi(e) : 1 << 30; }();

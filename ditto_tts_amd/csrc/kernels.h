@@ -86,6 +86,7 @@ inline bool fr_pays_64(int M) {
     return (rows + 63) / 64 >= 192;
 }
 
+extern int g_train_flags;   // gemm.hip: training-step A/B switches: bit 0 = the rotation's backward as its own pass (not in the dq / dk epilogues)
 extern int g_fr_dgrad;   // gemm.hip: training backward, long-K dgrads on the full-row kernel: bit 0 fc1|gate (K = 8d), bit 1 QKV (K = 3d)
 extern int g_fr_rot;     // gemm.hip: full-row kernel's K-loop rotation: 0 off, 1 on in the model (period = tiles per utterance), > 1 = period for ditto_gemm_ln_bf16 too
 // g_fr_tile (declared above): gemm.hip: full-row kernel's tile: 0 = rule, 64 = gemm_fr64.hip for every launch with K <= g_fr64_maxk, 128 = gemm_fr.hip
@@ -212,8 +213,13 @@ struct AttnBwdArgs {
     const float* lse;
     const void* o_bf16; int ldo;
     const float* h_after; const float* h_before; int ldh;
+    // fused path: the INVERSE half-split RoPE of dq and dk (the backward of the rotation the QKV GEMM's epilogue applied) in
+    // the kernels' epilogues, on the fp32 accumulators; tables [Sq, dh / 2] (self-attention: Skv == Sq).  null: no rotation.
+    const float* rope_cos; const float* rope_sin;
 };
 hipError_t launch_attention_bwd(const AttnBwdArgs& a, hipStream_t s);
+// true when launch_attention_bwd(a) applies a.rope_cos / a.rope_sin itself (the fused dh == 64 path)
+bool attention_bwd_fuses_rope(const AttnBwdArgs& a);
 hipError_t launch_attention_delta(const void* dout, int lddo, const void* o_bf16, int ldo, const float* h_after,
                                   const float* h_before, int ldh, float* delta, int B, int H, int Sq, hipStream_t s);
 hipError_t launch_attention_bwd64(const AttnBwdArgs& a, const float* lse, const float* delta, hipStream_t s);

@@ -233,6 +233,35 @@ def test_gradients_are_bit_reproducible():
         assert torch.equal(grads[0][n], grads[1][n]), n
 
 
+def test_rope_backward_in_the_attention_epilogue_vs_its_own_pass():
+    """head_dim 64: the backward of the self-attention rotation runs inside the dq / dk epilogues of the attention backward
+    (csrc/attention_bwd.hip) on the fp32 accumulators; train_flags 1 = the older separate in-place pass over the bf16 dq | dk.
+    Both against fp32 autograd of the oracle (rel-L2 <= 3e-2 per tensor), the fused one no worse than the pass on the QKV
+    weight gradient (it rounds to bf16 once instead of twice), and the two differ (the switch is live).  Ragged N = 200
+    exercises the partial last 64-row tile of the epilogue."""
+    cfg = DiTTOConfig(256, 2, 4, 64, 256, 20)
+    B, N, T = 2, 200, 72
+    x, text, t = synthetic_inputs(cfg, B, N, T, seed=11)
+    target = hash_normal((B, N, cfg.hidden_dim), "noise", 12)
+    _, _, want = _oracle_grads(cfg, 5, x, text, t, target)
+    got = {}
+    for flag in (0, 1):
+        hip.set_option("train_flags", flag)
+        try:
+            m = _build(cfg, 5).eval()
+            F.mse_loss(m(x.to(DEV), text.to(DEV), t.to(DEV)), target.to(DEV)).backward()
+            _check_grads(m, want, 3e-2)
+            got[flag] = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+        finally:
+            hip.set_option("train_flags", 0)
+    name = "blocks.0.attn.in_proj_weight"
+    r0, r1 = rel_l2(got[0][name], want[name]), rel_l2(got[1][name], want[name])
+    assert r0 <= r1 * 1.05, (r0, r1)
+    assert not torch.equal(got[0][name], got[1][name]), "train_flags did not switch the path"
+    d = cfg.hidden_dim                                   # dv takes no rotation: its rows of the gradient are bitwise the same
+    assert torch.equal(got[0]["blocks.1.attn.in_proj_weight"][2 * d:], got[1]["blocks.1.attn.in_proj_weight"][2 * d:])
+
+
 def test_large_batch_training_step_takes_the_full_row_forward():
     """From 160 row tiles on (B >= 20 at N = 1024) the training forward runs the cross out-projection + norm3 and fc2 + the
     next block's norm1 on the full-row kernel (csrc/gemm_fr.hip), its LayerNorm outputs landing in the tape slots the

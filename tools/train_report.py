@@ -28,12 +28,17 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--no-parity", action="store_true", help="accepted and ignored (older command lines)")
     ap.add_argument("--wgrad-wgs", type=int, default=0)
+    ap.add_argument("--train-flags", type=int, default=None, help="ditto_set_option('train_flags'): 1 = the rotation's "
+                    "backward as its own pass (A/B)")
     ap.add_argument("--gemm-flags", type=int, default=None, help="ditto_set_option('gemm_flags'): 321 default; "
                     "+2048 = the two-buffer weight-gradient kernel (A/B)")
     a = ap.parse_args()
     if a.gemm_flags is not None:
         from ditto_tts_amd import hip as _hip
         _hip.check(_hip.lib().ditto_set_option(b"gemm_flags", a.gemm_flags))
+    if a.train_flags is not None:
+        from ditto_tts_amd import hip as _hip
+        _hip.set_option("train_flags", a.train_flags)
     if a.wgrad_wgs:
         from ditto_tts_amd import hip
         hip.check(hip.lib().ditto_set_option(b"wgrad_wgs", a.wgrad_wgs))
