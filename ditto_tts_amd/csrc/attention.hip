@@ -1124,7 +1124,7 @@ size_t attention_train_workspace_bytes(int B, int H, int Sq, int Skv, int dh) {
     const size_t f = (size_t)cf * generic_fwd_bytes(Sq, Skv, dh);
     const int cb = bwd_chunk(B, H, Sq, Skv, dh, (size_t)2 << 30);
     const size_t b = plan_bwd(Sq, Skv, dh, cb).total;
-    const size_t dl = align256((size_t)B * H * Sq * 4);   // fused backward: delta [B, H, Sq]
+    const size_t dl = align256(attention_bwd_stats_bytes(B, H, Sq));   // fused backward: the per-tile {L, delta} records
     const size_t g = f > b ? f : b;
     return g > dl ? g : dl;
 }
@@ -1134,13 +1134,13 @@ bool attention_bwd_fuses_rope(const AttnBwdArgs& a) { return a.dh == DH && a.lse
 hipError_t launch_attention_bwd(const AttnBwdArgs& a, hipStream_t s) {
     if (a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Skv <= 0 || a.dh % 64) return hipErrorInvalidValue;
     if ((a.rope_cos || a.rope_sin) && !attention_bwd_fuses_rope(a)) return hipErrorInvalidValue;   // the caller asks first
-    if (a.dh == DH && a.lse) {   // fused: delta = rowsum(dO * O) into the workspace, then the two kernels
-        if (!a.workspace || a.workspace_bytes < (size_t)a.B * a.H * a.Sq * 4) return hipErrorInvalidValue;
-        float* delta = (float*)a.workspace;
-        hipError_t e = launch_attention_delta(a.dout, a.lddo, a.o_bf16, a.ldo, a.h_after, a.h_before, a.ldh, delta, a.B,
-                                              a.H, a.Sq, s);
+    if (a.dh == DH && a.lse) {   // fused: {L, delta = rowsum(dO * O)} records into the workspace, then the two kernels
+        if (!a.workspace || a.workspace_bytes < attention_bwd_stats_bytes(a.B, a.H, a.Sq)) return hipErrorInvalidValue;
+        float* stats = (float*)a.workspace;
+        hipError_t e = launch_attention_delta(a.dout, a.lddo, a.o_bf16, a.ldo, a.h_after, a.h_before, a.ldh, a.lse, stats,
+                                              a.B, a.H, a.Sq, s);
         if (e != hipSuccess) return e;
-        return launch_attention_bwd64(a, a.lse, delta, s);
+        return launch_attention_bwd64(a, stats, s);
     }
     if (!a.workspace || a.workspace_bytes < plan_bwd(a.Sq, a.Skv, a.dh, 1).total) return hipErrorInvalidValue;
     const int BH = a.B * a.H;

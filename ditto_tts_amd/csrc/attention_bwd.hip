@@ -25,6 +25,12 @@ namespace ditto {
 namespace {
 
 constexpr int DH = 64, BLK = 128, TILE = 64;
+// Timing-only knock-outs (WRONG results by design; tools/bwd_knockout.sh builds one library per bit and times them):
+//   1 = no P / dS vector work, 2 = tiles are DMA'd once (no global->LDS traffic in the loop), 4 = no barrier in the loop,
+//   8 = no accumulation MFMAs (second phase), 16 = no S / dP MFMAs (first phase), 32 = no LDS fragment reads in the loop
+#ifndef DITTO_DIAG_BWD
+#define DITTO_DIAG_BWD 0
+#endif
 constexpr int IMG = TILE * DH * 2;   // one 64-row x 128-B tile image: 8 KiB
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
 
@@ -32,8 +38,7 @@ struct BwdParams {
     const bf16* q; int ldq; const bf16* k; int ldk; const bf16* v; int ldv;
     const bf16* dout; int lddo;
     bf16* dq; int lddq; bf16* dk; int lddk; bf16* dv; int lddv;
-    const float* lse;     // [B, H, Sq] log2 domain
-    const float* delta;   // [B, H, Sq]
+    const float* stats;   // [B, H, ceil(Sq / 64), 128]: {L[64] (log2 domain) | delta[64]} per query tile (attn_delta_kernel)
     int B, H, Sq, Skv, nblk;
     float scale, scale_log2;
     unsigned drop_thr; float keep_scale; unsigned seed_lo, seed_hi; int layer;
@@ -47,31 +52,38 @@ DITTO_DEV bf16x8 cat4(bf16x4 a, bf16x4 b) {
     return r;
 }
 
-// delta[b,h,q] = sum_c dO[row, h*64 + c] * O[row, h*64 + c].  O = o_bf16 (cross-attention output) or
-// h_after - h_before (self-attention: the residual stream before / after the segment, no out-proj).
-// One wave per row, 4 columns per lane per pass, a head = 16 lanes.
+// Per-row statistics of the backward, one record per (batch, head, 64-query tile): stats[((b H + h) nt + tile) 128 + {i, 64 + i}]
+// = {L, delta} of query tile * 64 + i, nt = ceil(Sq / 64):  L = the forward's log2-domain log-sum-exp (copied here), delta =
+// sum_c dO[row, h*64 + c] * O[row, h*64 + c].  Rows past Sq hold L = 1e30 (P = exp2(-inf) = 0) and delta = 0, so the dkdv kernel
+// needs no row mask, and a tile's record is one 512-byte LDS-DMA.  O = o_bf16 (cross-attention output) or h_after - h_before
+// (self-attention: the residual stream before / after the segment, no out-proj).
+// One wave per (padded) row, 4 columns per lane per pass, a head = 16 lanes.
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ dout, int lddo,
                                                          const bf16* __restrict__ o_bf16, int ldo,
                                                          const float* __restrict__ h_after,
                                                          const float* __restrict__ h_before, int ldh,
-                                                         float* __restrict__ delta, int B, int H, int Sq) {
+                                                         const float* __restrict__ lse, float* __restrict__ stats, int B,
+                                                         int H, int Sq) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= B * Sq) return;
-    const int b = row / Sq, qi = row % Sq;
+    const int nt = (Sq + TILE - 1) / TILE, sqp = nt * TILE;
+    const int prow = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (prow >= B * sqp) return;
+    const int b = prow / sqp, qi = prow % sqp;
+    const bool real = qi < Sq;
+    const size_t row = (size_t)b * Sq + (real ? qi : Sq - 1);
     const int d = H * DH;
     for (int c0 = 0; c0 < d; c0 += 256) {
         const int col = c0 + lane * 4;
         float acc = 0.f;
-        if (col < d) {
-            const u32x2 g = *reinterpret_cast<const u32x2*>(dout + (size_t)row * lddo + col);
+        if (col < d && real) {
+            const u32x2 g = *reinterpret_cast<const u32x2*>(dout + row * lddo + col);
             float o[4];
             if (o_bf16) {
-                const u32x2 ov = *reinterpret_cast<const u32x2*>(o_bf16 + (size_t)row * ldo + col);
+                const u32x2 ov = *reinterpret_cast<const u32x2*>(o_bf16 + row * ldo + col);
                 o[0] = bf16_lo(ov[0]); o[1] = bf16_hi(ov[0]); o[2] = bf16_lo(ov[1]); o[3] = bf16_hi(ov[1]);
             } else {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(h_after + (size_t)row * ldh + col);
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(h_before + (size_t)row * ldh + col);
+                const f32x4 a = *reinterpret_cast<const f32x4*>(h_after + row * ldh + col);
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(h_before + row * ldh + col);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = a[e] - bb[e];
             }
@@ -79,22 +91,44 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
         }
 #pragma unroll
         for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-        if (col < d && (lane & 15) == 0) delta[((size_t)b * H + col / DH) * Sq + qi] = acc;
+        if (col < d && (lane & 15) == 0) {
+            const int hd = col / DH;
+            float* rec = stats + (((size_t)b * H + hd) * nt + qi / TILE) * 128 + (qi & (TILE - 1));
+            rec[0] = real ? lse[((size_t)b * H + hd) * Sq + qi] : 1e30f;
+            rec[64] = acc;
+        }
     }
 }
 
+template <int N>
+DITTO_DEV void bwd_vm_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 // ------------------------------------------------------------------------------------------------
-// Shared tile machinery.  A "row image" keeps 16-B chunk c of row r at c ^ ((r>>1)&7) (conflict-free
-// ds_read_b128 of MFMA A fragments); a "tr image" keeps it at c ^ (((r>>1)&1)<<2) (the 4 rows of a transposed
-// read block in 4 different 64-B bank quarters).  Both swizzles are applied to the DMA's SOURCE address.
-// MODE 0 = dq kernel   (block = queries; tiles = keys:    images K_row, V_row, K_tr)
-// MODE 1 = dkdv kernel (block = keys;    tiles = queries: images Q_row, dO_row, Q_tr, dO_tr  + L / delta)
+// Shared tile machinery.  ONE 64-row x 128-B image per operand tile serves both read patterns: 16-B chunk c of row r sits at
+// chunk position c ^ S(r), S(r) = (((r>>1)&1) << 2) | ((r>>2)&3) — a bit permutation of the (r>>1)&7 row swizzle (so the
+// ds_read_b128 of MFMA A fragments, 32 rows x one chunk, stay conflict-free), whose bit 2 separates rows r and r+2 (so the four
+// rows of a ds_read_b64_tr_b16 block, 4 rows x 64 B, land in four different 64-B bank quarters).  The swizzle is applied to the
+// DMA's SOURCE address.  (An earlier version kept a row image and a transposed-read image of every operand: twice the LDS-DMA
+// traffic and twice the LDS, which left room for one tile of look-ahead only; with the tile's DMA knocked out the dkdv kernel
+// ran 22 % faster — the loads were landing late.)
+// MODE 0 = dq kernel   (block = queries; tiles = keys:    images K, V)
+// MODE 1 = dkdv kernel (block = keys;    tiles = queries: images Q, dO  + the tile's L / delta record)
+// Ring of NBUF = 4 tile buffers, tile t+3 requested while tile t is computed, ONE barrier per tile placed behind the third
+// accumulation slot: by then every wave has its pieces of tile t+1 (counted vmcnt: DMAs retire in order) and is done with
+// tile t-1's buffer, so the request for tile t+3 and the first fragment reads of tile t+1 go out under the last MFMAs of tile t.
 // ------------------------------------------------------------------------------------------------
-template <int MODE>
-__global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void attn64_bwd_kernel(BwdParams p) {
-    constexpr int NIMG = MODE == 0 ? 3 : 4;
-    constexpr int BUF = NIMG * IMG + (MODE == 1 ? 512 : 0);   // + L[64] | delta[64] floats
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * BUF (MODE 1: 65 KiB, above the static limit)
+constexpr int NBUF = 4;
+constexpr int STAT_BYTES = 1024;   // L[64] | delta[64] floats, written twice over by one 64-lane 16-B DMA
+
+DITTO_DEV int img_swz(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
+
+// DROP: train-mode dropout on P (the hash mask of the forward) compiled in; without it no per-element hash, no branch.
+template <int MODE, bool DROP>
+__global__ __launch_bounds__(256, 2) void attn64_bwd_kernel(BwdParams p) {
+    constexpr int BUF = 2 * IMG + (MODE == 1 ? STAT_BYTES : 0);
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // NBUF * BUF: 64 / 68 KiB (two workgroups per CU)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nwg = p.nblk * p.H * p.B;
@@ -102,6 +136,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void attn64_bwd_kernel(BwdP
     const int blk = id % p.nblk, bh = id / p.nblk;
     const int h = bh % p.H, b = bh / p.H;
     const int ql = lane & 31, hh = lane >> 5;
+    const int nqt = (p.Sq + TILE - 1) / TILE;   // stats records per (batch, head)
 
     // block side ("own" rows: queries in MODE 0, keys in MODE 1) and tile side
     const int own_len = MODE == 0 ? p.Sq : p.Skv;
@@ -123,63 +158,76 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void attn64_bwd_kernel(BwdP
             f1[ks] = *reinterpret_cast<const bf16x8*>(s1 + 16 * ks);
         }
     }
-    float own_L = 0.f, own_delta = 0.f;   // MODE 0: per-lane (query) scalars
+    float own_L = 1e30f, own_delta = 0.f;   // MODE 0: per-lane (query) scalars
     if constexpr (MODE == 0) {
-        own_L = own_valid ? p.lse[(size_t)bh * p.Sq + own] : 1e30f;
-        own_delta = own_valid ? p.delta[(size_t)bh * p.Sq + own] : 0.f;
+        if (own_valid) {
+            const float* rec = p.stats + ((size_t)bh * nqt + own / TILE) * 128 + (own & (TILE - 1));
+            own_L = rec[0];
+            own_delta = rec[64];
+        }
     }
 
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
-    // tile sources: MODE 0: (K, V), MODE 1: (Q, dO)
+    // tile sources: MODE 0: (K, V), MODE 1: (Q, dO).  This lane's two (row, chunk) DMA sources of tile 0; tile tt is + tt * 64 rows
     const bf16* t0 = MODE == 0 ? p.k : p.q;
     const int ld0 = MODE == 0 ? p.ldk : p.ldq;
     const bf16* t1 = MODE == 0 ? p.v : p.dout;
     const int ld1 = MODE == 0 ? p.ldv : p.lddo;
+    const int ntile = (tile_len + TILE - 1) / TILE;
+    const bool ragged_tile = (tile_len & (TILE - 1)) != 0;
+    const bf16 *src0[2], *src1[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wid * 2 + i) * 8 + (lane >> 3), c = (lane & 7) ^ img_swz(row);
+        src0[i] = t0 + ((size_t)b * tile_len + row) * ld0 + h * DH + c * 8;
+        src1[i] = t1 + ((size_t)b * tile_len + row) * ld1 + h * DH + c * 8;
+    }
+    const size_t step0 = (size_t)TILE * ld0, step1 = (size_t)TILE * ld1;
+    const float* stat_src = p.stats + (size_t)bh * nqt * 128 + (lane & 31) * 4;
+    // 4 DMAs per wave and tile (wave 0 of the dkdv kernel: 5, the tile's L / delta record)
     auto dma_tile = [&](int tt, int buf) {
+        const unsigned dst = lds_base + (unsigned)(buf * BUF);
+        if (ragged_tile && tt == ntile - 1) {   // rows past the end are clamped (never read out of bounds); their P is 0
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int piece = wid * 2 + i;
-            const int row = piece * 8 + (lane >> 3), cpos = lane & 7;
-            int tr = tt * TILE + row;
-            tr = tr < tile_len ? tr : tile_len - 1;
-            const int crow = cpos ^ ((row >> 1) & 7), ctr = cpos ^ (((row >> 1) & 1) << 2);
-            const bf16* r0 = t0 + ((size_t)b * tile_len + tr) * ld0 + h * DH;
-            const bf16* r1 = t1 + ((size_t)b * tile_len + tr) * ld1 + h * DH;
-            const unsigned dst = lds_base + (unsigned)(buf * BUF + piece * 1024);
-            glds16(r0 + crow * 8, dst);                 // image 0: t0 rows
-            glds16(r1 + crow * 8, dst + IMG);           // image 1: t1 rows
-            glds16(r0 + ctr * 8, dst + 2 * IMG);        // image 2: t0 transposed-read
-            if constexpr (MODE == 1) glds16(r1 + ctr * 8, dst + 3 * IMG);   // image 3: t1 transposed-read
-        }
-    };
-    // MODE 1: the tile's 64 query rows' L and delta -> LDS (threads 0..31: one f32x4 each)
-    f32x4 stat_reg = {0.f, 0.f, 0.f, 0.f};
-    auto load_stats = [&](int tt) {
-        if constexpr (MODE == 1) {
-            if (tid < 32) {
-                const int j = (tid & 15) * 4;
-                const float* src = (tid < 16 ? p.lse : p.delta) + (size_t)bh * p.Sq;
-                const float fill = tid < 16 ? 1e30f : 0.f;   // rows past Sq: P = exp2(-inf) = 0
+            for (int i = 0; i < 2; ++i) {
+                const int piece = wid * 2 + i;
+                const int row = piece * 8 + (lane >> 3), c = (lane & 7) ^ img_swz(row);
+                int tr = tt * TILE + row;
+                tr = tr < tile_len ? tr : tile_len - 1;
+                glds16(t0 + ((size_t)b * tile_len + tr) * ld0 + h * DH + c * 8, dst + piece * 1024);
+                glds16(t1 + ((size_t)b * tile_len + tr) * ld1 + h * DH + c * 8, dst + IMG + piece * 1024);
+            }
+        } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int qi = tt * TILE + j + e;
-                    stat_reg[e] = qi < p.Sq ? src[qi] : fill;
-                }
+            for (int i = 0; i < 2; ++i) {
+                const int piece = wid * 2 + i;
+                glds16(src0[i] + (size_t)tt * step0, dst + piece * 1024);
+                glds16(src1[i] + (size_t)tt * step1, dst + IMG + piece * 1024);
             }
         }
-    };
-    auto write_stats = [&](int buf) {
         if constexpr (MODE == 1) {
-            if (tid < 32)
-                *reinterpret_cast<f32x4*>(smem + buf * BUF + NIMG * IMG + (tid < 16 ? 0 : 256) + (tid & 15) * 16) = stat_reg;
+            if (wid == 0) glds16(stat_src + (size_t)tt * 128, dst + 2 * IMG);
+        }
+    };
+    // wait until at most `younger` whole tiles requested after the one needed are still in flight (0, 1 or 2)
+    auto wait_tile = [&](int younger) {
+        if (MODE == 1 && wid == 0) {
+            if (younger >= 2) bwd_vm_wait<10>();
+            else if (younger == 1) bwd_vm_wait<5>();
+            else bwd_vm_wait<0>();
+        } else {
+            if (younger >= 2) bwd_vm_wait<8>();
+            else if (younger == 1) bwd_vm_wait<4>();
+            else bwd_vm_wait<0>();
         }
     };
 
-    const int row_off = ql * 128, row_swz = (ql >> 1) & 7;
+    const int row_off = ql * 128, row_swz = img_swz(ql);
     const int tr_q = (lane & 15) >> 2, tr_p = lane & 3;
     const int tr_colbyte = (16 * ((lane >> 4) & 1) + 4 * tr_p) * 2;
     const int tr_row0 = 4 * hh + tr_q;
-    const int tr_swz = ((tr_q >> 1) & 1) << 6;
+    // rows 16 s2 + tr_row0 and + 8: S = ((tr_q >> 1) & 1) << 2 | (hh [+ 2]) & 3
+    const int tr_swz0 = (((tr_q >> 1) & 1) << 6) | (hh << 4), tr_swz1 = (((tr_q >> 1) & 1) << 6) | (((hh + 2) & 3) << 4);
 
     f32x16 acc0[2], acc1[2];   // MODE 0: dQ^T in acc0 (acc1 unused)   MODE 1: dK^T in acc0, dV^T in acc1
 #pragma unroll
@@ -187,87 +235,172 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void attn64_bwd_kernel(BwdP
     const float c = p.scale_log2;
     const unsigned dstream = drop_stream(p.seed_lo, p.seed_hi, p.layer, bh);
 
-    const int ntile = (tile_len + TILE - 1) / TILE;
-    dma_tile(0, 0);
-    load_stats(0);
-    write_stats(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    for (int tt = 0; tt < ntile; ++tt) {
-        const char* base = smem + (tt & 1) * BUF;
-        if (tt + 1 < ntile) {
-            dma_tile(tt + 1, (tt + 1) & 1);
-            load_stats(tt + 1);
+    constexpr int G = 2;                        // k-steps (of 16) per pipeline step: 2 G fragments in flight, twice
+    constexpr int NSTEP = 8 / G;                // 2 row blocks x 4 k-steps
+    static_assert(NSTEP == 4, "the schedule below is written for four steps");
+    bf16x8 fa[2][2 * G];                        // [0] is loaded for the NEXT tile before the current one ends
+    auto ld_rows = [&](const char* base, int i, bf16x8* dst) {
+        if constexpr ((DITTO_DIAG_BWD & 32) != 0) return;
+        const int rb = (i * G) >> 2, ks0 = (i * G) & 3;
+#pragma unroll
+        for (int kk = 0; kk < G; ++kk) {
+            const int off = rb * 32 * 128 + row_off + (((2 * (ks0 + kk) + hh) ^ row_swz) << 4);
+            dst[2 * kk] = *reinterpret_cast<const bf16x8*>(base + off);
+            dst[2 * kk + 1] = *reinterpret_cast<const bf16x8*>(base + IMG + off);
         }
+    };
+
+#pragma unroll
+    for (int t0i = 0; t0i < NBUF - 1; ++t0i)
+        if (t0i < ntile) dma_tile(t0i, t0i);
+    wait_tile(ntile - 1 < NBUF - 2 ? ntile - 1 : NBUF - 2);
+    __syncthreads();
+    // the compiler's own wait for the fragment loads above must fall HERE, not at their first use inside the tile loop: it
+    // counts only the loads it knows, so its vmcnt(0) in the loop would drain the whole DMA ring once per tile
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(f0[ks]), "+v"(f1[ks]));
+    asm volatile("" : "+v"(own_L), "+v"(own_delta));
+    ld_rows(smem, 0, fa[0]);
+
+    // MASKED: the ragged last KEY tile of the dq kernel (keys past Skv get P = 0).  The dkdv kernel needs no mask: its tile
+    // rows are queries, and rows past Sq carry L = 1e30 in the stats record.
+    auto tile_body = [&](int tt, auto MASKED) {
+        const char* base = smem + (tt & (NBUF - 1)) * BUF;
+        // The tile body is a software pipeline written out by hand: every LDS fragment is requested one step before the MFMAs
+        // that consume it, and the vector work of 16 tile rows (P, dS) is interleaved with the MFMAs of another step, where it
+        // runs in the matrix pipe's shadow.  sched_barrier(0) pins the batches; the counted lgkmcnt waits are the compiler's.
         // ---- st = T0 * F0^T  (S^T or S),  dp = T1 * F1^T  (dP^T or dP): tile row in registers, own row on the lane ----
-        f32x16 st[2], dp[2];
+        f32x16 st[2], dp[2];   // every chain's first MFMA takes the constant 0 as its accumulator operand: no zeroing moves
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // transposed fragments of 16 tile rows (s2): [db] of image 0 (K^T | Q^T), MODE 1 also [2 + db] of image 1 (dO^T)
+        bf16x8 tf[2][MODE == 0 ? 2 : 4];
+        auto ld_tr = [&](int s2, bf16x8* dst) {
+            if constexpr ((DITTO_DIAG_BWD & 32) != 0) return;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { st[0][i] = 0.f; st[1][i] = 0.f; dp[0][i] = 0.f; dp[1][i] = 0.f; }
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int off = rb * 32 * 128 + row_off + (((2 * ks + hh) ^ row_swz) << 4);
-                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(base + off);
-                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(base + IMG + off);
-                st[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, f0[ks], st[rb], 0, 0, 0);
-                dp[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, f1[ks], dp[rb], 0, 0, 0);
+            for (int db = 0; db < 2; ++db) {
+                const char* r0 = base + (16 * s2 + tr_row0) * 128;
+                const char* a0 = r0 + ((tr_colbyte + 64 * db) ^ tr_swz0);
+                const char* a8 = r0 + 8 * 128 + ((tr_colbyte + 64 * db) ^ tr_swz1);
+                dst[db] = cat4(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0)),
+                               __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a8)));
+                if constexpr (MODE == 1)
+                    dst[2 + db] = cat4(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0 + IMG)),
+                                       __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a8 + IMG)));
             }
-        // ---- P, dS for the 32 tile rows this lane holds (tile row = rb*32 + (r&3) + 8*(r>>2) + 4*hh) ----
-        bf16x8 pf[4], dsf[4];
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) {
-            float Lr[8], Dr[8];
+        };
+        // MODE 1: L and delta of tile rows 16 s2 + 4 hh + {0..3} and + 8 (half-wave broadcast reads)
+        f32x4 sl[2], sd[2];
+        auto ld_stats = [&](int s2) {
             if constexpr (MODE == 1) {
-                // rows 16*s2 + 4*hh + {0..3} and + 8: two f32x4 of L and of delta from LDS (half-wave broadcast)
-                const char* sp = base + NIMG * IMG + (16 * s2 + 4 * hh) * 4;
-                const f32x4 l0 = *reinterpret_cast<const f32x4*>(sp), l1 = *reinterpret_cast<const f32x4*>(sp + 32);
-                const f32x4 d0 = *reinterpret_cast<const f32x4*>(sp + 256), d1 = *reinterpret_cast<const f32x4*>(sp + 288);
+                const char* sp = base + 2 * IMG + (16 * s2 + 4 * hh) * 4;
+                sl[0] = *reinterpret_cast<const f32x4*>(sp); sl[1] = *reinterpret_cast<const f32x4*>(sp + 32);
+                sd[0] = *reinterpret_cast<const f32x4*>(sp + 256); sd[1] = *reinterpret_cast<const f32x4*>(sp + 288);
+            }
+        };
+        // ---- P, dS for 16 tile rows (s2); this lane holds tile rows rb*32 + (r&3) + 8*(r>>2) + 4*hh of block rb = s2 >> 1 ----
+        bf16x8 pf[4], dsf[4];
+        auto p_ds = [&](int s2) {
+            if constexpr ((DITTO_DIAG_BWD & 1) != 0) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { Lr[e] = l0[e]; Lr[4 + e] = l1[e]; Dr[e] = d0[e]; Dr[4 + e] = d1[e]; }
+                for (int j = 0; j < 8; ++j) {
+                    dsf[s2][j] = (bf16)dp[s2 >> 1][8 * (s2 & 1) + j];
+                    if constexpr (MODE == 1) pf[s2][j] = (bf16)st[s2 >> 1][8 * (s2 & 1) + j];
+                }
+                return;
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int rr = 8 * (s2 & 1) + j;
                 const int trow = tt * TILE + (s2 >> 1) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * hh;
-                const float L = MODE == 0 ? own_L : Lr[j];
-                const float dl = MODE == 0 ? own_delta : Dr[j];
+                const float L = MODE == 0 ? own_L : sl[j >> 2][j & 3];
+                const float dl = MODE == 0 ? own_delta : sd[j >> 2][j & 3];
                 float sv = st[s2 >> 1][rr] * c - L;
-                if constexpr (MODE == 0) sv = trow < p.Skv ? sv : -1e30f;   // ragged last key tile
+                if constexpr (decltype(MASKED)::value) sv = trow < p.Skv ? sv : -1e30f;
                 const float pr = __builtin_amdgcn_exp2f(sv);
                 float g = dp[s2 >> 1][rr], pd = pr;
-                if (p.drop_thr) {
+                if constexpr (DROP) {
                     const int qi = MODE == 0 ? own : trow, kj = MODE == 0 ? trow : own;
                     const bool keep = drop_keep(dstream, qi, kj, p.drop_thr);
                     g = keep ? g * p.keep_scale : 0.f;
                     pd = keep ? pr * p.keep_scale : 0.f;
                 }
-                dsf[s2][j] = (bf16)(pr * (g - dl) * p.scale);
+                dsf[s2][j] = (bf16)(pr * (g - dl));   // dS / scale: the factor is applied once, to the accumulators (epilogue)
                 if constexpr (MODE == 1) pf[s2][j] = (bf16)pd;
             }
-        }
-        // ---- acc^T[d][own] += T^T[d][tile row] * X[tile row][own]  (transposed reads of the tr images) ----
+        };
+        // schedule (4 steps of 4 MFMAs, then 4 slots of 2 | 4):      requests                 MFMAs                  behind them
+        //   step 0                                                    rows(1)                  S,dP k 0-1 of block 0
+        //   step 1                                                    rows(2)                  k 2-3                  stats(0)
+        //   step 2                                                    rows(3)                  block 1 k 0-1          P,dS(0), stats(1)
+        //   step 3                                                    tr(0)                    block 1 k 2-3          P,dS(1), stats(2)
+        //   slot 0                                                    tr(1)                    acc += ..(0)           P,dS(2), stats(3)
+        //   slot 1                                                    tr(2)                    acc += ..(1)           P,dS(3)
+        //   slot 2                                                    tr(3)                    acc += ..(2)           wait tile t+1, BARRIER,
+        //                                                                                                             DMA tile t+3, rows(0) of t+1
+        //   slot 3                                                                             acc += ..(3)
+        // (the L / delta request for the NEXT rows goes out only after the vector work that reads the current ones: one buffer)
+        // inside a region that holds nm MFMAs and one p_ds: one MFMA, then an equal share of the vector instructions, and so on
+        constexpr int NVEC = (MODE == 0 ? 28 : 32) + (DROP ? (MODE == 0 ? 80 : 112) : 0);   // vector instructions of one p_ds
+        auto interleave = [&](auto NM) {
+            constexpr int nm = decltype(NM)::value;
 #pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2)
+            for (int k = 0; k < nm; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, NVEC / nm, 0);
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < NSTEP; ++i) {
+            if (i + 1 < NSTEP) ld_rows(base, i + 1, fa[(i + 1) & 1]);
+            else ld_tr(0, tf[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            const int rb = (i * G) >> 2, ks0 = (i * G) & 3;
+#pragma unroll
+            for (int kk = 0; kk < G; ++kk) {
+                if constexpr ((DITTO_DIAG_BWD & 16) != 0) continue;
+                const bool first = ks0 + kk == 0;
+                st[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i & 1][2 * kk], f0[ks0 + kk], first ? zero16 : st[rb], 0, 0, 0);
+                dp[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i & 1][2 * kk + 1], f1[ks0 + kk], first ? zero16 : dp[rb], 0, 0, 0);
+            }
+            if (i >= 2) p_ds(i - 2);
+            if (i >= 1) ld_stats(i - 1);
+            if (i >= 2) interleave(std::integral_constant<int, 2 * G>{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- acc^T[d][own] += T^T[d][tile row] * X[tile row][own]  (transposed reads of the same images) ----
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            if (s2 < 3) ld_tr(s2 + 1, tf[(s2 + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                const int colb = (tr_colbyte + 64 * db) ^ tr_swz;
-                const char* a0 = base + 2 * IMG + (16 * s2 + tr_row0) * 128 + colb;
-                const bf16x8 t0f = cat4(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0)),
-                                        __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0 + 8 * 128)));
-                acc0[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t0f, dsf[s2], acc0[db], 0, 0, 0);   // K^T dS^T | Q^T dS
-                if constexpr (MODE == 1) {
-                    const char* a1 = a0 + IMG;
-                    const bf16x8 t1f = cat4(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a1)),
-                                            __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a1 + 8 * 128)));
-                    acc1[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t1f, pf[s2], acc1[db], 0, 0, 0);  // dO^T P
-                }
+                if constexpr ((DITTO_DIAG_BWD & 8) != 0) continue;
+                acc0[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[s2 & 1][db], dsf[s2], acc0[db], 0, 0, 0);   // K^T dS^T | Q^T dS
+                if constexpr (MODE == 1)
+                    acc1[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[s2 & 1][2 + db], pf[s2], acc1[db], 0, 0, 0);  // dO^T P
             }
-        if (tt + 1 < ntile) write_stats((tt + 1) & 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
+            if (s2 < 2) p_ds(s2 + 2);
+            if (s2 < 1) ld_stats(3);
+            if (s2 < 2) interleave(std::integral_constant<int, MODE == 0 ? 2 : 4>{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (s2 == 2 && tt + 1 < ntile) {
+                // tiles requested so far: <= tt + NBUF - 2; tile tt + 1 has landed once only the ones behind it are in flight
+                const int younger = ntile - 2 - tt;
+                if constexpr ((DITTO_DIAG_BWD & 2) == 0) wait_tile(younger < NBUF - 3 ? younger : NBUF - 3);
+                if constexpr ((DITTO_DIAG_BWD & 4) == 0) __builtin_amdgcn_s_barrier();
+                if constexpr ((DITTO_DIAG_BWD & 2) == 0)
+                    if (tt + NBUF - 1 < ntile) dma_tile(tt + NBUF - 1, (tt + NBUF - 1) & (NBUF - 1));
+                ld_rows(smem + ((tt + 1) & (NBUF - 1)) * BUF, 0, fa[0]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    const bool ragged = MODE == 0 && ragged_tile;
+    const int nfull = ragged ? ntile - 1 : ntile;
+    for (int tt = 0; tt < nfull; ++tt) tile_body(tt, std::false_type{});
+    if (ragged) tile_body(ntile - 1, std::true_type{});
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[0][i] *= p.scale; acc0[1][i] *= p.scale; }   // dQ = scale dS' k, dK = scale dS'^T q
 
     // ---- epilogue: lane (own row, half hh) owns d = 32*db + 8*g + 4*hh + 0..3 ----
     if (!own_valid) return;
@@ -311,36 +444,47 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void attn64_bwd_kernel(BwdP
 
 }  // namespace
 
+size_t attention_bwd_stats_bytes(int B, int H, int Sq) { return (size_t)B * H * ((Sq + TILE - 1) / TILE) * 128 * sizeof(float); }
+
 hipError_t launch_attention_delta(const void* dout, int lddo, const void* o_bf16, int ldo, const float* h_after,
-                                  const float* h_before, int ldh, float* delta, int B, int H, int Sq, hipStream_t s) {
-    if ((lddo % 4) || (o_bf16 && ldo % 4) || (!o_bf16 && (ldh % 4 || !h_after || !h_before))) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((B * Sq + 3) / 4), dim3(256), 0, s, (const bf16*)dout, lddo,
-                       (const bf16*)o_bf16, ldo, h_after, h_before, ldh, delta, B, H, Sq);
+                                  const float* h_before, int ldh, const float* lse, float* stats, int B, int H, int Sq,
+                                  hipStream_t s) {
+    if ((lddo % 4) || (o_bf16 && ldo % 4) || (!o_bf16 && (ldh % 4 || !h_after || !h_before)) || !lse || !stats)
+        return hipErrorInvalidValue;
+    const int sqp = ((Sq + TILE - 1) / TILE) * TILE;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((B * sqp + 3) / 4), dim3(256), 0, s, (const bf16*)dout, lddo,
+                       (const bf16*)o_bf16, ldo, h_after, h_before, ldh, lse, stats, B, H, Sq);
     return hipGetLastError();
 }
 
-// fused backward (head_dim 64): lse (log2 domain, from the TRAIN forward) and delta (launch_attention_delta) given
-hipError_t launch_attention_bwd64(const AttnBwdArgs& a, const float* lse, const float* delta, hipStream_t s) {
-    if (a.dh != DH || a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Skv <= 0 || !lse || !delta) return hipErrorInvalidValue;
+// fused backward (head_dim 64): stats = the per-tile {L, delta} records of launch_attention_delta
+hipError_t launch_attention_bwd64(const AttnBwdArgs& a, const float* stats, hipStream_t s) {
+    if (a.dh != DH || a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Skv <= 0 || !stats) return hipErrorInvalidValue;
     if ((a.ldq | a.ldk | a.ldv | a.lddo) % 8 || (a.lddq | a.lddk | a.lddv) % 4) return hipErrorInvalidValue;
     BwdParams p;
     p.q = (const bf16*)a.q; p.ldq = a.ldq; p.k = (const bf16*)a.k; p.ldk = a.ldk; p.v = (const bf16*)a.v; p.ldv = a.ldv;
     p.dout = (const bf16*)a.dout; p.lddo = a.lddo;
     p.dq = (bf16*)a.dq; p.lddq = a.lddq; p.dk = (bf16*)a.dk; p.lddk = a.lddk; p.dv = (bf16*)a.dv; p.lddv = a.lddv;
-    p.lse = lse; p.delta = delta; p.B = a.B; p.H = a.H; p.Sq = a.Sq; p.Skv = a.Skv;
+    p.stats = stats; p.B = a.B; p.H = a.H; p.Sq = a.Sq; p.Skv = a.Skv;
     p.scale = a.scale; p.scale_log2 = a.scale * 1.4426950408889634f;
     p.drop_thr = dropout_threshold(a.dropout_p);
     p.keep_scale = p.drop_thr ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
     p.seed_lo = (unsigned)(a.seed & 0xFFFFFFFFu); p.seed_hi = (unsigned)(a.seed >> 32); p.layer = a.layer;
     p.rope_cos = a.rope_cos; p.rope_sin = a.rope_sin;
     if ((a.rope_cos == nullptr) != (a.rope_sin == nullptr) || (a.rope_cos && a.Sq != a.Skv)) return hipErrorInvalidValue;
-    constexpr int LDS0 = 2 * 3 * IMG, LDS1 = 2 * (4 * IMG + 512);
+    constexpr int LDS0 = NBUF * 2 * IMG, LDS1 = NBUF * (2 * IMG + STAT_BYTES);
     static DevOnce lds_once;
-    if (hipError_t e = set_max_lds_once(lds_once, {reinterpret_cast<const void*>(&attn64_bwd_kernel<1>)}, LDS1)) return e;
+    if (hipError_t e = set_max_lds_once(lds_once, {reinterpret_cast<const void*>(&attn64_bwd_kernel<0, false>),
+                                                   reinterpret_cast<const void*>(&attn64_bwd_kernel<0, true>),
+                                                   reinterpret_cast<const void*>(&attn64_bwd_kernel<1, false>),
+                                                   reinterpret_cast<const void*>(&attn64_bwd_kernel<1, true>)}, LDS1)) return e;
+    const bool drop = p.drop_thr != 0;
     p.nblk = (a.Sq + BLK - 1) / BLK;
-    hipLaunchKernelGGL((attn64_bwd_kernel<0>), dim3(p.nblk * a.H * a.B), dim3(256), LDS0, s, p);
+    if (drop) hipLaunchKernelGGL((attn64_bwd_kernel<0, true>), dim3(p.nblk * a.H * a.B), dim3(256), LDS0, s, p);
+    else hipLaunchKernelGGL((attn64_bwd_kernel<0, false>), dim3(p.nblk * a.H * a.B), dim3(256), LDS0, s, p);
     p.nblk = (a.Skv + BLK - 1) / BLK;
-    hipLaunchKernelGGL((attn64_bwd_kernel<1>), dim3(p.nblk * a.H * a.B), dim3(256), LDS1, s, p);
+    if (drop) hipLaunchKernelGGL((attn64_bwd_kernel<1, true>), dim3(p.nblk * a.H * a.B), dim3(256), LDS1, s, p);
+    else hipLaunchKernelGGL((attn64_bwd_kernel<1, false>), dim3(p.nblk * a.H * a.B), dim3(256), LDS1, s, p);
     return hipGetLastError();
 }
 
