@@ -18,7 +18,11 @@ LIB = os.path.join(HERE, "libditto_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # per-file extras.  attention.hip: without -fno-honor-nans hipcc canonicalises every MFMA output (v_max x,x)
 # before the row-max fmaxf chain (+32 VALU per KV tile); the softmax has no NaN semantics to preserve.
-EXTRA = {"attention.hip": ["-fno-honor-nans"], "attention_v4.hip": ["-fno-honor-nans"]}
+# attention_bwd.hip: the SLP vectoriser pairs the P / dS arithmetic into v_pk_add_f32 / v_pk_mul_f32, and packed fp32
+# instructions occupy the matrix pipe (a lone wave showed zero MFMA / vector overlap: removing the 24 MFMAs of a tile saved
+# exactly 24 x 32 cycles); scalar v_sub / v_mul issue beside the MFMAs.
+EXTRA = {"attention.hip": ["-fno-honor-nans"], "attention_v4.hip": ["-fno-honor-nans"],
+         "attention_bwd.hip": ["-fno-slp-vectorize"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC,
          "-Wall", "-Wno-unused-function"]
 

@@ -175,15 +175,18 @@ __global__ __launch_bounds__(256, 2) void attn64_bwd_kernel(BwdParams p) {
     const int ld1 = MODE == 0 ? p.ldv : p.lddo;
     const int ntile = (tile_len + TILE - 1) / TILE;
     const bool ragged_tile = (tile_len & (TILE - 1)) != 0;
-    const bf16 *src0[2], *src1[2];
+    // this lane's two (row, chunk) DMA sources of a tile: wave-uniform 64-bit tile base (scalar registers) + 32-bit byte offset
+    unsigned voff0[2], voff1[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = (wid * 2 + i) * 8 + (lane >> 3), c = (lane & 7) ^ img_swz(row);
-        src0[i] = t0 + ((size_t)b * tile_len + row) * ld0 + h * DH + c * 8;
-        src1[i] = t1 + ((size_t)b * tile_len + row) * ld1 + h * DH + c * 8;
+        voff0[i] = (unsigned)(row * ld0 + c * 8) * 2u;
+        voff1[i] = (unsigned)(row * ld1 + c * 8) * 2u;
     }
+    const bf16* base0 = t0 + (size_t)b * tile_len * ld0 + h * DH;
+    const bf16* base1 = t1 + (size_t)b * tile_len * ld1 + h * DH;
     const size_t step0 = (size_t)TILE * ld0, step1 = (size_t)TILE * ld1;
-    const float* stat_src = p.stats + (size_t)bh * nqt * 128 + (lane & 31) * 4;
+    const float* stat_base = p.stats + (size_t)bh * nqt * 128;   // wave-uniform; the lane's part is a 32-bit offset
     // 4 DMAs per wave and tile (wave 0 of the dkdv kernel: 5, the tile's L / delta record)
     auto dma_tile = [&](int tt, int buf) {
         const unsigned dst = lds_base + (unsigned)(buf * BUF);
@@ -201,12 +204,12 @@ __global__ __launch_bounds__(256, 2) void attn64_bwd_kernel(BwdParams p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int piece = wid * 2 + i;
-                glds16(src0[i] + (size_t)tt * step0, dst + piece * 1024);
-                glds16(src1[i] + (size_t)tt * step1, dst + IMG + piece * 1024);
+                glds16_so(voff0[i], base0 + (size_t)tt * step0, dst + piece * 1024);
+                glds16_so(voff1[i], base1 + (size_t)tt * step1, dst + IMG + piece * 1024);
             }
         }
         if constexpr (MODE == 1) {
-            if (wid == 0) glds16(stat_src + (size_t)tt * 128, dst + 2 * IMG);
+            if (wid == 0) glds16_so((unsigned)(lane & 31) * 16u, stat_base + (size_t)tt * 128, dst + 2 * IMG);
         }
     };
     // wait until at most `younger` whole tiles requested after the one needed are still in flight (0, 1 or 2)
@@ -238,9 +241,17 @@ __global__ __launch_bounds__(256, 2) void attn64_bwd_kernel(BwdParams p) {
     constexpr int G = 2;                        // k-steps (of 16) per pipeline step: 2 G fragments in flight, twice
     constexpr int NSTEP = 8 / G;                // 2 row blocks x 4 k-steps
     static_assert(NSTEP == 4, "the schedule below is written for four steps");
-    bf16x8 fa[2][2 * G];                        // [0] is loaded for the NEXT tile before the current one ends
+    // fragment look-ahead in pipeline units (4 steps + 4 slots per tile; unit u's fragments are requested while unit u - PD
+    // computes).  The dq kernel has the registers for two units; an LDS round trip behind a queue of reads is longer than the
+    // four MFMAs of one.
+    constexpr int PD = MODE == 0 ? 2 : 1, NB = PD + 1;
+    bf16x8 fa[NB][2 * G];                       // row-fragment units 0 .. PD-1 of the NEXT tile are requested before the current one ends
     auto ld_rows = [&](const char* base, int i, bf16x8* dst) {
-        if constexpr ((DITTO_DIAG_BWD & 32) != 0) return;
+        if constexpr ((DITTO_DIAG_BWD & 32) != 0) {   // opaque to the compiler: the MFMAs that read dst stay where they are
+#pragma unroll
+            for (int k = 0; k < 2 * G; ++k) asm volatile("" : "+v"(dst[k]));
+            return;
+        }
         const int rb = (i * G) >> 2, ks0 = (i * G) & 3;
 #pragma unroll
         for (int kk = 0; kk < G; ++kk) {
@@ -260,7 +271,8 @@ __global__ __launch_bounds__(256, 2) void attn64_bwd_kernel(BwdParams p) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(f0[ks]), "+v"(f1[ks]));
     asm volatile("" : "+v"(own_L), "+v"(own_delta));
-    ld_rows(smem, 0, fa[0]);
+#pragma unroll
+    for (int u = 0; u < PD; ++u) ld_rows(smem, u, fa[u]);
 
     // MASKED: the ragged last KEY tile of the dq kernel (keys past Skv get P = 0).  The dkdv kernel needs no mask: its tile
     // rows are queries, and rows past Sq carry L = 1e30 in the stats record.
@@ -273,9 +285,13 @@ __global__ __launch_bounds__(256, 2) void attn64_bwd_kernel(BwdParams p) {
         f32x16 st[2], dp[2];   // every chain's first MFMA takes the constant 0 as its accumulator operand: no zeroing moves
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         // transposed fragments of 16 tile rows (s2): [db] of image 0 (K^T | Q^T), MODE 1 also [2 + db] of image 1 (dO^T)
-        bf16x8 tf[2][MODE == 0 ? 2 : 4];
+        bf16x8 tf[NB][MODE == 0 ? 2 : 4];
         auto ld_tr = [&](int s2, bf16x8* dst) {
-            if constexpr ((DITTO_DIAG_BWD & 32) != 0) return;
+            if constexpr ((DITTO_DIAG_BWD & 32) != 0) {
+#pragma unroll
+                for (int k = 0; k < (MODE == 0 ? 2 : 4); ++k) asm volatile("" : "+v"(dst[k]));
+                return;
+            }
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
                 const char* r0 = base + (16 * s2 + tr_row0) * 128;
@@ -287,6 +303,13 @@ __global__ __launch_bounds__(256, 2) void attn64_bwd_kernel(BwdParams p) {
                     dst[2 + db] = cat4(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0 + IMG)),
                                        __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a8 + IMG)));
             }
+        };
+        // request the fragments of pipeline unit u: 0..3 = row fragments of step u, 4..7 = transposed fragments of slot u - 4,
+        // 8.. = row fragments of the next tile's steps (only behind the barrier of slot 2)
+        auto request = [&](int u) {
+            if (u < 4) ld_rows(base, u, fa[u % NB]);
+            else if (u < 8) ld_tr(u - 4, tf[(u - 4) % NB]);
+            else if (tt + 1 < ntile) ld_rows(smem + ((tt + 1) & (NBUF - 1)) * BUF, u - 8, fa[(u - 8) % NB]);
         };
         // MODE 1: L and delta of tile rows 16 s2 + 4 hh + {0..3} and + 8 (half-wave broadcast reads)
         f32x4 sl[2], sd[2];
@@ -308,24 +331,47 @@ __global__ __launch_bounds__(256, 2) void attn64_bwd_kernel(BwdParams p) {
                 }
                 return;
             }
+            // staged over the 8 elements (all exponent arguments, then all exponentials, ...): eight independent instructions
+            // between a value's producer and its consumer, so an in-order wave never waits on its own arithmetic latency
+            float sv[8], pr[8], gg[8], km[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int rr = 8 * (s2 & 1) + j;
-                const int trow = tt * TILE + (s2 >> 1) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * hh;
                 const float L = MODE == 0 ? own_L : sl[j >> 2][j & 3];
-                const float dl = MODE == 0 ? own_delta : sd[j >> 2][j & 3];
-                float sv = st[s2 >> 1][rr] * c - L;
-                if constexpr (decltype(MASKED)::value) sv = trow < p.Skv ? sv : -1e30f;
-                const float pr = __builtin_amdgcn_exp2f(sv);
-                float g = dp[s2 >> 1][rr], pd = pr;
-                if constexpr (DROP) {
-                    const int qi = MODE == 0 ? own : trow, kj = MODE == 0 ? trow : own;
-                    const bool keep = drop_keep(dstream, qi, kj, p.drop_thr);
-                    g = keep ? g * p.keep_scale : 0.f;
-                    pd = keep ? pr * p.keep_scale : 0.f;
+                sv[j] = st[s2 >> 1][rr] * c - L;
+                if constexpr (decltype(MASKED)::value) {
+                    const int trow = tt * TILE + (s2 >> 1) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * hh;
+                    sv[j] = trow < p.Skv ? sv[j] : -1e30f;
                 }
-                dsf[s2][j] = (bf16)(pr * (g - dl));   // dS / scale: the factor is applied once, to the accumulators (epilogue)
-                if constexpr (MODE == 1) pf[s2][j] = (bf16)pd;
+            }
+            if constexpr (DROP) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int rr = 8 * (s2 & 1) + j;
+                    const int trow = tt * TILE + (s2 >> 1) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * hh;
+                    const int qi = MODE == 0 ? own : trow, kj = MODE == 0 ? trow : own;
+                    km[j] = drop_keep(dstream, qi, kj, p.drop_thr) ? p.keep_scale : 0.f;   // one select, two products
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pr[j] = __builtin_amdgcn_exp2f(sv[j]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float dl = MODE == 0 ? own_delta : sd[j >> 2][j & 3];
+                const float g = dp[s2 >> 1][8 * (s2 & 1) + j];
+                gg[j] = DROP ? g * km[j] - dl : g - dl;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gg[j] *= pr[j];   // dS / scale: the factor is applied once, to the accumulators (epilogue)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dsf[s2][j] = (bf16)gg[j];
+            if constexpr (MODE == 1) {
+                if constexpr (DROP) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pr[j] *= km[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[s2][j] = (bf16)pr[j];
             }
         };
         // schedule (4 steps of 4 MFMAs, then 4 slots of 2 | 4):      requests                 MFMAs                  behind them
@@ -341,47 +387,65 @@ __global__ __launch_bounds__(256, 2) void attn64_bwd_kernel(BwdParams p) {
         // (the L / delta request for the NEXT rows goes out only after the vector work that reads the current ones: one buffer)
         // inside a region that holds nm MFMAs and one p_ds: one MFMA, then an equal share of the vector instructions, and so on
         constexpr int NVEC = (MODE == 0 ? 28 : 32) + (DROP ? (MODE == 0 ? 80 : 112) : 0);   // vector instructions of one p_ds
-        auto interleave = [&](auto NM) {
-            constexpr int nm = decltype(NM)::value;
+        // a region = NM MFMAs + ND LDS reads (the NEXT step's fragments) + optionally the vector work of one p_ds: one MFMA, then an
+        // equal share of the reads and of the vector instructions, and so on.  A lone wave showed why (one workgroup per CU,
+        // knock-out builds): with the reads issued as a batch in front of the MFMAs every step exposed an LDS round trip (922 of
+        // 2512 cycles per tile), and vector work only runs in the matrix pipe's shadow behind an MFMA of the same wave.
+        auto interleave = [&](auto NM, auto ND, auto VEC) {
+            constexpr int nm = decltype(NM)::value, nd = decltype(ND)::value;
 #pragma unroll
             for (int k = 0; k < nm; ++k) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, NVEC / nm, 0);
+                if constexpr (nd > 0) __builtin_amdgcn_sched_group_barrier(0x100, (nd + nm - 1) / nm, 0);
+                if constexpr (decltype(VEC)::value) __builtin_amdgcn_sched_group_barrier(0x002, NVEC / nm, 0);
             }
         };
+        constexpr int NSTAT = MODE == 1 ? 4 : 0;    // LDS reads of one ld_stats
+        constexpr int NTR = MODE == 0 ? 4 : 8;      // ds_read_b64_tr_b16 of one ld_tr
 #pragma unroll
         for (int i = 0; i < NSTEP; ++i) {
-            if (i + 1 < NSTEP) ld_rows(base, i + 1, fa[(i + 1) & 1]);
-            else ld_tr(0, tf[0]);
-            __builtin_amdgcn_sched_barrier(0);
             const int rb = (i * G) >> 2, ks0 = (i * G) & 3;
 #pragma unroll
             for (int kk = 0; kk < G; ++kk) {
-                if constexpr ((DITTO_DIAG_BWD & 16) != 0) continue;
+                if constexpr ((DITTO_DIAG_BWD & 16) != 0) {
+                    asm volatile("" : "+v"(st[rb]), "+v"(dp[rb]));
+                    continue;
+                }
                 const bool first = ks0 + kk == 0;
-                st[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i & 1][2 * kk], f0[ks0 + kk], first ? zero16 : st[rb], 0, 0, 0);
-                dp[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i & 1][2 * kk + 1], f1[ks0 + kk], first ? zero16 : dp[rb], 0, 0, 0);
+                st[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i % NB][2 * kk], f0[ks0 + kk], first ? zero16 : st[rb], 0, 0, 0);
+                dp[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i % NB][2 * kk + 1], f1[ks0 + kk], first ? zero16 : dp[rb], 0, 0, 0);
             }
+            request(i + PD);
             if (i >= 2) p_ds(i - 2);
             if (i >= 1) ld_stats(i - 1);
-            if (i >= 2) interleave(std::integral_constant<int, 2 * G>{});
+            if (i == 0) interleave(std::integral_constant<int, 2 * G>{}, std::integral_constant<int, 4>{}, std::false_type{});
+            else if (i == 1) interleave(std::integral_constant<int, 2 * G>{}, std::integral_constant<int, 4 + NSTAT>{}, std::false_type{});
+            else if (i == 2) interleave(std::integral_constant<int, 2 * G>{}, std::integral_constant<int, 4 + NSTAT>{}, std::true_type{});
+            else interleave(std::integral_constant<int, 2 * G>{}, std::integral_constant<int, NTR + NSTAT>{}, std::true_type{});
+            // (with PD = 2 steps 2 and 3 request transposed fragments, not rows: the read counts above are upper bounds there)
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- acc^T[d][own] += T^T[d][tile row] * X[tile row][own]  (transposed reads of the same images) ----
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) {
-            if (s2 < 3) ld_tr(s2 + 1, tf[(s2 + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                if constexpr ((DITTO_DIAG_BWD & 8) != 0) continue;
-                acc0[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[s2 & 1][db], dsf[s2], acc0[db], 0, 0, 0);   // K^T dS^T | Q^T dS
+                if constexpr ((DITTO_DIAG_BWD & 8) != 0) {   // the operands stay live (and so does the work that makes them)
+                    asm volatile("" : "+v"(acc0[db]) : "v"(dsf[s2]), "v"(tf[s2 % NB][db]));
+                    if constexpr (MODE == 1) asm volatile("" : "+v"(acc1[db]) : "v"(pf[s2]), "v"(tf[s2 % NB][2 + db]));
+                    continue;
+                }
+                acc0[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[s2 % NB][db], dsf[s2], acc0[db], 0, 0, 0);   // K^T dS^T | Q^T dS
                 if constexpr (MODE == 1)
-                    acc1[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[s2 & 1][2 + db], pf[s2], acc1[db], 0, 0, 0);  // dO^T P
+                    acc1[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[s2 % NB][2 + db], pf[s2], acc1[db], 0, 0, 0);  // dO^T P
             }
+            if (4 + s2 + PD < 8 || s2 == 3) request(4 + s2 + PD);   // slot 2's request for the next tile goes out behind its barrier
             if (s2 < 2) p_ds(s2 + 2);
             if (s2 < 1) ld_stats(3);
-            if (s2 < 2) interleave(std::integral_constant<int, MODE == 0 ? 2 : 4>{});
+            constexpr int NM2 = MODE == 0 ? 2 : 4;
+            if (s2 == 0) interleave(std::integral_constant<int, NM2>{}, std::integral_constant<int, NTR + NSTAT>{}, std::true_type{});
+            else if (s2 == 1) interleave(std::integral_constant<int, NM2>{}, std::integral_constant<int, NTR>{}, std::true_type{});
+            else if (s2 == 2) interleave(std::integral_constant<int, NM2>{}, std::integral_constant<int, NTR>{}, std::false_type{});
             __builtin_amdgcn_sched_barrier(0);
             if (s2 == 2 && tt + 1 < ntile) {
                 // tiles requested so far: <= tt + NBUF - 2; tile tt + 1 has landed once only the ones behind it are in flight
@@ -390,7 +454,8 @@ __global__ __launch_bounds__(256, 2) void attn64_bwd_kernel(BwdParams p) {
                 if constexpr ((DITTO_DIAG_BWD & 4) == 0) __builtin_amdgcn_s_barrier();
                 if constexpr ((DITTO_DIAG_BWD & 2) == 0)
                     if (tt + NBUF - 1 < ntile) dma_tile(tt + NBUF - 1, (tt + NBUF - 1) & (NBUF - 1));
-                ld_rows(smem + ((tt + 1) & (NBUF - 1)) * BUF, 0, fa[0]);
+#pragma unroll
+                for (int u = 8; u <= 4 + 2 + PD; ++u) request(u);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -472,12 +537,15 @@ hipError_t launch_attention_bwd64(const AttnBwdArgs& a, const float* stats, hipS
     p.seed_lo = (unsigned)(a.seed & 0xFFFFFFFFu); p.seed_hi = (unsigned)(a.seed >> 32); p.layer = a.layer;
     p.rope_cos = a.rope_cos; p.rope_sin = a.rope_sin;
     if ((a.rope_cos == nullptr) != (a.rope_sin == nullptr) || (a.rope_cos && a.Sq != a.Skv)) return hipErrorInvalidValue;
-    constexpr int LDS0 = NBUF * 2 * IMG, LDS1 = NBUF * (2 * IMG + STAT_BYTES);
+    // diagnostic: DITTO_BWD_LDS_PAD=32768 pads the launch's LDS so that ONE workgroup fits a CU (one wave per SIMD): a lone wave's
+    // timeline is serial, so knock-out builds (tools/bwd_knockout.sh) then read as additive shares of a tile's cycles
+    static const int lds_pad = [] { const char* e = getenv("DITTO_BWD_LDS_PAD"); return e ? atoi(e) : 0; }();
+    const int LDS0 = NBUF * 2 * IMG + lds_pad, LDS1 = NBUF * (2 * IMG + STAT_BYTES) + lds_pad;
     static DevOnce lds_once;
     if (hipError_t e = set_max_lds_once(lds_once, {reinterpret_cast<const void*>(&attn64_bwd_kernel<0, false>),
                                                    reinterpret_cast<const void*>(&attn64_bwd_kernel<0, true>),
                                                    reinterpret_cast<const void*>(&attn64_bwd_kernel<1, false>),
-                                                   reinterpret_cast<const void*>(&attn64_bwd_kernel<1, true>)}, LDS1)) return e;
+                                                   reinterpret_cast<const void*>(&attn64_bwd_kernel<1, true>)}, LDS1 + 32768)) return e;
     const bool drop = p.drop_thr != 0;
     p.nblk = (a.Sq + BLK - 1) / BLK;
     if (drop) hipLaunchKernelGGL((attn64_bwd_kernel<0, true>), dim3(p.nblk * a.H * a.B), dim3(256), LDS0, s, p);

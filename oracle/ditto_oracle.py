@@ -302,6 +302,16 @@ def _lowbias32(h):
     return h
 
 
+def _mix24(h):
+    """per-element hash: two rounds of xorshift + 24-bit multiply (csrc/common.h mix24: the multiply the GPU runs at full rate)"""
+    import numpy as np
+    h = h.astype(np.uint64)
+    M24, M32 = np.uint64(0xFFFFFF), np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(15); h = ((h & M24) * np.uint64(0xB5297B)) & M32
+    h ^= h >> np.uint64(13); h = ((h & M24) * np.uint64(0x6C8E9D)) & M32
+    return h
+
+
 def hash_dropout_mask(seed: int, layer: int, B: int, H: int, Sq: int, Skv: int, p: float) -> Tensor:
     """keep-mask float32 [B, H, Sq, Skv] in {0, 1}: keep iff hash(stream(seed, layer, b*H+h), i, j) >= p * 2^32."""
     import numpy as np
@@ -314,7 +324,7 @@ def hash_dropout_mask(seed: int, layer: int, B: int, H: int, Sq: int, Skv: int, 
     i = np.arange(Sq, dtype=np.uint64)[:, None]
     j = np.arange(Skv, dtype=np.uint64)[None, :]
     ctr = (i * np.uint64(0x9E3779B1) + j * np.uint64(0x85EBCA6B)) & M32               # [Sq, Skv]
-    h = _lowbias32(stream[:, None, None] ^ ctr[None])
+    h = _mix24(stream[:, None, None] ^ ctr[None])
     return torch.from_numpy((h >= thr).astype(np.float32)).view(B, H, Sq, Skv)
 
 
