@@ -115,9 +115,11 @@ DITTO_DEV void bwd_vm_wait() {
 // ran 22 % faster — the loads were landing late.)
 // MODE 0 = dq kernel   (block = queries; tiles = keys:    images K, V)
 // MODE 1 = dkdv kernel (block = keys;    tiles = queries: images Q, dO  + the tile's L / delta record)
-// Ring of NBUF = 4 tile buffers, tile t+3 requested while tile t is computed, ONE barrier per tile placed behind the third
-// accumulation slot: by then every wave has its pieces of tile t+1 (counted vmcnt: DMAs retire in order) and is done with
-// tile t-1's buffer, so the request for tile t+3 and the first fragment reads of tile t+1 go out under the last MFMAs of tile t.
+// Ring of NBUF = 4 tile buffers and the two-tile software pipeline of the loop: see the comment at the loop.
+// Measured issue costs that shape it (tools/probe_mfma_valu.hip, one wave per SIMD): a v_mfma_f32_32x32x16_bf16 gap runs
+// max(32, 8 + sum of the vector instructions' costs) cycles with v_fma_f32 5.2 and v_exp_f32 9 (the MFMA's own 8 issue cycles
+// never hide; accumulators in AGPRs change nothing) — a tile of the dq kernel carries ~870 cycles of P / dS vector issue against
+// 768 of MFMA, so the kernels are bound by vector ISSUE, and everything that is not an MFMA or P / dS arithmetic is overhead.
 // ------------------------------------------------------------------------------------------------
 constexpr int NBUF = 4;
 constexpr int STAT_BYTES = 1024;   // L[64] | delta[64] floats, written twice over by one 64-lane 16-B DMA
@@ -125,8 +127,11 @@ constexpr int STAT_BYTES = 1024;   // L[64] | delta[64] floats, written twice ov
 DITTO_DEV int img_swz(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
 
 // DROP: train-mode dropout on P (the hash mask of the forward) compiled in; without it no per-element hash, no branch.
-template <int MODE, bool DROP>
+// RAG (dq kernel only): Skv is not a multiple of 64: keys past Skv are masked per element (P = 0) in every tile; shapes with whole
+// tiles compile the mask out.  The dkdv kernel needs no mask: its tile rows are queries, and rows past Sq carry L = 1e30.
+template <int MODE, bool DROP, bool RAG = false>
 __global__ __launch_bounds__(256, 2) void attn64_bwd_kernel(BwdParams p) {
+    static_assert(MODE == 0 || !RAG, "only the dq kernel masks keys");
     constexpr int BUF = 2 * IMG + (MODE == 1 ? STAT_BYTES : 0);
     extern __shared__ __attribute__((aligned(16))) char smem[];   // NBUF * BUF: 64 / 68 KiB (two workgroups per CU)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -238,21 +243,35 @@ __global__ __launch_bounds__(256, 2) void attn64_bwd_kernel(BwdParams p) {
     const float c = p.scale_log2;
     const unsigned dstream = drop_stream(p.seed_lo, p.seed_hi, p.layer, bh);
 
-    constexpr int G = 2;                        // k-steps (of 16) per pipeline step: 2 G fragments in flight, twice
-    constexpr int NSTEP = 8 / G;                // 2 row blocks x 4 k-steps
-    static_assert(NSTEP == 4, "the schedule below is written for four steps");
-    // fragment look-ahead in pipeline units (4 steps + 4 slots per tile; unit u's fragments are requested while unit u - PD
-    // computes).  The dq kernel has the registers for two units; an LDS round trip behind a queue of reads is longer than the
-    // four MFMAs of one.
-    constexpr int PD = MODE == 0 ? 2 : 1, NB = PD + 1;
-    bf16x8 fa[NB][2 * G];                       // row-fragment units 0 .. PD-1 of the NEXT tile are requested before the current one ends
-    auto ld_rows = [&](const char* base, int i, bf16x8* dst) {
+    // ---- the tile loop: a software pipeline across TWO tiles, written out by hand ----
+    // Per tile: A0..A3 = four steps of 4 MFMAs (S | S^T and dP | dP^T of row block 0: A0, A1; of block 1: A2, A3), V0..V3 = the
+    // P / dS vector work of 16 tile rows each (V0, V1 need A1; V2, V3 need A3), B0..B3 = four accumulation slots of 2 | 4 MFMAs
+    // (Bs needs Vs).  A wave's vector instructions run in the matrix pipe's shadow only when they FOLLOW an MFMA of the same wave
+    // (a lone wave per SIMD showed the one-tile order A A A+V A+V B+V B+V B B as the plain sum MFMA + vector + LDS + DMA), so
+    // every region below pairs one MFMA group with half a V, A steps of tile t+1 alternating with B slots of tile t:
+    //     r0  A0(t+1) + V2b(t)     r1  B2(t) + V3a(t)       r2  A1(t+1) + V3b(t)     r3  B3(t) + V0a(t+1)
+    //     r4  A2(t+1) + V0b(t+1)   r5  B0(t+1) + V1a(t+1)   r6  A3(t+1) + V1b(t+1)   r7  B1(t+1) + V2a(t+1)
+    // with fewer registers than one tile at a time needs: block 1's S / dP of tile t die in r2, tile t+1's are born in r4, and
+    // every P / dS group is consumed one region after its second half is made (two groups live, not four).
+    // The next A step's row fragments are requested BEHIND the current one's MFMAs, into the same registers (consumed two
+    // regions later), likewise the transposed fragments of the next B slot; a V half's L / delta go, two regions ahead, into the
+    // buffer the half before last has just read.  Ring of NBUF = 4 tile buffers: tiles t, t+1 in use, t+2 landed, t+3 in flight;
+    // ONE barrier per iteration (behind r6): every wave has its pieces of tile t+2 (vmcnt(0): it is the youngest request) and
+    // is done with tile t-1's buffer, so the request for tile t+3 and the first fragment reads of tile t+2 follow it.
+    constexpr int G = 2;                        // k-steps (of 16) per A step: 2 G fragments
+    bf16x8 fa[2 * G];                           // the row fragments of one A step
+    bf16x8 tf[MODE == 0 ? 2 : 4];               // the transposed fragments of one B slot: [db] of image 0, MODE 1 also [2 + db] of image 1
+    f32x16 st[2], dp[2];                        // [row block]: tile row in registers, own row on the lane
+    bf16x8 pf[2], dsf[2];                       // [16-row group & 1]: a group is consumed before the one after next is made
+    f32x4 sl[2], sd[2];                         // MODE 1: L / delta of the 4 tile rows of a V half, [half]
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto ld_rows = [&](const char* base, int u, bf16x8* dst) {
         if constexpr ((DITTO_DIAG_BWD & 32) != 0) {   // opaque to the compiler: the MFMAs that read dst stay where they are
 #pragma unroll
             for (int k = 0; k < 2 * G; ++k) asm volatile("" : "+v"(dst[k]));
             return;
         }
-        const int rb = (i * G) >> 2, ks0 = (i * G) & 3;
+        const int rb = (u * G) >> 2, ks0 = (u * G) & 3;
 #pragma unroll
         for (int kk = 0; kk < G; ++kk) {
             const int off = rb * 32 * 128 + row_off + (((2 * (ks0 + kk) + hh) ^ row_swz) << 4);
@@ -260,210 +279,205 @@ __global__ __launch_bounds__(256, 2) void attn64_bwd_kernel(BwdParams p) {
             dst[2 * kk + 1] = *reinterpret_cast<const bf16x8*>(base + IMG + off);
         }
     };
-
+    auto ld_tr = [&](const char* base, int s2, bf16x8* dst) {
+        if constexpr ((DITTO_DIAG_BWD & 32) != 0) {
 #pragma unroll
-    for (int t0i = 0; t0i < NBUF - 1; ++t0i)
-        if (t0i < ntile) dma_tile(t0i, t0i);
-    wait_tile(ntile - 1 < NBUF - 2 ? ntile - 1 : NBUF - 2);
+            for (int k = 0; k < (MODE == 0 ? 2 : 4); ++k) asm volatile("" : "+v"(dst[k]));
+            return;
+        }
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            const char* r0 = base + (16 * s2 + tr_row0) * 128;
+            const char* a0 = r0 + ((tr_colbyte + 64 * db) ^ tr_swz0);
+            const char* a8 = r0 + 8 * 128 + ((tr_colbyte + 64 * db) ^ tr_swz1);
+            dst[db] = cat4(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0)),
+                           __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a8)));
+            if constexpr (MODE == 1)
+                dst[2 + db] = cat4(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0 + IMG)),
+                                   __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a8 + IMG)));
+        }
+    };
+    // MODE 1: L and delta of tile rows 16 s2 + 8 half + 4 hh + {0..3} (half-wave broadcast reads)
+    auto ld_stats = [&](const char* base, int s2, int half) {
+        if constexpr (MODE == 1) {
+            const char* sp = base + 2 * IMG + (16 * s2 + 8 * half + 4 * hh) * 4;
+            sl[half] = *reinterpret_cast<const f32x4*>(sp);
+            sd[half] = *reinterpret_cast<const f32x4*>(sp + 256);
+        }
+    };
+    // A step u (tile t+1): 4 MFMAs on row unit u
+    auto a_step = [&](int u) {
+        const int rb = (u * G) >> 2, ks0 = (u * G) & 3;
+#pragma unroll
+        for (int kk = 0; kk < G; ++kk) {
+            if constexpr ((DITTO_DIAG_BWD & 16) != 0) {
+                asm volatile("" : "+v"(st[rb]), "+v"(dp[rb]));
+                continue;
+            }
+            const bool first = ks0 + kk == 0;   // a chain's first MFMA takes the constant 0 as its accumulator operand
+            st[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2 * kk], f0[ks0 + kk], first ? zero16 : st[rb], 0, 0, 0);
+            dp[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2 * kk + 1], f1[ks0 + kk], first ? zero16 : dp[rb], 0, 0, 0);
+        }
+    };
+    // B slot s2 (tile t): acc^T[d][own] += T^T[d][tile row] * X[tile row][own]  (transposed reads of the same images)
+    auto b_slot = [&](int s2) {
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            if constexpr ((DITTO_DIAG_BWD & 8) != 0) {   // the operands stay live (and so does the work that makes them)
+                asm volatile("" : "+v"(acc0[db]) : "v"(dsf[s2 & 1]), "v"(tf[db]));
+                if constexpr (MODE == 1) asm volatile("" : "+v"(acc1[db]) : "v"(pf[s2 & 1]), "v"(tf[2 + db]));
+                continue;
+            }
+            acc0[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[db], dsf[s2 & 1], acc0[db], 0, 0, 0);   // K^T dS^T | Q^T dS
+            if constexpr (MODE == 1)
+                acc1[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[2 + db], pf[s2 & 1], acc1[db], 0, 0, 0);  // dO^T P
+        }
+    };
+    // V half: P, dS of tile rows rb*32 + (r&3) + 8*(r>>2) + 4*hh, r = 8 (s2 & 1) + 4 half + {0..3}, of block rb = s2 >> 1.
+    // Staged over the 4 elements (exponent arguments, exponentials, ...): independent instructions between a value's producer and
+    // its consumer.  (Compiled without SLP packing: packed fp32 instructions occupy the matrix pipe, ditto_tts_amd/build.py.)
+    auto v_half = [&](int tile, int s2, int half) {
+        const int r0 = 8 * (s2 & 1) + 4 * half;
+        if constexpr ((DITTO_DIAG_BWD & 1) != 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dsf[s2 & 1][4 * half + j] = (bf16)dp[s2 >> 1][r0 + j];
+                if constexpr (MODE == 1) pf[s2 & 1][4 * half + j] = (bf16)st[s2 >> 1][r0 + j];
+            }
+            return;
+        }
+        float sv[4], pr[4], gg[4], km[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sv[j] = st[s2 >> 1][r0 + j] * c - (MODE == 0 ? own_L : sl[half][j]);
+            if constexpr (RAG) {
+                const int rr = r0 + j;
+                const int trow = tile * TILE + (s2 >> 1) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * hh;
+                sv[j] = trow < p.Skv ? sv[j] : -1e30f;
+            }
+        }
+        if constexpr (DROP) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rr = r0 + j;
+                const int trow = tile * TILE + (s2 >> 1) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * hh;
+                const int qi = MODE == 0 ? own : trow, kj = MODE == 0 ? trow : own;
+                km[j] = drop_keep(dstream, qi, kj, p.drop_thr) ? p.keep_scale : 0.f;   // one select, two products
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pr[j] = __builtin_amdgcn_exp2f(sv[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float dl = MODE == 0 ? own_delta : sd[half][j];
+            const float g = dp[s2 >> 1][r0 + j];
+            gg[j] = DROP ? g * km[j] - dl : g - dl;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gg[j] *= pr[j];   // dS / scale: the factor is applied once, to the accumulators (epilogue)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dsf[s2 & 1][4 * half + j] = (bf16)gg[j];
+        if constexpr (MODE == 1) {
+            if constexpr (DROP) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pr[j] *= km[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pf[s2 & 1][4 * half + j] = (bf16)pr[j];
+        }
+    };
+    // a region = NM MFMAs + NV vector instructions, one MFMA then an equal share of the vector instructions and so on (a
+    // scheduling hint), and BEHIND them the region's LDS requests (pinned: they overwrite the fragments those MFMAs read)
+    constexpr int NVH = (MODE == 0 ? 18 : 20) + (DROP ? 36 : 0);   // vector instructions of one V half
+    constexpr int NMB = MODE == 0 ? 2 : 4;                          // MFMAs of a B slot
+    auto interleave = [&](auto NM, auto NV) {
+        constexpr int nm = decltype(NM)::value, nv = decltype(NV)::value;
+        if constexpr (nm > 0 && nv > 0) {
+#pragma unroll
+            for (int k = 0; k < nm; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, (nv + nm - 1) / nm, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#define DITTO_BWD_MIX(nm, nv) interleave(std::integral_constant<int, (nm)>{}, std::integral_constant<int, (nv)>{})
+
+    dma_tile(0, 0);
+    if (ntile > 1) dma_tile(1, 1);
+    wait_tile(ntile > 1 ? 1 : 0);
     __syncthreads();
     // the compiler's own wait for the fragment loads above must fall HERE, not at their first use inside the tile loop: it
     // counts only the loads it knows, so its vmcnt(0) in the loop would drain the whole DMA ring once per tile
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(f0[ks]), "+v"(f1[ks]));
     asm volatile("" : "+v"(own_L), "+v"(own_delta));
-#pragma unroll
-    for (int u = 0; u < PD; ++u) ld_rows(smem, u, fa[u]);
+    ld_rows(smem, 0, fa);
 
-    // MASKED: the ragged last KEY tile of the dq kernel (keys past Skv get P = 0).  The dkdv kernel needs no mask: its tile
-    // rows are queries, and rows past Sq carry L = 1e30 in the stats record.
-    auto tile_body = [&](int tt, auto MASKED) {
-        const char* base = smem + (tt & (NBUF - 1)) * BUF;
-        // The tile body is a software pipeline written out by hand: every LDS fragment is requested one step before the MFMAs
-        // that consume it, and the vector work of 16 tile rows (P, dS) is interleaved with the MFMAs of another step, where it
-        // runs in the matrix pipe's shadow.  sched_barrier(0) pins the batches; the counted lgkmcnt waits are the compiler's.
-        // ---- st = T0 * F0^T  (S^T or S),  dp = T1 * F1^T  (dP^T or dP): tile row in registers, own row on the lane ----
-        f32x16 st[2], dp[2];   // every chain's first MFMA takes the constant 0 as its accumulator operand: no zeroing moves
-        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        // transposed fragments of 16 tile rows (s2): [db] of image 0 (K^T | Q^T), MODE 1 also [2 + db] of image 1 (dO^T)
-        bf16x8 tf[NB][MODE == 0 ? 2 : 4];
-        auto ld_tr = [&](int s2, bf16x8* dst) {
-            if constexpr ((DITTO_DIAG_BWD & 32) != 0) {
-#pragma unroll
-                for (int k = 0; k < (MODE == 0 ? 2 : 4); ++k) asm volatile("" : "+v"(dst[k]));
-                return;
-            }
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                const char* r0 = base + (16 * s2 + tr_row0) * 128;
-                const char* a0 = r0 + ((tr_colbyte + 64 * db) ^ tr_swz0);
-                const char* a8 = r0 + 8 * 128 + ((tr_colbyte + 64 * db) ^ tr_swz1);
-                dst[db] = cat4(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0)),
-                               __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a8)));
-                if constexpr (MODE == 1)
-                    dst[2 + db] = cat4(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0 + IMG)),
-                                       __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a8 + IMG)));
-            }
-        };
-        // request the fragments of pipeline unit u: 0..3 = row fragments of step u, 4..7 = transposed fragments of slot u - 4,
-        // 8.. = row fragments of the next tile's steps (only behind the barrier of slot 2)
-        auto request = [&](int u) {
-            if (u < 4) ld_rows(base, u, fa[u % NB]);
-            else if (u < 8) ld_tr(u - 4, tf[(u - 4) % NB]);
-            else if (tt + 1 < ntile) ld_rows(smem + ((tt + 1) & (NBUF - 1)) * BUF, u - 8, fa[(u - 8) % NB]);
-        };
-        // MODE 1: L and delta of tile rows 16 s2 + 4 hh + {0..3} and + 8 (half-wave broadcast reads)
-        f32x4 sl[2], sd[2];
-        auto ld_stats = [&](int s2) {
-            if constexpr (MODE == 1) {
-                const char* sp = base + 2 * IMG + (16 * s2 + 4 * hh) * 4;
-                sl[0] = *reinterpret_cast<const f32x4*>(sp); sl[1] = *reinterpret_cast<const f32x4*>(sp + 32);
-                sd[0] = *reinterpret_cast<const f32x4*>(sp + 256); sd[1] = *reinterpret_cast<const f32x4*>(sp + 288);
-            }
-        };
-        // ---- P, dS for 16 tile rows (s2); this lane holds tile rows rb*32 + (r&3) + 8*(r>>2) + 4*hh of block rb = s2 >> 1 ----
-        bf16x8 pf[4], dsf[4];
-        auto p_ds = [&](int s2) {
-            if constexpr ((DITTO_DIAG_BWD & 1) != 0) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    dsf[s2][j] = (bf16)dp[s2 >> 1][8 * (s2 & 1) + j];
-                    if constexpr (MODE == 1) pf[s2][j] = (bf16)st[s2 >> 1][8 * (s2 & 1) + j];
-                }
-                return;
-            }
-            // staged over the 8 elements (all exponent arguments, then all exponentials, ...): eight independent instructions
-            // between a value's producer and its consumer, so an in-order wave never waits on its own arithmetic latency
-            float sv[8], pr[8], gg[8], km[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int rr = 8 * (s2 & 1) + j;
-                const float L = MODE == 0 ? own_L : sl[j >> 2][j & 3];
-                sv[j] = st[s2 >> 1][rr] * c - L;
-                if constexpr (decltype(MASKED)::value) {
-                    const int trow = tt * TILE + (s2 >> 1) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * hh;
-                    sv[j] = trow < p.Skv ? sv[j] : -1e30f;
-                }
-            }
-            if constexpr (DROP) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int rr = 8 * (s2 & 1) + j;
-                    const int trow = tt * TILE + (s2 >> 1) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * hh;
-                    const int qi = MODE == 0 ? own : trow, kj = MODE == 0 ? trow : own;
-                    km[j] = drop_keep(dstream, qi, kj, p.drop_thr) ? p.keep_scale : 0.f;   // one select, two products
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pr[j] = __builtin_amdgcn_exp2f(sv[j]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float dl = MODE == 0 ? own_delta : sd[j >> 2][j & 3];
-                const float g = dp[s2 >> 1][8 * (s2 & 1) + j];
-                gg[j] = DROP ? g * km[j] - dl : g - dl;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) gg[j] *= pr[j];   // dS / scale: the factor is applied once, to the accumulators (epilogue)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) dsf[s2][j] = (bf16)gg[j];
-            if constexpr (MODE == 1) {
-                if constexpr (DROP) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) pr[j] *= km[j];
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pf[s2][j] = (bf16)pr[j];
-            }
-        };
-        // schedule (4 steps of 4 MFMAs, then 4 slots of 2 | 4):      requests                 MFMAs                  behind them
-        //   step 0                                                    rows(1)                  S,dP k 0-1 of block 0
-        //   step 1                                                    rows(2)                  k 2-3                  stats(0)
-        //   step 2                                                    rows(3)                  block 1 k 0-1          P,dS(0), stats(1)
-        //   step 3                                                    tr(0)                    block 1 k 2-3          P,dS(1), stats(2)
-        //   slot 0                                                    tr(1)                    acc += ..(0)           P,dS(2), stats(3)
-        //   slot 1                                                    tr(2)                    acc += ..(1)           P,dS(3)
-        //   slot 2                                                    tr(3)                    acc += ..(2)           wait tile t+1, BARRIER,
-        //                                                                                                             DMA tile t+3, rows(0) of t+1
-        //   slot 3                                                                             acc += ..(3)
-        // (the L / delta request for the NEXT rows goes out only after the vector work that reads the current ones: one buffer)
-        // inside a region that holds nm MFMAs and one p_ds: one MFMA, then an equal share of the vector instructions, and so on
-        constexpr int NVEC = (MODE == 0 ? 28 : 32) + (DROP ? (MODE == 0 ? 80 : 112) : 0);   // vector instructions of one p_ds
-        // a region = NM MFMAs + ND LDS reads (the NEXT step's fragments) + optionally the vector work of one p_ds: one MFMA, then an
-        // equal share of the reads and of the vector instructions, and so on.  A lone wave showed why (one workgroup per CU,
-        // knock-out builds): with the reads issued as a batch in front of the MFMAs every step exposed an LDS round trip (922 of
-        // 2512 cycles per tile), and vector work only runs in the matrix pipe's shadow behind an MFMA of the same wave.
-        auto interleave = [&](auto NM, auto ND, auto VEC) {
-            constexpr int nm = decltype(NM)::value, nd = decltype(ND)::value;
-#pragma unroll
-            for (int k = 0; k < nm; ++k) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if constexpr (nd > 0) __builtin_amdgcn_sched_group_barrier(0x100, (nd + nm - 1) / nm, 0);
-                if constexpr (decltype(VEC)::value) __builtin_amdgcn_sched_group_barrier(0x002, NVEC / nm, 0);
-            }
-        };
-        constexpr int NSTAT = MODE == 1 ? 4 : 0;    // LDS reads of one ld_stats
-        constexpr int NTR = MODE == 0 ? 4 : 8;      // ds_read_b64_tr_b16 of one ld_tr
-#pragma unroll
-        for (int i = 0; i < NSTEP; ++i) {
-            const int rb = (i * G) >> 2, ks0 = (i * G) & 3;
-#pragma unroll
-            for (int kk = 0; kk < G; ++kk) {
-                if constexpr ((DITTO_DIAG_BWD & 16) != 0) {
-                    asm volatile("" : "+v"(st[rb]), "+v"(dp[rb]));
-                    continue;
-                }
-                const bool first = ks0 + kk == 0;
-                st[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i % NB][2 * kk], f0[ks0 + kk], first ? zero16 : st[rb], 0, 0, 0);
-                dp[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i % NB][2 * kk + 1], f1[ks0 + kk], first ? zero16 : dp[rb], 0, 0, 0);
-            }
-            request(i + PD);
-            if (i >= 2) p_ds(i - 2);
-            if (i >= 1) ld_stats(i - 1);
-            if (i == 0) interleave(std::integral_constant<int, 2 * G>{}, std::integral_constant<int, 4>{}, std::false_type{});
-            else if (i == 1) interleave(std::integral_constant<int, 2 * G>{}, std::integral_constant<int, 4 + NSTAT>{}, std::false_type{});
-            else if (i == 2) interleave(std::integral_constant<int, 2 * G>{}, std::integral_constant<int, 4 + NSTAT>{}, std::true_type{});
-            else interleave(std::integral_constant<int, 2 * G>{}, std::integral_constant<int, NTR + NSTAT>{}, std::true_type{});
-            // (with PD = 2 steps 2 and 3 request transposed fragments, not rows: the read counts above are upper bounds there)
-            __builtin_amdgcn_sched_barrier(0);
+    // one iteration: the second half of tile t (CUR) and the first half of tile t+1 (NXT)
+    auto body = [&](int t, auto HAS_CUR, auto HAS_NEXT) {
+        constexpr bool CUR = decltype(HAS_CUR)::value, NXT = decltype(HAS_NEXT)::value;
+        constexpr int MA = NXT ? 2 * G : 0, VC = CUR ? NVH : 0, VN = NXT ? NVH : 0;
+        const char* cb = smem + (t & (NBUF - 1)) * BUF;          // tile t
+        const char* nb = smem + ((t + 1) & (NBUF - 1)) * BUF;    // tile t + 1
+        constexpr int MBC = CUR ? NMB : 0, MBN = NXT ? NMB : 0;
+        // r0: A0(t+1) + V2b(t)
+        if constexpr (NXT) a_step(0);
+        if constexpr (CUR) v_half(t, 2, 1);
+        DITTO_BWD_MIX(MA, VC);
+        if constexpr (NXT) ld_rows(nb, 1, fa);
+        if constexpr (CUR) ld_stats(cb, 3, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // r1: B2(t) + V3a(t)
+        if constexpr (CUR) { b_slot(2); v_half(t, 3, 0); }
+        DITTO_BWD_MIX(MBC, VC);
+        if constexpr (CUR) ld_tr(cb, 3, tf);
+        if constexpr (NXT) ld_stats(nb, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // r2: A1(t+1) + V3b(t)
+        if constexpr (NXT) a_step(1);
+        if constexpr (CUR) v_half(t, 3, 1);
+        DITTO_BWD_MIX(MA, VC);
+        if constexpr (NXT) { ld_rows(nb, 2, fa); ld_stats(nb, 0, 1); }
+        __builtin_amdgcn_sched_barrier(0);
+        // r3: B3(t) + V0a(t+1)
+        if constexpr (CUR) b_slot(3);
+        if constexpr (NXT) v_half(t + 1, 0, 0);
+        DITTO_BWD_MIX(MBC, VN);
+        if constexpr (NXT) { ld_tr(nb, 0, tf); ld_stats(nb, 1, 0); }
+        __builtin_amdgcn_sched_barrier(0);
+        // r4: A2(t+1) + V0b(t+1)
+        if constexpr (NXT) { a_step(2); v_half(t + 1, 0, 1); }
+        DITTO_BWD_MIX(MA, VN);
+        if constexpr (NXT) { ld_rows(nb, 3, fa); ld_stats(nb, 1, 1); }
+        __builtin_amdgcn_sched_barrier(0);
+        // r5: B0(t+1) + V1a(t+1)
+        if constexpr (NXT) { b_slot(0); v_half(t + 1, 1, 0); }
+        DITTO_BWD_MIX(MBN, VN);
+        if constexpr (NXT) { ld_tr(nb, 1, tf); ld_stats(nb, 2, 0); }
+        __builtin_amdgcn_sched_barrier(0);
+        // r6: A3(t+1) + V1b(t+1)
+        if constexpr (NXT) { a_step(3); v_half(t + 1, 1, 1); }
+        DITTO_BWD_MIX(MA, VN);
+        if constexpr (NXT) ld_stats(nb, 2, 1);
+        if (t + 2 < ntile) {
+            if constexpr ((DITTO_DIAG_BWD & 2) == 0) bwd_vm_wait<0>();   // tile t + 2 is the youngest request
+            if constexpr ((DITTO_DIAG_BWD & 4) == 0) __builtin_amdgcn_s_barrier();
+            if constexpr ((DITTO_DIAG_BWD & 2) == 0)
+                if (t + 3 < ntile) dma_tile(t + 3, (t + 3) & (NBUF - 1));
+            ld_rows(smem + ((t + 2) & (NBUF - 1)) * BUF, 0, fa);
         }
-        // ---- acc^T[d][own] += T^T[d][tile row] * X[tile row][own]  (transposed reads of the same images) ----
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) {
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                if constexpr ((DITTO_DIAG_BWD & 8) != 0) {   // the operands stay live (and so does the work that makes them)
-                    asm volatile("" : "+v"(acc0[db]) : "v"(dsf[s2]), "v"(tf[s2 % NB][db]));
-                    if constexpr (MODE == 1) asm volatile("" : "+v"(acc1[db]) : "v"(pf[s2]), "v"(tf[s2 % NB][2 + db]));
-                    continue;
-                }
-                acc0[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[s2 % NB][db], dsf[s2], acc0[db], 0, 0, 0);   // K^T dS^T | Q^T dS
-                if constexpr (MODE == 1)
-                    acc1[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[s2 % NB][2 + db], pf[s2], acc1[db], 0, 0, 0);  // dO^T P
-            }
-            if (4 + s2 + PD < 8 || s2 == 3) request(4 + s2 + PD);   // slot 2's request for the next tile goes out behind its barrier
-            if (s2 < 2) p_ds(s2 + 2);
-            if (s2 < 1) ld_stats(3);
-            constexpr int NM2 = MODE == 0 ? 2 : 4;
-            if (s2 == 0) interleave(std::integral_constant<int, NM2>{}, std::integral_constant<int, NTR + NSTAT>{}, std::true_type{});
-            else if (s2 == 1) interleave(std::integral_constant<int, NM2>{}, std::integral_constant<int, NTR>{}, std::true_type{});
-            else if (s2 == 2) interleave(std::integral_constant<int, NM2>{}, std::integral_constant<int, NTR>{}, std::false_type{});
-            __builtin_amdgcn_sched_barrier(0);
-            if (s2 == 2 && tt + 1 < ntile) {
-                // tiles requested so far: <= tt + NBUF - 2; tile tt + 1 has landed once only the ones behind it are in flight
-                const int younger = ntile - 2 - tt;
-                if constexpr ((DITTO_DIAG_BWD & 2) == 0) wait_tile(younger < NBUF - 3 ? younger : NBUF - 3);
-                if constexpr ((DITTO_DIAG_BWD & 4) == 0) __builtin_amdgcn_s_barrier();
-                if constexpr ((DITTO_DIAG_BWD & 2) == 0)
-                    if (tt + NBUF - 1 < ntile) dma_tile(tt + NBUF - 1, (tt + NBUF - 1) & (NBUF - 1));
-#pragma unroll
-                for (int u = 8; u <= 4 + 2 + PD; ++u) request(u);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
+        __builtin_amdgcn_sched_barrier(0);
+        // r7: B1(t+1) + V2a(t+1)
+        if constexpr (NXT) { b_slot(1); v_half(t + 1, 2, 0); }
+        DITTO_BWD_MIX(MBN, VN);
+        if constexpr (NXT) { ld_tr(nb, 2, tf); ld_stats(nb, 3, 0); }
+        __builtin_amdgcn_sched_barrier(0);
     };
-    const bool ragged = MODE == 0 && ragged_tile;
-    const int nfull = ragged ? ntile - 1 : ntile;
-    for (int tt = 0; tt < nfull; ++tt) tile_body(tt, std::false_type{});
-    if (ragged) tile_body(ntile - 1, std::true_type{});
+#undef DITTO_BWD_MIX
+    body(-1, std::false_type{}, std::true_type{});
+    for (int t = 0; t + 1 < ntile; ++t) body(t, std::true_type{}, std::true_type{});
+    body(ntile - 1, std::true_type{}, std::false_type{});
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[0][i] *= p.scale; acc0[1][i] *= p.scale; }   // dQ = scale dS' k, dK = scale dS'^T q
 
@@ -542,17 +556,22 @@ hipError_t launch_attention_bwd64(const AttnBwdArgs& a, const float* stats, hipS
     static const int lds_pad = [] { const char* e = getenv("DITTO_BWD_LDS_PAD"); return e ? atoi(e) : 0; }();
     const int LDS0 = NBUF * 2 * IMG + lds_pad, LDS1 = NBUF * (2 * IMG + STAT_BYTES) + lds_pad;
     static DevOnce lds_once;
-    if (hipError_t e = set_max_lds_once(lds_once, {reinterpret_cast<const void*>(&attn64_bwd_kernel<0, false>),
-                                                   reinterpret_cast<const void*>(&attn64_bwd_kernel<0, true>),
+    if (hipError_t e = set_max_lds_once(lds_once, {reinterpret_cast<const void*>(&attn64_bwd_kernel<0, false, false>),
+                                                   reinterpret_cast<const void*>(&attn64_bwd_kernel<0, true, false>),
+                                                   reinterpret_cast<const void*>(&attn64_bwd_kernel<0, false, true>),
+                                                   reinterpret_cast<const void*>(&attn64_bwd_kernel<0, true, true>),
                                                    reinterpret_cast<const void*>(&attn64_bwd_kernel<1, false>),
                                                    reinterpret_cast<const void*>(&attn64_bwd_kernel<1, true>)}, LDS1 + 32768)) return e;
-    const bool drop = p.drop_thr != 0;
+    const bool drop = p.drop_thr != 0, rag = (a.Skv & (TILE - 1)) != 0;
     p.nblk = (a.Sq + BLK - 1) / BLK;
-    if (drop) hipLaunchKernelGGL((attn64_bwd_kernel<0, true>), dim3(p.nblk * a.H * a.B), dim3(256), LDS0, s, p);
-    else hipLaunchKernelGGL((attn64_bwd_kernel<0, false>), dim3(p.nblk * a.H * a.B), dim3(256), LDS0, s, p);
+    const dim3 g0(p.nblk * a.H * a.B), blk(256);
+    if (drop && rag) hipLaunchKernelGGL((attn64_bwd_kernel<0, true, true>), g0, blk, LDS0, s, p);
+    else if (drop) hipLaunchKernelGGL((attn64_bwd_kernel<0, true, false>), g0, blk, LDS0, s, p);
+    else if (rag) hipLaunchKernelGGL((attn64_bwd_kernel<0, false, true>), g0, blk, LDS0, s, p);
+    else hipLaunchKernelGGL((attn64_bwd_kernel<0, false, false>), g0, blk, LDS0, s, p);
     p.nblk = (a.Skv + BLK - 1) / BLK;
-    if (drop) hipLaunchKernelGGL((attn64_bwd_kernel<1, true>), dim3(p.nblk * a.H * a.B), dim3(256), LDS1, s, p);
-    else hipLaunchKernelGGL((attn64_bwd_kernel<1, false>), dim3(p.nblk * a.H * a.B), dim3(256), LDS1, s, p);
+    if (drop) hipLaunchKernelGGL((attn64_bwd_kernel<1, true>), dim3(p.nblk * a.H * a.B), blk, LDS1, s, p);
+    else hipLaunchKernelGGL((attn64_bwd_kernel<1, false>), dim3(p.nblk * a.H * a.B), blk, LDS1, s, p);
     return hipGetLastError();
 }
 
