@@ -22,7 +22,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # instructions occupy the matrix pipe (a lone wave showed zero MFMA / vector overlap: removing the 24 MFMAs of a tile saved
 # exactly 24 x 32 cycles); scalar v_sub / v_mul issue beside the MFMAs.
 EXTRA = {"attention.hip": ["-fno-honor-nans"], "attention_v4.hip": ["-fno-honor-nans"],
-         "attention_bwd.hip": ["-fno-slp-vectorize"]}
+         "attention_bwd.hip": ["-fno-slp-vectorize"], "attention_train.hip": ["-fno-honor-nans", "-fno-slp-vectorize"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC,
          "-Wall", "-Wno-unused-function"]
 

@@ -163,6 +163,15 @@ __global__ __launch_bounds__(256, 2) void attn64_bwd_kernel(BwdParams p) {
             f1[ks] = *reinterpret_cast<const bf16x8*>(s1 + 16 * ks);
         }
     }
+    // MODE 0: the query fragments carry scale * log2(e), rounded to bf16 exactly as the training forward rounds them
+    // (attn64v2_kernel<.., TRAIN>), so K Q'^T is already in log2 units, and the chain's first MFMA starts from -L: the scores
+    // come out of the matrix pipe as S' - L, no per-element scale and subtract
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f0[ks][i] = (bf16)((float)f0[ks][i] * p.scale_log2);
+    }
     float own_L = 1e30f, own_delta = 0.f;   // MODE 0: per-lane (query) scalars
     if constexpr (MODE == 0) {
         if (own_valid) {
@@ -265,6 +274,9 @@ __global__ __launch_bounds__(256, 2) void attn64_bwd_kernel(BwdParams p) {
     bf16x8 pf[2], dsf[2];                       // [16-row group & 1]: a group is consumed before the one after next is made
     f32x4 sl[2], sd[2];                         // MODE 1: L / delta of the 4 tile rows of a V half, [half]
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 neg_l16;   // MODE 0: every register = -L of the lane's query
+#pragma unroll
+    for (int i = 0; i < 16; ++i) neg_l16[i] = MODE == 0 ? -own_L : 0.f;
     auto ld_rows = [&](const char* base, int u, bf16x8* dst) {
         if constexpr ((DITTO_DIAG_BWD & 32) != 0) {   // opaque to the compiler: the MFMAs that read dst stay where they are
 #pragma unroll
@@ -315,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void attn64_bwd_kernel(BwdParams p) {
                 continue;
             }
             const bool first = ks0 + kk == 0;   // a chain's first MFMA takes the constant 0 as its accumulator operand
-            st[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2 * kk], f0[ks0 + kk], first ? zero16 : st[rb], 0, 0, 0);
+            st[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2 * kk], f0[ks0 + kk], first ? (MODE == 0 ? neg_l16 : zero16) : st[rb], 0, 0, 0);
             dp[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2 * kk + 1], f1[ks0 + kk], first ? zero16 : dp[rb], 0, 0, 0);
         }
     };
@@ -349,7 +361,7 @@ __global__ __launch_bounds__(256, 2) void attn64_bwd_kernel(BwdParams p) {
         float sv[4], pr[4], gg[4], km[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            sv[j] = st[s2 >> 1][r0 + j] * c - (MODE == 0 ? own_L : sl[half][j]);
+            sv[j] = MODE == 0 ? st[s2 >> 1][r0 + j] : st[s2 >> 1][r0 + j] * c - sl[half][j];
             if constexpr (RAG) {
                 const int rr = r0 + j;
                 const int trow = tile * TILE + (s2 >> 1) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * hh;

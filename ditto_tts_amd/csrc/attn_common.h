@@ -22,6 +22,8 @@ struct AttnParams {
     unsigned drop_thr; float keep_scale; unsigned seed_lo, seed_hi; int layer;
 };
 
+hipError_t launch_attention_train64(const AttnParams& p, bool resid, hipStream_t s);   // attention_train.hip
+
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
 
 DITTO_DEV bf16x8 cat4(bf16x4 a, bf16x4 b) {

@@ -12,6 +12,7 @@ mkdir -p /tmp/diag_objs
 for f in *.hip; do
   extra=""; { [ "$f" = attention.hip ] || [ "$f" = attention_v4.hip ]; } && extra="-fno-honor-nans"
   [ "$f" = attention_bwd.hip ] && extra="-fno-slp-vectorize"
+  [ "$f" = attention_train.hip ] && extra="-fno-honor-nans -fno-slp-vectorize"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I ../../include -I . -Wno-unused-function $extra "$@" -c $f -o /tmp/diag_objs/${f%.hip}.o &
 done
 wait
