@@ -5,17 +5,19 @@
 // from q, k and the forward's log-sum-exp, never stored:
 //     P = exp2(c s - L),   dP = mask/(1-p) * (dO v^T),   dS = P * (dP - delta) * scale,   delta = rowsum(dO * O)
 //     dV = (mask/(1-p) * P)^T dO,    dQ = dS k,    dK = dS^T q.
-// Two kernels, each the forward kernel's structure (attention.hip) with different operands, so that every output
-// is owned by exactly one workgroup: NO atomics and no cross-workgroup sum => bit-reproducible gradients.
+// Two kernels, so that every output is owned by exactly one workgroup: NO atomics and no cross-workgroup sum =>
+// bit-reproducible gradients.
 //   dq kernel    one workgroup = 128 queries; streams 64-key tiles.   S^T = K Q^T and dP^T = V dO^T have the QUERY
-//                on the lane (L and delta are per-lane scalars); dS^T, packed to bf16 in registers, is the B operand
-//                of dQ^T += K^T dS^T (K^T through ds_read_b64_tr_b16 from a second, transposed-read image of K).
+//                on the lane (L and delta are per-lane scalars; the query fragments carry scale * log2(e) and the score
+//                chain starts from -L, as in the training forward); dS^T, packed to bf16 in registers, is the B operand
+//                of dQ^T += K^T dS^T (K^T by ds_read_b64_tr_b16 from the same LDS image the row reads use).
 //   dkdv kernel  one workgroup = 128 keys; streams 64-query tiles.   S = Q K^T and dP = dO V^T have the KEY on the
 //                lane (K, V fragments live in registers for the whole kernel); P and dS in registers are the B
 //                operands of dV^T += dO^T P and dK^T += Q^T dS (Q^T, dO^T by transposed reads).
 // This costs 7 products instead of the 5 of a single-kernel backward (S and dP are computed in both), 14 B H Sq Skv
 // dh FLOPs per call: 40 % more MFMA work bought for determinism and for not needing fp32 dQ atomics.
-// Roofline: MFMA-bound; K/V (dq kernel) or Q/dO (dkdv kernel) of one head are re-read from the XCD's L2.
+// Roofline: nominally MFMA (K/V or Q/dO of one head are re-read from the XCD's L2), in practice vector ISSUE: a 64-row
+// tile carries as many cycles of P / dS arithmetic as of MFMA (see the comment above the kernel and profiles/r03_attn_bwd.txt).
 #include <type_traits>
 
 #include "gemm_common.h"
