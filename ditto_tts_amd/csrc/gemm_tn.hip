@@ -322,9 +322,32 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_wide_kernel(TnParams p) {
     // DMA: a stage = 16 pieces of 1 KiB (2 k-rows x 512 B) per operand; this wave moves pieces 2*wid, 2*wid+1 of X and Y
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;
     const int prow = lane >> 5, cpos = lane & 31;          // row inside the piece, 16-B chunk position
+    // a lane's (k-row, chunk) offsets inside a stage never change: whole K-tiles take a wave-uniform 64-bit base in scalar
+    // registers (one scalar add per K-tile) + these 32-bit offsets; only a tile that crosses K falls back to per-lane addresses
+    unsigned vox[2], voy[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wid * 2 + i) * 2 + prow;
+        const int c = cpos ^ ((r & 3) << 2);
+        int cx = m0 + c * 8; cx = cx + 8 <= p.Mo ? cx : (p.Mo >= 8 ? p.Mo - 8 : 0);
+        int cy = n0 + c * 8; cy = cy + 8 <= p.No ? cy : (p.No >= 8 ? p.No - 8 : 0);
+        vox[i] = (unsigned)(r * p.ldx + cx) * 2u;
+        voy[i] = (unsigned)(r * p.ldy + cy) * 2u;
+    }
     auto stage = [&](int kt) {
         const int st = kt & (R_NST - 1);
         const int k0 = (kbase + kt) * RK;
+        if (k0 + RK <= p.K) {
+            const bf16* bx = p.X + (size_t)k0 * p.ldx;
+            const bf16* by = p.Y + (size_t)k0 * p.ldy;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int piece = wid * 2 + i;
+                glds16_so(vox[i], bx, lds_base + (unsigned)(st * W_STAGE + piece * 1024));
+                glds16_so(voy[i], by, lds_base + (unsigned)(st * W_STAGE + W_TILE + piece * 1024));
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int piece = wid * 2 + i;
@@ -392,18 +415,27 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_wide_kernel(TnParams p) {
         wait_behind(nkt - 1 < R_NST - 2 ? nkt - 1 : R_NST - 2);
         asm volatile("s_barrier" ::: "memory");
         read_frags(smem, 0, f0x, f0y);
+        // the next half-step's 12 transposed reads go out BETWEEN the 8 MFMAs of the current one (two per MFMA gap: issued as
+        // a batch in front of the MFMAs they delayed the first one and queued behind each other; attention_bwd.hip, round 3)
+        auto spread = [&]() {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (k < 6) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
         for (int kt = 0; kt + 1 < nkt; ++kt) {                             // the last tile is peeled: one path per body
-            read_frags(smem + (kt & (R_NST - 1)) * W_STAGE, 1, f1x, f1y);
-            __builtin_amdgcn_sched_barrier(0);
             mma(f0x, f0y);
-            __builtin_amdgcn_sched_barrier(0);
+            read_frags(smem + (kt & (R_NST - 1)) * W_STAGE, 1, f1x, f1y);
+            spread();
             wait_behind(kt + 2 < nkt ? 1 : 0);
             asm volatile("s_barrier" ::: "memory");
             if (kt + R_NST - 1 < nkt) stage(kt + R_NST - 1);
-            read_frags(smem + ((kt + 1) & (R_NST - 1)) * W_STAGE, 0, f0x, f0y);
             __builtin_amdgcn_sched_barrier(0);
             mma(f1x, f1y);
-            __builtin_amdgcn_sched_barrier(0);
+            read_frags(smem + ((kt + 1) & (R_NST - 1)) * W_STAGE, 0, f0x, f0y);
+            spread();
         }
         read_frags(smem + ((nkt - 1) & (R_NST - 1)) * W_STAGE, 1, f1x, f1y);
         __builtin_amdgcn_sched_barrier(0);
