@@ -70,7 +70,10 @@ def _heads(t, B, S, H, dh):
 
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("B,H,Sq,Skv,dh,p", [(1, 2, 64, 64, 64, 0.0), (2, 2, 100, 72, 64, 0.1), (1, 1, 48, 80, 256, 0.1),
-                                              (2, 3, 130, 130, 64, 0.0), (1, 2, 257, 321, 64, 0.1)])
+                                              (2, 3, 130, 130, 64, 0.0), (1, 2, 257, 321, 64, 0.1),
+                                              (1, 2, 256, 192, 64, 0.1),     # whole tiles + dropout (no mask instantiation)
+                                              (1, 1, 128, 640, 64, 0.0),     # 10 key tiles: the 4-buffer ring wraps twice
+                                              (1, 1, 704, 64, 64, 0.1)])     # 11 query tiles for the dk,dv kernel's ring
 def test_attention_dropout_forward_and_backward_vs_autograd(B, H, Sq, Skv, dh, p, fused):
     """bf16 operands: compare against fp32 autograd on the SAME bf16-rounded q/k/v/dO.  Tolerance 2e-2 rel-L2
     (P and dS are rounded to bf16 between the two products).  fused = the head_dim-64 flash kernels (forward with
