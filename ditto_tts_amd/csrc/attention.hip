@@ -915,13 +915,9 @@ bool attention_bwd_fuses_rope(const AttnBwdArgs& a) { return a.dh == DH && a.lse
 hipError_t launch_attention_bwd(const AttnBwdArgs& a, hipStream_t s) {
     if (a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Skv <= 0 || a.dh % 64) return hipErrorInvalidValue;
     if ((a.rope_cos || a.rope_sin) && !attention_bwd_fuses_rope(a)) return hipErrorInvalidValue;   // the caller asks first
-    if (a.dh == DH && a.lse) {   // fused: {L, delta = rowsum(dO * O)} records into the workspace, then the two kernels
+    if (a.dh == DH && a.lse) {   // fused: the two kernels; the {L, delta = rowsum(dO * O)} records live in the workspace
         if (!a.workspace || a.workspace_bytes < attention_bwd_stats_bytes(a.B, a.H, a.Sq)) return hipErrorInvalidValue;
-        float* stats = (float*)a.workspace;
-        hipError_t e = launch_attention_delta(a.dout, a.lddo, a.o_bf16, a.ldo, a.h_after, a.h_before, a.ldh, a.lse, stats,
-                                              a.B, a.H, a.Sq, s);
-        if (e != hipSuccess) return e;
-        return launch_attention_bwd64(a, stats, s);
+        return launch_attention_bwd64(a, (float*)a.workspace, s);
     }
     if (!a.workspace || a.workspace_bytes < plan_bwd(a.Sq, a.Skv, a.dh, 1).total) return hipErrorInvalidValue;
     const int BH = a.B * a.H;

@@ -40,7 +40,11 @@ struct BwdParams {
     const bf16* q; int ldq; const bf16* k; int ldk; const bf16* v; int ldv;
     const bf16* dout; int lddo;
     bf16* dq; int lddq; bf16* dk; int lddk; bf16* dv; int lddv;
-    const float* stats;   // [B, H, ceil(Sq / 64), 128]: {L[64] (log2 domain) | delta[64]} per query tile (attn_delta_kernel)
+    float* stats;         // [B, H, ceil(Sq / 64), 128]: {L[64] (log2 domain) | delta[64]} per query tile: WRITTEN by the dq kernel
+                          // (it holds dO fragments of its queries anyway), read by the dk,dv kernel that follows it on the stream
+    const float* lse;     // [B, H, Sq] log2 domain, from the training forward
+    const bf16* o; int ldo;                                  // O (cross-attention), or
+    const float* h_after; const float* h_before; int ldh;   // O = h_after - h_before (self-attention: never stored)
     int B, H, Sq, Skv, nblk;
     float scale, scale_log2;
     unsigned drop_thr; float keep_scale; unsigned seed_lo, seed_hi; int layer;
@@ -55,52 +59,11 @@ DITTO_DEV bf16x8 cat4(bf16x4 a, bf16x4 b) {
 }
 
 // Per-row statistics of the backward, one record per (batch, head, 64-query tile): stats[((b H + h) nt + tile) 128 + {i, 64 + i}]
-// = {L, delta} of query tile * 64 + i, nt = ceil(Sq / 64):  L = the forward's log2-domain log-sum-exp (copied here), delta =
-// sum_c dO[row, h*64 + c] * O[row, h*64 + c].  Rows past Sq hold L = 1e30 (P = exp2(-inf) = 0) and delta = 0, so the dkdv kernel
-// needs no row mask, and a tile's record is one 512-byte LDS-DMA.  O = o_bf16 (cross-attention output) or h_after - h_before
-// (self-attention: the residual stream before / after the segment, no out-proj).
-// One wave per (padded) row, 4 columns per lane per pass, a head = 16 lanes.
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ dout, int lddo,
-                                                         const bf16* __restrict__ o_bf16, int ldo,
-                                                         const float* __restrict__ h_after,
-                                                         const float* __restrict__ h_before, int ldh,
-                                                         const float* __restrict__ lse, float* __restrict__ stats, int B,
-                                                         int H, int Sq) {
-    const int lane = threadIdx.x & 63;
-    const int nt = (Sq + TILE - 1) / TILE, sqp = nt * TILE;
-    const int prow = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (prow >= B * sqp) return;
-    const int b = prow / sqp, qi = prow % sqp;
-    const bool real = qi < Sq;
-    const size_t row = (size_t)b * Sq + (real ? qi : Sq - 1);
-    const int d = H * DH;
-    for (int c0 = 0; c0 < d; c0 += 256) {
-        const int col = c0 + lane * 4;
-        float acc = 0.f;
-        if (col < d && real) {
-            const u32x2 g = *reinterpret_cast<const u32x2*>(dout + row * lddo + col);
-            float o[4];
-            if (o_bf16) {
-                const u32x2 ov = *reinterpret_cast<const u32x2*>(o_bf16 + row * ldo + col);
-                o[0] = bf16_lo(ov[0]); o[1] = bf16_hi(ov[0]); o[2] = bf16_lo(ov[1]); o[3] = bf16_hi(ov[1]);
-            } else {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(h_after + row * ldh + col);
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(h_before + row * ldh + col);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = a[e] - bb[e];
-            }
-            acc = bf16_lo(g[0]) * o[0] + bf16_hi(g[0]) * o[1] + bf16_lo(g[1]) * o[2] + bf16_hi(g[1]) * o[3];
-        }
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-        if (col < d && (lane & 15) == 0) {
-            const int hd = col / DH;
-            float* rec = stats + (((size_t)b * H + hd) * nt + qi / TILE) * 128 + (qi & (TILE - 1));
-            rec[0] = real ? lse[((size_t)b * H + hd) * Sq + qi] : 1e30f;
-            rec[64] = acc;
-        }
-    }
-}
+// = {L, delta} of query tile * 64 + i, nt = ceil(Sq / 64):  L = the forward's log2-domain log-sum-exp, delta = sum_c dO[row, h*64 + c]
+// * O[row, h*64 + c].  Rows past Sq hold L = 1e30 (P = exp2(-inf) = 0) and delta = 0, so the dk,dv kernel needs no row mask,
+// and a tile's record is one 512-byte LDS-DMA.  The dq kernel writes them in its prologue: a lane already holds 32 of its
+// query's 64 dO columns as MFMA fragments, loads the same columns of O, and one exchange with lane ^ 32 completes the dot
+// product.  (A separate row pre-pass did this before: 41 us per call, 2 x 12 calls per training step.)
 
 template <int N>
 DITTO_DEV void bwd_vm_wait() {
@@ -176,10 +139,40 @@ __global__ __launch_bounds__(256, 2) void attn64_bwd_kernel(BwdParams p) {
     }
     float own_L = 1e30f, own_delta = 0.f;   // MODE 0: per-lane (query) scalars
     if constexpr (MODE == 0) {
+        // delta = rowsum(dO * O) of the lane's query: its 32 columns (d = 16 ks + 8 hh + 0..7) here, the other 32 in lane ^ 32
+        float part = 0.f;
+        const size_t grow = (size_t)b * p.Sq + own;
+        if (p.o) {
+            const bf16* op = p.o + grow * p.ldo + h * DH + 8 * hh;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 ov = *reinterpret_cast<const bf16x8*>(op + 16 * ks);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) part += (float)f1[ks][i] * (float)ov[i];
+            }
+        } else {
+            const float* ap = p.h_after + grow * p.ldh + h * DH + 8 * hh;
+            const float* bp = p.h_before + grow * p.ldh + h * DH + 8 * hh;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int q4 = 0; q4 < 2; ++q4) {
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(ap + 16 * ks + 4 * q4);
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + 16 * ks + 4 * q4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) part += (float)f1[ks][4 * q4 + i] * (av[i] - bv[i]);
+                }
+        }
+        part += __shfl_xor(part, 32, 64);
         if (own_valid) {
-            const float* rec = p.stats + ((size_t)bh * nqt + own / TILE) * 128 + (own & (TILE - 1));
-            own_L = rec[0];
-            own_delta = rec[64];
+            own_L = p.lse[(size_t)bh * p.Sq + own];
+            own_delta = part;
+        }
+        const int row_u = blk * BLK + wid * 32 + ql;   // unclamped: rows in [Sq, nqt * 64) get the fill values
+        if (hh == 0 && row_u < nqt * TILE) {
+            float* rec = p.stats + ((size_t)bh * nqt + row_u / TILE) * 128 + (row_u & (TILE - 1));
+            rec[0] = own_L;
+            rec[64] = own_delta;
         }
     }
 
@@ -539,26 +532,19 @@ __global__ __launch_bounds__(256, 2) void attn64_bwd_kernel(BwdParams p) {
 
 size_t attention_bwd_stats_bytes(int B, int H, int Sq) { return (size_t)B * H * ((Sq + TILE - 1) / TILE) * 128 * sizeof(float); }
 
-hipError_t launch_attention_delta(const void* dout, int lddo, const void* o_bf16, int ldo, const float* h_after,
-                                  const float* h_before, int ldh, const float* lse, float* stats, int B, int H, int Sq,
-                                  hipStream_t s) {
-    if ((lddo % 4) || (o_bf16 && ldo % 4) || (!o_bf16 && (ldh % 4 || !h_after || !h_before)) || !lse || !stats)
-        return hipErrorInvalidValue;
-    const int sqp = ((Sq + TILE - 1) / TILE) * TILE;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((B * sqp + 3) / 4), dim3(256), 0, s, (const bf16*)dout, lddo,
-                       (const bf16*)o_bf16, ldo, h_after, h_before, ldh, lse, stats, B, H, Sq);
-    return hipGetLastError();
-}
-
-// fused backward (head_dim 64): stats = the per-tile {L, delta} records of launch_attention_delta
-hipError_t launch_attention_bwd64(const AttnBwdArgs& a, const float* stats, hipStream_t s) {
-    if (a.dh != DH || a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Skv <= 0 || !stats) return hipErrorInvalidValue;
+// fused backward (head_dim 64): stats = attention_bwd_stats_bytes of scratch for the per-tile {L, delta} records (the dq kernel
+// writes them, the dk,dv kernel reads them); a.lse from the training forward; O = a.o_bf16, or a.h_after - a.h_before
+hipError_t launch_attention_bwd64(const AttnBwdArgs& a, float* stats, hipStream_t s) {
+    if (a.dh != DH || a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Skv <= 0 || !stats || !a.lse) return hipErrorInvalidValue;
     if ((a.ldq | a.ldk | a.ldv | a.lddo) % 8 || (a.lddq | a.lddk | a.lddv) % 4) return hipErrorInvalidValue;
+    if (a.o_bf16 ? a.ldo % 8 != 0 : (!a.h_after || !a.h_before || a.ldh % 4 != 0)) return hipErrorInvalidValue;
     BwdParams p;
     p.q = (const bf16*)a.q; p.ldq = a.ldq; p.k = (const bf16*)a.k; p.ldk = a.ldk; p.v = (const bf16*)a.v; p.ldv = a.ldv;
     p.dout = (const bf16*)a.dout; p.lddo = a.lddo;
     p.dq = (bf16*)a.dq; p.lddq = a.lddq; p.dk = (bf16*)a.dk; p.lddk = a.lddk; p.dv = (bf16*)a.dv; p.lddv = a.lddv;
-    p.stats = stats; p.B = a.B; p.H = a.H; p.Sq = a.Sq; p.Skv = a.Skv;
+    p.stats = stats; p.lse = a.lse; p.o = (const bf16*)a.o_bf16; p.ldo = a.ldo;
+    p.h_after = a.h_after; p.h_before = a.h_before; p.ldh = a.ldh;
+    p.B = a.B; p.H = a.H; p.Sq = a.Sq; p.Skv = a.Skv;
     p.scale = a.scale; p.scale_log2 = a.scale * 1.4426950408889634f;
     p.drop_thr = dropout_threshold(a.dropout_p);
     p.keep_scale = p.drop_thr ? 1.0f / (1.0f - a.dropout_p) : 1.0f;

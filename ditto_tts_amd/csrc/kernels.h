@@ -220,11 +220,8 @@ struct AttnBwdArgs {
 hipError_t launch_attention_bwd(const AttnBwdArgs& a, hipStream_t s);
 // true when launch_attention_bwd(a) applies a.rope_cos / a.rope_sin itself (the fused dh == 64 path)
 bool attention_bwd_fuses_rope(const AttnBwdArgs& a);
-hipError_t launch_attention_delta(const void* dout, int lddo, const void* o_bf16, int ldo, const float* h_after,
-                                  const float* h_before, int ldh, const float* lse, float* stats, int B, int H, int Sq,
-                                  hipStream_t s);
-size_t attention_bwd_stats_bytes(int B, int H, int Sq);   // the {L, delta} records launch_attention_delta writes
-hipError_t launch_attention_bwd64(const AttnBwdArgs& a, const float* stats, hipStream_t s);
+size_t attention_bwd_stats_bytes(int B, int H, int Sq);   // scratch for the per-tile {L, delta} records of the fused backward
+hipError_t launch_attention_bwd64(const AttnBwdArgs& a, float* stats, hipStream_t s);
 size_t attention_train_workspace_bytes(int B, int H, int Sq, int Skv, int dh);   // forward + backward scratch
 
 // ---------------- gemm_tn.hip : out fp32 [Mo, No] = X[K, Mo]^T Y[K, No], both operands K-major (wgrad) ----------------

@@ -84,5 +84,5 @@ for p in [float(x) for x in a.p.split(",")]:
         tf.append(timed(fwd, p))
         tb.append(timed(bwd, p))
     f, b = sorted(tf)[len(tf) // 2], sorted(tb)[len(tb) // 2]
-    print(f"p={p}: forward+lse {f:.1f} us ({fl_f / f / 1e6:.0f} TFLOP/s)   backward (delta + dq + dkdv) {b:.1f} us "
+    print(f"p={p}: forward+lse {f:.1f} us ({fl_f / f / 1e6:.0f} TFLOP/s)   backward (dq [+ delta] + dk,dv) {b:.1f} us "
           f"({3.5 * fl_f / b / 1e6:.0f} TFLOP/s on the 14 B H Sq Skv dh count, {2.5 * fl_f / b / 1e6:.0f} on the minimal 10)")
