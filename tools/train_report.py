@@ -65,10 +65,17 @@ def main():
         if i:
             times["fwd"].append(t1 - t0); times["bwd"].append(t2 - t1); times["opt"].append(t3 - t2)
     med = {k: sorted(v)[len(v) // 2] * 1e3 for k, v in times.items()}
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(a.steps):                      # as a training loop runs it: no synchronisation between the phases
+        loss = F.mse_loss(m(x, text, t), noise)
+        opt.zero_grad(); loss.backward()
+        opt.step()
+    torch.cuda.synchronize()
+    loop_ms = (time.perf_counter() - t0) / a.steps * 1e3
     fl = 3 * cfg.flops_per_utt_step(N, T, cached_kv=False) * B
     tot = sum(med.values())
     print(f"train step {a.config} B={B} N={N} T={T}: fwd {med['fwd']:.1f} ms, bwd {med['bwd']:.1f} ms, "
-          f"AdamW+repack {med['opt']:.1f} ms  -> {B / tot * 1e3:.1f} utt/s, {fl / tot / 1e9:.0f} TFLOP/s "
+          f"AdamW+repack {med['opt']:.1f} ms (sum {tot:.1f}; back to back {loop_ms:.1f} ms/step)  -> {B / tot * 1e3:.1f} utt/s, {fl / tot / 1e9:.0f} TFLOP/s "
           f"(3x forward FLOPs), loss {float(loss):.4f}, peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
 
 
