@@ -218,20 +218,21 @@ DITTO_DEV unsigned pack_fp8x4(float a, float b, float c, float d) {
 }
 
 // Counter-based dropout mask of the training path (train.hip header): keep iff hash(stream, query, key) >= thr.
-// The per-(batch, head) stream is a full 32-bit mix (lowbias32, twice per kernel launch and lane); the PER-ELEMENT hash is two
-// rounds of xorshift + 24-bit multiply (v_mul_u32_u24 runs at full rate, v_mul_lo_u32 at a quarter: 6 full-rate instructions
-// instead of 2 quarter-rate + 6, in the element loop of the forward and of both backward kernels).  Each round folds the word's
-// top bits down first, so the 24 bits the multiply sees carry all 32; the compare reads the product's top bits.  Keep rate,
-// lag-1 correlations along query / key / diagonal and 8x8 block variance over 1024 x 1024 masks are within one sigma of
-// lowbias32's (oracle/ditto_oracle.py hash_dropout_mask is the same function; tests/test_oracle_dropout_hash.py).
+// The per-(batch, head) stream is a full 32-bit mix (lowbias32, twice per kernel launch and lane); the PER-ELEMENT hash is ONE
+// round of xorshift + 24-bit multiply on stream ^ (query * C1 + key * C2) — the counter is itself a multiplicative hash of
+// (query, key), the fold brings the word's top bits into the 24 the multiply reads, and the compare reads the product's top
+// bits.  v_mul_u32_u24 runs at full rate (v_mul_lo_u32 at a quarter): 3 full-rate instructions behind the xor, where
+// lowbias32 took 2 quarter-rate + 6, in the element loop of the forward and of both backward kernels (the dropout mask cost
+// 3.6 ms of a 57 ms training step with a two-round version).  Keep rate, correlations along query / key / diagonal at lags
+// 1..64 and 8x8 block variance over 1024 x 1024 masks are within noise of lowbias32's (oracle/ditto_oracle.py
+// hash_dropout_mask is the same function; tests/test_oracle_dropout_hash.py).
 DITTO_DEV unsigned lowbias32(unsigned h) {
     h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
     return h;
 }
 DITTO_DEV unsigned mix24(unsigned h) {
-    h ^= h >> 15; h = (h & 0xFFFFFFu) * 0xB5297Bu;   // v_mul_u32_u24 (the mask is free: the instruction reads 24 bits)
-    h ^= h >> 13; h = (h & 0xFFFFFFu) * 0x6C8E9Du;
-    return h;
+    h ^= h >> 13;
+    return (h & 0xFFFFFFu) * 0xD2B74Fu;   // v_mul_u32_u24 (the mask is free: the instruction reads 24 bits)
 }
 DITTO_DEV unsigned drop_stream(unsigned seed_lo, unsigned seed_hi, int layer, int bh) {
     return lowbias32(seed_lo ^ lowbias32(seed_hi + (unsigned)layer * 0x632BE5ABu + (unsigned)bh * 0x9E3779B1u));

@@ -303,13 +303,11 @@ def _lowbias32(h):
 
 
 def _mix24(h):
-    """per-element hash: two rounds of xorshift + 24-bit multiply (csrc/common.h mix24: the multiply the GPU runs at full rate)"""
+    """per-element hash: one round of xorshift + 24-bit multiply (csrc/common.h mix24: the multiply the GPU runs at full rate)"""
     import numpy as np
     h = h.astype(np.uint64)
-    M24, M32 = np.uint64(0xFFFFFF), np.uint64(0xFFFFFFFF)
-    h ^= h >> np.uint64(15); h = ((h & M24) * np.uint64(0xB5297B)) & M32
-    h ^= h >> np.uint64(13); h = ((h & M24) * np.uint64(0x6C8E9D)) & M32
-    return h
+    h ^= h >> np.uint64(13)
+    return ((h & np.uint64(0xFFFFFF)) * np.uint64(0xD2B74F)) & np.uint64(0xFFFFFFFF)
 
 
 def hash_dropout_mask(seed: int, layer: int, B: int, H: int, Sq: int, Skv: int, p: float) -> Tensor:
