@@ -447,6 +447,17 @@ def train_step_line(dev, state_cache, steps=3):
            "peak_mem_gib": torch.cuda.max_memory_allocated(dev) / 2**30}
     del m, opt, x, text, noise, loss
     torch.cuda.empty_cache()
+    # the line validates itself: every parameter gradient of a 2-layer model of the SAME widths, kernel class pinned to this
+    # batch, train mode with dropout, against fp32 autograd of the CPU oracle (oracle/checks.py; after the timed region)
+    try:
+        from oracle.checks import train_grad_parity
+        torch.set_num_threads(usable_cores())
+        gp = train_grad_parity(dev)
+        out["grad_parity"] = {k: gp[k] for k in ("worst_rel_l2", "tensor", "median_rel_l2", "loss_rel", "n_tensors", "tol",
+                                                 "ok", "what")}
+    except Exception as e:  # noqa: BLE001 - a checker failure must not lose the timed numbers; it is reported instead
+        out["grad_parity"] = {"ok": False, "error": repr(e)}
+    torch.cuda.empty_cache()
     return out
 
 
@@ -518,6 +529,12 @@ def main():
         torch.cuda.synchronize(dev)
         elapsed = time.perf_counter() - t0
         dist.barrier()
+        # every rank's own time for the K steps (a straggler GPU or link shows here the first time a node is available);
+        # the contract's figure is the MAX
+        per_rank = torch.zeros(world, device=dev, dtype=torch.float64)
+        per_rank[rank] = elapsed
+        dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
+        rank_ms = [float(v) / args.steps * 1e3 for v in per_rank.tolist()]
         elapsed = max_over_ranks(elapsed)
 
         # ---- extra loops, HIP-event-timed on the compute stream (median of >= 5) ----
@@ -594,7 +611,7 @@ def main():
             phases = {}
             t0 = time.perf_counter()
             lat = sample_sharded(shard_loop, text_full, xT_full, (T, cfg.text_dim), (N, cfg.hidden_dim), dev,
-                                 phases=phases, sync=lambda: torch.cuda.synchronize(dev))
+                                 phases=phases, sync=lambda: torch.cuda.synchronize(dev), text_dtype=torch.bfloat16)
             torch.cuda.synchronize(dev)
             total = time.perf_counter() - t0
             dist.barrier()
@@ -649,6 +666,7 @@ def main():
                        "hip_graph": bool(use_graph),
                        "noise": "per-utterance Philox4x32-10 inside the update kernel" if seeded_noise else "torch generator -> noise tensor"},
             "step_tflops_per_gpu": step_tflops, "step_frac_of_mfma_peak": step_frac,
+            "per_rank_ms_per_step": rank_ms, "rank_min_ms": min(rank_ms), "rank_max_ms": max(rank_ms),
             "loops": {"n": len(loop_ms), "timer": "HIP events on the compute stream, max over ranks",
                       "ms_per_step": loop_ms,
                       "median_ms_per_step": sorted(loop_ms)[len(loop_ms) // 2] if loop_ms else None,

@@ -27,8 +27,20 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "
          "-Wall", "-Wno-unused-function"]
 
 
+# csrc/experimental/: opt-in A/B kernels that no dispatch rule selects (attention_v4.hip: attention at one wave per SIMD;
+# gemm_o3.hip: three GEMM workgroups per CU — both measured slower than the shipped kernels).  They are
+# compiled only with DITTO_EXPERIMENTAL=1 in the environment (every file then sees -DDITTO_EXPERIMENTAL and the dispatchers
+# accept gemm_tile 130 / attn_flags 4096); the default library neither contains nor pays for them.
+EXPERIMENTAL = os.environ.get("DITTO_EXPERIMENTAL", "0") not in ("", "0")
+STAMP = os.path.join(CSRC, ".experimental_on" if EXPERIMENTAL else ".experimental_off")
+
+
 def _sources():
-    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+    srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+    if EXPERIMENTAL:
+        exp = os.path.join(CSRC, "experimental")
+        srcs += sorted(os.path.join(exp, f) for f in os.listdir(exp) if f.endswith(".hip"))
+    return srcs
 
 
 def _deps():
@@ -46,12 +58,18 @@ def _stale(target, deps):
 
 def build(force: bool = False, verbose: bool = True) -> str:
     srcs, hdrs = _sources(), _deps()
+    if not os.path.exists(STAMP):           # the experimental switch changed since the last build: everything is stale
+        force = True
+        for f in (".experimental_on", ".experimental_off"):
+            if os.path.exists(os.path.join(CSRC, f)):
+                os.remove(os.path.join(CSRC, f))
+    flags = FLAGS + (["-DDITTO_EXPERIMENTAL"] if EXPERIMENTAL else [])
     objs, jobs = [], []
     for s in srcs:
         o = s[:-4] + ".o"
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([HIPCC, *FLAGS, *EXTRA.get(os.path.basename(s), []), "-c", s, "-o", o])
+            jobs.append([HIPCC, *flags, *EXTRA.get(os.path.basename(s), []), "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -66,6 +84,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+    open(STAMP, "w").close()
     return LIB
 
 

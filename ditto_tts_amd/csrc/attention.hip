@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256, WPS) void attn64_kernel(AttnParams p) {
     for (int i = 0; i < 16; ++i) { ot[0][i] = 0.f; ot[1][i] = 0.f; }
     float m_run = -1e30f, l_run = 0.f;
     const float c = p.scale_log2;
-    unsigned dstream = 0;
+    DropStream dstream{};
     if constexpr (TRAIN) dstream = drop_stream(p.seed_lo, p.seed_hi, p.layer, bh);
 
     const int nkt = (p.Skv + KBLK - 1) / KBLK;
@@ -736,7 +736,9 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
         }
         if (a.q_prescaled && !(g_attn_flags & 32)) {   // q already carries scale * log2(e): the reduced-VALU kernel
             // one wave per SIMD, 64 queries per wave (attention_v4.hip): attn_flags 4096 = wherever the shape allows
+#ifdef DITTO_EXPERIMENTAL
             if ((g_attn_flags & 4096) && attn64v4_supports(p)) return launch_attn64v4(p, a.resid_f32 != nullptr, s);
+#endif
             const dim3 gridv(p.nqb * a.H * a.B);
             // whole pairs of key tiles: the software-pipelined, hand-interleaved kernel where it measures faster — small grids
             // (batch-1 serving, 96 workgroups: 13.6 us against 15.6 for attn64v2's deep-prefetch instantiation) and long key

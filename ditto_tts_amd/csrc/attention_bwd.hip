@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void attn64_bwd_kernel(BwdParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[0][i] = 0.f; acc0[1][i] = 0.f; acc1[0][i] = 0.f; acc1[1][i] = 0.f; }
     const float c = p.scale_log2;
-    const unsigned dstream = drop_stream(p.seed_lo, p.seed_hi, p.layer, bh);
+    const DropStream dstream = drop_stream(p.seed_lo, p.seed_hi, p.layer, bh);
 
     // ---- the tile loop: a software pipeline across TWO tiles, written out by hand ----
     // Per tile: A0..A3 = four steps of 4 MFMAs (S | S^T and dP | dP^T of row block 0: A0, A1; of block 1: A2, A3), V0..V3 = the

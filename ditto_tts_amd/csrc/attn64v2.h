@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, WPS) void attn64v2_kernel(AttnParams p) {
                 for (int i = 0; i < 8; ++i) qf[ks][i] = (bf16)((float)qf[ks][i] * p.scale_log2);
         }
     }
-    unsigned dstream = 0;
+    DropStream dstream{};
     if constexpr (DROP) dstream = drop_stream(p.seed_lo, p.seed_hi, p.layer, bh);
     const int nkt = (p.Skv + KBLK - 1) / KBLK;
     const bool ragged = (p.Skv & (KBLK - 1)) != 0;

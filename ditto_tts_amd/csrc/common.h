@@ -218,27 +218,33 @@ DITTO_DEV unsigned pack_fp8x4(float a, float b, float c, float d) {
 }
 
 // Counter-based dropout mask of the training path (train.hip header): keep iff hash(stream, query, key) >= thr.
-// The per-(batch, head) stream is a full 32-bit mix (lowbias32, twice per kernel launch and lane); the PER-ELEMENT hash is ONE
-// round of xorshift + 24-bit multiply on stream ^ (query * C1 + key * C2) — the counter is itself a multiplicative hash of
-// (query, key), the fold brings the word's top bits into the 24 the multiply reads, and the compare reads the product's top
-// bits.  v_mul_u32_u24 runs at full rate (v_mul_lo_u32 at a quarter): 3 full-rate instructions behind the xor, where
-// lowbias32 took 2 quarter-rate + 6, in the element loop of the forward and of both backward kernels (the dropout mask cost
-// 3.6 ms of a 57 ms training step with a two-round version).  Keep rate, correlations along query / key / diagonal at lags
-// 1..64 and 8x8 block variance over 1024 x 1024 masks are within noise of lowbias32's (oracle/ditto_oracle.py
-// hash_dropout_mask is the same function; tests/test_oracle_dropout_hash.py).
+// The per-(batch, head) stream is TWO full 32-bit mixes (lowbias32; once per kernel launch and wave); the PER-ELEMENT hash
+// runs on full-rate instructions only:
+//     x = a + (query * C1 + key * C2);  x ^= x >> 13;  x += b;  x ^= x >> 9;  h = (x & 0xFFFFFF) * C
+// (v_add, v_lshrrev, v_xad, v_lshrrev, v_xor, v_mul_u32_u24: v_mul_lo_u32 runs at a quarter of their rate, and the mask is
+// evaluated in the element loops of the forward and of both backward kernels).  Both stream words enter by ADDs, i.e.
+// NON-linearly over GF(2), in front of an xor-fold each.  Round 3 xored ONE word in front of ONE fold:
+// fold(a ^ ctr) = fold(a) ^ fold(ctr), so every stream saw the same 24-bit image of (query, key), and the 3.6 % of a
+// 1024 x 1024 tile that collide there decided identically in EVERY stream (cross-stream mask correlation rms 0.023, max 0.11).
+// One add + one fold still leaves rare stream pairs correlated at 0.01-0.015 (3 of 2016 pairs); with the second add + fold:
+// 2016 pairs of 1024 x 1024 masks at p = 0.1 have correlation rms 0.97 sigma, max 3.3 sigma (sigma = 1 / 1024: what
+// lowbias32 per element gives), positions that collide in one stream agree in the others at the independent rate 0.82, lag
+// correlations along query / key / diagonal within 2.7 sigma (tests/test_oracle_dropout_hash.py).
+// oracle/ditto_oracle.py hash_dropout_mask is the same function.
 DITTO_DEV unsigned lowbias32(unsigned h) {
     h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
     return h;
 }
-DITTO_DEV unsigned mix24(unsigned h) {
-    h ^= h >> 13;
-    return (h & 0xFFFFFFu) * 0xD2B74Fu;   // v_mul_u32_u24 (the mask is free: the instruction reads 24 bits)
+struct DropStream { unsigned a, b; };
+DITTO_DEV DropStream drop_stream(unsigned seed_lo, unsigned seed_hi, int layer, int bh) {
+    const unsigned a = lowbias32(seed_lo ^ lowbias32(seed_hi + (unsigned)layer * 0x632BE5ABu + (unsigned)bh * 0x9E3779B1u));
+    return DropStream{a, lowbias32(a ^ 0x5BD1E995u)};
 }
-DITTO_DEV unsigned drop_stream(unsigned seed_lo, unsigned seed_hi, int layer, int bh) {
-    return lowbias32(seed_lo ^ lowbias32(seed_hi + (unsigned)layer * 0x632BE5ABu + (unsigned)bh * 0x9E3779B1u));
-}
-DITTO_DEV bool drop_keep(unsigned stream, int i, int j, unsigned thr) {
-    return mix24(stream ^ ((unsigned)i * 0x9E3779B1u + (unsigned)j * 0x85EBCA6Bu)) >= thr;
+DITTO_DEV bool drop_keep(DropStream st, int i, int j, unsigned thr) {
+    unsigned x = st.a + ((unsigned)i * 0x9E3779B1u + (unsigned)j * 0x85EBCA6Bu);
+    x = (x ^ (x >> 13)) + st.b;                          // v_xad_u32
+    x ^= x >> 9;
+    return (x & 0xFFFFFFu) * 0xD2B74Fu >= thr;           // v_mul_u32_u24 (the mask is free: the instruction reads 24 bits)
 }
 
 // Bijective XCD-aware block remap (guide §5 "XCD swizzle must be bijective"): blocks b and b+8

@@ -131,6 +131,19 @@ int check_cfg(const ditto_config* c) {
     return DITTO_OK;
 }
 
+// A pinned kernel class (fr_class_rows > 0: "decide as the unsplit batch of that many rows would") that says full-row while THIS
+// launch cannot run a full-row kernel (fewer rows than one 64-row tile) would silently take the tiled GEMMs, whose last bits
+// differ: the promise of the pin — sharding changes no bit — would be broken without a sign.  Fail instead.
+int check_class_pin(int M, int d, bool fp8) {
+    if (g_fr_class_rows <= 0 || !g_fr_mask || M >= 64) return DITTO_OK;
+    const bool wants = d == 768 ? (!fp8 && fr_rule_rows(g_fr_class_rows) != 0) : (d == 1024 && fr_pays_64(M));
+    if (!wants) return DITTO_OK;
+    return fail(DITTO_ERR_SHAPE, "kernel class pinned to a batch of %d rows (full-row GEMM + LayerNorm kernels), but this launch has "
+                                 "%d rows, fewer than one 64-row tile: it cannot take that class and its bits would differ from the "
+                                 "unsplit batch's.  Give every shard at least 64 rows, or run the whole batch unfused "
+                                 "(ditto_set_option(\"fr_mask\", 0)).", g_fr_class_rows, M);
+}
+
 }  // namespace ditto
 
 namespace {
@@ -198,6 +211,7 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
     const bool fr_out = lp.WcoP && (g_fr_mask & 1) && fr_outproj_ok(M, d);
     const bool fr_fc2 = !fp8 && lp.W2P && (g_fr_mask & 2) && fr_fc2_ok(M, d);
     const int fr_rot = N % 128 == 0 ? N / 128 : 0;   // tiles per utterance: the K-loop rotation period (gemm_fr.hip)
+    if (int rc = ditto::check_class_pin(M, d, fp8)) return rc;
         // ---- self-attention (src/components/DiT.py:103-139) ----
         if (!ln1_done) {
             ProfScope ps(m, s, DITTO_KC_LAYERNORM);
@@ -845,8 +859,41 @@ int ditto_gemm_fp8(const void* A, int lda, const void* W, const float* wscale, c
     return DITTO_OK;
 }
 
+// plain integer switches: one slot each (ditto_get_option reads them; ditto_set_option validates per name below)
+static int* option_slot(const char* name) {
+    static const struct { const char* n; int* p; } tab[] = {
+        {"gemm_tile", &g_gemm_tile}, {"attn_flags", &g_attn_flags}, {"gemm_flags", &g_gemm_flags}, {"gemm_group", &g_gemm_group},
+        {"pp_mask", &g_pp_mask}, {"fr_mask", &g_fr_mask}, {"fr_class_rows", &g_fr_class_rows}, {"fr_dgrad", &g_fr_dgrad},
+        {"train_flags", &g_train_flags}, {"fr_u_fp8", &g_fr_u_fp8}, {"fr_tile", &g_fr_tile}, {"fr64_maxk", &g_fr64_maxk},
+        {"fr_stagger", &g_fr_stagger}, {"fr_rot", &g_fr_rot}, {"pp_nb", &g_pp_nb}, {"pp_stagger", &g_pp_stagger},
+        {"splitk_wgs", &g_splitk_wgs}};
+    for (auto& e : tab) if (!strcmp(name, e.n)) return e.p;
+    return nullptr;
+}
+
+int ditto_get_option(const char* name, int* value) {
+    if (!name || !value) return fail(DITTO_ERR_ARG, "null argument to ditto_get_option");
+    if (!strcmp(name, "experimental")) {   // 1: built with the opt-in A/B kernels of csrc/experimental/ (DITTO_EXPERIMENTAL=1)
+#ifdef DITTO_EXPERIMENTAL
+        *value = 1;
+#else
+        *value = 0;
+#endif
+        return DITTO_OK;
+    }
+    if (!strcmp(name, "wgrad_wgs")) { *value = get_wgrad_wgs(); return DITTO_OK; }
+    if (const int* p = option_slot(name)) { *value = *p; return DITTO_OK; }
+    return fail(DITTO_ERR_ARG, "unknown option '%s'", name);
+}
+
 int ditto_set_option(const char* name, int value) {
     if (!name) return fail(DITTO_ERR_ARG, "null option name");
+#ifndef DITTO_EXPERIMENTAL
+    if ((!strcmp(name, "gemm_tile") && value == 130) || (!strcmp(name, "attn_flags") && (value & 4096)))
+        return fail(DITTO_ERR_ARG, "%s = %d selects a kernel of csrc/experimental/ (gemm_o3.hip / attention_v4.hip: opt-in A/B "
+                                   "kernels no rule selects), which this library was built without (DITTO_EXPERIMENTAL=1 python -m "
+                                   "ditto_tts_amd.build --force)", name, value);
+#endif
     if (!strcmp(name, "gemm_tile")) {
         if (value != 0 && value != 127 && value != 128 && value != 256 && value != 129 && value != 130 && value != 131 && value != 192)
             return fail(DITTO_ERR_ARG, "gemm_tile must be 0, 127 (128x128 deep prefetch), 128, 129 (256x128 ring), 130 (128x256, 3 workgroups/CU), "
@@ -945,6 +992,7 @@ int ditto_full_row_plan(const ditto_config* cfg, int B, int N, int* outproj, int
     if ((long long)B * N > 0x7fffffffLL) return fail(DITTO_ERR_SHAPE, "B * N exceeds 2^31 - 1 rows");
     const int d = cfg->hidden_dim, M = B * N;
     const bool fp8c = (cfg->flags & DITTO_CFG_FP8_LINEAR) != 0;          // plan_arena packs the stage-major copies for these:
+    if (int rc = check_class_pin(M, d, fp8c)) return rc;                  // what the forward itself would answer
     const bool have_o = (d == 768 && !fp8c) || d == 1024, have_2 = (d == 768 || d == 1024) && !fp8c;
     *outproj = have_o && (g_fr_mask & 1) && fr_outproj_ok(M, d);
     *fc2 = have_2 && (g_fr_mask & 2) && fr_fc2_ok(M, d);

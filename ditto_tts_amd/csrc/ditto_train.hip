@@ -154,6 +154,7 @@ int check_train(const ditto_model* m) {
 
 namespace ditto {
 void set_wgrad_wgs(int v) { g_wgrad_wgs = v; }
+int get_wgrad_wgs() { return g_wgrad_wgs; }
 }
 
 extern "C" {

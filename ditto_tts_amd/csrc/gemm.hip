@@ -327,7 +327,9 @@ hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s) {
     // the ReLU epilogue is built for the 128x128 and 256x256 structures only
     if (epi == EPI_BIAS_RELU_BF16 && forced != 128 && forced != 127 && forced != 256)
         forced = (long)((a.M + 255) / 256) * ((a.N + 255) / 256) >= 4 * 256 ? 256 : 128;
-    if (forced == 130) return launch_gemm_o3(p, epi, s);
+#ifdef DITTO_EXPERIMENTAL
+    if (forced == 130) return launch_gemm_o3(p, epi, s);   // csrc/experimental/gemm_o3.hip (ditto_set_option refuses 130 otherwise)
+#endif
     if (forced == 131 && gemm_pp_supports(p, epi)) return launch_gemm_pp(p, epi, s);
     // Ping-pong 128x256 tiles (gemm_pp.hip) by GEMM class.  pp_mask bits: 1 narrow bf16 output (cross q-proj), 2 narrow
     // fp32 in-place residual with K <= 1024 (cross out-proj), 4 narrow fp32 output (final projection), 8 narrow residual

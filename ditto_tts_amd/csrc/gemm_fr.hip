@@ -586,7 +586,7 @@ hipError_t launch_fr_t(const FrParams& fp, int grid, hipStream_t s) {
 }  // namespace
 
 bool gemm_fr_supports(int M, int N, int K, size_t lda, size_t ldw) {
-    if (N != FN || K % 64 || K < 64 || M < FM) return false;
+    if (N != FN || K % 64 || K < 64 || M < 64) return false;   // 64 <= M < 128 runs the 64-row kernel (kernels.h fr_launch_kernel)
     if ((size_t)M * lda * 2 >= (1ull << 32) || (size_t)N * ldw * 2 >= (1ull << 32)) return false;
     return true;
 }

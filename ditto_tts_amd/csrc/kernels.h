@@ -68,7 +68,8 @@ extern int g_fr_class_rows;   // gemm.hip
 //   15: 6.99 / 6.52 / 6.85   16: 6.43 / 6.46   17: 7.73 / 8.12 / 7.47   18: 7.93 / 8.34 / 7.68   19: 8.30 / 8.75 / 8.16   >= 20: direct
 // i.e. the 128-row kernel (gemm_frd.hip) from 136 of its tiles on; below that the 64-row kernel (gemm_fr64.hip, two workgroups
 // per CU) from 176 of ITS tiles on — except where the unfused N = d GEMMs' 256 x 192 tiles make exactly one round of the 256
-// CUs (16 x 1024 rows), which is the one place in that range where they are not quantised away.  The two full-row kernels
+// CUs (16 x 1024 rows; the rule below excludes every row count that rounds up to those 64 tiles of 256 rows, 16129 .. 16384),
+// which is the one place in that range where they are not quantised away.  The two full-row kernels
 // produce the same h bits (u within a bf16 rounding tie), the unfused path differs in the last bits: the CLASS boundary that
 // callers pin (fr_class_rows) is "full-row or not".
 extern int g_fr_tile;

@@ -47,6 +47,8 @@ int small_batch_k_splits(int M, int N, int K);
 WsPlan plan_ws(const ditto_config& c, int B, int N, int T);
 int check_cfg(const ditto_config* c);
 void set_wgrad_wgs(int v);   // ditto_train.hip: split-K target of the wgrad GEMMs (ditto_set_option("wgrad_wgs"))
+int get_wgrad_wgs();
+int check_class_pin(int M, int d, bool fp8);   // ditto_api.hip: a pinned full-row class that this launch cannot take -> error
 
 }  // namespace ditto
 

@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256) void softmax_drop_rows_kernel(const float* __r
                                                                 unsigned thr, float keep_scale) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= Sq) return;
-    const unsigned stream = thr ? drop_stream(seed_lo, seed_hi, layer, bh0 + row / rows_per_bh) : 0u;
+    const DropStream stream = thr ? drop_stream(seed_lo, seed_hi, layer, bh0 + row / rows_per_bh) : DropStream{};
     const int qi = row % rows_per_bh;
     const float* s = S + (size_t)row * ld;
     float m = -1e30f;
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __re
                                                                unsigned thr, float keep_scale) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= Sq) return;
-    const unsigned stream = thr ? drop_stream(seed_lo, seed_hi, layer, bh0 + row / rows_per_bh) : 0u;
+    const DropStream stream = thr ? drop_stream(seed_lo, seed_hi, layer, bh0 + row / rows_per_bh) : DropStream{};
     const int qi = row % rows_per_bh;
     const float* s = S + (size_t)row * ld;
     const float* dp = dPd + (size_t)row * ld;

@@ -85,17 +85,23 @@ def gather_batch(shard: torch.Tensor, total: int, root: int = 0, group=None) -> 
 def sample_sharded(sample_fn: Callable[[torch.Tensor, torch.Tensor, int], torch.Tensor],
                    text_full: Optional[torch.Tensor], xT_full: Optional[torch.Tensor], text_tail, x_tail,
                    device, root: int = 0, group=None, phases: Optional[dict] = None,
-                   sync: Optional[Callable[[], None]] = None, pin_class: bool = True) -> Optional[torch.Tensor]:
+                   sync: Optional[Callable[[], None]] = None, pin_class: bool = True,
+                   text_dtype: torch.dtype = torch.float32) -> Optional[torch.Tensor]:
     """Scatter (text_emb, x_T) from root, run `sample_fn(text_shard, xT_shard, first_global_index)` on every
     rank (the whole denoise loop — no communication inside), gather the final latents on root.
 
-    The text conditioning travels as bf16 (it is the operand of bf16 GEMMs and of an fp32 mean only, and
-    every rank — root included — computes on the bf16-rounded values, so the world size changes no bit); x_T and the
-    latents travel as fp32.
+    `text_dtype`: what the text conditioning travels as.  torch.float32 (default) is exact: every rank computes on the
+    caller's fp32 text, as the reference does and as the plain single-process sampler does, so the gathered latents equal
+    `sample_fn(text_full, xT_full, 0)` bit for bit at every world size.  torch.bfloat16 halves the scatter (SURVEY.md §8e:
+    50.3 MB instead of 100.7 MB per peer at C3 — 0.3 ms of a 0.6 s loop on a 153 GB/s xGMI link); the engine's K/V GEMM
+    rounds the text to bf16 anyway, but GlobalAdaLN pools it in fp32 (src/components/DiT.py:27), so the result then equals
+    `sample_fn(text_full.bfloat16().float(), ...)` — still independent of the world size (every rank, root included,
+    computes on the rounded values), but NOT the plain sampler's bits.  x_T and the latents always travel as fp32.
 
     `pin_class` (GPU shards only): run `sample_fn` under `hip.batch_class(rows of the GLOBAL batch)`, so that every
     shard's launches pick the kernel class the unsplit batch would pick (the full-row GEMM sums in another order than
-    the tiled one) and the gathered latents are bit-identical at every world size.
+    the tiled one) and the gathered latents are bit-identical at every world size.  A shard too small to take a pinned
+    full-row class (fewer than 64 rows per launch) raises instead of silently running another class.
 
     `phases` (optional dict) receives this rank's wall seconds of the three phases, {"scatter_s", "loop_s",
     "gather_s"}; `sync` (e.g. `torch.cuda.synchronize`) is called at each phase boundary so the figures are device
@@ -104,9 +110,12 @@ def sample_sharded(sample_fn: Callable[[torch.Tensor, torch.Tensor, int], torch.
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     tick = (lambda: (sync() if sync else None, time.perf_counter())[1]) if phases is not None else (lambda: 0.0)
     t0 = tick()
-    text16 = text_full.to(torch.bfloat16) if rank == root else None
-    text = scatter_batch(text16, text_tail, torch.bfloat16, device, root, group).to(torch.float32)
-    del text16
+    if text_dtype == torch.float32:
+        text = scatter_batch(text_full if rank == root else None, text_tail, torch.float32, device, root, group)
+    else:
+        text_t = text_full.to(text_dtype) if rank == root else None
+        text = scatter_batch(text_t, text_tail, text_dtype, device, root, group).to(torch.float32)
+        del text_t
     xT = scatter_batch(xT_full, x_tail, torch.float32, device, root, group)
     meta = torch.zeros(1, dtype=torch.int64, device=device)
     if rank == root:

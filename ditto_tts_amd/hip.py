@@ -161,6 +161,7 @@ SYMBOLS = {
     "ditto_attention_causal_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
     "ditto_layernorm_dual": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "ditto_set_option": (_i, [C.c_char_p, _i]),
+    "ditto_get_option": (_i, [C.c_char_p, C.POINTER(C.c_int)]),
     "ditto_full_row_plan": (_i, [C.POINTER(Config), _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ditto_profile_enable": (_i, [_vp, _i]),
     "ditto_profile_read": (_i, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
@@ -186,7 +187,7 @@ def lib() -> C.CDLL:
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = res, args
-        if l.ditto_abi_version() != 7:
+        if l.ditto_abi_version() != 8:
             raise RuntimeError("libditto_hip.so ABI version mismatch")
         _lib = l
     return _lib
@@ -202,23 +203,34 @@ def set_option(name: str, value: int):
     check(lib().ditto_set_option(name.encode(), int(value)))
 
 
+def get_option(name: str) -> int:
+    """ditto_get_option: the current value of a switch ("experimental": 1 if the csrc/experimental/ kernels are built in)."""
+    v = C.c_int(0)
+    check(lib().ditto_get_option(name.encode(), C.byref(v)))
+    return int(v.value)
+
+
 class batch_class:
     """Context manager: every forward inside decides its kernel class (tiled GEMM + LayerNorm, or the full-row GEMM
     with the LayerNorm fused: different summation orders, so different last bits) as a batch of `rows` = B x N rows
     would.  A caller that splits one batch over several launches or GPUs wraps the pieces in
     `batch_class(rows of the unsplit batch)`: an utterance's bits are then the same however the batch was split
-    (ditto_set_option("fr_class_rows"); dist.sample_sharded and SpeechGenerator's seeds= path use it).  Process-wide,
-    like every ditto_set_option switch; restores "decide per launch" (0) on exit."""
+    (ditto_set_option("fr_class_rows"); dist.sample_sharded and SpeechGenerator's seeds= path use it).  PROCESS-WIDE,
+    like every ditto_set_option switch: it also governs forwards that other threads or streams of this process enqueue
+    meanwhile.  Nests: exit restores the value found on entry.  A launch that cannot take the pinned class (a full-row
+    class with fewer than 64 rows in the launch) raises DittoHipError instead of silently running another class."""
 
     def __init__(self, rows: int):
         self.rows = int(rows)
+        self._prev = 0
 
     def __enter__(self):
+        self._prev = get_option("fr_class_rows")
         set_option("fr_class_rows", min(self.rows, 0x7FFFFFFF))
         return self
 
     def __exit__(self, *exc):
-        set_option("fr_class_rows", 0)
+        set_option("fr_class_rows", self._prev)
         return False
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DITTO_ABI_VERSION 7
+#define DITTO_ABI_VERSION 8
 
 typedef enum ditto_status {
     DITTO_OK = 0,
@@ -225,8 +225,9 @@ int ditto_attention_bf16(const void* q, int ldq, const void* k, int ldk, const v
 /* scratch bytes ditto_attention_bf16 needs (0 for the fused dh = 64 kernel) */
 size_t ditto_attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh);
 
-/* Full-row GEMM with the residual add and the FOLLOWING LayerNorm fused (N = 768: csrc/gemm_frd.hip, M >= 128, or
- * csrc/gemm_fr.hip / its 64-row twin csrc/gemm_fr64.hip under "fr_tile" 128 / 64; N = 1024: csrc/gemm_fr64.hip, M >= 64):
+/* Full-row GEMM with the residual add and the FOLLOWING LayerNorm fused (N = 768: csrc/gemm_frd.hip, or csrc/gemm_fr.hip / its
+ * 64-row twin csrc/gemm_fr64.hip under "fr_tile" 128 / 64 — 64 <= M < 128 always runs the 64-row twin, same fp32 bits;
+ * N = 1024: csrc/gemm_fr64.hip; M >= 64 everywhere):
  *   out fp32 [M,N] = residual + A[M,K] W[N,K]^T + bias   (residual may alias out: the in-place stream update of
  *   src/components/DiT.py:148 / :155),   u bf16 [M,ldu] = LayerNorm(out) * gamma + beta  (eps 1e-5; the norm of :152 / the
  *   next block's :105).  gamma = beta = u = NULL: no LayerNorm output.  K % 64 == 0.
@@ -254,7 +255,9 @@ int ditto_gemm_tn_bf16(const void* X, int ldx, const void* Y, int ldy, float* ou
  * (csrc/gemm_fr.hip): bit 0 = cross out-proj + norm3, bit 1 = fc2 + the next block's norm1.
  * "fr_class_rows": the full-row kernel sums over k in a different order than the tiled GEMMs, so an utterance's bits depend on
  * whether its launch took it — a function of the launch's row count (>= 136 tiles of 128 rows, or 176 .. 271 tiles of 64 rows
- * other than 16384 rows exactly: csrc/kernels.h fr_rule_rows, a measured rule).  A caller that splits ONE batch
+ * except the 16129 .. 16384 rows that round up to 64 tiles of 256: csrc/kernels.h fr_rule_rows, a measured rule).  A pinned
+ * class that a launch cannot take (full-row kernels, fewer than 64 rows in the launch) is an error (DITTO_ERR_SHAPE), never a
+ * silent change of class.  A caller that splits ONE batch
  * over several launches or GPUs sets this to the rows (B * N) of the unsplit batch: every launch then decides as that batch
  * would and sharding changes no bit (ditto_tts_amd/dist.py sample_sharded does).  0 (default) = each launch on its own rows.
  * "fr_tile": which N = 768 full-row kernel: 0 (default) / 130 = 128-row tiles with the weights fetched straight from L2 into
@@ -283,6 +286,10 @@ int ditto_gemm_tn_bf16(const void* X, int ldx, const void* Y, int ldy, float* ou
  * are split over (K-splits with an ordered fp32 reduce; 256 is the measured choice: -10 % step time at B = 1).
  * Default 0 = never split, which keeps an utterance's result bit-identical whatever else is in its batch. */
 int ditto_set_option(const char* name, int value);
+/* Reads a switch back (callers that change one temporarily restore what they found: ditto_tts_amd/hip.py batch_class).
+ * Also "experimental": 1 when the library contains the opt-in A/B kernels of csrc/experimental/ ("gemm_tile" 130,
+ * "attn_flags" bit 12 — refused by ditto_set_option otherwise). */
+int ditto_get_option(const char* name, int* value);
 
 /* Which launches of one DiT block (reference src/components/DiT.py:148+152, :155+:105) a forward over B utterances of N
  * frames runs on the full-row kernel, under the current "fr_mask" / "fr_class_rows" options: *outproj, *fc2 = 0 / 1.  Host

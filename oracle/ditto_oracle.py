@@ -302,12 +302,28 @@ def _lowbias32(h):
     return h
 
 
-def _mix24(h):
-    """per-element hash: one round of xorshift + 24-bit multiply (csrc/common.h mix24: the multiply the GPU runs at full rate)"""
+def _elem_hash(a, b, ctr):
+    """per-element hash (csrc/common.h drop_keep): x = a + ctr; x ^= x >> 13; x += b; x ^= x >> 9; (x & 0xFFFFFF) * C — the two
+    stream words enter by ADDs (non-linear over GF(2)), each in front of an xor-fold; the multiply is the 24-bit one the GPU
+    runs at full rate"""
     import numpy as np
-    h = h.astype(np.uint64)
-    h ^= h >> np.uint64(13)
-    return ((h & np.uint64(0xFFFFFF)) * np.uint64(0xD2B74F)) & np.uint64(0xFFFFFFFF)
+    M32 = np.uint64(0xFFFFFFFF)
+    x = (a.astype(np.uint64) + ctr.astype(np.uint64)) & M32
+    x ^= x >> np.uint64(13)
+    x = (x + b.astype(np.uint64)) & M32
+    x ^= x >> np.uint64(9)
+    return ((x & np.uint64(0xFFFFFF)) * np.uint64(0xD2B74F)) & M32
+
+
+def hash_dropout_streams(seed: int, layer: int, nbh: int):
+    """the two 32-bit words (a, b) of each (batch, head) stream bh = b * H + h (csrc/common.h drop_stream)"""
+    import numpy as np
+    M32 = np.uint64(0xFFFFFFFF)
+    lo, hi = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    bh = np.arange(nbh, dtype=np.uint64)
+    inner = _lowbias32((hi + np.uint64(layer) * np.uint64(0x632BE5AB) + bh * np.uint64(0x9E3779B1)) & M32)
+    a = _lowbias32(lo ^ inner)
+    return a, _lowbias32(a ^ np.uint64(0x5BD1E995))
 
 
 def hash_dropout_mask(seed: int, layer: int, B: int, H: int, Sq: int, Skv: int, p: float) -> Tensor:
@@ -315,14 +331,11 @@ def hash_dropout_mask(seed: int, layer: int, B: int, H: int, Sq: int, Skv: int, 
     import numpy as np
     M32 = np.uint64(0xFFFFFFFF)
     thr = np.uint64(min(int(float(np.float32(p)) * 4294967296.0), 0xFFFFFFFF))
-    lo, hi = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
-    bh = np.arange(B * H, dtype=np.uint64)
-    inner = _lowbias32((hi + np.uint64(layer) * np.uint64(0x632BE5AB) + bh * np.uint64(0x9E3779B1)) & M32)
-    stream = _lowbias32(lo ^ inner)                                                   # [B*H]
+    a, b = hash_dropout_streams(seed, layer, B * H)                                   # [B*H] each
     i = np.arange(Sq, dtype=np.uint64)[:, None]
     j = np.arange(Skv, dtype=np.uint64)[None, :]
     ctr = (i * np.uint64(0x9E3779B1) + j * np.uint64(0x85EBCA6B)) & M32               # [Sq, Skv]
-    h = _mix24(stream[:, None, None] ^ ctr[None])
+    h = _elem_hash(a[:, None, None], b[:, None, None], ctr[None])
     return torch.from_numpy((h >= thr).astype(np.float32)).view(B, H, Sq, Skv)
 
 

@@ -151,7 +151,7 @@ static void refusals_before_any_gpu_call() {
     // the full-row GEMM addresses A with 32-bit byte offsets: refuse M * lda * 2 >= 2^32 for the lda actually passed
     float* fo = reinterpret_cast<float*>(p);
     EXPECT(ditto_gemm_ln_bf16(p, 3072, p, nullptr, nullptr, fo, 768, nullptr, nullptr, nullptr, 0, 699392, 768, 3072, nullptr) == DITTO_ERR_SHAPE, "gemm_ln accepted wrapping A offsets");
-    EXPECT(ditto_gemm_ln_bf16(p, 768, p, nullptr, nullptr, fo, 768, nullptr, nullptr, nullptr, 0, 64, 768, 768, nullptr) == DITTO_ERR_SHAPE, "gemm_ln M < 128");
+    EXPECT(ditto_gemm_ln_bf16(p, 768, p, nullptr, nullptr, fo, 768, nullptr, nullptr, nullptr, 0, 63, 768, 768, nullptr) == DITTO_ERR_SHAPE, "gemm_ln M < 64 (one 64-row tile is the least the full-row kernels take)");
     EXPECT(ditto_gemm_ln_bf16(p, 768, p, nullptr, nullptr, fo, 768, nullptr, nullptr, nullptr, 0, 256, 512, 768, nullptr) == DITTO_ERR_SHAPE, "gemm_ln N != 768");
     EXPECT(ditto_gemm_ln_bf16(p, 768, p, nullptr, nullptr, fo, 768, reinterpret_cast<const float*>(p), nullptr, nullptr, 0, 256, 768, 768, nullptr) == DITTO_ERR_ARG, "gemm_ln gamma without beta");
     EXPECT(ditto_gemm_tn_bf16(nullptr, 8, nullptr, 8, nullptr, 8, 8, 8, 8, 1, 128, nullptr, 0, nullptr) != DITTO_OK, "gemm_tn(null)");

@@ -25,7 +25,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, n), f"{n} declared in ditto_hip.h but not exported by libditto_hip.so"
         assert n in hip.SYMBOLS, f"{n} has no ctypes prototype in ditto_tts_amd/hip.py"
     assert sorted(hip.SYMBOLS) == names
-    assert lib.ditto_abi_version() == 7
+    assert lib.ditto_abi_version() == 8
 
 
 def test_struct_layout_matches_header():
@@ -91,7 +91,10 @@ def test_full_row_plan_is_judged_per_launch_and_pinnable():
         with hip.batch_class(32 * 1024):                             # ...and pinned to the class of the unsplit batch
             assert hip.full_row_plan(cfg, 16, 1024) == (True, True)
             assert hip.full_row_plan(cfg, 1, 1024) == (True, True)
-            assert hip.full_row_plan(cfg, 1, 64) == (False, False)   # fewer rows than one 128-row tile: never
+            assert hip.full_row_plan(cfg, 1, 64) == (True, True)     # one 64-row tile: the 64-row kernel (same bits)
+            with pytest.raises(hip.DittoHipError, match="pinned"):   # fewer rows than that cannot take the pinned class:
+                hip.full_row_plan(cfg, 1, 48)                        # an error (as from the forward), never another class
+        assert hip.full_row_plan(cfg, 1, 48) == (False, False)       # unpinned: the tiled GEMMs
         assert hip.full_row_plan(cfg, 16, 1024) == (False, False)    # the pin is gone
         # M * lda * 2 >= 2^32 with lda = 4 d = 3072: M >= 699051 rows.  The out-projection (lda = d) still fits.
         assert hip.full_row_plan(cfg, 682, 1024) == (True, True)     # 698368 rows

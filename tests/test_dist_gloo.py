@@ -1,7 +1,9 @@
-"""N > 1 path on CPU: world_size-2 gloo.  Batch sharding must not change any utterance's result
+"""N > 1 path on CPU: gloo at world sizes 2 and 4.  Batch sharding must not change any utterance's result
 (per-utterance outputs bit-identical for every world size).  The per-rank "sampler" here is
 the oracle's CPU loop on a tiny model (tests may use the oracle); the product's scatter/gather code
-(ditto_tts_amd/dist.py) is what is under test."""
+(ditto_tts_amd/dist.py) is what is under test: uneven shards (5 utterances over 2 and over 4 ranks), EMPTY shards
+(2 utterances over 4 ranks), the exact fp32 text transport (== the direct call on the caller's text) and the opt-in
+bf16 transport (== the direct call on the rounded text, at every world size)."""
 import os
 import socket
 
@@ -15,7 +17,7 @@ from ditto_tts_amd.dist import allreduce_gradients, gather_batch, sample_sharded
 from ditto_tts_amd.synth import hash_normal, synthetic_state_dict
 
 CFG = DiTTOConfig(64, 1, 1, 32, 64, 4)
-B, N, T, STEPS = 5, 8, 6, 4
+N, T, STEPS = 8, 6, 4
 
 
 def _sample_fn(sd):
@@ -32,7 +34,7 @@ def _sample_fn(sd):
     return fn
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, B):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -48,8 +50,9 @@ def _worker(rank, world, port, q):
         if rank == 0:
             assert torch.equal(back, text)
         out = sample_sharded(_sample_fn(sd), text, xT, (T, 64), (N, 64), "cpu")
+        out16 = sample_sharded(_sample_fn(sd), text, xT, (T, 64), (N, 64), "cpu", text_dtype=torch.bfloat16)
         if rank == 0:
-            q.put(out)
+            q.put((out, out16))
     finally:
         dist.destroy_process_group()
 
@@ -62,24 +65,42 @@ def _free_port():
     return p
 
 
-@pytest.mark.timeout(300)
-def test_world2_equals_world1_bitwise():
-    sd = synthetic_state_dict(CFG, seed=4)
-    text, xT = hash_normal((B, T, 64), "text", 1), hash_normal((B, N, 64), "xT", 1)
-    torch.set_num_threads(1)
-    # the conditioning travels (and is consumed, on root too) as bf16: SURVEY.md 8e, dist.sample_sharded
-    want = _sample_fn(sd)(text.to(torch.bfloat16).float(), xT, 0)
+def _spawn(target, world, *args):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=target, args=(r, world, port, q, *args)) for r in range(world)]
     for p in procs:
         p.start()
     got = q.get(timeout=240)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+    return got
+
+
+def test_shard_bounds_cover_the_batch_in_order():
+    for total in (0, 1, 2, 5, 8, 31, 256):
+        for world in (1, 2, 3, 4, 8):
+            b = [shard_bounds(total, world, r) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == total
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,B", [(2, 5), (4, 5), (4, 2)])      # shards 3+2; 2+1+1+1; 1+1+0+0 (two EMPTY shards)
+def test_sharded_sampling_equals_the_direct_call_bitwise(world, B):
+    sd = synthetic_state_dict(CFG, seed=4)
+    text, xT = hash_normal((B, T, 64), "text", 1), hash_normal((B, N, 64), "xT", 1)
+    torch.set_num_threads(1)
+    want = _sample_fn(sd)(text, xT, 0)                               # the UNMODIFIED direct call: fp32 text, as the reference
+    want16 = _sample_fn(sd)(text.to(torch.bfloat16).float(), xT, 0)  # opt-in bf16 transport: every rank on the rounded text
+    got, got16 = _spawn(_worker, world, B)
     assert torch.equal(got, want)
+    assert torch.equal(got16, want16)
+    assert not torch.equal(want, want16)                             # (the two transports really differ)
 
 
 def _grad_worker(rank, world, port, q):
@@ -98,18 +119,10 @@ def _grad_worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-def test_gradient_allreduce_is_the_mean_over_ranks():
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    nb, got = q.get(timeout=240)
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+@pytest.mark.parametrize("world", [2, 4])
+def test_gradient_allreduce_is_the_mean_over_ranks(world):
+    nb, got = _spawn(_grad_worker, world)
     assert nb >= 2 and got[3] is None
     for i, shape in enumerate(((7, 5), (3,), (11, 2))):
-        want = (hash_normal(shape, f"g{i}", 0) + hash_normal(shape, f"g{i}", 1)) * 0.5
-        assert torch.allclose(got[i], want, rtol=0, atol=1e-7)
+        want = sum(hash_normal(shape, f"g{i}", r) for r in range(world)) / world
+        assert torch.allclose(got[i], want, rtol=0, atol=1e-6)

@@ -45,11 +45,42 @@ def test_sharded_sampling_on_rccl_equals_direct(rccl_world1):
         return sg._SpeechGenerator__sample_latents(text_shard, x_shard, cond_by_audio=True,
                                                    noises=lambda i: noises[i][first:first + x_shard.shape[0]])
 
-    want = fn(text.to(torch.bfloat16).float(), xT, 0)     # the conditioning travels and is consumed as bf16
+    want = fn(text, xT, 0)                                # the UNMODIFIED direct call on the caller's fp32 text
     got = sample_sharded(fn, text, xT, (T, 128), (N, 128), DEV)
     assert torch.equal(got, want)
+    # opt-in bf16 transport (SURVEY.md 8e's 50 MB per peer): every rank computes on the rounded text
+    got16 = sample_sharded(fn, text, xT, (T, 128), (N, 128), DEV, text_dtype=torch.bfloat16)
+    assert torch.equal(got16, fn(text.to(torch.bfloat16).float(), xT, 0)) and not torch.equal(got16, got)
     sh = scatter_batch(text, (T, 128), torch.float32, DEV)
     assert torch.equal(gather_batch(sh, B), text)
+    # an EMPTY batch through the same collectives (what a rank with an empty shard does at world > B)
+    e = scatter_batch(text[:0], (T, 128), torch.float32, DEV)
+    assert e.shape == (0, T, 128) and gather_batch(e, 0).shape == (0, T, 128)
+
+
+@torch.no_grad()
+def test_pinned_class_restores_and_refuses_what_it_cannot_honour(rccl_world1):
+    """hip.batch_class nests (exit restores the value found on entry) and a launch that cannot take a pinned full-row class —
+    fewer rows than one 64-row tile — raises instead of silently running the tiled kernels (whose bits differ)."""
+    from ditto_tts_amd import hip
+    assert hip.get_option("fr_class_rows") == 0
+    with hip.batch_class(32768):
+        with hip.batch_class(512):
+            assert hip.get_option("fr_class_rows") == 512
+        assert hip.get_option("fr_class_rows") == 32768
+    assert hip.get_option("fr_class_rows") == 0
+    cfg = DiTTOConfig(768, 1, 12, 64, 768, 6)
+    m = DiTTO(768, 1, 12, 64, 768, 6)
+    m.load_state_dict(synthetic_state_dict(cfg, 3))
+    m = m.to(DEV).eval()
+    x = hash_normal((1, 48, 768), "x", 1).to(DEV)
+    text = hash_normal((1, 16, 768), "t", 1).to(DEV)
+    t = torch.zeros(1, dtype=torch.long, device=DEV)
+    plain = m(x, text, t)
+    with hip.batch_class(32768):                          # a C2-sized class on a 48-row launch
+        with pytest.raises(hip.DittoHipError, match="pinned"):
+            m(x, text, t)
+    assert torch.equal(m(x, text, t), plain)              # ... and the switch is back
 
 
 def test_gradient_bucket_path_on_rccl(rccl_world1):
@@ -101,10 +132,9 @@ def _rccl_worker(rank, world, port, q):
         assert set(phases) == {"scatter_s", "loop_s", "gather_s"}
         got2 = sample_sharded(fn_seeded, text, xT, (T, 256), (N, 256), dev)
         if rank == 0:
-            t16 = text.to(torch.bfloat16).float()             # what every rank computed on (bf16 transport)
             from ditto_tts_amd.hip import batch_class
             with batch_class(B * N):                           # sample_sharded pins the unsplit batch's kernel class
-                want, want2 = fn(t16, xT, 0), fn_seeded(t16, xT, 0)
+                want, want2 = fn(text, xT, 0), fn_seeded(text, xT, 0)   # the direct call on the caller's fp32 text
             q.put((bool(torch.equal(got, want)) and bool(torch.equal(got2, want2)), bool(torch.isfinite(got).all()),
                    tuple(got.shape)))
     finally:

@@ -69,6 +69,8 @@ def test_g2_full_ditto_s(golden):
 def test_g2_with_forced_gemm_structure(golden, tile):
     """Every fused epilogue (RoPE, gated MLP, residual, K-concatenated final) through BOTH GEMM tile structures."""
     from ditto_tts_amd import hip
+    from gpu_util import skip_unless_experimental
+    skip_unless_experimental(gemm_tile=tile)
     g = golden("G2_ditto_s.npz")
     cfg = DiTTOConfig(768, 12, 12, 256, 768, 50)
     m = build(cfg, 2)

@@ -165,6 +165,24 @@ def test_parameter_gradients_vs_oracle_autograd(cfg, B, N, T):
     _check_grads(m, want, 3e-2)
 
 
+@pytest.mark.parametrize("train_mode,pin_class", [(True, True), (False, True), (True, False)])
+def test_parameter_gradients_at_the_timed_dimensions_vs_oracle_autograd(train_mode, pin_class):
+    """SURVEY §8f row 1 at the dimensions bench.py TIMES (oracle/checks.py train_grad_parity): 2 layers of d = 768, 12 heads of
+    64, N = 256, T = 192, B = 2, the reference's training closure (src/TrainDiTTO.py:85-91) with the cross-attention dropout
+    active, the kernel class pinned to the timed batch of 32 x 1024 rows so that the full-row forward GEMMs + fused
+    LayerNorms, the full-row dgrads, the fused attention backward and the 256 x 256 weight-gradient tiles are the kernels
+    that run.  Every parameter gradient against fp32 autograd of the oracle: rel-L2 <= 3e-2 per tensor (bf16 operands, fp32
+    accumulation).  (False, True) = eval mode; (True, False) = the same model on the kernels of its own 512 rows."""
+    from oracle.checks import train_grad_parity
+    r = train_grad_parity(DEV, train_mode=train_mode, pin_class=pin_class)
+    assert not r["unexpected"], r["unexpected"]
+    assert r["n_tensors"] > 50
+    if pin_class:
+        assert r["full_row_forward"] == [True, True], "the timed (full-row) forward kernels did not engage"
+    assert r["out_rel_l2"] < 2e-2 and r["loss_rel"] < 2e-2, r
+    assert r["worst_rel_l2"] < r["tol"], r
+
+
 def test_train_mode_dropout_values_and_gradients_vs_oracle():
     """model.train(): cross-attention dropout p = 0.1 with the hashed mask; forward values and gradients."""
     cfg = DiTTOConfig(128, 2, 2, 64, 128, 20)

@@ -9,11 +9,11 @@ set -e
 out=$1; shift
 cd "$(dirname "$0")/../ditto_tts_amd/csrc"
 mkdir -p /tmp/diag_objs
-for f in *.hip; do
-  extra=""; { [ "$f" = attention.hip ] || [ "$f" = attention_v4.hip ]; } && extra="-fno-honor-nans"
+for f in *.hip ${DITTO_EXPERIMENTAL:+experimental/*.hip}; do
+  extra=""; { [ "$f" = attention.hip ] || [ "$f" = experimental/attention_v4.hip ]; } && extra="-fno-honor-nans"
   [ "$f" = attention_bwd.hip ] && extra="-fno-slp-vectorize"
   [ "$f" = attention_train.hip ] && extra="-fno-honor-nans -fno-slp-vectorize"
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I ../../include -I . -Wno-unused-function $extra "$@" -c $f -o /tmp/diag_objs/${f%.hip}.o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I ../../include -I . -Wno-unused-function $extra "$@" ${DITTO_EXPERIMENTAL:+-DDITTO_EXPERIMENTAL} -c $f -o /tmp/diag_objs/$(basename ${f%.hip}).o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../$out /tmp/diag_objs/*.o
