@@ -280,10 +280,7 @@ __global__ __launch_bounds__(256, WPS) void attn64_kernel(AttnParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = ot[db][4 * g + e] * inv;
             if constexpr (RESID) {
-                float* rp = p.resid + grow * p.ldr + col;
-                f32x4 r = *reinterpret_cast<const f32x4*>(p.resid_in + grow * p.ldr + col);
-                r += o;  // x = attn_out + residual (src/components/DiT.py:139)
-                *reinterpret_cast<f32x4*>(rp) = r;
+                attn_resid_update(p, grow, col, o);   // x = attn_out + residual (src/components/DiT.py:139)
             } else {
                 u32x2 st2;
                 st2[0] = pack_bf16x2(o[0], o[1]);
@@ -593,10 +590,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn64v3_kernel(AttnParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = ot[db][4 * g + e] * inv;
             if constexpr (RESID) {
-                float* rp = p.resid + grow * p.ldr + col;
-                f32x4 r = *reinterpret_cast<const f32x4*>(p.resid_in + grow * p.ldr + col);
-                r += o;
-                *reinterpret_cast<f32x4*>(rp) = r;
+                attn_resid_update(p, grow, col, o);   // x = attn_out + residual (src/components/DiT.py:139)
             } else {
                 u32x2 st2;
                 st2[0] = pack_bf16x2(o[0], o[1]);
@@ -714,12 +708,14 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     if (a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Skv <= 0) return hipErrorInvalidValue;
     const float LOG2E = 1.4426950408889634f;
     if (a.causal && a.dropout_p > 0.f) return hipErrorInvalidValue;   // no caller: the decoder stack runs in eval mode
+    if (a.resid_bf16 && (a.dh != DH || a.force_generic || a.causal || a.lse_out || a.dropout_p > 0.f))
+        return hipErrorInvalidValue;                                   // the bf16 stream exists on the fused inference kernels only
     if (a.dh == DH && !a.force_generic && !a.causal) {
         if ((a.ldq | a.ldk | a.ldv) % 8) return hipErrorInvalidValue;
         AttnParams p;
         p.q = (const bf16*)a.q; p.ldq = a.ldq; p.k = (const bf16*)a.k; p.ldk = a.ldk;
         p.v = (const bf16*)a.v; p.ldv = a.ldv; p.out = (bf16*)a.out_bf16; p.ldo = a.ldo;
-        p.resid = a.resid_f32; p.ldr = a.ldr; p.resid_in = a.resid_in ? a.resid_in : a.resid_f32; p.B = a.B; p.H = a.H; p.Sq = a.Sq; p.Skv = a.Skv;
+        p.resid = a.resid_f32; p.ldr = a.ldr; p.resid_in = a.resid_in ? a.resid_in : a.resid_f32; p.resid_bf16 = a.resid_bf16 ? 1 : 0; p.B = a.B; p.H = a.H; p.Sq = a.Sq; p.Skv = a.Skv;
         p.nqb = (a.Sq + QBLK - 1) / QBLK;
         p.scale_log2 = a.scale * LOG2E;
         p.lse = a.lse_out; p.drop_thr = dropout_threshold(a.dropout_p);
@@ -737,7 +733,7 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
         if (a.q_prescaled && !(g_attn_flags & 32)) {   // q already carries scale * log2(e): the reduced-VALU kernel
             // one wave per SIMD, 64 queries per wave (attention_v4.hip): attn_flags 4096 = wherever the shape allows
 #ifdef DITTO_EXPERIMENTAL
-            if ((g_attn_flags & 4096) && attn64v4_supports(p)) return launch_attn64v4(p, a.resid_f32 != nullptr, s);
+            if ((g_attn_flags & 4096) && attn64v4_supports(p) && !a.resid_bf16) return launch_attn64v4(p, a.resid_f32 != nullptr, s);
 #endif
             const dim3 gridv(p.nqb * a.H * a.B);
             // whole pairs of key tiles: the software-pipelined, hand-interleaved kernel where it measures faster — small grids

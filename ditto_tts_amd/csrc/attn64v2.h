@@ -249,10 +249,7 @@ __global__ __launch_bounds__(256, WPS) void attn64v2_kernel(AttnParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = ot[db][4 * g + e] * inv;
             if constexpr (RESID) {
-                float* rp = p.resid + grow * p.ldr + col;
-                f32x4 r = *reinterpret_cast<const f32x4*>(p.resid_in + grow * p.ldr + col);
-                r += o;
-                *reinterpret_cast<f32x4*>(rp) = r;
+                attn_resid_update(p, grow, col, o);
             } else {
                 u32x2 st2;
                 st2[0] = pack_bf16x2(o[0], o[1]);

@@ -15,6 +15,7 @@ struct AttnParams {
     bf16* out; int ldo;
     float* resid; int ldr;
     const float* resid_in;
+    int resid_bf16;                // resid / resid_in point to BF16 rows (ldr in bf16 elements): the bf16 residual stream
     int B, H, Sq, Skv, nqb;
     float scale_log2;  // scale * log2(e)
     // training forward (TRAIN instantiations only)
@@ -23,6 +24,23 @@ struct AttnParams {
 };
 
 hipError_t launch_attention_train64(const AttnParams& p, bool resid, hipStream_t s);   // attention_train.hip
+
+// the self-attention epilogue's stream update  h[row, col .. col+3] = h_in[...] + o  (src/components/DiT.py:139: no out-proj),
+// on an fp32 stream or a bf16 one (wave-uniform branch, outside every loop)
+DITTO_DEV void attn_resid_update(const AttnParams& p, size_t grow, int col, f32x4 o) {
+    if (p.resid_bf16) {
+        const u32x2 w = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16*>(p.resid_in) + grow * p.ldr + col);
+        o[0] += __builtin_bit_cast(float, w[0] << 16); o[1] += __builtin_bit_cast(float, w[0] & 0xFFFF0000u);
+        o[2] += __builtin_bit_cast(float, w[1] << 16); o[3] += __builtin_bit_cast(float, w[1] & 0xFFFF0000u);
+        u32x2 st;
+        st[0] = pack_bf16x2(o[0], o[1]); st[1] = pack_bf16x2(o[2], o[3]);
+        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16*>(p.resid) + grow * p.ldr + col) = st;
+    } else {
+        f32x4 r = *reinterpret_cast<const f32x4*>(p.resid_in + grow * p.ldr + col);
+        r += o;
+        *reinterpret_cast<f32x4*>(p.resid + grow * p.ldr + col) = r;
+    }
+}
 
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
 

@@ -83,6 +83,9 @@ static inline size_t text_scratch_bytes(const ditto_config& c, int B, int T) {
 // the batch size, so with it an utterance's result is no longer bit-identical across batch compositions — the
 // property tests/test_gpu_model.py::test_full_size_c2_properties holds the default path to.
 static int g_splitk_wgs = [] { const char* e = getenv("DITTO_SPLITK_WGS"); return e ? atoi(e) : 0; }();
+// "residual_bf16": the residual stream h between the segments of a block lives in HBM as bf16 (fp32 only inside accumulators
+// and LayerNorm statistics) wherever the launch takes the full-row class at d = 768 / head_dim 64 (ditto_forward decides)
+int g_resid_bf16 = [] { const char* e = getenv("DITTO_RESIDUAL_BF16"); return e ? atoi(e) : 0; }();
 int small_batch_k_splits(int M, int N, int K) {
     if (g_splitk_wgs <= 0) return 1;
     const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
@@ -197,7 +200,7 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
                      void* attn_ws, size_t attn_ws_bytes, float* splitk_ws, size_t splitk_bytes, const char* kv, int kv_layer, int kv_ld,
                      const float* rope_cos, const float* rope_sin, int B, int N, int T, hipStream_t s,
                      float* tap_self = nullptr, float* tap_cross = nullptr, bool ln1_done = false,
-                     const float* next_g1 = nullptr, const float* next_be1 = nullptr) {
+                     const float* next_g1 = nullptr, const float* next_be1 = nullptr, bool hb = false) {
     const ditto_config& c = m->cfg;
     const int d = c.hidden_dim, H = c.num_heads, dh = d / H, M = B * N;
     const float scale = 1.0f / sqrtf((float)dh);
@@ -212,10 +215,13 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
     const bool fr_fc2 = !fp8 && lp.W2P && (g_fr_mask & 2) && fr_fc2_ok(M, d);
     const int fr_rot = N % 128 == 0 ? N / 128 : 0;   // tiles per utterance: the K-loop rotation period (gemm_fr.hip)
     if (int rc = ditto::check_class_pin(M, d, fp8)) return rc;
+    // hb: `h` holds BF16 rows (the bf16 residual stream; ditto_forward decides, and only where both fused launches run)
+    if (hb && (!fr_out || !fr_fc2 || dh != 64 || tap_self || tap_cross)) return fail(DITTO_ERR_ARG, "internal: bf16 stream outside its class");
         // ---- self-attention (src/components/DiT.py:103-139) ----
         if (!ln1_done) {
             ProfScope ps(m, s, DITTO_KC_LAYERNORM);
             if (fp8) HIP_TRY(launch_layernorm_fp8(h, lp.g1, lp.be1, u, d, M, d, s));
+            else if (hb) HIP_TRY(launch_layernorm_xbf16(h, lp.g1, lp.be1, u, d, M, d, s));
             else HIP_TRY(launch_layernorm(h, lp.g1, lp.be1, u, d, M, d, s));
         }
         {
@@ -235,11 +241,16 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
             a.q = qkv; a.ldq = 3 * d; a.k = qkv + (size_t)d * 2; a.ldk = 3 * d; a.v = qkv + (size_t)2 * d * 2;
             a.ldv = 3 * d; a.resid_f32 = h; a.ldr = d; a.B = B; a.H = H; a.Sq = N; a.Skv = N; a.dh = dh;
             a.scale = scale; a.workspace = attn_ws; a.workspace_bytes = attn_ws_bytes; a.q_prescaled = (dh == 64);
+            a.resid_bf16 = hb;
             HIP_TRY(launch_attention(a, s));
         }
         if (tap_self) HIP_TRY(hipMemcpyAsync(tap_self, h, (size_t)M * d * 4, hipMemcpyDeviceToDevice, s));
         // ---- cross-attention (src/components/DiT.py:141-148), K/V from the per-utterance cache ----
-        { ProfScope ps(m, s, DITTO_KC_LAYERNORM); HIP_TRY(launch_layernorm(h, lp.g2, lp.be2, u, d, M, d, s)); }
+        {
+            ProfScope ps(m, s, DITTO_KC_LAYERNORM);
+            if (hb) HIP_TRY(launch_layernorm_xbf16(h, lp.g2, lp.be2, u, d, M, d, s));
+            else HIP_TRY(launch_layernorm(h, lp.g2, lp.be2, u, d, M, d, s));
+        }
         {
             ProfScope ps(m, s, DITTO_KC_GEMM_QPROJ);
             GemmArgs g{};
@@ -262,7 +273,7 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
             GemmParams gp{};
             gp.A = (const bf16*)u; gp.lda = d; gp.W = (const bf16*)lp.WcoP; gp.ldw = d; gp.w_rows = d; gp.bias = lp.bco;
             gp.residual = h; gp.ldr = d; gp.out = h; gp.ldo = d; gp.M = M; gp.N = d; gp.K = d;
-            HIP_TRY(launch_gemm_fr(gp, lp.g3, lp.be3, qkv, d, fr_rot, s, fp8));
+            HIP_TRY(launch_gemm_fr(gp, lp.g3, lp.be3, qkv, d, fr_rot, s, fp8, hb));
         } else {
             ProfScope ps(m, s, DITTO_KC_GEMM_OUTPROJ);
             GemmArgs g{};
@@ -291,8 +302,9 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
             GemmParams gp{};
             gp.A = (const bf16*)act; gp.lda = 4 * d; gp.W = (const bf16*)lp.W2P; gp.ldw = 4 * d; gp.w_rows = d; gp.bias = lp.b2;
             gp.residual = h; gp.ldr = d; gp.out = h; gp.ldo = d; gp.M = M; gp.N = d; gp.K = 4 * d;
-            if (xcat_or_null) { gp.out2 = (bf16*)(xcat_or_null + (size_t)d * 2); gp.ldo2 = 2 * d; }
-            HIP_TRY(launch_gemm_fr(gp, next_g1, next_be1, next_g1 ? u : nullptr, d, fr_rot, s));
+            if (xcat_or_null && hb) { gp.out = xcat_or_null + (size_t)d * 2; gp.ldo = 2 * d; }   // bf16 h_L IS proj_out's operand
+            else if (xcat_or_null) { gp.out2 = (bf16*)(xcat_or_null + (size_t)d * 2); gp.ldo2 = 2 * d; }
+            HIP_TRY(launch_gemm_fr(gp, next_g1, next_be1, next_g1 ? u : nullptr, d, fr_rot, s, false, hb));
         } else {
             ProfScope ps(m, s, DITTO_KC_GEMM_FC2);
             GemmArgs g{};
@@ -524,18 +536,28 @@ int ditto_forward(ditto_model_t m, const float* x, const void* cond, const int64
     const char* kv = (const char*)cond;
     const float* tmod = (const float*)(kv + al((size_t)B * T * L * 2 * d * 2));
 
+    // fc2 on the full-row kernel also emits the NEXT block's norm1 (fr_mask bit 1): that block then skips its LayerNorm
+    const bool fp8c = (c.flags & DITTO_CFG_FP8_LINEAR) != 0;
+    const bool chain_ln1 = (g_fr_mask & 2) && !fp8c && m->layers[0].W2P && fr_fc2_ok(M, d);
+    // bf16 residual stream ("residual_bf16"): only where EVERY consumer of h has the bf16 form — d = 768, head_dim 64, both fused
+    // launches of a block on gemm_frd.hip (the full-row class); any other launch keeps the fp32 stream
+    const bool hb = g_resid_bf16 && !fp8c && d == 768 && d / c.num_heads == 64 && chain_ln1 && (g_fr_mask & 1) &&
+                    m->layers[0].WcoP && fr_outproj_ok(M, d) && fr_launch_kernel(M, d) == 130 && fr_launch_kernel(M, 4 * d) == 130;
+    // block 0's norm1 rides in the GlobalAdaLN kernel (same statistics order as the LayerNorm kernel: the same bits)
+    const bool ln1_in_adaln = !fp8c && !(g_gemm_flags & 32768);      // gemm_flags bit 15: A/B, the separate launch
     {   // GlobalAdaLN (src/components/DiT.py:25-40) + bf16 copy of the raw input for proj_in
         ProfScope ps(m, s, DITTO_KC_ADALN);
-        HIP_TRY(launch_adaln(x, m->ttab, tmod, t, c.diffusion_steps, h, xcat, 2 * d, B, N, d, s));
+        HIP_TRY(launch_adaln(x, m->ttab, tmod, t, c.diffusion_steps, h, xcat, 2 * d, B, N, d, s, hb,
+                             ln1_in_adaln ? m->layers[0].g1 : nullptr, ln1_in_adaln ? m->layers[0].be1 : nullptr,
+                             ln1_in_adaln ? u : nullptr));
     }
-    // fc2 on the full-row kernel also emits the NEXT block's norm1 (fr_mask bit 1): that block then skips its LayerNorm
-    const bool chain_ln1 = (g_fr_mask & 2) && !(c.flags & DITTO_CFG_FP8_LINEAR) && m->layers[0].W2P && fr_fc2_ok(M, d);
     for (int l = 0; l < L; ++l)
         if (int rc = run_block(m, l, h, u, qkv, act, l == L - 1 ? xcat : nullptr, attn_ws, w.attn_bytes,
                                (float*)(ws + w.splitk), w.splitk_bytes, kv, l,
-                               L * 2 * d, rope_cos, rope_sin, B, N, T, s, nullptr, nullptr, chain_ln1 && l > 0,
+                               L * 2 * d, rope_cos, rope_sin, B, N, T, s, nullptr, nullptr,
+                               (chain_ln1 && l > 0) || (ln1_in_adaln && l == 0),
                                chain_ln1 && l + 1 < L ? m->layers[l + 1].g1 : nullptr,
-                               chain_ln1 && l + 1 < L ? m->layers[l + 1].be1 : nullptr))
+                               chain_ln1 && l + 1 < L ? m->layers[l + 1].be1 : nullptr, hb))
             return rc;
     {   // eps = proj_in(x_raw) + proj_out(h_L)  (src/model/DiTTO.py:83,93-94), one K = 2d GEMM
         ProfScope ps(m, s, DITTO_KC_GEMM_FINAL);
@@ -866,7 +888,7 @@ static int* option_slot(const char* name) {
         {"pp_mask", &g_pp_mask}, {"fr_mask", &g_fr_mask}, {"fr_class_rows", &g_fr_class_rows}, {"fr_dgrad", &g_fr_dgrad},
         {"train_flags", &g_train_flags}, {"fr_u_fp8", &g_fr_u_fp8}, {"fr_tile", &g_fr_tile}, {"fr64_maxk", &g_fr64_maxk},
         {"fr_stagger", &g_fr_stagger}, {"fr_rot", &g_fr_rot}, {"pp_nb", &g_pp_nb}, {"pp_stagger", &g_pp_stagger},
-        {"splitk_wgs", &g_splitk_wgs}};
+        {"splitk_wgs", &g_splitk_wgs}, {"residual_bf16", &g_resid_bf16}};
     for (auto& e : tab) if (!strcmp(name, e.n)) return e.p;
     return nullptr;
 }
@@ -976,6 +998,11 @@ int ditto_set_option(const char* name, int value) {
     if (!strcmp(name, "pp_stagger")) {
         if (value < -1 || value > 100000) return fail(DITTO_ERR_ARG, "pp_stagger must be in [-1, 100000] (10 ns ticks; -1 = rule)");
         g_pp_stagger = value;
+        return DITTO_OK;
+    }
+    if (!strcmp(name, "residual_bf16")) {
+        if (value < 0 || value > 1) return fail(DITTO_ERR_ARG, "residual_bf16 must be 0 or 1");
+        g_resid_bf16 = value;
         return DITTO_OK;
     }
     if (!strcmp(name, "splitk_wgs")) {

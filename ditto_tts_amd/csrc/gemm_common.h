@@ -369,10 +369,12 @@ struct FrParams {
     int rot_period;                           // > 0: 128-row tiles t and t + rot_period start their K loop at the same place
     int stagger_ticks;                        // gemm_fr64: start delay (10 ns ticks) of the workgroup holding its CU's second LDS allocation
     bool u_fp8;                               // gemm_fr64, N = 1024: u is fp8 e4m3 bytes ([M, ldu] bytes) for the fp8 linear path
+    bool hb = false;                          // gemm_frd only: residual and out are BF16 [M, ldr / ldo] (the bf16 residual stream)
 };
 bool gemm_fr_supports(int M, int N, int K, size_t lda, size_t ldw);
 hipError_t launch_gemm_fr(const GemmParams& p, const float* gamma, const float* beta, void* u_bf16, int ldu, int rot_period,
-                          hipStream_t s, bool u_fp8 = false);   // u_fp8 (N = 1024 only): u is fp8 e4m3 bytes
+                          hipStream_t s, bool u_fp8 = false, bool hb = false);   // u_fp8 (N = 1024 only): u is fp8 e4m3 bytes;
+                                                                                 // hb: bf16 residual / out (gemm_frd only: else an error)
 // The two full-row launches of a DiT block over M rows of width d, each judged on the operand strides IT runs with (the
 // kernel builds 32-bit byte offsets from M * lda: fc2 reads A at lda = 4d).  One predicate for the inference forward, the
 // LayerNorm chaining decision and the training forward, so that the three cannot disagree.

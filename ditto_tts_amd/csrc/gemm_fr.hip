@@ -592,7 +592,7 @@ bool gemm_fr_supports(int M, int N, int K, size_t lda, size_t ldw) {
 }
 
 hipError_t launch_gemm_fr(const GemmParams& p_in, const float* gamma, const float* beta, void* u_bf16, int ldu,
-                          int rot_period, hipStream_t s, bool u_fp8) {
+                          int rot_period, hipStream_t s, bool u_fp8, bool hb) {
     FrParams fp;
     fp.g = p_in;
     fp.g.flags = g_gemm_flags;
@@ -602,6 +602,8 @@ hipError_t launch_gemm_fr(const GemmParams& p_in, const float* gamma, const floa
     fp.rot_period = g_fr_rot ? rot_period : 0;
     fp.stagger_ticks = 0;
     fp.u_fp8 = u_fp8;
+    fp.hb = hb;
+    if (hb && (p_in.N != FN || fr_launch_kernel(p_in.M, p_in.K) != 130)) return hipErrorInvalidValue;   // gemm_frd.hip only
     if (p_in.N == 1024) return launch_gemm_fr64(fp, s);          // d = 1024: 64 x 1024 tiles, one workgroup per CU
     if (u_fp8) return hipErrorInvalidValue;
     // which N = 768 kernel (kernels.h fr_launch_kernel): all three produce the same h bits, a speed rule only

@@ -26,6 +26,8 @@
 //             bf16 bit of a few elements.
 //   LDS       A 2 x 16 KiB + bias row 3 KiB in the loop; the epilogue stages every output row through a wave-private
 //             32 KiB (whole-line stores) + gamma | beta + row statistics: 138 KiB.
+#include <type_traits>
+
 #include "gemm_common.h"
 
 namespace ditto {
@@ -108,7 +110,9 @@ static_assert(frd_vm(0, 0, false) == 11 && frd_vm(0, 5, false) == 12 && frd_vm(1
 static_assert(frd_vm(0, 3, true) == 11 && frd_vm(2, 0, true) == 11 && frd_vm(2, 5, true) == 6 && frd_vm(3, 0, true) == 5 &&
               frd_vm(3, 5, true) == 0, "last-slab wait counts");
 
-template <bool LN, bool RES>
+// HB: the residual stream is bf16 in HBM (fp.hb): residual read and h written as bf16 (fp32 only in the accumulators and the
+// LayerNorm, which still sees the UNROUNDED fp32 row); p.residual / p.out point to bf16, ldr / ldo in bf16 elements.
+template <bool LN, bool RES, bool HB = false>
 __global__ __launch_bounds__(256, 1) void gemm_frd_kernel(FrParams fp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const GemmParams& p = fp.g;
@@ -193,21 +197,32 @@ __global__ __launch_bounds__(256, 1) void gemm_frd_kernel(FrParams fp) {
     const float* lbeta = lgamma + DN;
     f32x16 acca[DNA][4], accv[6 - DNA][4];
     {
-        const float* rp[4] = {nullptr, nullptr, nullptr, nullptr};
+        const char* rp[4] = {nullptr, nullptr, nullptr, nullptr};
         if constexpr (RES) {
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
                 int gr = m0 + mb * 32 + r32;
                 gr = gr < p.M ? gr : p.M - 1;
-                rp[mb] = p.residual + (size_t)gr * p.ldr + wid * 192 + 4 * hh;
+                if constexpr (HB) rp[mb] = reinterpret_cast<const char*>(reinterpret_cast<const bf16*>(p.residual) + (size_t)gr * p.ldr + wid * 192 + 4 * hh);
+                else rp[mb] = reinterpret_cast<const char*>(p.residual + (size_t)gr * p.ldr + wid * 192 + 4 * hh);
             }
         }
         constexpr int WD = 4, NG = 24;                               // window depth; groups = (nb, mb) blocks, mb fastest
-        f32x4 T[WD][4];
-        auto issue_group = [&](auto GI, f32x4 (&t)[4]) {
+        using res_t = typename std::conditional<HB, u32x2, f32x4>::type;   // four columns of one row: bf16 x 4 or fp32 x 4
+        res_t T[WD][4];
+        auto issue_group = [&](auto GI, res_t (&t)[4]) {
             constexpr int nb = decltype(GI)::value >> 2, mb = decltype(GI)::value & 3;
-            if constexpr (RES) {
-                const float* ptr = rp[mb];
+            if constexpr (RES && HB) {
+                const char* ptr = rp[mb];
+                asm volatile("global_load_dwordx2 %0, %4, off offset:%5\n\t"
+                             "global_load_dwordx2 %1, %4, off offset:%6\n\t"
+                             "global_load_dwordx2 %2, %4, off offset:%7\n\t"
+                             "global_load_dwordx2 %3, %4, off offset:%8"
+                             : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3])
+                             : "v"(ptr), "n"(nb * 64), "n"(nb * 64 + 16), "n"(nb * 64 + 32), "n"(nb * 64 + 48)
+                             : "memory");
+            } else if constexpr (RES) {
+                const char* ptr = rp[mb];
                 asm volatile("global_load_dwordx4 %0, %4, off offset:%5\n\t"
                              "global_load_dwordx4 %1, %4, off offset:%6\n\t"
                              "global_load_dwordx4 %2, %4, off offset:%7\n\t"
@@ -217,10 +232,10 @@ __global__ __launch_bounds__(256, 1) void gemm_frd_kernel(FrParams fp) {
                              : "memory");
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) t[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int i = 0; i < 4; ++i) t[i] = res_t{};
             }
         };
-        auto finish_group = [&](auto GI, f32x4 (&t)[4]) {
+        auto finish_group = [&](auto GI, res_t (&t)[4]) {
             constexpr int gi = decltype(GI)::value, nb = gi >> 2, mb = gi & 3;
             constexpr int younger = NG - 1 - gi < WD - 1 ? NG - 1 - gi : WD - 1;
             if constexpr (RES)
@@ -234,7 +249,12 @@ __global__ __launch_bounds__(256, 1) void gemm_frd_kernel(FrParams fp) {
             for (int g = 0; g < 4; ++g) {
                 const f32x4 b4 = *reinterpret_cast<const f32x4*>(lbias + wid * 192 + nb * 32 + 8 * g + 4 * hh);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[4 * g + e] = t[g][e] + b4[e];
+                for (int e = 0; e < 4; ++e) {
+                    float r;
+                    if constexpr (HB) r = __builtin_bit_cast(float, (e & 1) ? (t[g][e >> 1] & 0xFFFF0000u) : (t[g][e >> 1] << 16));
+                    else r = t[g][e];
+                    v[4 * g + e] = r + b4[e];
+                }
             }
             if constexpr (nb < DNA) { acca[nb < DNA ? nb : 0][mb] = v; FD_PIN_A(acca[nb < DNA ? nb : 0][mb]); }
             else { accv[nb < DNA ? 0 : nb - DNA][mb] = v; FD_PIN_V(accv[nb < DNA ? 0 : nb - DNA][mb]); }
@@ -402,6 +422,7 @@ __global__ __launch_bounds__(256, 1) void gemm_frd_kernel(FrParams fp) {
     const int srow = lane >> 3, sq = lane & 7;                      // read-back: row srow (+ 8 i), 16-B chunk sq
     const int grow0 = m0 + srow;
     float* hrow = (float*)p.out + (size_t)(grow0 < p.M ? grow0 : 0) * p.ldo + wid * 192 + sq * 4;
+    bf16* hbrow = (bf16*)p.out + (size_t)(grow0 < p.M ? grow0 : 0) * p.ldo + wid * 192 + sq * 8;   // HB
     bf16* urow = fp.u ? fp.u + (size_t)(grow0 < p.M ? grow0 : 0) * fp.ldu + wid * 192 + sq * 8 : nullptr;
     bf16* orow = p.out2 ? p.out2 + (size_t)(grow0 < p.M ? grow0 : 0) * p.ldo2 + wid * 192 + sq * 8 : nullptr;
 #pragma unroll
@@ -423,26 +444,47 @@ __global__ __launch_bounds__(256, 1) void gemm_frd_kernel(FrParams fp) {
                 const f32x16& v = nb < DNA ? acca[nb < DNA ? nb : 0][mb] : accv[nb < DNA ? 0 : nb - DNA][mb];
                 const f32x4 v4 = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
                 const int row = mb * 32 + r32;
-                *reinterpret_cast<f32x4*>(hst + row * 128 + (((2 * g + hh) ^ (row & 7)) << 4)) = v4;
-                f32x4 y = v4;                                        // bf16 side: LayerNorm output, or the plain copy
-                if constexpr (LN) y = (v4 - mean[mb]) * rstd[mb] * g4 + b4;
-                u32x2 st;
-                st[0] = pack_bf16x2(y[0], y[1]); st[1] = pack_bf16x2(y[2], y[3]);
-                *reinterpret_cast<u32x2*>(ust + row * 128 + ((((nb & 1) * 4 + g) ^ (row & 7)) << 4) + hh * 8) = st;
+                if constexpr (HB) {                                  // h as bf16: the same [128 rows][64 columns] image as u
+                    u32x2 sh;
+                    sh[0] = pack_bf16x2(v4[0], v4[1]); sh[1] = pack_bf16x2(v4[2], v4[3]);
+                    *reinterpret_cast<u32x2*>(hst + row * 128 + ((((nb & 1) * 4 + g) ^ (row & 7)) << 4) + hh * 8) = sh;
+                } else {
+                    *reinterpret_cast<f32x4*>(hst + row * 128 + (((2 * g + hh) ^ (row & 7)) << 4)) = v4;
+                }
+                if constexpr (LN || !HB) {
+                    f32x4 y = v4;                                    // bf16 side: LayerNorm output, or the plain copy
+                    if constexpr (LN) y = (v4 - mean[mb]) * rstd[mb] * g4 + b4;
+                    u32x2 st;
+                    st[0] = pack_bf16x2(y[0], y[1]); st[1] = pack_bf16x2(y[2], y[3]);
+                    *reinterpret_cast<u32x2*>(ust + row * 128 + ((((nb & 1) * 4 + g) ^ (row & 7)) << 4) + hh * 8) = st;
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (!HB) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < 4; ++q) {
 #pragma unroll
-            for (int i = 4 * q; i < 4 * q + 4; ++i) {
-                const int row = srow + 8 * i;
-                const u32x4 hv = *reinterpret_cast<const u32x4*>(hst + row * 128 + ((sq ^ (row & 7)) << 4));
-                if (grow0 + 8 * i < FD_DIAG_M) store16<true, true>(hrow + (size_t)(8 * i) * p.ldo + nb * 32, hv, 0);
+                for (int i = 4 * q; i < 4 * q + 4; ++i) {
+                    const int row = srow + 8 * i;
+                    const u32x4 hv = *reinterpret_cast<const u32x4*>(hst + row * 128 + ((sq ^ (row & 7)) << 4));
+                    if (grow0 + 8 * i < FD_DIAG_M) store16<true, true>(hrow + (size_t)(8 * i) * p.ldo + nb * 32, hv, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
+        } else if (nb & 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int i = 4 * q; i < 4 * q + 4; ++i) {
+                    const int row = srow + 8 * i;
+                    const u32x4 hv = *reinterpret_cast<const u32x4*>(hst + row * 128 + ((sq ^ (row & 7)) << 4));
+                    if (grow0 + 8 * i < FD_DIAG_M) *reinterpret_cast<u32x4*>(hbrow + (size_t)(8 * i) * p.ldo + (nb - 1) * 32) = hv;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        if (nb & 1) {
+        if ((nb & 1) && (LN || !HB)) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -462,11 +504,11 @@ __global__ __launch_bounds__(256, 1) void gemm_frd_kernel(FrParams fp) {
     }
 }
 
-template <bool LN, bool RES>
+template <bool LN, bool RES, bool HB = false>
 hipError_t launch_frd_t(const FrParams& fp, int grid, hipStream_t s) {
     static DevOnce lds_once;
-    if (hipError_t e = set_max_lds_once(lds_once, {reinterpret_cast<const void*>(&gemm_frd_kernel<LN, RES>)}, D_LDS)) return e;
-    hipLaunchKernelGGL((gemm_frd_kernel<LN, RES>), dim3(grid), dim3(256), D_LDS, s, fp);
+    if (hipError_t e = set_max_lds_once(lds_once, {reinterpret_cast<const void*>(&gemm_frd_kernel<LN, RES, HB>)}, D_LDS)) return e;
+    hipLaunchKernelGGL((gemm_frd_kernel<LN, RES, HB>), dim3(grid), dim3(256), D_LDS, s, fp);
     return hipGetLastError();
 }
 
@@ -478,6 +520,10 @@ hipError_t launch_gemm_frd(const FrParams& fp_in, hipStream_t s) {
     fp.g.tiles_m = (fp.g.M + DM - 1) / DM;
     fp.g.tiles_n = 1;
     const bool ln = fp.gamma && fp.u, res = fp.g.residual != nullptr;
+    if (fp.hb) {   // bf16 residual stream (the model path's two launches: always with a residual)
+        if (!res || fp.g.out2) return hipErrorInvalidValue;
+        return ln ? launch_frd_t<true, true, true>(fp, fp.g.tiles_m, s) : launch_frd_t<false, true, true>(fp, fp.g.tiles_m, s);
+    }
     if (ln) return res ? launch_frd_t<true, true>(fp, fp.g.tiles_m, s) : launch_frd_t<true, false>(fp, fp.g.tiles_m, s);
     return res ? launch_frd_t<false, true>(fp, fp.g.tiles_m, s) : launch_frd_t<false, false>(fp, fp.g.tiles_m, s);
 }

@@ -19,8 +19,14 @@ hipError_t launch_pack_fp8(const float* src, void* dst_fp8, float* scales, int r
                            int mult, int row_off, hipStream_t s);
 // GlobalAdaLN apply: h = LN_noaffine(x) * (1 + ttab[t[b]][j] + tmod[b][j]) + (ttab[t[b]][d+j] + tmod[b][d+j]);
 // also writes bf16(x) (the RAW input) to raw_bf16 [M, ldraw] for the fused proj_in.
+// h_bf16: h_out is BF16 [M, d] (the bf16 residual stream).  g1 / be1 / u1_bf16 (all or none): also write block 0's norm1,
+// u1 bf16 [M, d] = LN(h) * g1 + be1 from the fp32 row in registers (the LayerNorm launch in front of block 0 disappears).
 hipError_t launch_adaln(const float* x, const float* ttab, const float* tmod, const int64_t* t, int steps,
-                        float* h_out, void* raw_bf16, int ldraw, int B, int N, int d, hipStream_t s);
+                        float* h_out, void* raw_bf16, int ldraw, int B, int N, int d, hipStream_t s, bool h_bf16 = false,
+                        const float* g1 = nullptr, const float* be1 = nullptr, void* u1_bf16 = nullptr);
+// LayerNorm whose INPUT rows are bf16 [M, d] (the bf16 residual stream)
+hipError_t launch_layernorm_xbf16(const void* x_bf16, const float* gamma, const float* beta, void* out_bf16, int ldo, int M,
+                                  int d, hipStream_t s);
 hipError_t launch_cast_bf16(const float* src, void* dst_bf16, size_t n, hipStream_t s);
 // out = residual + bias + sum of `nsplit` fp32 partial products (contiguous [M, N], `stride` elements apart), in order
 hipError_t launch_splitk_finish(const float* partial, int nsplit, size_t stride, const float* bias,
@@ -178,6 +184,7 @@ struct AttnArgs {
     void* out_bf16; int ldo;         // used when resid_f32 == nullptr
     float* resid_f32; int ldr;       // if set: resid[row, h*dh + c] = resid_in[...] + O   (self-attention, no out-proj)
     const float* resid_in;           // nullptr -> resid_f32 (in place); the training forward keeps both streams
+    bool resid_bf16 = false;         // resid_f32 / resid_in point to BF16 [.., ldr] (the bf16 residual stream; fused dh == 64 path)
     int B, H, Sq, Skv, dh;
     float scale;                     // 1/sqrt(dh)
     void* workspace; size_t workspace_bytes;   // generic (dh != 64) path only

@@ -23,19 +23,28 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, co
                                                  const float* __restrict__ beta, const float* __restrict__ ttab,
                                                  const float* __restrict__ tmod, const int64_t* __restrict__ t,
                                                  int steps, int rows_per_batch, bf16* __restrict__ out_bf16, int ldo,
-                                                 float* __restrict__ out_f32, int M, int d) {
+                                                 float* __restrict__ out_f32, int M, int d, int x_bf16, int h_bf16,
+                                                 const float* __restrict__ g1, const float* __restrict__ be1,
+                                                 bf16* __restrict__ u1) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const int nv = d >> 2;
     const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * d);
+    const u32x2* xb = reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16*>(x) + (size_t)row * d);   // x_bf16: bf16 rows
     f32x4 v[CH];
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         const int i = lane + 64 * c;
         if (i < nv) {
-            v[c] = xr[i];
+            if (x_bf16) {
+                const u32x2 w = xb[i];
+                v[c] = f32x4{__builtin_bit_cast(float, w[0] << 16), __builtin_bit_cast(float, w[0] & 0xFFFF0000u),
+                             __builtin_bit_cast(float, w[1] << 16), __builtin_bit_cast(float, w[1] & 0xFFFF0000u)};
+            } else {
+                v[c] = xr[i];
+            }
             s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
         } else {
             v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -97,6 +106,8 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, co
         const f32x4* tm = reinterpret_cast<const f32x4*>(tmod + (size_t)b_idx * 2 * d);
         bf16* orow = out_bf16 + (size_t)row * ldo;
         f32x4* hrow = reinterpret_cast<f32x4*>(out_f32 + (size_t)row * d);
+        u32x2* hbrow = reinterpret_cast<u32x2*>(reinterpret_cast<bf16*>(out_f32) + (size_t)row * d);   // h_bf16: the bf16 stream
+        float s1 = 0.f;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const int i = lane + 64 * c;
@@ -109,12 +120,51 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, co
                     const float shift = sh_t[e] + sh_x[e];                // DiT.py:35
                     h[e] = (v[c][e] - mean) * rstd * scale + shift;       // DiT.py:38-39
                 }
-                hrow[i] = h;
+                if (h_bf16) {
+                    u32x2 o;
+                    o[0] = pack_bf16x2(h[0], h[1]);
+                    o[1] = pack_bf16x2(h[2], h[3]);
+                    hbrow[i] = o;
+                } else {
+                    hrow[i] = h;
+                }
                 if (out_bf16) {
                     u32x2 o;
                     o[0] = pack_bf16x2(v[c][0], v[c][1]);
                     o[1] = pack_bf16x2(v[c][2], v[c][3]);
                     *reinterpret_cast<u32x2*>(orow + 4 * i) = o;
+                }
+                v[c] = h;                                                 // kept for the fused norm1 below
+                s1 += (h[0] + h[1]) + (h[2] + h[3]);
+            }
+        }
+        // u1 set: block 0's norm1 (src/components/DiT.py:105) of the row just produced, from the fp32 values in registers
+        // (the separate LayerNorm launch in front of block 0 and its 100 MB read disappear)
+        if (u1) {
+            const float mean1 = wave_sum(s1) / (float)d;
+            float q1 = 0.f;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int i = lane + 64 * c;
+                if (i < nv) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float dlt = v[c][e] - mean1;
+                        q1 += dlt * dlt;
+                    }
+                }
+            }
+            const float rstd1 = rsqrtf(wave_sum(q1) / (float)d + 1e-5f);
+            bf16* urow = u1 + (size_t)row * d;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int i = lane + 64 * c;
+                if (i < nv) {
+                    const f32x4 g = reinterpret_cast<const f32x4*>(g1)[i], b = reinterpret_cast<const f32x4*>(be1)[i];
+                    u32x2 o;
+                    o[0] = pack_bf16x2((v[c][0] - mean1) * rstd1 * g[0] + b[0], (v[c][1] - mean1) * rstd1 * g[1] + b[1]);
+                    o[1] = pack_bf16x2((v[c][2] - mean1) * rstd1 * g[2] + b[2], (v[c][3] - mean1) * rstd1 * g[3] + b[3]);
+                    *reinterpret_cast<u32x2*>(urow + 4 * i) = o;
                 }
             }
         }
@@ -124,13 +174,14 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, co
 template <int MODE>
 static hipError_t ln_dispatch(const float* x, const float* gamma, const float* beta, const float* ttab,
                               const float* tmod, const int64_t* t, int steps, int rpb, bf16* ob, int ldo, float* of,
-                              int M, int d, hipStream_t s) {
+                              int M, int d, hipStream_t s, int x_bf16 = 0, int h_bf16 = 0, const float* g1 = nullptr,
+                              const float* be1 = nullptr, bf16* u1 = nullptr) {
     const int ch = (d / 4 + 63) / 64;
     dim3 grid((M + 3) / 4), block(256);
 #define LN_CASE(C)                                                                                             \
     case C:                                                                                                    \
         hipLaunchKernelGGL((ln_kernel<C, MODE>), grid, block, 0, s, x, gamma, beta, ttab, tmod, t, steps, rpb, \
-                           ob, ldo, of, M, d);                                                                 \
+                           ob, ldo, of, M, d, x_bf16, h_bf16, g1, be1, u1);                                    \
         break;
     switch (ch) {
         LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(7) LN_CASE(8)
@@ -151,8 +202,16 @@ hipError_t launch_layernorm_fp8(const float* x, const float* gamma, const float*
 }
 
 hipError_t launch_adaln(const float* x, const float* ttab, const float* tmod, const int64_t* t, int steps,
-                        float* h_out, void* raw_bf16, int ldraw, int B, int N, int d, hipStream_t s) {
-    return ln_dispatch<1>(x, nullptr, nullptr, ttab, tmod, t, steps, N, (bf16*)raw_bf16, ldraw, h_out, B * N, d, s);
+                        float* h_out, void* raw_bf16, int ldraw, int B, int N, int d, hipStream_t s, bool h_bf16,
+                        const float* g1, const float* be1, void* u1_bf16) {
+    return ln_dispatch<1>(x, nullptr, nullptr, ttab, tmod, t, steps, N, (bf16*)raw_bf16, ldraw, h_out, B * N, d, s, 0,
+                          h_bf16 ? 1 : 0, g1, be1, (bf16*)u1_bf16);
+}
+// LayerNorm of a BF16 row stream (the bf16 residual stream): x bf16 [M, d]
+hipError_t launch_layernorm_xbf16(const void* x_bf16, const float* gamma, const float* beta, void* out_bf16, int ldo, int M,
+                                  int d, hipStream_t s) {
+    return ln_dispatch<0>((const float*)x_bf16, gamma, beta, nullptr, nullptr, nullptr, 0, 1, (bf16*)out_bf16, ldo, nullptr, M,
+                          d, s, 1);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -184,10 +184,16 @@ def lib() -> C.CDLL:
         # device initialisation and ours disagreed on a GPU box ("no ROCm-capable device is detected" at the first launch).
         import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
-        for name, (res, args) in SYMBOLS.items():
-            fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol
+        frozen = bool(os.environ.get("DITTO_HIP_LIB"))   # a diagnostic or FROZEN earlier build for same-box A/Bs (tools/):
+        for name, (res, args) in SYMBOLS.items():        # it may predate entry points added since (they are then absent)
+            try:
+                fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol
+            except AttributeError:
+                if frozen:
+                    continue
+                raise
             fn.restype, fn.argtypes = res, args
-        if l.ditto_abi_version() != 8:
+        if l.ditto_abi_version() != 8 and not (frozen and l.ditto_abi_version() == 7):
             raise RuntimeError("libditto_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -706,3 +706,83 @@ def test_per_utterance_seeded_noise_and_sampling():
     assert not torch.equal(other, full[:1])
     with pytest.raises(ValueError, match="excludes"):
         sg._SpeechGenerator__sample_latents(text.to(DEV), x.to(DEV), seeds=seeds, noises=lambda i: z)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bf16 residual stream (ditto_set_option("residual_bf16", 1) / DITTO_RESIDUAL_BF16=1): h between the segments of a block
+# lives in HBM as bf16 — fp32 only in the accumulators and the LayerNorm statistics — wherever a launch takes the full-row
+# class at d = 768 / head_dim 64 (csrc/ditto_api.hip ditto_forward).  Replaces the fp32 `x = ... + residual` stream of
+# src/components/DiT.py:139,148,155.  Same tolerances as the fp32 stream (2e-2 / 0.1 (1 + sigma)).
+# ---------------------------------------------------------------------------------------------------------------
+class _stream_bf16:
+    def __init__(self, on=1): self.on = on
+    def __enter__(self): self.prev = hip.get_option("residual_bf16"); hip.set_option("residual_bf16", self.on)
+    def __exit__(self, *e): hip.set_option("residual_bf16", self.prev)
+
+
+@torch.no_grad()
+def test_bf16_residual_stream_g2_golden_and_taps(golden):
+    """G2 (the reference's own 12-layer DiTTO-S output) with the kernel class pinned to the timed batch, so that the
+    full-row kernels and with them the bf16 stream engage at G2's 256 rows: both streams within tolerance, and different."""
+    g = golden("G2_ditto_s.npz")
+    cfg = DiTTOConfig(768, 12, 12, 256, 768, 50)
+    m = build(cfg, 2)
+    x, text, t = (z.to(DEV) for z in synthetic_inputs(cfg, 2, 128, 96, seed=22))
+    with hip.batch_class(32 * 1024):
+        assert hip.full_row_plan(cfg, 2, 128) == (True, True)
+        f32 = m(x, text, t)
+        with _stream_bf16():
+            b16 = m(x, text, t)
+            again = m(x, text, t)
+    r32, r16 = close(f32, g["out"]), close(b16, g["out"])
+    print(f"G2 12L rel-L2: fp32 stream {r32:.3e}, bf16 stream {r16:.3e}")
+    assert not torch.equal(f32, b16), "residual_bf16 did not switch the stream"
+    assert torch.equal(b16, again)
+    assert r16 < 1e-2                                     # the adoption bar of the round (half the stated tolerance)
+    plain = m(x, text, t)                                 # unpinned: 256 rows take the tiled GEMMs and the fp32 stream ...
+    with _stream_bf16():
+        assert torch.equal(m(x, text, t), plain)          # ... whatever the switch says
+
+
+@torch.no_grad()
+def test_bf16_residual_stream_headline_shape_against_oracle():
+    """C2 at the timed batch (B = 32, N = T = 1024): utterance 0 against the fp32 oracle with the bf16 stream; batch
+    invariance (its bits in a batch of 20 and under a permutation) holds for the bf16 stream as for the fp32 one."""
+    from oracle import ditto_oracle as O
+    p = PRESETS["C2"]
+    cfg, N, T = p["cfg"], p["N"], p["T"]
+    m = build(cfg, 1234)
+    x0, text0, t0 = synthetic_inputs(cfg, 1, N, T, seed=7)
+    x1, text1, t1 = synthetic_inputs(cfg, 31, N, T, seed=8)
+    xd, td, tt = torch.cat([x0, x1]).to(DEV), torch.cat([text0, text1]).to(DEV), torch.cat([t0, t1]).to(DEV)
+    want = O.ditto_forward(synthetic_state_dict(cfg, 1234), cfg.num_layers, cfg.num_heads, x0, text0, t0)
+    f32 = m(xd, td, tt)
+    with _stream_bf16():
+        out = m(xd, td, tt)
+        assert torch.equal(m(xd[:20].contiguous(), td[:20].contiguous(), tt[:20].contiguous())[0], out[0])
+        perm = torch.randperm(32, generator=torch.Generator().manual_seed(5)).to(DEV)
+        assert torch.equal(m(xd[perm].contiguous(), td[perm].contiguous(), tt[perm].contiguous()), out[perm])
+    r32, r16 = close(f32[:1], want), close(out[:1], want)
+    print(f"C2 B=32 rel-L2 vs oracle: fp32 stream {r32:.3e}, bf16 stream {r16:.3e}; between the streams {rel_l2(out, f32):.3e}")
+    assert r16 < 1e-2 and not torch.equal(out, f32)
+
+
+@torch.no_grad()
+def test_bf16_residual_stream_sampling_loop_tracks_the_fp32_stream():
+    """The 50-step seeded loop at C2's size (B = 20: full-row class), bf16 stream against fp32 stream: the latents stay
+    within the loop tolerance of SURVEY.md 8c (rel-L2 <= 2e-2 at the last step; |x| grows to ~1e5 with untrained weights,
+    the sampler state x itself stays fp32 in both)."""
+    p = PRESETS["C2"]
+    cfg = p["cfg"]
+    m = build(cfg, 2)
+    sg = SpeechGenerator(ditto_model=m, device=DEV)
+    B, N, T = 20, p["N"], p["T"]
+    x, text, _ = synthetic_inputs(cfg, B, N, T, seed=11)
+    xd, td = x.to(DEV), text.to(DEV)
+    seeds = torch.arange(B, device=DEV) + 77
+    a = sg._SpeechGenerator__sample_latents(td, xd, seeds=seeds)
+    with _stream_bf16():
+        b = sg._SpeechGenerator__sample_latents(td, xd, seeds=seeds)
+    r = rel_l2(b, a)
+    print(f"C2 50-step loop, bf16 vs fp32 stream: rel-L2 {r:.3e}")
+    assert torch.isfinite(b).all() and r < 2e-2 and not torch.equal(a, b)
