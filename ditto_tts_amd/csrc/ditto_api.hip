@@ -58,6 +58,9 @@ ArenaPlan plan_arena(const ditto_config& c) {
         const bool fp8c = (c.flags & DITTO_CFG_FP8_LINEAR) != 0;
         const bool fr_o = (d == 768 && !fp8c) || d == 1024, fr_2 = (d == 768 || d == 1024) && !fp8c;
         q.WcoP = fr_o ? take(d * d * 2) : 0; q.W2P = fr_2 ? take(4 * d * d * 2) : 0;
+        // ... and of the cross q-projection for the fused norm2 + q-projection kernel (gemm_lnq.hip, d == 768): both MFMA shapes' images
+        const bool lnq = d == 768 && !fp8c;
+        q.WcqP = lnq ? take(d * d * 2) : 0; q.WcqP32 = lnq ? take(d * d * 2) : 0;
     }
     p.Wkv = take(L * 2 * d * d * 2); p.bkv = take(L * 2 * d * 4);
     p.Wfin = take(d * 2 * d * 2); p.bfin = take(d * 4);
@@ -85,6 +88,9 @@ static inline size_t text_scratch_bytes(const ditto_config& c, int B, int T) {
 static int g_splitk_wgs = [] { const char* e = getenv("DITTO_SPLITK_WGS"); return e ? atoi(e) : 0; }();
 // "residual_bf16": the residual stream h between the segments of a block lives in HBM as bf16 (fp32 only inside accumulators
 // and LayerNorm statistics) wherever the launch takes the full-row class at d = 768 / head_dim 64 (ditto_forward decides)
+// "lnq": norm2 fused into the cross-attention q-projection (gemm_lnq.hip) for launches of the full-row class at d = 768:
+// 0 = off (LayerNorm launch + tiled GEMM), 32 / 16 = on, with that MFMA shape (32x32x16 / 16x16x32)
+int g_lnq = [] { const char* e = getenv("DITTO_LNQ"); return e ? atoi(e) : 0; }();
 int g_resid_bf16 = [] { const char* e = getenv("DITTO_RESIDUAL_BF16"); return e ? atoi(e) : 0; }();
 int small_batch_k_splits(int M, int N, int K) {
     if (g_splitk_wgs <= 0) return 1;
@@ -246,12 +252,17 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
         }
         if (tap_self) HIP_TRY(hipMemcpyAsync(tap_self, h, (size_t)M * d * 4, hipMemcpyDeviceToDevice, s));
         // ---- cross-attention (src/components/DiT.py:141-148), K/V from the per-utterance cache ----
-        {
-            ProfScope ps(m, s, DITTO_KC_LAYERNORM);
-            if (hb) HIP_TRY(launch_layernorm_xbf16(h, lp.g2, lp.be2, u, d, M, d, s));
-            else HIP_TRY(launch_layernorm(h, lp.g2, lp.be2, u, d, M, d, s));
-        }
-        {
+        // norm2 + q-projection in one launch (gemm_lnq.hip) for the full-row class at d = 768; else LayerNorm launch + tiled GEMM
+        const bool lnq = g_lnq && lp.WcqP && d == 768 && fr_pays(M);
+        if (lnq) {
+            ProfScope ps(m, s, DITTO_KC_GEMM_QPROJ);
+            HIP_TRY(launch_gemm_lnq(h, d, hb, lp.g2, lp.be2, g_lnq == 16 ? lp.WcqP32 : lp.WcqP, lp.bcq, qkv, d, M, d, g_lnq, s));
+        } else {
+            {
+                ProfScope ps(m, s, DITTO_KC_LAYERNORM);
+                if (hb) HIP_TRY(launch_layernorm_xbf16(h, lp.g2, lp.be2, u, d, M, d, s));
+                else HIP_TRY(launch_layernorm(h, lp.g2, lp.be2, u, d, M, d, s));
+            }
             ProfScope ps(m, s, DITTO_KC_GEMM_QPROJ);
             GemmArgs g{};
             g.A = u; g.lda = d; g.W = lp.Wcq; g.bias = lp.bcq; g.out = qkv; g.ldo = d; g.M = M; g.N = d; g.K = d;
@@ -415,6 +426,10 @@ int ditto_model_create(const ditto_config* cfg, const ditto_weights* w, void* ar
         const bool fr_o = (d == 768 && !fp8) || d == 1024, fr_2 = (d == 768 || d == 1024) && !fp8;   // as plan_arena
         if (fr_o) HIP_TRY(launch_pack_bf16_stage_major(lw.cross_out_proj_weight, A + q.WcoP, d, d, s));
         if (fr_2) HIP_TRY(launch_pack_bf16_stage_major(lw.mlp_fc2_weight, A + q.W2P, d, 4 * d, s));
+        if (d == 768 && !fp8) {   // from the PACKED q-projection (it carries the folded scale * log2(e))
+            HIP_TRY(launch_repack_bf16_stage_major(A + q.Wcq, A + q.WcqP, d, d, s, 16));
+            HIP_TRY(launch_repack_bf16_stage_major(A + q.Wcq, A + q.WcqP32, d, d, s, 32));
+        }
         HIP_TRY(hipMemcpyAsync(A + q.bco, lw.cross_out_proj_bias, d * 4, hipMemcpyDeviceToDevice, s));
         // gated MLP: rows interleaved [16 x fc1 | 16 x gate] so both halves of a product meet in one lane
         HIP_TRY(launch_pack_vec(lw.mlp_fc1_bias, (float*)(A + q.b1g), 4 * d, 16, 2, 0, s));
@@ -432,6 +447,7 @@ int ditto_model_create(const ditto_config* cfg, const ditto_weights* w, void* ar
         lp.sqkv = (const float*)(A + q.sqkv); lp.s1g = (const float*)(A + q.s1g); lp.s2 = (const float*)(A + q.s2);
         if (fr_o) lp.WcoP = A + q.WcoP;
         if (fr_2) lp.W2P = A + q.W2P;
+        if (d == 768 && !fp8) { lp.WcqP = A + q.WcqP; lp.WcqP32 = A + q.WcqP32; }
         lp.g1 = (const float*)(A + q.g1); lp.be1 = (const float*)(A + q.be1); lp.g2 = (const float*)(A + q.g2);
         lp.be2 = (const float*)(A + q.be2); lp.g3 = (const float*)(A + q.g3); lp.be3 = (const float*)(A + q.be3);
     }
@@ -770,6 +786,19 @@ int ditto_gemm_tn_bf16(const void* X, int ldx, const void* Y, int ldy, float* ou
     return DITTO_OK;
 }
 
+int ditto_gemm_lnq_bf16(const void* h, int ldh, int h_is_bf16, const float* gamma, const float* beta, const void* W,
+                        const float* bias, void* out_bf16, int ldo, int M, int mfma_shape, void* w_scratch,
+                        ditto_stream_t stream) {
+    if (!h || !gamma || !beta || !W || !out_bf16 || !w_scratch || M <= 0 || ldh < 768 || ldo < 768 || ldh % 4 || ldo % 8)
+        return fail(DITTO_ERR_ARG, "bad argument to ditto_gemm_lnq_bf16");
+    if (mfma_shape != 32 && mfma_shape != 16) return fail(DITTO_ERR_ARG, "mfma_shape must be 32 (32x32x16) or 16 (16x16x32)");
+    if ((uintptr_t)w_scratch % 256) return fail(DITTO_ERR_ARG, "w_scratch must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(launch_repack_bf16_stage_major(W, w_scratch, 768, 768, s, mfma_shape == 32 ? 16 : 32));
+    HIP_TRY(launch_gemm_lnq(h, ldh, h_is_bf16 != 0, gamma, beta, w_scratch, bias, out_bf16, ldo, M, 768, mfma_shape, s));
+    return DITTO_OK;
+}
+
 int ditto_gemm_ln_bf16(const void* A, int lda, const void* W, const float* bias, const float* residual, float* out,
                        int ldo, const float* gamma, const float* beta, void* u_bf16, int ldu, int M, int N, int K,
                        ditto_stream_t stream) {
@@ -888,7 +917,7 @@ static int* option_slot(const char* name) {
         {"pp_mask", &g_pp_mask}, {"fr_mask", &g_fr_mask}, {"fr_class_rows", &g_fr_class_rows}, {"fr_dgrad", &g_fr_dgrad},
         {"train_flags", &g_train_flags}, {"fr_u_fp8", &g_fr_u_fp8}, {"fr_tile", &g_fr_tile}, {"fr64_maxk", &g_fr64_maxk},
         {"fr_stagger", &g_fr_stagger}, {"fr_rot", &g_fr_rot}, {"pp_nb", &g_pp_nb}, {"pp_stagger", &g_pp_stagger},
-        {"splitk_wgs", &g_splitk_wgs}, {"residual_bf16", &g_resid_bf16}};
+        {"splitk_wgs", &g_splitk_wgs}, {"residual_bf16", &g_resid_bf16}, {"lnq", &g_lnq}};
     for (auto& e : tab) if (!strcmp(name, e.n)) return e.p;
     return nullptr;
 }
@@ -998,6 +1027,11 @@ int ditto_set_option(const char* name, int value) {
     if (!strcmp(name, "pp_stagger")) {
         if (value < -1 || value > 100000) return fail(DITTO_ERR_ARG, "pp_stagger must be in [-1, 100000] (10 ns ticks; -1 = rule)");
         g_pp_stagger = value;
+        return DITTO_OK;
+    }
+    if (!strcmp(name, "lnq")) {
+        if (value != 0 && value != 16 && value != 32) return fail(DITTO_ERR_ARG, "lnq must be 0 (off), 32 or 16 (MFMA shape)");
+        g_lnq = value;
         return DITTO_OK;
     }
     if (!strcmp(name, "residual_bf16")) {

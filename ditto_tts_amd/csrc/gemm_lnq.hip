@@ -1,0 +1,354 @@
+// gemm_lnq.hip — LayerNorm (norm2) fused INTO the cross-attention q-projection, d = 768 (gfx950).
+//
+//     u = LayerNorm(h) * gamma + beta        (reference src/components/DiT.py:142-143; eps 1e-5, never written to HBM)
+//     q[M, 768] (bf16) = u W_q^T + b_q       (the q third of nn.MultiheadAttention's in-projection, :144-148 -> torch
+//                                             functional.py; scale * log2(e) is folded into W_q / b_q at model creation)
+//
+// Before: ln_kernel (h -> u, 27 us, 150 MB) + a tiled d x d GEMM (u -> q, 48 us) = two launches, 250 MB, for 38.7 GFLOP.
+// Here a workgroup owns 64 WHOLE rows: one pass over h leaves the 64 normalised rows in the LDS as the bf16 A operand
+// (64 x 768 x 2 B = 96 KiB, resident for the whole K loop: the main loop carries no A traffic at all), W_q streams
+// straight from L2 into registers as in gemm_frd.hip (stage-major image, one global_load_dwordx4 per MFMA fragment, a
+// register ring behind counted vmcnt waits — the only vector-memory operations of the loop, so the count is a constant),
+// and the output tile leaves through the same 96 KiB as whole 128-B lines.
+//
+//   tile      64 rows x 768 columns, one workgroup (4 waves, one per SIMD) per CU; wave wn owns all 64 rows x columns
+//             [192 wn, +192): 192 accumulators, all in AGPRs.  M = 32768: 512 tiles = two rounds of the 256 CUs.
+//   SHAPE 32  v_mfma_f32_32x32x16_bf16, weights as the instruction's A operand (the accumulator is C^T: a lane owns 4
+//             consecutive output columns of one row): 2 x 6 blocks, K = 16 per stage, 48 stages, ring of 4 stages.
+//   SHAPE 16  v_mfma_f32_16x16x32_bf16, same roles: 4 x 12 blocks, K = 32 per stage, 24 stages, ring of 2 stages — the
+//             same bytes, MFMA cycles and look-ahead (64 k); the A/B of VERDICT r3 item 3 (the chip can hold a higher
+//             clock on one MFMA shape than on the other: MI355X_MICROARCH.md, DVFS give-back item 7).
+//   W image   SHAPE 32: Wp[K/16][768][16] (launch_repack_bf16_stage_major, group 16); SHAPE 16: Wp[K/32][768][32]
+//             (group 32).  Fragment (stage, column block) of a wave = 1 contiguous KiB; a lane takes 16 bytes of it.
+//   A image   [64 rows][1536 B], 16-byte chunk c of row r at c ^ (r & 15) (low four bits: a 256-B span holds 16 chunks =
+//             all 64 banks, and row strides are multiples of 256 B): conflict-free for the LayerNorm's ds_write_b64, the
+//             fragment ds_read_b128 of both shapes, the epilogue's ds_write_b64 and its row-contiguous read-back.
+//   LayerNorm one wave per row, the row in registers, statistics in ln_kernel's order (rowwise.hip): for the same h the
+//             normalised row is the LayerNorm kernel's bit for bit.  h is fp32 or bf16 (the bf16 residual stream).
+#include <type_traits>
+
+#include "gemm_common.h"
+
+namespace ditto {
+
+namespace {
+
+constexpr int QM = 64, QN = 768, QKD = 768;
+constexpr int Q_AROW = QKD * 2;            // 1536 B per A row
+constexpr int Q_A = QM * Q_AROW;           // 96 KiB: the normalised rows, later the output tile
+constexpr int Q_BIAS = Q_A;                // bias row (3 KiB) behind it
+constexpr int Q_LDS = Q_A + QN * 4;        // 99 KiB
+
+template <int V>
+struct QC { static constexpr int value = V; };
+
+template <int SHAPE>
+struct Geo;
+template <>
+struct Geo<32> {
+    static constexpr int NBW = 6, MBW = 2, KS = 16, NKT = QKD / 16, R = 4, PER = 8;   // PER: stages per A-swizzle period
+    using acc_t = f32x16;
+};
+template <>
+struct Geo<16> {
+    static constexpr int NBW = 12, MBW = 4, KS = 32, NKT = QKD / 32, R = 2, PER = 4;
+    using acc_t = f32x4;
+};
+
+DITTO_DEV void q_mfma(f32x16& c, const f32x4& w, const bf16x8& a) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(w), "v"(a));
+}
+DITTO_DEV void q_mfma(f32x4& c, const f32x4& w, const bf16x8& a) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(w), "v"(a));
+}
+// last MFMA of a chain: its wait states inside the statement (hipcc knows nothing about an asm producer: gemm_fr.hip)
+DITTO_DEV void q_mfma_last(f32x16& c, const f32x4& w, const bf16x8& a) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 15" : "+a"(c) : "v"(w), "v"(a));
+}
+DITTO_DEV void q_mfma_last(f32x4& c, const f32x4& w, const bf16x8& a) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 9" : "+a"(c) : "v"(w), "v"(a));
+}
+template <int IMM>
+DITTO_DEV void q_wload(f32x4& dst, unsigned voff, const char* base) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(base), "n"(IMM) : "memory");
+}
+template <int VM>
+DITTO_DEV void q_wait(f32x4& frag) {   // counted wait that ties the fragment's registers: no use moves above it
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(frag) : "n"(VM) : "memory");
+}
+
+// Loads a wave has issued AFTER the load of W fragment (s, nb) when MFMA (s, nb) is about to issue (issue order: the ring
+// prologue stage by stage, then fragment nb of stage s + R right behind the MFMAs of (s, nb)); `rem` = stages after s.
+constexpr int lnq_vm(int NBW, int R, int nb, int rem) {
+    const int full = rem < R - 1 ? rem : R - 1;          // whole stages s+1 .. s+R-1 that exist
+    return (NBW - 1 - nb) + full * NBW + (rem >= R ? nb : 0);
+}
+static_assert(lnq_vm(6, 4, 0, 47) == 23 && lnq_vm(6, 4, 5, 10) == 23 && lnq_vm(6, 4, 0, 3) == 23 && lnq_vm(6, 4, 5, 3) == 18 &&
+              lnq_vm(6, 4, 0, 0) == 5 && lnq_vm(6, 4, 5, 0) == 0 && lnq_vm(12, 2, 3, 9) == 23 && lnq_vm(12, 2, 11, 1) == 12 &&
+              lnq_vm(12, 2, 11, 0) == 0, "wait counts");
+
+struct LnqParams {
+    const void* h; int ldh;                 // fp32 or bf16 rows (XB)
+    const float* gamma; const float* beta;
+    const char* Wp;                         // stage-major weight image of the SHAPE
+    const float* bias;
+    bf16* out; int ldo;
+    int M;
+};
+
+template <int SHAPE, bool XB>
+__global__ __launch_bounds__(256, 1) void gemm_lnq_kernel(LnqParams p) {
+    using G = Geo<SHAPE>;
+    using acc_t = typename G::acc_t;
+    constexpr int NBW = G::NBW, MBW = G::MBW, NKT = G::NKT, R = G::R, PER = G::PER;
+    constexpr int W_STAGE = QN * G::KS * 2;                              // bytes of one stage of W (24 / 48 KiB)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * QM;
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+
+    // bias row -> LDS (3 pieces of 1 KiB), wave 3; landed and visible behind the barrier that ends the LayerNorm
+    if (wid == 3) {
+        if (p.bias) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) glds16(p.bias + i * 256 + lane * 4, lds_base + (unsigned)(Q_BIAS + i * 1024));
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) *reinterpret_cast<f32x4*>(smem + Q_BIAS + i * 1024 + lane * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+
+    // ---- W: straight into registers.  (The ring's first loads go out AFTER the LayerNorm: an asm load issued between a
+    //      compiler-visible load and the compiler's own counted wait for it would make that wait too short.)
+    // fragment (stage, nb) of this wave: stage * W_STAGE + (NBW wn + nb) KiB; the lane's 16 bytes inside the KiB:
+    //   SHAPE 32: row (lane & 31) x 32 B + (lane >> 5) x 16;   SHAPE 16: row (lane & 15) x 64 B + (lane >> 4) x 16
+    const unsigned vw = (unsigned)(wid * NBW * 1024) +
+                        (SHAPE == 32 ? (unsigned)((lane & 31) * 32 + (lane >> 5) * 16) : (unsigned)((lane & 15) * 64 + (lane >> 4) * 16));
+    const char* wbase = p.Wp;                                            // wave-uniform, advanced by W_STAGE per stage issued
+    f32x4 wr[R][NBW];
+    auto issue_w = [&](auto NB, f32x4& dst) {
+        constexpr int nb = decltype(NB)::value;
+        q_wload<(nb & 3) * 1024>(dst, vw + (unsigned)((nb >> 2) * 4096), wbase);
+    };
+    auto issue_stage = [&](f32x4 (&slot)[NBW]) {
+        issue_w(QC<0>{}, slot[0]); issue_w(QC<1>{}, slot[1]); issue_w(QC<2>{}, slot[2]);
+        issue_w(QC<3>{}, slot[3]); issue_w(QC<4>{}, slot[4]); issue_w(QC<5>{}, slot[5]);
+        if constexpr (NBW == 12) {
+            issue_w(QC<6>{}, slot[6]); issue_w(QC<7>{}, slot[7]); issue_w(QC<8>{}, slot[8]);
+            issue_w(QC<9>{}, slot[9]); issue_w(QC<10>{}, slot[10]); issue_w(QC<11>{}, slot[11]);
+        }
+        wbase += W_STAGE;
+    };
+
+    // ---- LayerNorm of the tile's 64 rows -> LDS (bf16, swizzled): wave w takes rows 16 w .. 16 w + 15, eight at a time ----
+    {
+        f32x4 g4[3], b4[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            g4[c] = reinterpret_cast<const f32x4*>(p.gamma)[lane + 64 * c];
+            b4[c] = reinterpret_cast<const f32x4*>(p.beta)[lane + 64 * c];
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x4 v[8][3];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                int gr = m0 + wid * 16 + half * 8 + r;
+                gr = gr < p.M ? gr : p.M - 1;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if constexpr (XB) {
+                        const u32x2 w2 = reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16*>(p.h) + (size_t)gr * p.ldh)[lane + 64 * c];
+                        v[r][c] = f32x4{bf16_lo(w2[0]), bf16_hi(w2[0]), bf16_lo(w2[1]), bf16_hi(w2[1])};
+                    } else {
+                        v[r][c] = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.h) + (size_t)gr * p.ldh)[lane + 64 * c];
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                // ln_kernel's arithmetic, statement for statement (rowwise.hip): the same bits for the same row
+                float s = 0.f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) s += (v[r][c][0] + v[r][c][1]) + (v[r][c][2] + v[r][c][3]);
+                const float mean = wave_sum(s) / (float)QKD;
+                float q = 0.f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float dlt = v[r][c][e] - mean;
+                        q += dlt * dlt;
+                    }
+                }
+                const float rstd = rsqrtf(wave_sum(q) / (float)QKD + 1e-5f);
+                const int row = wid * 16 + half * 8 + r;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    u32x2 o;
+                    o[0] = pack_bf16x2((v[r][c][0] - mean) * rstd * g4[c][0] + b4[c][0], (v[r][c][1] - mean) * rstd * g4[c][1] + b4[c][1]);
+                    o[1] = pack_bf16x2((v[r][c][2] - mean) * rstd * g4[c][2] + b4[c][2], (v[r][c][3] - mean) * rstd * g4[c][3] + b4[c][3]);
+                    const int chunk = (lane + 64 * c) >> 1;                // 16-B chunk of the row holding k = 4 (lane + 64 c) ..
+                    *reinterpret_cast<u32x2*>(smem + row * Q_AROW + ((chunk ^ (row & 15)) << 4) + (lane & 1) * 8) = o;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // (wave 3: the bias pieces)
+    __syncthreads();
+
+    // ring prologue: from here on the W loads are the ONLY vector-memory operations until the epilogue's stores
+#pragma unroll
+    for (int r = 0; r < R; ++r) issue_stage(wr[r]);
+
+    // ---- accumulators: zero, pinned in AGPRs ----
+    acc_t acc[NBW][MBW];
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < MBW; ++mb) {
+#pragma unroll
+            for (int e = 0; e < (int)(sizeof(acc_t) / 4); ++e) acc[nb][mb][e] = 0.f;
+            asm volatile("" : "+a"(acc[nb][mb]));
+        }
+
+    // ---- A fragment addressing.  SHAPE 32: lane (m = lane & 31, hh = lane >> 5) of row block mb reads row 32 mb + m, chunk
+    //      2 s + hh;  SHAPE 16: lane (m = lane & 15, kq = lane >> 4) reads row 16 mb + m, chunk 4 s + kq.  row & 15 = m & 15 for
+    //      every mb, and the chunk's low four bits are ((KCH s) & 15) ^ sub (no carry), so the swizzled byte offset is
+    //      row * 1536 + (whole 256-B spans) + ((((KCH s) & 15) << 4) ^ y),  y = (sub ^ (m & 15)) << 4: PER distinct lane terms. ----
+    constexpr int KCH = SHAPE == 32 ? 2 : 4;                              // 16-B chunks of A per stage
+    const int am = SHAPE == 32 ? (lane & 31) : (lane & 15);
+    const int asub = SHAPE == 32 ? (lane >> 5) : (lane >> 4);
+    const unsigned ay = (unsigned)((asub ^ (am & 15)) << 4);
+    unsigned aoff[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) aoff[j] = (unsigned)(am * Q_AROW) + ((unsigned)(((KCH * j) & 15) << 4) ^ ay);
+    constexpr int MB_STRIDE = (SHAPE == 32 ? 32 : 16) * Q_AROW;           // bytes between row blocks
+    bf16x8 a0[MBW], a1[MBW];
+    auto read_a = [&](bf16x8 (&dst)[MBW], int span_bytes, unsigned lane_off) {
+#pragma unroll
+        for (int mb = 0; mb < MBW; ++mb)
+            dst[mb] = *reinterpret_cast<const bf16x8*>(smem + lane_off + span_bytes + mb * MB_STRIDE);
+    };
+    read_a(a0, 0, aoff[0]);
+
+    // One stage: MFMAs of (s, nb) behind the fragment's counted wait, then fragment nb of stage s + R into the same registers;
+    // the next stage's A fragments are read behind the first column block.  J: position in the swizzle period (compile time),
+    // REM: stages after this one when that is < R (the tail), else R.
+    auto stage = [&](auto J, auto REMC, int span_next, f32x4 (&slot)[NBW], bf16x8 (&ACUR)[MBW], bf16x8 (&ANXT)[MBW]) {
+        constexpr int j = decltype(J)::value, remc = decltype(REMC)::value;
+        constexpr bool last = remc == 0, do_w = remc >= R;
+        auto block = [&](auto NB) {
+            constexpr int nb = decltype(NB)::value;
+            q_wait<lnq_vm(NBW, R, nb, remc)>(slot[nb]);
+#pragma unroll
+            for (int mb = 0; mb < MBW; ++mb) {
+                if constexpr (last) q_mfma_last(acc[nb][mb], slot[nb], ACUR[mb]);
+                else q_mfma(acc[nb][mb], slot[nb], ACUR[mb]);
+            }
+            if constexpr (do_w) issue_w(NB, slot[nb]);
+            if constexpr (nb == 0 && !last) read_a(ANXT, span_next, aoff[(j + 1) % PER]);
+        };
+        block(QC<0>{}); block(QC<1>{}); block(QC<2>{}); block(QC<3>{}); block(QC<4>{}); block(QC<5>{});
+        if constexpr (NBW == 12) {
+            block(QC<6>{}); block(QC<7>{}); block(QC<8>{}); block(QC<9>{}); block(QC<10>{}); block(QC<11>{});
+        }
+        if constexpr (do_w) wbase += W_STAGE;
+    };
+    // a period = PER stages = one 256-B span of A (16 chunks); stage s of the period reads the NEXT stage's fragments, which
+    // sit in the next span when j = PER - 1
+    constexpr int NPER = NKT / PER;                                       // 6 periods
+    static_assert(NKT % PER == 0 && PER % R == 0 && PER % 2 == 0, "period structure");
+    auto period = [&](auto LASTP, int span) {
+        constexpr bool lastp = decltype(LASTP)::value != 0;
+        // REM for stage j of the last period: PER - 1 - j (capped at R: the steady-state value)
+        if constexpr (PER == 8) {
+            stage(QC<0>{}, QC<(lastp ? (7 < R ? 7 : R) : R)>{}, span, wr[0], a0, a1);
+            stage(QC<1>{}, QC<(lastp ? (6 < R ? 6 : R) : R)>{}, span, wr[1], a1, a0);
+            stage(QC<2>{}, QC<(lastp ? (5 < R ? 5 : R) : R)>{}, span, wr[2], a0, a1);
+            stage(QC<3>{}, QC<(lastp ? (4 < R ? 4 : R) : R)>{}, span, wr[3], a1, a0);
+            stage(QC<4>{}, QC<(lastp ? 3 : R)>{}, span, wr[0], a0, a1);
+            stage(QC<5>{}, QC<(lastp ? 2 : R)>{}, span, wr[1], a1, a0);
+            stage(QC<6>{}, QC<(lastp ? 1 : R)>{}, span, wr[2], a0, a1);
+            stage(QC<7>{}, QC<(lastp ? 0 : R)>{}, span + 256, wr[3], a1, a0);
+        } else {
+            stage(QC<0>{}, QC<(lastp ? (3 < R ? 3 : R) : R)>{}, span, wr[0], a0, a1);
+            stage(QC<1>{}, QC<(lastp ? (2 < R ? 2 : R) : R)>{}, span, wr[1], a1, a0);
+            stage(QC<2>{}, QC<(lastp ? 1 : R)>{}, span, wr[0], a0, a1);
+            stage(QC<3>{}, QC<(lastp ? 0 : R)>{}, span + 256, wr[1], a1, a0);
+        }
+    };
+    int span = 0;
+    for (int pi = 0; pi + 1 < NPER; ++pi) {
+        period(QC<0>{}, span);
+        span += 256;
+    }
+    period(QC<1>{}, span);
+
+    // ---------------- epilogue: q = acc + bias -> bf16, staged through the A region (every wave is done reading it) ----------------
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    __syncthreads();
+    const float* lbias = reinterpret_cast<const float*>(smem + Q_BIAS);
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+#pragma unroll
+        for (int mb = 0; mb < MBW; ++mb) {
+            asm volatile("" : "+a"(acc[nb][mb]));                         // re-pin: the copy below is a NEW value, never hoisted
+            const acc_t v = acc[nb][mb];
+            if constexpr (SHAPE == 32) {
+                const int row = mb * 32 + (lane & 31);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = wid * 192 + nb * 32 + 8 * g + 4 * (lane >> 5);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(lbias + col);
+                    u32x2 st;
+                    st[0] = pack_bf16x2(v[4 * g] + b[0], v[4 * g + 1] + b[1]);
+                    st[1] = pack_bf16x2(v[4 * g + 2] + b[2], v[4 * g + 3] + b[3]);
+                    *reinterpret_cast<u32x2*>(smem + row * Q_AROW + (((col >> 3) ^ (row & 15)) << 4) + (col & 7) * 2) = st;
+                }
+            } else {
+                const int row = mb * 16 + (lane & 15);
+                const int col = wid * 192 + nb * 16 + 4 * (lane >> 4);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(lbias + col);
+                u32x2 st;
+                st[0] = pack_bf16x2(v[0] + b[0], v[1] + b[1]);
+                st[1] = pack_bf16x2(v[2] + b[2], v[3] + b[3]);
+                *reinterpret_cast<u32x2*>(smem + row * Q_AROW + (((col >> 3) ^ (row & 15)) << 4) + (col & 7) * 2) = st;
+            }
+        }
+    }
+    __syncthreads();
+    // read-back: 64 rows x 96 chunks of 16 B, chunk id = tid + 256 i: lanes walk a row's chunks, whole 128-B lines per store
+#pragma unroll 4
+    for (int i = 0; i < QM * 96 / 256; ++i) {
+        const int id = tid + 256 * i;
+        const int row = id / 96, c = id - row * 96;
+        const u32x4 val = *reinterpret_cast<const u32x4*>(smem + row * Q_AROW + ((c ^ (row & 15)) << 4));
+        if (m0 + row < p.M) *reinterpret_cast<u32x4*>(p.out + (size_t)(m0 + row) * p.ldo + c * 8) = val;
+    }
+}
+
+template <int SHAPE, bool XB>
+hipError_t launch_lnq_t(const LnqParams& p, hipStream_t s) {
+    static DevOnce lds_once;
+    if (hipError_t e = set_max_lds_once(lds_once, {reinterpret_cast<const void*>(&gemm_lnq_kernel<SHAPE, XB>)}, Q_LDS)) return e;
+    hipLaunchKernelGGL((gemm_lnq_kernel<SHAPE, XB>), dim3((p.M + QM - 1) / QM), dim3(256), Q_LDS, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// h: fp32 [M, ldh] (h_bf16 false) or bf16 [M, ldh]; Wp: the stage-major image of W_q for `shape` (32: group 16, 16: group 32)
+hipError_t launch_gemm_lnq(const void* h, int ldh, bool h_bf16, const float* gamma, const float* beta, const void* Wp,
+                           const float* bias, void* out_bf16, int ldo, int M, int d, int shape, hipStream_t s) {
+    if (d != QN || M <= 0 || !h || !gamma || !beta || !Wp || !out_bf16 || (shape != 32 && shape != 16)) return hipErrorInvalidValue;
+    if (ldh % 4 || ldo % 8) return hipErrorInvalidValue;
+    LnqParams p;
+    p.h = h; p.ldh = ldh; p.gamma = gamma; p.beta = beta; p.Wp = (const char*)Wp; p.bias = bias;
+    p.out = (bf16*)out_bf16; p.ldo = ldo; p.M = M;
+    if (shape == 32) return h_bf16 ? launch_lnq_t<32, true>(p, s) : launch_lnq_t<32, false>(p, s);
+    return h_bf16 ? launch_lnq_t<16, true>(p, s) : launch_lnq_t<16, false>(p, s);
+}
+
+}  // namespace ditto

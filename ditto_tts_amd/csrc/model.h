@@ -20,6 +20,7 @@ inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct LayerPack {
     const void *Wqkv, *Wcq, *Wco, *W1g, *W2;
+    const void *WcqP = nullptr, *WcqP32 = nullptr;   // stage-major images of the cross q-projection for gemm_lnq.hip (d == 768 bf16): k-group 16 / 32
     const void *WcoP = nullptr, *W2P = nullptr;   // stage-major copies for the full-row kernels (d == 768 bf16; d == 1024: WcoP always, W2P bf16)
     const float *sqkv, *s1g, *s2;   // fp8 weight scales (DITTO_CFG_FP8_LINEAR)
     const float *bqkv, *bcq, *bco, *b1g, *b2;
@@ -35,7 +36,7 @@ struct LayerPackT {
 
 struct ArenaPlan {
     size_t total = 0;
-    struct L { size_t Wqkv, Wcq, Wco, W1g, W2, bqkv, bcq, bco, b1g, b2, g1, be1, g2, be2, g3, be3, sqkv, s1g, s2, WcoP, W2P; };
+    struct L { size_t Wqkv, Wcq, Wco, W1g, W2, bqkv, bcq, bco, b1g, b2, g1, be1, g2, be2, g3, be3, sqkv, s1g, s2, WcoP, W2P, WcqP, WcqP32; };
     std::vector<L> layers;
     size_t Wkv, bkv, Wfin, bfin, ttab, wx, bx, invf, invf_rev;
 };

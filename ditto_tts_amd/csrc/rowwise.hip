@@ -608,21 +608,22 @@ hipError_t launch_pack_bf16_stage_major(const float* src, void* dst, int N, int 
 }
 // the same re-layout of an already packed bf16 [N, K] image (the transposed weights of the dgrad GEMMs)
 __global__ __launch_bounds__(256) void repack_bf16_stage_major_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst,
-                                                                      int N, int K) {
-    const size_t n8 = (size_t)N * K / 8;                 // 16-B chunks: a chunk stays whole inside its 16-element group
+                                                                      int N, int K, int G) {
+    const size_t n8 = (size_t)N * K / 8;                 // 16-B chunks: a chunk stays whole inside its G-element group
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
         const size_t e = i * 8;
         const int r = (int)(e / K), c = (int)(e % K);
-        *reinterpret_cast<u32x4*>(dst + ((size_t)(c >> 4) * N + r) * 16 + (c & 15)) = *reinterpret_cast<const u32x4*>(src + e);
+        *reinterpret_cast<u32x4*>(dst + ((size_t)(c / G) * N + r) * G + (c % G)) = *reinterpret_cast<const u32x4*>(src + e);
     }
 }
-hipError_t launch_repack_bf16_stage_major(const void* src, void* dst, int N, int K, hipStream_t s) {
-    if (K % 16) return hipErrorInvalidValue;
+// group = k per stage: 16 (the 32x32x16 kernels' image Wp[K/16][N][16]) or 32 (the 16x16x32 image Wp[K/32][N][32], gemm_lnq.hip)
+hipError_t launch_repack_bf16_stage_major(const void* src, void* dst, int N, int K, hipStream_t s, int group) {
+    if ((group != 16 && group != 32) || K % group) return hipErrorInvalidValue;
     const size_t n8 = (size_t)N * K / 8;
     size_t g = (n8 + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(repack_bf16_stage_major_kernel, dim3((unsigned)(g ? g : 1)), dim3(256), 0, s, (const bf16*)src,
-                       (bf16*)dst, N, K);
+                       (bf16*)dst, N, K, group);
     return hipGetLastError();
 }
 __global__ void scale_vec_kernel(float* __restrict__ v, int n, float f) {

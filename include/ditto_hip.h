@@ -237,6 +237,16 @@ int ditto_gemm_ln_bf16(const void* A, int lda, const void* W, const float* bias,
                        int ldo, const float* gamma, const float* beta, void* u_bf16, int ldu, int M, int N, int K,
                        ditto_stream_t stream);
 
+/* LayerNorm fused INTO the GEMM that consumes it (csrc/gemm_lnq.hip; the model path's norm2 + cross-attention q-projection,
+ * src/components/DiT.py:142-145, d = 768):  out bf16 [M, ldo] = (LayerNorm(h) * gamma + beta) W[768, 768]^T + bias, eps 1e-5;
+ * the normalised rows live in the LDS only.  h: fp32 [M, ldh] or (h_is_bf16) bf16 [M, ldh]; W: bf16, nn.Linear layout
+ * [768 out, 768 in]; bias may be NULL.  mfma_shape 32 / 16 = v_mfma_f32_32x32x16_bf16 / 16x16x32 (two builds of one kernel).
+ * w_scratch: 768 * 768 * 2 bytes, 256-byte aligned: receives the stage-major image of W the kernel streams (the model keeps
+ * these images in its arena).  Any M >= 1. */
+int ditto_gemm_lnq_bf16(const void* h, int ldh, int h_is_bf16, const float* gamma, const float* beta, const void* W,
+                        const float* bias, void* out_bf16, int ldo, int M, int mfma_shape, void* w_scratch,
+                        ditto_stream_t stream);
+
 /* Weight-gradient GEMM of the backward pass (csrc/gemm_tn.hip): out fp32 [Mo, No] = X[K, Mo]^T Y[K, No], both operands
  * K-major bf16 (rows = the contraction index, as activations and their gradients lie in memory), i.e. dW = dY^T X of
  * nn.Linear (what autograd computes for reference src/TrainDiTTO.py:90).  tile = 128 (128x128, two workgroups per CU) or
@@ -282,6 +292,11 @@ int ditto_gemm_tn_bf16(const void* X, int ldx, const void* Y, int ldy, float* ou
  * persistent 256x256 kernel runs its K loop flat over the tile switch, bit-identical results).
  * "gemm_group": forced super-column width of the GEMM tile order (A/B tool; 0 = the built-in rule, which a sweep of
  * 3 / 4 / 6 / 12 / 24 at C2 B = 32 did not beat).
+ * "residual_bf16": 1 = the residual stream h between the segments of a block lives in HBM as bf16 (fp32 only inside the
+ * accumulators and the LayerNorm statistics) for launches of the full-row class at d = 768 / head_dim 64; 0 = fp32 stream.
+ * The sampler state x and eps stay fp32 either way.  (DITTO_RESIDUAL_BF16 in the environment sets the initial value.)
+ * "lnq": norm2 fused into the cross-attention q-projection (csrc/gemm_lnq.hip) for launches of the full-row class at d = 768:
+ * 0 = LayerNorm launch + tiled GEMM, 32 / 16 = fused, on that MFMA shape.  (DITTO_LNQ sets the initial value.)
  * "splitk_wgs": low-latency mode for batches of 1-2 utterances: workgroups the long-K GEMMs (fc2, final projection)
  * are split over (K-splits with an ordered fp32 reduce; 256 is the measured choice: -10 % step time at B = 1).
  * Default 0 = never split, which keeps an utterance's result bit-identical whatever else is in its batch. */

@@ -672,3 +672,71 @@ def test_full_row_gemm_on_64_row_tiles_is_bitwise_the_128_row_kernel(lib, M, K, 
         assert rel_l2(h64, want) < 1e-5 and max_abs(h64, want) < 2e-4, key
         assert torch.equal(h64, h128), (key, float((h64 - h128).abs().max()))
         assert torch.equal(u64, u128), (key, float((u64.float() - u128.float()).abs().max()))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# csrc/gemm_lnq.hip: LayerNorm fused INTO the GEMM that consumes it (the model's norm2 + cross-attention q-projection)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [32, 16])
+@pytest.mark.parametrize("h_bf16", [False, True])
+@pytest.mark.parametrize("M", [64, 1, 63, 65, 200, 1024, 2048 + 37])
+def test_layernorm_fused_into_the_q_projection(lib, M, h_bf16, shape):
+    """ditto_gemm_lnq_bf16: out = (LayerNorm(h) * gamma + beta) W^T + bias with the normalised rows in the LDS only, both MFMA
+    shapes, fp32 and bf16 rows, ragged M (a partial last 64-row tile, a single row).  Against (a) the fp32 ops on the SAME
+    bf16-rounded normalised rows — the kernel's LayerNorm is the LayerNorm kernel's arithmetic statement for statement, so
+    that rounding is reproduced exactly — tolerance 4e-3 (bf16 output), and (b) the two-launch path it replaces
+    (ditto_layernorm_bf16 + ditto_gemm_bf16): same inputs to the MFMAs, so the difference is summation order + one
+    output rounding (rel-L2 < 3e-3); rows do not depend on what else is in the launch (bitwise, against a 1-row launch)."""
+    d = 768
+    h = (asym((M, d), 31) * 1.7 + 0.4).to(DEV)
+    if h_bf16:
+        hin = bf16(h)
+        href = hin.float()
+    else:
+        hin, href = h, h
+    gamma = (1 + 0.2 * asym((d,), 32)).to(DEV)
+    beta = (0.1 * asym((d,), 33)).to(DEV)
+    W = bf16((asym((d, d), 34) / math.sqrt(d)).to(DEV))
+    bias = (0.1 * asym((d,), 35)).to(DEV)
+    scratch = torch.empty(d * d * 2, dtype=torch.uint8, device=DEV)
+    out = torch.full((M, d), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.check(lib.ditto_gemm_lnq_bf16(hin.data_ptr(), d, int(h_bf16), gamma.data_ptr(), beta.data_ptr(), W.data_ptr(),
+                                      bias.data_ptr(), out.data_ptr(), d, M, shape, scratch.data_ptr(), stream()))
+    assert torch.isfinite(out.float()).all()
+    # (b) the two launches it replaces (fp32 rows: ditto_layernorm_bf16 takes fp32)
+    u = torch.empty(M, d, dtype=torch.bfloat16, device=DEV)
+    hip.check(lib.ditto_layernorm_bf16(href.contiguous().data_ptr(), gamma.data_ptr(), beta.data_ptr(), u.data_ptr(), M, d, stream()))
+    two = torch.empty(M, d, dtype=torch.bfloat16, device=DEV)
+    hip.check(lib.ditto_gemm_bf16(u.data_ptr(), d, W.data_ptr(), bias.data_ptr(), None, two.data_ptr(), d, M, d, d, 0, stream()))
+    # (a) fp32 ops on the LayerNorm kernel's own bf16 output
+    want = u.float() @ W.float().T + bias
+    assert rel_l2(out.float(), want) < 4e-3, rel_l2(out.float(), want)
+    assert rel_l2(out.float(), two.float()) < 3e-3
+    # no bias; and one row alone gives that row's bits
+    out0 = torch.empty_like(out)
+    hip.check(lib.ditto_gemm_lnq_bf16(hin.data_ptr(), d, int(h_bf16), gamma.data_ptr(), beta.data_ptr(), W.data_ptr(),
+                                      None, out0.data_ptr(), d, M, shape, scratch.data_ptr(), stream()))
+    assert rel_l2(out0.float(), want - bias) < 4e-3
+    r = M // 2
+    one = torch.empty(1, d, dtype=torch.bfloat16, device=DEV)
+    hip.check(lib.ditto_gemm_lnq_bf16(hin[r:r + 1].contiguous().data_ptr(), d, int(h_bf16), gamma.data_ptr(), beta.data_ptr(),
+                                      W.data_ptr(), bias.data_ptr(), one.data_ptr(), d, 1, shape, scratch.data_ptr(), stream()))
+    assert torch.equal(one[0], out[r])
+
+
+def test_fused_q_projection_normalises_exactly_like_the_layernorm_kernel(lib):
+    """With W = identity the fused kernel's output IS bf16(its normalised rows) (products by 1 and 0 are exact, the fp32 sum
+    of one non-zero term is exact): bit-identical to ditto_layernorm_bf16 for both MFMA shapes."""
+    d, M = 768, 320
+    h = (asym((M, d), 41) * 2.3 - 0.7).to(DEV)
+    gamma = (1 + 0.3 * asym((d,), 42)).to(DEV)
+    beta = (0.2 * asym((d,), 43)).to(DEV)
+    W = bf16(torch.eye(d, device=DEV))
+    scratch = torch.empty(d * d * 2, dtype=torch.uint8, device=DEV)
+    u = torch.empty(M, d, dtype=torch.bfloat16, device=DEV)
+    hip.check(lib.ditto_layernorm_bf16(h.data_ptr(), gamma.data_ptr(), beta.data_ptr(), u.data_ptr(), M, d, stream()))
+    for shape in (32, 16):
+        out = torch.empty(M, d, dtype=torch.bfloat16, device=DEV)
+        hip.check(lib.ditto_gemm_lnq_bf16(h.data_ptr(), d, 0, gamma.data_ptr(), beta.data_ptr(), W.data_ptr(), None,
+                                          out.data_ptr(), d, M, shape, scratch.data_ptr(), stream()))
+        assert torch.equal(out, u), shape

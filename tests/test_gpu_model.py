@@ -786,3 +786,29 @@ def test_bf16_residual_stream_sampling_loop_tracks_the_fp32_stream():
     r = rel_l2(b, a)
     print(f"C2 50-step loop, bf16 vs fp32 stream: rel-L2 {r:.3e}")
     assert torch.isfinite(b).all() and r < 2e-2 and not torch.equal(a, b)
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("shape", [32, 16])
+@pytest.mark.parametrize("stream16", [0, 1])
+def test_norm2_fused_into_the_q_projection_g2_golden(golden, shape, stream16):
+    """ditto_set_option("lnq", 32 | 16): norm2 + the cross-attention q-projection as one launch (csrc/gemm_lnq.hip) in the
+    model, on the fp32 and on the bf16 residual stream, kernel class pinned to the timed batch: G2 within tolerance,
+    deterministic, and within 4e-3 of the two-launch path (same operands, another summation order)."""
+    g = golden("G2_ditto_s.npz")
+    cfg = DiTTOConfig(768, 12, 12, 256, 768, 50)
+    m = build(cfg, 2)
+    x, text, t = (z.to(DEV) for z in synthetic_inputs(cfg, 2, 128, 96, seed=22))
+    prev = hip.get_option("lnq")
+    try:
+        with hip.batch_class(32 * 1024), _stream_bf16(stream16):
+            hip.set_option("lnq", 0)
+            two = m(x, text, t)
+            hip.set_option("lnq", shape)
+            out = m(x, text, t)
+            again = m(x, text, t)
+    finally:
+        hip.set_option("lnq", prev)
+    r = close(out, g["out"])
+    print(f"G2 12L, lnq {shape}, bf16 stream {stream16}: rel-L2 {r:.3e}; vs two launches {rel_l2(out, two):.3e}")
+    assert torch.equal(out, again) and not torch.equal(out, two) and rel_l2(out, two) < 4e-3

@@ -176,7 +176,7 @@ def test_parameter_gradients_at_the_timed_dimensions_vs_oracle_autograd(train_mo
     from oracle.checks import train_grad_parity
     r = train_grad_parity(DEV, train_mode=train_mode, pin_class=pin_class)
     assert not r["unexpected"], r["unexpected"]
-    assert r["n_tensors"] > 50
+    assert r["n_tensors"] > 40
     if pin_class:
         assert r["full_row_forward"] == [True, True], "the timed (full-row) forward kernels did not engage"
     assert r["out_rel_l2"] < 2e-2 and r["loss_rel"] < 2e-2, r
