@@ -50,6 +50,16 @@ DITTO_DEV float wave_max(float v) {
     return v;
 }
 
+// LayerNorm row arithmetic shared by ln_kernel (rowwise.hip) and the fused norm2 + q-projection kernel (gemm_lnq.hip), with
+// every fused multiply-add written out: left to -ffp-contract=fast the SAME source expression contracts differently in
+// different surroundings (contraction follows basic-block structure), and the two kernels must give the same bits.
+DITTO_DEV float ln_sum4(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+DITTO_DEV float ln_sq_acc(float q, float v, float mean) {
+    const float dlt = v - mean;
+    return __builtin_fmaf(dlt, dlt, q);
+}
+DITTO_DEV float ln_norm(float v, float mean, float rstd, float g, float b) { return __builtin_fmaf((v - mean) * rstd, g, b); }
+
 // two fp32 -> packed bf16x2 in one dword (hipcc emits v_cvt_pk_bf16_f32; RNE, NaN-preserving)
 DITTO_DEV unsigned pack_bf16x2(float lo, float hi) {
     bf16x2 p;

@@ -256,7 +256,8 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
         const bool lnq = g_lnq && lp.WcqP && d == 768 && fr_pays(M);
         if (lnq) {
             ProfScope ps(m, s, DITTO_KC_GEMM_QPROJ);
-            HIP_TRY(launch_gemm_lnq(h, d, hb, lp.g2, lp.be2, g_lnq == 16 ? lp.WcqP32 : lp.WcqP, lp.bcq, qkv, d, M, d, g_lnq, s));
+            HIP_TRY(launch_gemm_lnq(h, d, hb, lp.g2, lp.be2, g_lnq == 16 ? lp.WcqP32 : lp.WcqP, lp.bcq, qkv, d, M, d, g_lnq,
+                                    N % 64 == 0 ? N / 64 : 0, s));
         } else {
             {
                 ProfScope ps(m, s, DITTO_KC_LAYERNORM);
@@ -795,7 +796,8 @@ int ditto_gemm_lnq_bf16(const void* h, int ldh, int h_is_bf16, const float* gamm
     if ((uintptr_t)w_scratch % 256) return fail(DITTO_ERR_ARG, "w_scratch must be 256-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(launch_repack_bf16_stage_major(W, w_scratch, 768, 768, s, mfma_shape == 32 ? 16 : 32));
-    HIP_TRY(launch_gemm_lnq(h, ldh, h_is_bf16 != 0, gamma, beta, w_scratch, bias, out_bf16, ldo, M, 768, mfma_shape, s));
+    HIP_TRY(launch_gemm_lnq(h, ldh, h_is_bf16 != 0, gamma, beta, w_scratch, bias, out_bf16, ldo, M, 768, mfma_shape,
+                            g_fr_rot > 1 ? g_fr_rot : 0, s));   // "fr_rot" > 1: the unit entry rotates too, with that period in tiles
     return DITTO_OK;
 }
 
@@ -917,7 +919,7 @@ static int* option_slot(const char* name) {
         {"pp_mask", &g_pp_mask}, {"fr_mask", &g_fr_mask}, {"fr_class_rows", &g_fr_class_rows}, {"fr_dgrad", &g_fr_dgrad},
         {"train_flags", &g_train_flags}, {"fr_u_fp8", &g_fr_u_fp8}, {"fr_tile", &g_fr_tile}, {"fr64_maxk", &g_fr64_maxk},
         {"fr_stagger", &g_fr_stagger}, {"fr_rot", &g_fr_rot}, {"pp_nb", &g_pp_nb}, {"pp_stagger", &g_pp_stagger},
-        {"splitk_wgs", &g_splitk_wgs}, {"residual_bf16", &g_resid_bf16}, {"lnq", &g_lnq}};
+        {"splitk_wgs", &g_splitk_wgs}, {"residual_bf16", &g_resid_bf16}, {"lnq", &g_lnq}, {"lnq_ring", &g_lnq_ring}};
     for (auto& e : tab) if (!strcmp(name, e.n)) return e.p;
     return nullptr;
 }
@@ -1027,6 +1029,11 @@ int ditto_set_option(const char* name, int value) {
     if (!strcmp(name, "pp_stagger")) {
         if (value < -1 || value > 100000) return fail(DITTO_ERR_ARG, "pp_stagger must be in [-1, 100000] (10 ns ticks; -1 = rule)");
         g_pp_stagger = value;
+        return DITTO_OK;
+    }
+    if (!strcmp(name, "lnq_ring")) {
+        if (value != 0 && value != 2 && value != 4 && value != 8) return fail(DITTO_ERR_ARG, "lnq_ring must be 0 (default), 4 or 8 (shape 32), 2 or 4 (shape 16)");
+        g_lnq_ring = value;
         return DITTO_OK;
     }
     if (!strcmp(name, "lnq")) {

@@ -14,9 +14,9 @@
 //   tile      64 rows x 768 columns, one workgroup (4 waves, one per SIMD) per CU; wave wn owns all 64 rows x columns
 //             [192 wn, +192): 192 accumulators, all in AGPRs.  M = 32768: 512 tiles = two rounds of the 256 CUs.
 //   SHAPE 32  v_mfma_f32_32x32x16_bf16, weights as the instruction's A operand (the accumulator is C^T: a lane owns 4
-//             consecutive output columns of one row): 2 x 6 blocks, K = 16 per stage, 48 stages, ring of 4 stages.
-//   SHAPE 16  v_mfma_f32_16x16x32_bf16, same roles: 4 x 12 blocks, K = 32 per stage, 24 stages, ring of 2 stages — the
-//             same bytes, MFMA cycles and look-ahead (64 k); the A/B of VERDICT r3 item 3 (the chip can hold a higher
+//             consecutive output columns of one row): 2 x 6 blocks, K = 16 per stage, 48 stages, ring of 8 (or 4) stages.
+//   SHAPE 16  v_mfma_f32_16x16x32_bf16, same roles: 4 x 12 blocks, K = 32 per stage, 24 stages, ring of 4 (or 2) stages — the
+//             same bytes, MFMA cycles and look-ahead; the A/B of VERDICT r3 item 3 (the chip can hold a higher
 //             clock on one MFMA shape than on the other: MI355X_MICROARCH.md, DVFS give-back item 7).
 //   W image   SHAPE 32: Wp[K/16][768][16] (launch_repack_bf16_stage_major, group 16); SHAPE 16: Wp[K/32][768][32]
 //             (group 32).  Fragment (stage, column block) of a wave = 1 contiguous KiB; a lane takes 16 bytes of it.
@@ -46,12 +46,12 @@ template <int SHAPE>
 struct Geo;
 template <>
 struct Geo<32> {
-    static constexpr int NBW = 6, MBW = 2, KS = 16, NKT = QKD / 16, R = 4, PER = 8;   // PER: stages per A-swizzle period
+    static constexpr int NBW = 6, MBW = 2, KS = 16, NKT = QKD / 16, PER = 8;   // PER: stages per A-swizzle period (one 256-B span)
     using acc_t = f32x16;
 };
 template <>
 struct Geo<16> {
-    static constexpr int NBW = 12, MBW = 4, KS = 32, NKT = QKD / 32, R = 2, PER = 4;
+    static constexpr int NBW = 12, MBW = 4, KS = 32, NKT = QKD / 32, PER = 4;
     using acc_t = f32x4;
 };
 
@@ -94,18 +94,30 @@ struct LnqParams {
     const float* bias;
     bf16* out; int ldo;
     int M;
+    int rot_period;                         // > 0: tiles t and t + rot_period start their K loop at the same place (tiles per utterance)
 };
 
-template <int SHAPE, bool XB>
+// R: depth of the W register ring in stages.  What the ring holds in flight per CU (4 waves x R x NBW KiB) against the L2's
+// latency under load is what paces the loop: the weights of a 64-row tile are 1.18 MB, twice the bytes per MFMA of gemm_frd's
+// 128-row tile.
+template <int SHAPE, int R, bool XB>
 __global__ __launch_bounds__(256, 1) void gemm_lnq_kernel(LnqParams p) {
     using G = Geo<SHAPE>;
     using acc_t = typename G::acc_t;
-    constexpr int NBW = G::NBW, MBW = G::MBW, NKT = G::NKT, R = G::R, PER = G::PER;
+    constexpr int NBW = G::NBW, MBW = G::MBW, NKT = G::NKT, PER = G::PER;
+    constexpr int NPER = NKT / PER;                                       // 6 periods of one 256-B span of A each
+    static_assert(NKT % PER == 0 && PER % R == 0 && R * NBW - 1 <= 63, "period structure / vmcnt range");
     constexpr int W_STAGE = QN * G::KS * 2;                              // bytes of one stage of W (24 / 48 KiB)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.x * QM;
+    // XCD-contiguous tiles (blocks b and b + 8 share an XCD: neighbouring tiles, i.e. neighbouring K-loop phases, on one L2)
+    const int ntile = gridDim.x;
+    const int tile = (ntile & 7) == 0 ? (int)(blockIdx.x & 7) * (ntile >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int m0 = tile * QM;
+    // K-loop rotation by whole periods: the workgroups of an XCD do not all ask their L2 for the same weight lines at once.
+    // A function of the tile's place INSIDE its utterance, so an utterance's bits do not depend on its place in the batch.
+    const int p0 = p.rot_period > 0 ? (tile % p.rot_period) % NPER : 0;
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;
 
     // bias row -> LDS (3 pieces of 1 KiB), wave 3; landed and visible behind the barrier that ends the LayerNorm
@@ -125,7 +137,12 @@ __global__ __launch_bounds__(256, 1) void gemm_lnq_kernel(LnqParams p) {
     //   SHAPE 32: row (lane & 31) x 32 B + (lane >> 5) x 16;   SHAPE 16: row (lane & 15) x 64 B + (lane >> 4) x 16
     const unsigned vw = (unsigned)(wid * NBW * 1024) +
                         (SHAPE == 32 ? (unsigned)((lane & 31) * 32 + (lane >> 5) * 16) : (unsigned)((lane & 15) * 64 + (lane >> 4) * 16));
-    const char* wbase = p.Wp;                                            // wave-uniform, advanced by W_STAGE per stage issued
+    const char* wbase = p.Wp + (size_t)p0 * PER * W_STAGE;               // wave-uniform, advanced by W_STAGE per stage issued
+    int w_to_wrap = (NPER - p0) * PER;                                    // stages until the rotated loop wraps to k = 0
+    auto advance_w = [&]() {
+        wbase += W_STAGE;
+        if (--w_to_wrap == 0) wbase = p.Wp;
+    };
     f32x4 wr[R][NBW];
     auto issue_w = [&](auto NB, f32x4& dst) {
         constexpr int nb = decltype(NB)::value;
@@ -138,7 +155,7 @@ __global__ __launch_bounds__(256, 1) void gemm_lnq_kernel(LnqParams p) {
             issue_w(QC<6>{}, slot[6]); issue_w(QC<7>{}, slot[7]); issue_w(QC<8>{}, slot[8]);
             issue_w(QC<9>{}, slot[9]); issue_w(QC<10>{}, slot[10]); issue_w(QC<11>{}, slot[11]);
         }
-        wbase += W_STAGE;
+        advance_w();
     };
 
     // ---- LayerNorm of the tile's 64 rows -> LDS (bf16, swizzled): wave w takes rows 16 w .. 16 w + 15, eight at a time ----
@@ -168,27 +185,24 @@ __global__ __launch_bounds__(256, 1) void gemm_lnq_kernel(LnqParams p) {
             }
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                // ln_kernel's arithmetic, statement for statement (rowwise.hip): the same bits for the same row
+                // ln_kernel's arithmetic (rowwise.hip) through the same helpers (common.h): the same bits for the same row
                 float s = 0.f;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) s += (v[r][c][0] + v[r][c][1]) + (v[r][c][2] + v[r][c][3]);
+                for (int c = 0; c < 3; ++c) s += ln_sum4(v[r][c]);
                 const float mean = wave_sum(s) / (float)QKD;
                 float q = 0.f;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float dlt = v[r][c][e] - mean;
-                        q += dlt * dlt;
-                    }
+                    for (int e = 0; e < 4; ++e) q = ln_sq_acc(q, v[r][c][e], mean);
                 }
                 const float rstd = rsqrtf(wave_sum(q) / (float)QKD + 1e-5f);
                 const int row = wid * 16 + half * 8 + r;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     u32x2 o;
-                    o[0] = pack_bf16x2((v[r][c][0] - mean) * rstd * g4[c][0] + b4[c][0], (v[r][c][1] - mean) * rstd * g4[c][1] + b4[c][1]);
-                    o[1] = pack_bf16x2((v[r][c][2] - mean) * rstd * g4[c][2] + b4[c][2], (v[r][c][3] - mean) * rstd * g4[c][3] + b4[c][3]);
+                    o[0] = pack_bf16x2(ln_norm(v[r][c][0], mean, rstd, g4[c][0], b4[c][0]), ln_norm(v[r][c][1], mean, rstd, g4[c][1], b4[c][1]));
+                    o[1] = pack_bf16x2(ln_norm(v[r][c][2], mean, rstd, g4[c][2], b4[c][2]), ln_norm(v[r][c][3], mean, rstd, g4[c][3], b4[c][3]));
                     const int chunk = (lane + 64 * c) >> 1;                // 16-B chunk of the row holding k = 4 (lane + 64 c) ..
                     *reinterpret_cast<u32x2*>(smem + row * Q_AROW + ((chunk ^ (row & 15)) << 4) + (lane & 1) * 8) = o;
                 }
@@ -231,7 +245,7 @@ __global__ __launch_bounds__(256, 1) void gemm_lnq_kernel(LnqParams p) {
         for (int mb = 0; mb < MBW; ++mb)
             dst[mb] = *reinterpret_cast<const bf16x8*>(smem + lane_off + span_bytes + mb * MB_STRIDE);
     };
-    read_a(a0, 0, aoff[0]);
+    read_a(a0, p0 * 256, aoff[0]);
 
     // One stage: MFMAs of (s, nb) behind the fragment's counted wait, then fragment nb of stage s + R into the same registers;
     // the next stage's A fragments are read behind the first column block.  J: position in the swizzle period (compile time),
@@ -254,37 +268,34 @@ __global__ __launch_bounds__(256, 1) void gemm_lnq_kernel(LnqParams p) {
         if constexpr (NBW == 12) {
             block(QC<6>{}); block(QC<7>{}); block(QC<8>{}); block(QC<9>{}); block(QC<10>{}); block(QC<11>{});
         }
-        if constexpr (do_w) wbase += W_STAGE;
+        if constexpr (do_w) advance_w();
     };
-    // a period = PER stages = one 256-B span of A (16 chunks); stage s of the period reads the NEXT stage's fragments, which
-    // sit in the next span when j = PER - 1
-    constexpr int NPER = NKT / PER;                                       // 6 periods
-    static_assert(NKT % PER == 0 && PER % R == 0 && PER % 2 == 0, "period structure");
-    auto period = [&](auto LASTP, int span) {
+    // a period = PER stages = one 256-B span of A (16 chunks); a stage reads the NEXT stage's fragments, which sit in the next
+    // period's span when j = PER - 1.  Stage j of a period uses ring slot j % R.
+    auto period = [&](auto LASTP, int span, int span_after) {
         constexpr bool lastp = decltype(LASTP)::value != 0;
-        // REM for stage j of the last period: PER - 1 - j (capped at R: the steady-state value)
-        if constexpr (PER == 8) {
-            stage(QC<0>{}, QC<(lastp ? (7 < R ? 7 : R) : R)>{}, span, wr[0], a0, a1);
-            stage(QC<1>{}, QC<(lastp ? (6 < R ? 6 : R) : R)>{}, span, wr[1], a1, a0);
-            stage(QC<2>{}, QC<(lastp ? (5 < R ? 5 : R) : R)>{}, span, wr[2], a0, a1);
-            stage(QC<3>{}, QC<(lastp ? (4 < R ? 4 : R) : R)>{}, span, wr[3], a1, a0);
-            stage(QC<4>{}, QC<(lastp ? 3 : R)>{}, span, wr[0], a0, a1);
-            stage(QC<5>{}, QC<(lastp ? 2 : R)>{}, span, wr[1], a1, a0);
-            stage(QC<6>{}, QC<(lastp ? 1 : R)>{}, span, wr[2], a0, a1);
-            stage(QC<7>{}, QC<(lastp ? 0 : R)>{}, span + 256, wr[3], a1, a0);
+#define LNQ_REM(j) QC<(lastp ? ((PER - 1 - (j)) < R ? (PER - 1 - (j)) : R) : R)>{}
+        stage(QC<0>{}, LNQ_REM(0), span, wr[0 % R], a0, a1);
+        stage(QC<1>{}, LNQ_REM(1), span, wr[1 % R], a1, a0);
+        stage(QC<2>{}, LNQ_REM(2), span, wr[2 % R], a0, a1);
+        if constexpr (PER == 4) {
+            stage(QC<3>{}, LNQ_REM(3), span_after, wr[3 % R], a1, a0);
         } else {
-            stage(QC<0>{}, QC<(lastp ? (3 < R ? 3 : R) : R)>{}, span, wr[0], a0, a1);
-            stage(QC<1>{}, QC<(lastp ? (2 < R ? 2 : R) : R)>{}, span, wr[1], a1, a0);
-            stage(QC<2>{}, QC<(lastp ? 1 : R)>{}, span, wr[0], a0, a1);
-            stage(QC<3>{}, QC<(lastp ? 0 : R)>{}, span + 256, wr[1], a1, a0);
+            stage(QC<3>{}, LNQ_REM(3), span, wr[3 % R], a1, a0);
+            stage(QC<4>{}, LNQ_REM(4), span, wr[4 % R], a0, a1);
+            stage(QC<5>{}, LNQ_REM(5), span, wr[5 % R], a1, a0);
+            stage(QC<6>{}, LNQ_REM(6), span, wr[6 % R], a0, a1);
+            stage(QC<7>{}, LNQ_REM(7), span_after, wr[7 % R], a1, a0);
         }
+#undef LNQ_REM
     };
-    int span = 0;
+    int pcur = p0;
     for (int pi = 0; pi + 1 < NPER; ++pi) {
-        period(QC<0>{}, span);
-        span += 256;
+        const int pnext = pcur + 1 == NPER ? 0 : pcur + 1;
+        period(QC<0>{}, pcur * 256, pnext * 256);
+        pcur = pnext;
     }
-    period(QC<1>{}, span);
+    period(QC<1>{}, pcur * 256, 0);
 
     // ---------------- epilogue: q = acc + bias -> bf16, staged through the A region (every wave is done reading it) ----------------
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -329,26 +340,34 @@ __global__ __launch_bounds__(256, 1) void gemm_lnq_kernel(LnqParams p) {
     }
 }
 
-template <int SHAPE, bool XB>
+template <int SHAPE, int R, bool XB>
 hipError_t launch_lnq_t(const LnqParams& p, hipStream_t s) {
     static DevOnce lds_once;
-    if (hipError_t e = set_max_lds_once(lds_once, {reinterpret_cast<const void*>(&gemm_lnq_kernel<SHAPE, XB>)}, Q_LDS)) return e;
-    hipLaunchKernelGGL((gemm_lnq_kernel<SHAPE, XB>), dim3((p.M + QM - 1) / QM), dim3(256), Q_LDS, s, p);
+    if (hipError_t e = set_max_lds_once(lds_once, {reinterpret_cast<const void*>(&gemm_lnq_kernel<SHAPE, R, XB>)}, Q_LDS)) return e;
+    hipLaunchKernelGGL((gemm_lnq_kernel<SHAPE, R, XB>), dim3((p.M + QM - 1) / QM), dim3(256), Q_LDS, s, p);
     return hipGetLastError();
 }
 
 }  // namespace
 
-// h: fp32 [M, ldh] (h_bf16 false) or bf16 [M, ldh]; Wp: the stage-major image of W_q for `shape` (32: group 16, 16: group 32)
+int g_lnq_ring = [] { const char* e = getenv("DITTO_LNQ_RING"); return e ? atoi(e) : 0; }();   // 0 = the shape's default depth
+
+// h: fp32 [M, ldh] (h_bf16 false) or bf16 [M, ldh]; Wp: the stage-major image of W_q for `shape` (32: group 16, 16: group 32);
+// rot_period: tiles (of 64 rows) per utterance when that is whole, else 0 (no K-loop rotation)
 hipError_t launch_gemm_lnq(const void* h, int ldh, bool h_bf16, const float* gamma, const float* beta, const void* Wp,
-                           const float* bias, void* out_bf16, int ldo, int M, int d, int shape, hipStream_t s) {
+                           const float* bias, void* out_bf16, int ldo, int M, int d, int shape, int rot_period, hipStream_t s) {
     if (d != QN || M <= 0 || !h || !gamma || !beta || !Wp || !out_bf16 || (shape != 32 && shape != 16)) return hipErrorInvalidValue;
     if (ldh % 4 || ldo % 8) return hipErrorInvalidValue;
     LnqParams p;
     p.h = h; p.ldh = ldh; p.gamma = gamma; p.beta = beta; p.Wp = (const char*)Wp; p.bias = bias;
-    p.out = (bf16*)out_bf16; p.ldo = ldo; p.M = M;
-    if (shape == 32) return h_bf16 ? launch_lnq_t<32, true>(p, s) : launch_lnq_t<32, false>(p, s);
-    return h_bf16 ? launch_lnq_t<16, true>(p, s) : launch_lnq_t<16, false>(p, s);
+    p.out = (bf16*)out_bf16; p.ldo = ldo; p.M = M; p.rot_period = rot_period > 0 ? rot_period : 0;
+    const int ring = g_lnq_ring;
+    if (shape == 32) {
+        if (ring == 4) return h_bf16 ? launch_lnq_t<32, 4, true>(p, s) : launch_lnq_t<32, 4, false>(p, s);
+        return h_bf16 ? launch_lnq_t<32, 8, true>(p, s) : launch_lnq_t<32, 8, false>(p, s);
+    }
+    if (ring == 2) return h_bf16 ? launch_lnq_t<16, 2, true>(p, s) : launch_lnq_t<16, 2, false>(p, s);
+    return h_bf16 ? launch_lnq_t<16, 4, true>(p, s) : launch_lnq_t<16, 4, false>(p, s);
 }
 
 }  // namespace ditto

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, co
             } else {
                 v[c] = xr[i];
             }
-            s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+            s += ln_sum4(v[c]);
         } else {
             v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -57,10 +57,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, co
         const int i = lane + 64 * c;
         if (i < nv) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float dlt = v[c][e] - mean;
-                q += dlt * dlt;
-            }
+            for (int e = 0; e < 4; ++e) q = ln_sq_acc(q, v[c][e], mean);
         }
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
@@ -77,8 +74,8 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, co
                     b = reinterpret_cast<const f32x4*>(beta)[i];
                 }
                 *reinterpret_cast<unsigned*>(orow + 4 * i) =
-                    pack_fp8x4((v[c][0] - mean) * rstd * g[0] + b[0], (v[c][1] - mean) * rstd * g[1] + b[1],
-                               (v[c][2] - mean) * rstd * g[2] + b[2], (v[c][3] - mean) * rstd * g[3] + b[3]);
+                    pack_fp8x4(ln_norm(v[c][0], mean, rstd, g[0], b[0]), ln_norm(v[c][1], mean, rstd, g[1], b[1]),
+                               ln_norm(v[c][2], mean, rstd, g[2], b[2]), ln_norm(v[c][3], mean, rstd, g[3], b[3]));
             }
         }
     } else if constexpr (MODE == 0) {
@@ -93,8 +90,8 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, co
                     b = reinterpret_cast<const f32x4*>(beta)[i];
                 }
                 u32x2 o;
-                o[0] = pack_bf16x2((v[c][0] - mean) * rstd * g[0] + b[0], (v[c][1] - mean) * rstd * g[1] + b[1]);
-                o[1] = pack_bf16x2((v[c][2] - mean) * rstd * g[2] + b[2], (v[c][3] - mean) * rstd * g[3] + b[3]);
+                o[0] = pack_bf16x2(ln_norm(v[c][0], mean, rstd, g[0], b[0]), ln_norm(v[c][1], mean, rstd, g[1], b[1]));
+                o[1] = pack_bf16x2(ln_norm(v[c][2], mean, rstd, g[2], b[2]), ln_norm(v[c][3], mean, rstd, g[3], b[3]));
                 *reinterpret_cast<u32x2*>(orow + 4 * i) = o;
             }
         }
@@ -135,7 +132,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, co
                     *reinterpret_cast<u32x2*>(orow + 4 * i) = o;
                 }
                 v[c] = h;                                                 // kept for the fused norm1 below
-                s1 += (h[0] + h[1]) + (h[2] + h[3]);
+                s1 += ln_sum4(h);
             }
         }
         // u1 set: block 0's norm1 (src/components/DiT.py:105) of the row just produced, from the fp32 values in registers
@@ -148,10 +145,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, co
                 const int i = lane + 64 * c;
                 if (i < nv) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float dlt = v[c][e] - mean1;
-                        q1 += dlt * dlt;
-                    }
+                    for (int e = 0; e < 4; ++e) q1 = ln_sq_acc(q1, v[c][e], mean1);
                 }
             }
             const float rstd1 = rsqrtf(wave_sum(q1) / (float)d + 1e-5f);
@@ -162,8 +156,8 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, co
                 if (i < nv) {
                     const f32x4 g = reinterpret_cast<const f32x4*>(g1)[i], b = reinterpret_cast<const f32x4*>(be1)[i];
                     u32x2 o;
-                    o[0] = pack_bf16x2((v[c][0] - mean1) * rstd1 * g[0] + b[0], (v[c][1] - mean1) * rstd1 * g[1] + b[1]);
-                    o[1] = pack_bf16x2((v[c][2] - mean1) * rstd1 * g[2] + b[2], (v[c][3] - mean1) * rstd1 * g[3] + b[3]);
+                    o[0] = pack_bf16x2(ln_norm(v[c][0], mean1, rstd1, g[0], b[0]), ln_norm(v[c][1], mean1, rstd1, g[1], b[1]));
+                    o[1] = pack_bf16x2(ln_norm(v[c][2], mean1, rstd1, g[2], b[2]), ln_norm(v[c][3], mean1, rstd1, g[3], b[3]));
                     *reinterpret_cast<u32x2*>(urow + 4 * i) = o;
                 }
             }
