@@ -90,8 +90,8 @@ static int g_splitk_wgs = [] { const char* e = getenv("DITTO_SPLITK_WGS"); retur
 // and LayerNorm statistics) wherever the launch takes the full-row class at d = 768 / head_dim 64 (ditto_forward decides)
 // "lnq": norm2 fused into the cross-attention q-projection (gemm_lnq.hip) for launches of the full-row class at d = 768:
 // 0 = off (LayerNorm launch + tiled GEMM), 32 / 16 = on, with that MFMA shape (32x32x16 / 16x16x32)
-int g_lnq = [] { const char* e = getenv("DITTO_LNQ"); return e ? atoi(e) : 0; }();
-int g_resid_bf16 = [] { const char* e = getenv("DITTO_RESIDUAL_BF16"); return e ? atoi(e) : 0; }();
+int g_lnq = [] { const char* e = getenv("DITTO_LNQ"); return e ? atoi(e) : 32; }();
+int g_resid_bf16 = [] { const char* e = getenv("DITTO_RESIDUAL_BF16"); return e ? atoi(e) : 1; }();
 int small_batch_k_splits(int M, int N, int K) {
     if (g_splitk_wgs <= 0) return 1;
     const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
@@ -558,8 +558,15 @@ int ditto_forward(ditto_model_t m, const float* x, const void* cond, const int64
     const bool chain_ln1 = (g_fr_mask & 2) && !fp8c && m->layers[0].W2P && fr_fc2_ok(M, d);
     // bf16 residual stream ("residual_bf16"): only where EVERY consumer of h has the bf16 form — d = 768, head_dim 64, both fused
     // launches of a block on gemm_frd.hip (the full-row class); any other launch keeps the fp32 stream
-    const bool hb = g_resid_bf16 && !fp8c && d == 768 && d / c.num_heads == 64 && chain_ln1 && (g_fr_mask & 1) &&
-                    m->layers[0].WcoP && fr_outproj_ok(M, d) && fr_launch_kernel(M, d) == 130 && fr_launch_kernel(M, 4 * d) == 130;
+    const bool hb_class = g_resid_bf16 && !fp8c && d == 768 && d / c.num_heads == 64 && chain_ln1 && (g_fr_mask & 1) &&
+                          m->layers[0].WcoP && fr_outproj_ok(M, d) &&
+                          (g_fr_tile == 130 || (g_fr_tile == 0 && fr_rule_rows(g_fr_class_rows > 0 ? g_fr_class_rows : M) == 130));
+    // (only gemm_frd.hip has the bf16 form: a launch of fewer than 128 rows under a PINNED class would run the 64-row kernel)
+    if (hb_class && M < 128)
+        return fail(DITTO_ERR_SHAPE, "kernel class pinned to a batch of %d rows (bf16 residual stream on the 128-row full-row kernel), "
+                                     "but this launch has %d rows: it cannot take that class.  Give every shard at least 128 rows, or "
+                                     "ditto_set_option(\"residual_bf16\", 0).", g_fr_class_rows, M);
+    const bool hb = hb_class;
     // block 0's norm1 rides in the GlobalAdaLN kernel (same statistics order as the LayerNorm kernel: the same bits)
     const bool ln1_in_adaln = !fp8c && !(g_gemm_flags & 32768);      // gemm_flags bit 15: A/B, the separate launch
     {   // GlobalAdaLN (src/components/DiT.py:25-40) + bf16 copy of the raw input for proj_in

