@@ -679,7 +679,7 @@ def test_full_row_gemm_on_64_row_tiles_is_bitwise_the_128_row_kernel(lib, M, K, 
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.fixture(params=[(0, 1), (-1, 5), (0, 16)])
 def lnq_variant(lib, request):
-    """(ring, rot): W register ring depth 0 = default (8 stages at shape 32, 4 at shape 16), -1 = the shallow one (4 / 2);
+    """(ring, rot): W register ring depth 0 = default (4 stages at shape 32, 2 at shape 16), -1 = the deep one (8 / 4);
     fr_rot > 1 = the unit entry rotates its K loop with that period in 64-row tiles (the model path rotates by tiles per
     utterance)."""
     yield request.param
@@ -699,7 +699,7 @@ def test_layernorm_fused_into_the_q_projection(lib, lnq_variant, M, h_bf16, shap
     output rounding (rel-L2 < 3e-3); rows do not depend on what else is in the launch (bitwise, against a 1-row launch)."""
     d = 768
     ring, rot = lnq_variant
-    hip.set_option("lnq_ring", 0 if ring == 0 else (4 if shape == 32 else 2))
+    hip.set_option("lnq_ring", 0 if ring == 0 else (8 if shape == 32 else 4))
     hip.set_option("fr_rot", rot)
     h = (asym((M, d), 31) * 1.7 + 0.4).to(DEV)
     if h_bf16:

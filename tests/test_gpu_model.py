@@ -17,6 +17,10 @@ from gpu_util import max_abs, rel_l2
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 RTOL = 2e-2
+# Two kernel CLASSES of one model (tiled GEMMs + LayerNorm launches + fp32 residual stream  |  full-row GEMMs with fused
+# LayerNorms, and since round 4 the bf16 residual stream) agree to the bf16 stream's rounding noise: 12 layers x 3 roundings of h
+# (measured 6.6e-3 to 6.9e-3 at C2; the fp32-stream classes differed by <= 4e-3).  Each class is within RTOL of the oracle.
+CLASS_TOL = 1e-2
 
 
 def build(cfg, seed):
@@ -267,7 +271,7 @@ def test_full_size_c2_large_batch_takes_the_full_row_path():
         junk = torch.randn(1 << 22, device=DEV)          # counted vmcnt): different cache / allocator state in between
         assert torch.equal(m(xd, td, tt), out)
         del junk
-    assert rel_l2(out, plain) < 4e-3
+    assert rel_l2(out, plain) < CLASS_TOL
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(1)).to(DEV)
     assert torch.equal(m(xd[perm].contiguous(), td[perm].contiguous(), tt[perm].contiguous()), out[perm])
     x2, text2, t2 = synthetic_inputs(cfg, 4, N, T, seed=9)
@@ -302,7 +306,7 @@ def test_mid_batch_takes_the_64_row_full_row_kernel():
     assert torch.equal(m(xd[:B][perm].contiguous(), td[:B][perm].contiguous(), tt[:B][perm].contiguous()), out[perm])
     assert torch.equal(m(xd[:B].contiguous(), td[:B].contiguous(), tt[:B].contiguous()), out)
     big = m(xd, td, tt)                                  # 20 utterances: the 128-row kernel, other GEMM tile structures
-    assert rel_l2(big[:B], out) < 4e-3
+    assert rel_l2(big[:B], out) < CLASS_TOL
 
 
 @torch.no_grad()
@@ -376,7 +380,7 @@ def test_full_row_path_on_ragged_rows():
     finally:
         hip.set_option("fr_mask", 3)
     assert not torch.equal(plain, out), "the full-row path did not run"
-    assert rel_l2(out, plain) < 4e-3
+    assert rel_l2(out, plain) < CLASS_TOL
 
 
 @torch.no_grad()
@@ -730,7 +734,8 @@ def test_bf16_residual_stream_g2_golden_and_taps(golden):
     x, text, t = (z.to(DEV) for z in synthetic_inputs(cfg, 2, 128, 96, seed=22))
     with hip.batch_class(32 * 1024):
         assert hip.full_row_plan(cfg, 2, 128) == (True, True)
-        f32 = m(x, text, t)
+        with _stream_bf16(0):
+            f32 = m(x, text, t)
         with _stream_bf16():
             b16 = m(x, text, t)
             again = m(x, text, t)
@@ -756,7 +761,8 @@ def test_bf16_residual_stream_headline_shape_against_oracle():
     x1, text1, t1 = synthetic_inputs(cfg, 31, N, T, seed=8)
     xd, td, tt = torch.cat([x0, x1]).to(DEV), torch.cat([text0, text1]).to(DEV), torch.cat([t0, t1]).to(DEV)
     want = O.ditto_forward(synthetic_state_dict(cfg, 1234), cfg.num_layers, cfg.num_heads, x0, text0, t0)
-    f32 = m(xd, td, tt)
+    with _stream_bf16(0):
+        f32 = m(xd, td, tt)
     with _stream_bf16():
         out = m(xd, td, tt)
         assert torch.equal(m(xd[:20].contiguous(), td[:20].contiguous(), tt[:20].contiguous())[0], out[0])
@@ -780,7 +786,8 @@ def test_bf16_residual_stream_sampling_loop_tracks_the_fp32_stream():
     x, text, _ = synthetic_inputs(cfg, B, N, T, seed=11)
     xd, td = x.to(DEV), text.to(DEV)
     seeds = torch.arange(B, device=DEV) + 77
-    a = sg._SpeechGenerator__sample_latents(td, xd, seeds=seeds)
+    with _stream_bf16(0):
+        a = sg._SpeechGenerator__sample_latents(td, xd, seeds=seeds)
     with _stream_bf16():
         b = sg._SpeechGenerator__sample_latents(td, xd, seeds=seeds)
     r = rel_l2(b, a)
