@@ -123,15 +123,50 @@ def kernel_flops(cfg, B, N, T):
     }
 
 
+def stream_is_bf16(cfg, B, N):
+    """Does a forward of B x N rows carry its residual stream as bf16 (csrc/ditto_api.hip ditto_forward's rule: option
+    "residual_bf16" on, d = 768, head_dim 64, bf16 linears, both fused full-row launches = the full-row class)?"""
+    from ditto_tts_amd import hip
+    try:
+        return bool(hip.get_option("residual_bf16")) and cfg.hidden_dim == 768 and cfg.hidden_dim // cfg.num_heads == 64 \
+            and not cfg.fp8_linear and hip.full_row_plan(cfg, B, N) == (True, True)
+    except Exception:  # noqa: BLE001 - an older library selected with DITTO_HIP_LIB
+        return False
+
+
 def kernel_bytes(cfg, B, N, T, seeded=True):
     """Algorithmic HBM bytes of ONE launch of the memory-bound classes."""
     d, M = cfg.hidden_dim, B * N
+    hs = 2.0 if stream_is_bf16(cfg, B, N) else 4.0       # bytes per element of the residual stream h
     return {
-        "layernorm": M * d * (4 + 2.0),                 # fp32 in, bf16 out
-        "adaln": M * d * (4 + 4 + 2.0),                 # fp32 in, fp32 out + bf16 raw copy
+        "layernorm": M * d * (hs + 2.0),                # h in, bf16 out
+        # fp32 x in; h out + bf16 raw copy (proj_in's operand) + block 0's norm1 output (bf16; fused since round 4)
+        "adaln": M * d * (4 + hs + 2.0 + (0.0 if cfg.fp8_linear else 2.0)),
         # seeded kernel: x and eps in, x out (the noise is generated in registers); noise-tensor kernel: + z in
         "p_sample_update": M * d * 4 * (3.0 if seeded else 4.0),
     }
+
+
+def floor_table(cfg, B, N, T, classes):
+    """profiles/r04_floor_table.json: per kernel class the time (us) its launch takes with the removable overheads knocked out
+    in diagnostic builds (main loop without epilogue, operands L2-hot, no stores: tools/r04_run5.sh) —
+    measured OFFLINE on the timed shape, so only reported for it.  step_floor_ms = the step if every class ran at its floor
+    (classes without a floor entry at their time in THIS run); step_frac_at_floor = the executed FLOPs at that time / 2.5 PF."""
+    if not (B == 32 and N == 1024 and T == 1024 and cfg.hidden_dim == 768 and cfg.num_layers == 12 and not cfg.fp8_linear):
+        return None
+    try:
+        tab = json.load(open(os.path.join(ROOT, "profiles", "r04_floor_table.json")))
+    except (OSError, ValueError):
+        return None
+    us = 0.0
+    for name, e in classes.items():
+        per = tab.get(name, {}).get("floor_us")
+        us += e["launches_per_step"] * (per if per is not None else e["avg_ms"] * 1e3)
+    one_off = cfg.flops_text_kv(T) / cfg.diffusion_steps
+    fl = B * (cfg.flops_per_utt_step(N, T, cached_kv=True) + one_off)
+    return {"step_floor_ms": us * 1e-3, "step_frac_at_floor": fl / (us * 1e-6) / 1e12 / PEAK_BF16_TFLOPS,
+            "per_class_floor_us": {k: v.get("floor_us") for k, v in tab.items() if isinstance(v, dict)},
+            "source": "profiles/r04_floor_table.json (offline diagnostic builds on this shape; DESIGN.md section 9)"}
 
 
 def class_peak(cfg, name):
@@ -579,6 +614,26 @@ def main():
                           cfg.flops_text_kv(T) * ((args.steps + S - 1) // S) / args.steps)
                 sweep.append({"batch_per_gpu": b, "ms_per_step": ms, "value": b / (ms * 1e-3),
                               "step_tflops": fl / (ms * 1e-3) / 1e12})
+                if b == 1 and b != B:
+                    # the opt-in single-utterance serving mode (hip.set_low_latency: fc2 / final projection split over K; an
+                    # utterance's bits then depend on the batch size, which is why it is not the default)
+                    from ditto_tts_amd import hip as _hip
+                    _hip.set_low_latency(True)
+                    try:
+                        r = StepRunner(eng, sg, cfg, b, N, T, dev, 2000 + b, use_graph, args.noise == "seeded")
+                        r.run(0, 5)
+                        torch.cuda.synchronize(dev)
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        r.run(0, args.steps)
+                        e1.record()
+                        e1.synchronize()
+                        ms_ll = e0.elapsed_time(e1) / args.steps
+                        del r
+                    finally:
+                        _hip.set_low_latency(False)
+                    sweep.append({"batch_per_gpu": b, "mode": "low_latency (opt-in split-K)", "ms_per_step": ms_ll,
+                                  "value": b / (ms_ll * 1e-3), "step_tflops": fl / (ms_ll * 1e-3) / 1e12})
 
         # ---- C3 as a strong-scaling point: global batch on rank 0 -> scatter -> 50-step loops -> gather ----
         c3 = None
@@ -674,6 +729,8 @@ def main():
             "sweep": sweep or None,
             "c3_strong": c3,
             "roofline": roof,
+            "floor": floor_table(cfg, B, N, T, classes) if classes else None,
+            "residual_stream": "bf16 (fp32 in accumulators and LayerNorm statistics)" if stream_is_bf16(cfg, B, N) else "fp32",
             "parity": parity,
             "other_configs": other,
             "kernel_classes": classes,
