@@ -132,7 +132,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 #endif
                 src = (const char*)p.W + (size_t)gr * p.ldw * ESZ + k0b + c * 16;
             }
+#if defined(DITTO_G256_A_POLICY) || defined(DITTO_G256_W_POLICY)   // A/B builds: cache policy of the A / W operand streams
+#ifndef DITTO_G256_A_POLICY
+#define DITTO_G256_A_POLICY ""
+#endif
+#ifndef DITTO_G256_W_POLICY
+#define DITTO_G256_W_POLICY ""
+#endif
+            if constexpr (half < 2) DITTO_GLDS16_POLICY(src, lds_base + (unsigned)(buf * KT_BYTES + half * HALF_BYTES + piece * 1024), DITTO_G256_A_POLICY);
+            else DITTO_GLDS16_POLICY(src, lds_base + (unsigned)(buf * KT_BYTES + half * HALF_BYTES + piece * 1024), DITTO_G256_W_POLICY);
+#else
             glds16(src, lds_base + (unsigned)(buf * KT_BYTES + half * HALF_BYTES + piece * 1024));
+#endif
         }
     };
     // tile 0 -> buffer 0 (all four halves), tile 1's B halves -> buffer 1: the state the loop's P1 expects

@@ -92,6 +92,19 @@ DITTO_DEV void glds16(const void* gsrc, unsigned lds_dst) {
                  : "memory");
 }
 
+// The same with a cache-policy suffix on the load ("nt", "sc1", ...): A/B builds of the operand streams' L2 retention
+// (tools/build_diag.sh -DDITTO_G256_A_POLICY='"nt"' / -DDITTO_G256_W_POLICY='"nt"'; round 4: the gated GEMM's A panel is
+// re-fetched from the Infinity Cache every tile round because A + W of a round exceed an XCD's 4 MiB L2)
+#define DITTO_GLDS16_POLICY(gsrc, lds_dst, POLICY)                                                                        \
+    do {                                                                                                                  \
+        unsigned keep_;                                                                                                   \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off " POLICY          \
+                     "\n\ts_mov_b32 m0, %0"                                                                               \
+                     : "=&s"(keep_)                                                                                       \
+                     : "v"(gsrc), "s"(lds_dst)                                                                            \
+                     : "memory");                                                                                         \
+    } while (0)
+
 // LDS-DMA with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset: the per-K-tile address update
 // is one scalar add on the base instead of a 64-bit vector add per load (the loads of a kernel's main loop differ only
 // by the K offset).

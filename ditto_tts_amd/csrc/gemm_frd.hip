@@ -85,7 +85,10 @@ DITTO_DEV void frd_wait(f32x4& frag) {   // counted wait that ties the fragment'
 }
 DITTO_DEV void frd_dma(unsigned voff, const char* base, unsigned dst) {
 #ifndef DITTO_DIAG_FR_NODMA
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(dst) : "memory");
+#ifndef DITTO_FRD_A_POLICY     // A/B builds: cache policy of the A slab stream (tools/build_diag.sh -DDITTO_FRD_A_POLICY='"nt"')
+#define DITTO_FRD_A_POLICY ""
+#endif
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 " DITTO_FRD_A_POLICY ::"v"(voff), "s"(base), "s"(dst) : "memory");
 #endif
 }
 

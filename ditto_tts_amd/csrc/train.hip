@@ -393,6 +393,31 @@ DITTO_DEV u32x4 pack8(const float* f) {
     for (int i = 0; i < 4; ++i) o[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
     return o;
 }
+// da, dg of one element.  erf by the forward epilogue's rational form z P(z^2) / Q(z^2) (common.h fast_gelu_sigmoid2: 4.3e-7 in
+// fp32), so that Phi(a) = (Q + z P) / (2 Q) costs one reciprocal, phi(a) one v_exp, sigmoid one v_exp + one v_rcp: ~35 vector
+// instructions per element where erff + __expf + two IEEE divisions took ~90 — the kernel moves 1 GB per launch and was half
+// VALU-bound next to it (211 us = 4.8 TB/s, round 3).
+DITTO_DEV void gated_bwd_elem(float a, float g, float dy, float& da, float& dg) {
+    const float z = __builtin_amdgcn_fmed3f(a * 0.70710678118654752440f, -4.0f, 4.0f);
+    const float u = z * z;
+    float pn = fmaf(u, 1.9217200275534196e-08f, -1.990321152334218e-06f);
+    pn = fmaf(pn, u, 0.00015553680714219809f);
+    pn = fmaf(pn, u, 0.0042930529452860355f);
+    pn = fmaf(pn, u, 0.05243346840143204f);
+    pn = fmaf(pn, u, 0.2139447033405304f);
+    pn = fmaf(pn, u, 1.1283786296844482f);
+    float qd = fmaf(u, 0.0010980380466207862f, 0.01555109117180109f);
+    qd = fmaf(qd, u, 0.12079962342977524f);
+    qd = fmaf(qd, u, 0.5229312181472778f);
+    qd = fmaf(qd, u, 1.0f);
+    const float cdf = fmaf(z, pn, qd) * (0.5f * fast_rcp(qd));                       // Phi(a)
+    const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(a * a * -0.72134752044448170368f);   // phi(a)
+    const float sg = fast_rcp(1.0f + __builtin_amdgcn_exp2f(g * -1.4426950408889634f));
+    const float t = dy * sg;
+    da = t * fmaf(a, pdf, cdf);
+    dg = t * (a * cdf) * (1.0f - sg);
+}
+
 __global__ __launch_bounds__(256) void gated_bwd_kernel(const bf16* __restrict__ dact, const bf16* __restrict__ pre,
                                                         bf16* __restrict__ dpre, int M, int F) {
     const int per_row = F / 8;
@@ -406,13 +431,7 @@ __global__ __launch_bounds__(256) void gated_bwd_kernel(const bf16* __restrict__
         unpack8(*reinterpret_cast<const u32x4*>(pre + off + 16), g);
         unpack8(*reinterpret_cast<const u32x4*>(dact + (size_t)m * F + 8 * j), dy);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float sg = sigmoid_f(g[k]);
-            const float cdf = 0.5f * (1.0f + erff(a[k] * 0.70710678118654752440f));
-            const float pdf = 0.39894228040143267794f * __expf(-0.5f * a[k] * a[k]);
-            da[k] = dy[k] * sg * (cdf + a[k] * pdf);
-            dgt[k] = dy[k] * (a[k] * cdf) * sg * (1.0f - sg);
-        }
+        for (int k = 0; k < 8; ++k) gated_bwd_elem(a[k], g[k], dy[k], da[k], dgt[k]);
         *reinterpret_cast<u32x4*>(dpre + off) = pack8(da);
         *reinterpret_cast<u32x4*>(dpre + off + 16) = pack8(dgt);
     }
@@ -438,13 +457,7 @@ __global__ __launch_bounds__(256) void gated_bwd_colsum_kernel(const bf16* __res
         unpack8(*reinterpret_cast<const u32x4*>(pre + off + 16), g);
         unpack8(*reinterpret_cast<const u32x4*>(dact + (size_t)m * F + 8 * j), dy);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float sg = sigmoid_f(g[k]);
-            const float cdf = 0.5f * (1.0f + erff(a[k] * 0.70710678118654752440f));
-            const float pdf = 0.39894228040143267794f * __expf(-0.5f * a[k] * a[k]);
-            da[k] = dy[k] * sg * (cdf + a[k] * pdf);
-            dgt[k] = dy[k] * (a[k] * cdf) * sg * (1.0f - sg);
-        }
+        for (int k = 0; k < 8; ++k) gated_bwd_elem(a[k], g[k], dy[k], da[k], dgt[k]);
         const u32x4 pa = pack8(da), pg = pack8(dgt);
         *reinterpret_cast<u32x4*>(dpre + off) = pa;
         *reinterpret_cast<u32x4*>(dpre + off + 16) = pg;
