@@ -56,7 +56,7 @@ DITTO_DEV bf16x8 cat4(bf16x4 a, bf16x4 b) {
 // bf16's exponent range, accumulated in fp32 — and the 32-register O^T rescale is skipped on most tiles.
 constexpr float ATT_RESCALE_THR_LOG2 = 8.0f;
 
-// attention_v4.hip: one wave per SIMD, 64 queries per wave (pre-scaled q, Skv % 64 == 0, Skv >= 128)
+// attention_v4.hip: one wave per SIMD, 64 queries per wave (pre-scaled q, whole 64-key tiles: Skv % 64 == 0, Skv >= 64)
 bool attn64v4_supports(const AttnParams& p);
 hipError_t launch_attn64v4(const AttnParams& p, bool resid, hipStream_t s);
 

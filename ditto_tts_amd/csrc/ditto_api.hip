@@ -238,8 +238,13 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
             g.rope_cos = rope_cos; g.rope_sin = rope_sin; g.rope_rows_per_batch = N; g.rope_cols = 2 * d;
             if (fused_rope && !(g_gemm_flags & 1024)) g.rope_freq_rev = m->invf_rev;   // flag 1024: A/B, table loads
             g.fp8 = fp8; g.wscale = fp8 ? lp.sqkv : nullptr;
+#ifdef DITTO_DIAG_QKV_PLAIN   // tools/build_diag.sh: the QKV GEMM with the plain bias epilogue (NO RoPE: wrong results) — what
+                              // would the 256 x 192 kernel (whole tile rounds at M = 32768; gemm_tile 192) buy this class?
+            HIP_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
+#else
             HIP_TRY(launch_gemm(g, fused_rope ? EPI_QKV_ROPE : EPI_BIAS_BF16, s));
             if (!fused_rope) HIP_TRY(launch_rope_inplace(qkv, 3 * d, rope_cos, rope_sin, M, N, 2 * d, dh, s));
+#endif
         }
         {
             ProfScope ps(m, s, DITTO_KC_ATTN_SELF);

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256, 1) void attn64v4_kernel(AttnParams p) {
     unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     const int nwg = p.nqb * p.H * p.B;
-    // gridDim.x == nwg: one item per workgroup.  gridDim.x < nwg (attn_flags 32768: one workgroup per CU): a workgroup walks
+    // gridDim.x == nwg: one item per workgroup.  gridDim.x < nwg (attn_flags bit 18: one workgroup per CU): a workgroup walks
     // the items blockIdx.x, blockIdx.x + gridDim.x, ... one after the other (no re-dispatch between them); round r of the grid
     // covers the ids [r gridDim.x, (r + 1) gridDim.x), XCD-contiguous inside the round.
   for (int item = blockIdx.x; item < nwg; item += gridDim.x) {
@@ -580,7 +580,7 @@ hipError_t launch_v4_t(const AttnParams& p, bool resid, hipStream_t s) {
                                                    reinterpret_cast<const void*>(&attn64v4_kernel<false, NS, G>)}, v4_lds_bytes(NS)))
         return e;
     int nwg = p.nqb * p.H * p.B;
-    if ((g_attn_flags & 32768) && nwg > 256) nwg = 256;      // A/B: persistent workgroups, one per CU
+    if ((g_attn_flags & (1 << 18)) && nwg > 256) nwg = 256;  // A/B (bit 18): persistent workgroups, one per CU
     const dim3 grid(nwg);
     if (resid) hipLaunchKernelGGL((attn64v4_kernel<true, NS, G>), grid, dim3(256), v4_lds_bytes(NS), s, p);
     else hipLaunchKernelGGL((attn64v4_kernel<false, NS, G>), grid, dim3(256), v4_lds_bytes(NS), s, p);
@@ -591,9 +591,10 @@ hipError_t launch_v4_t(const AttnParams& p, bool resid, hipStream_t s) {
 hipError_t launch_attn64v4(const AttnParams& p_in, bool resid, hipStream_t s) {
     AttnParams p = p_in;
     p.nqb = (p.Sq + V4_QWG - 1) / V4_QWG;
-    // attn_flags bits 13-14 (A/B): ring depth / barrier period: 0 -> 8 tiles, a barrier per iteration; 1 -> 8 tiles, a barrier
-    // per 2 iterations; 2 -> 4 tiles, per iteration; 3 -> 10 tiles, per 3 iterations
-    switch ((g_attn_flags >> 13) & 3) {
+    // attn_flags bits 16-17 (A/B; moved off bits 13-14 in round 4: bit 13 = 8192 is attention.hip's "older training forward"
+    // switch): ring depth / barrier period: 0 -> 8 tiles, a barrier per iteration; 1 -> 8 tiles, a barrier per 2 iterations;
+    // 2 -> 4 tiles, per iteration; 3 -> 10 tiles, per 3 iterations
+    switch ((g_attn_flags >> 16) & 3) {
         case 1: return launch_v4_t<8, 2>(p, resid, s);
         case 2: return launch_v4_t<4, 1>(p, resid, s);
         case 3: return launch_v4_t<10, 3>(p, resid, s);
