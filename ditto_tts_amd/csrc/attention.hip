@@ -655,15 +655,16 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const bf16* __restri
 
 // in-place half-split RoPE on bf16 rows (generic head_dim): columns [0, ncols) are heads of width dh.
 __global__ __launch_bounds__(256) void rope_inplace_kernel(bf16* __restrict__ x, int ld, const float* __restrict__ cs,
-                                                           const float* __restrict__ sn, int M, int rpb, int ncols,
-                                                           int dh, float sin_sign) {
+                                                           const float* __restrict__ sn, int M, int rpb, int nheads,
+                                                           int dh, float sin_sign, int hstride) {
     const int half = dh >> 1;
-    const size_t npairs = (size_t)M * (ncols >> 1);
+    const int ppr = nheads * half;                          // rotation pairs per row
+    const size_t npairs = (size_t)M * ppr;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < npairs; i += (size_t)gridDim.x * blockDim.x) {
-        const int row = (int)(i / (ncols >> 1)), pc = (int)(i % (ncols >> 1));
+        const int row = (int)(i / ppr), pc = (int)(i % ppr);
         const int head = pc / half, j = pc % half;
         const int pos = row % rpb;
-        bf16* pl = x + (size_t)row * ld + head * dh + j;
+        bf16* pl = x + (size_t)row * ld + head * hstride + j;
         const float lo = (float)pl[0], hi = (float)pl[half];
         const float cc = cs[(size_t)pos * half + j], ss = sin_sign * sn[(size_t)pos * half + j];
         pl[0] = (bf16)(lo * cc - hi * ss);
@@ -695,12 +696,14 @@ size_t attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh) {
 }
 
 hipError_t launch_rope_inplace(void* x, int ld, const float* cs, const float* sn, int M, int rpb, int ncols, int dh,
-                               hipStream_t s, float sin_sign) {
-    const size_t npairs = (size_t)M * (ncols / 2);
+                               hipStream_t s, float sin_sign, int hstride) {
+    if (hstride <= 0) hstride = dh;
+    const int nheads = ncols / hstride;
+    const size_t npairs = (size_t)M * nheads * (dh / 2);
     size_t g = (npairs + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(rope_inplace_kernel, dim3((unsigned)(g ? g : 1)), dim3(256), 0, s, (bf16*)x, ld, cs, sn, M, rpb,
-                       ncols, dh, sin_sign);
+                       nheads, dh, sin_sign, hstride);
     return hipGetLastError();
 }
 

@@ -41,28 +41,30 @@ int fail(int code, const char* fmt, ...) {
 ArenaPlan plan_arena(const ditto_config& c) {
     ArenaPlan p;
     const size_t d = c.hidden_dim, L = c.num_layers;
+    const size_t dp = cfg_dp(c);                                      // attention-side width (= d unless heads are padded)
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
     p.layers.resize(L);
     for (size_t l = 0; l < L; ++l) {
         auto& q = p.layers[l];
         const size_t we = (c.flags & DITTO_CFG_FP8_LINEAR) ? 1 : 2;   // bytes per element of the fp8-able weights
-        q.Wqkv = take(3 * d * d * we); q.Wcq = take(d * d * 2); q.Wco = take(d * d * 2);
+        q.Wqkv = take(3 * dp * d * we); q.Wcq = take(dp * d * 2); q.Wco = take(d * dp * 2);
         q.W1g = take(8 * d * d * we); q.W2 = take(4 * d * d * we);
-        q.sqkv = take(3 * d * 4); q.s1g = take(8 * d * 4); q.s2 = take(d * 4);   // fp8 per-row weight scales
-        q.bqkv = take(3 * d * 4); q.bcq = take(d * 4); q.bco = take(d * 4); q.b1g = take(8 * d * 4); q.b2 = take(d * 4);
+        q.sqkv = take(3 * dp * 4); q.s1g = take(8 * d * 4); q.s2 = take(d * 4);   // fp8 per-row weight scales
+        q.bqkv = take(3 * dp * 4); q.bcq = take(dp * 4); q.bco = take(d * 4); q.b1g = take(8 * d * 4); q.b2 = take(d * 4);
         q.g1 = take(d * 4); q.be1 = take(d * 4); q.g2 = take(d * 4); q.be2 = take(d * 4); q.g3 = take(d * 4);
         q.be3 = take(d * 4);
         // stage-major bf16 copies of the N = d projections for the full-row kernels (gemm_fr.hip: d == 768, bf16 linears;
         // gemm_fr64.hip: d == 1024 — the cross out-projection is bf16 in the fp8 configuration too, fc2 only without it)
         const bool fp8c = (c.flags & DITTO_CFG_FP8_LINEAR) != 0;
-        const bool fr_o = (d == 768 && !fp8c) || d == 1024, fr_2 = (d == 768 || d == 1024) && !fp8c;
+        const bool pad = dp != d;                                    // padded heads: the tiled GEMMs + LayerNorm launches only
+        const bool fr_o = !pad && ((d == 768 && !fp8c) || d == 1024), fr_2 = !pad && (d == 768 || d == 1024) && !fp8c;
         q.WcoP = fr_o ? take(d * d * 2) : 0; q.W2P = fr_2 ? take(4 * d * d * 2) : 0;
         // ... and of the cross q-projection for the fused norm2 + q-projection kernel (gemm_lnq.hip, d == 768): both MFMA shapes' images
-        const bool lnq = d == 768 && !fp8c;
+        const bool lnq = !pad && d == 768 && !fp8c;
         q.WcqP = lnq ? take(d * d * 2) : 0; q.WcqP32 = lnq ? take(d * d * 2) : 0;
     }
-    p.Wkv = take(L * 2 * d * d * 2); p.bkv = take(L * 2 * d * 4);
+    p.Wkv = take(L * 2 * dp * d * 2); p.bkv = take(L * 2 * dp * 4);
     p.Wfin = take(d * 2 * d * 2); p.bfin = take(d * 4);
     p.ttab = take((size_t)c.diffusion_steps * 2 * d * 4);
     p.wx = take(2 * d * (size_t)c.text_dim * 4); p.bx = take(2 * d * 4);
@@ -105,10 +107,10 @@ int small_batch_k_splits(int M, int N, int K) {
 
 WsPlan plan_ws(const ditto_config& c, int B, int N, int T) {
     WsPlan w;
-    const size_t d = c.hidden_dim, M = (size_t)B * N, dh = d / c.num_heads;
+    const size_t d = c.hidden_dim, M = (size_t)B * N, dh = cfg_dhp(c), dp = cfg_dp(c);   // dh: the PHYSICAL head width
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
-    w.h = take(M * d * 4); w.u = take(M * d * 2); w.qkv = take(M * 3 * d * 2); w.act = take(M * 4 * d * 2);
+    w.h = take(M * d * 4); w.u = take(M * dp * 2); w.qkv = take(M * 3 * dp * 2); w.act = take(M * 4 * d * 2);
     w.xcat = take(M * 2 * d * 2); w.eps = take(M * d * 4);
     const size_t a1 = attention_workspace_bytes(B, c.num_heads, N, N, (int)dh);
     const size_t a2 = attention_workspace_bytes(B, c.num_heads, N, T, (int)dh);
@@ -133,7 +135,13 @@ int check_cfg(const ditto_config* c) {
     if (c->hidden_dim % 64) return fail(DITTO_ERR_SHAPE, "hidden_dim must be a multiple of 64 (MFMA K tile)");
     if (c->hidden_dim > 2048) return fail(DITTO_ERR_SHAPE, "hidden_dim > 2048 not supported by the LayerNorm kernel");
     const int dh = c->hidden_dim / c->num_heads;
-    if (dh % 64) return fail(DITTO_ERR_SHAPE, "head_dim (%d) must be a multiple of 64", dh);
+    if (dh % 2) return fail(DITTO_ERR_SHAPE, "head_dim (%d) must be even (half-split RoPE, src/components/DiT.py:52-54)", dh);
+    // head_dim % 64 != 0 (the reference takes any hidden_dim % num_heads == 0, src/components/DiT.py:78-86; e.g. 1152 / 16 = 72)
+    // runs with the heads PADDED to the next multiple of 64 inside the block (model.h cfg_dhp): inference only, bf16 linears
+    if (dh % 64 && (c->flags & DITTO_CFG_FP8_LINEAR))
+        return fail(DITTO_ERR_SHAPE, "fp8 linear layers need head_dim %% 64 == 0 (head_dim %d)", dh);
+    if (dh % 64 && 4 * c->hidden_dim < cfg_dp(*c))
+        return fail(DITTO_ERR_SHAPE, "head_dim %d pads to %d: more than 4x hidden_dim of attention width is not supported", dh, cfg_dhp(*c));
     if ((c->flags & DITTO_CFG_FP8_LINEAR) && c->hidden_dim % 128)
         return fail(DITTO_ERR_SHAPE, "fp8 linear layers need hidden_dim %% 128 == 0");
     if (c->flags & ~DITTO_CFG_FP8_LINEAR) return fail(DITTO_ERR_ARG, "unknown config flag");
@@ -143,8 +151,8 @@ int check_cfg(const ditto_config* c) {
 // A pinned kernel class (fr_class_rows > 0: "decide as the unsplit batch of that many rows would") that says full-row while THIS
 // launch cannot run a full-row kernel (fewer rows than one 64-row tile) would silently take the tiled GEMMs, whose last bits
 // differ: the promise of the pin — sharding changes no bit — would be broken without a sign.  Fail instead.
-int check_class_pin(int M, int d, bool fp8) {
-    if (g_fr_class_rows <= 0 || !g_fr_mask || M >= 64) return DITTO_OK;
+int check_class_pin(int M, int d, bool fp8, bool has_fr) {   // has_fr: the model has full-row kernels at all (not on padded heads)
+    if (!has_fr || g_fr_class_rows <= 0 || !g_fr_mask || M >= 64) return DITTO_OK;
     const bool wants = d == 768 ? (!fp8 && fr_rule_rows(g_fr_class_rows) != 0) : (d == 1024 && fr_pays_64(M));
     if (!wants) return DITTO_OK;
     return fail(DITTO_ERR_SHAPE, "kernel class pinned to a batch of %d rows (full-row GEMM + LayerNorm kernels), but this launch has "
@@ -211,6 +219,11 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
     const int d = c.hidden_dim, H = c.num_heads, dh = d / H, M = B * N;
     const float scale = 1.0f / sqrtf((float)dh);
     const bool fused_rope = (dh == 64);
+    // padded heads (head_dim % 64 != 0): q / k / v and the attention outputs are dp = H * dhp wide, heads at a stride of dhp
+    // (zero pads: the packed weights have zero rows / columns there), the attention runs the GEMM-composed path on dhp-wide
+    // heads with the TRUE head_dim's softmax scale; the self-attention's head merge + residual is a compaction pass
+    const int dhp = cfg_dhp(c), dp = cfg_dp(c);
+    const bool pad = dp != d;
     const bool fp8 = (c.flags & DITTO_CFG_FP8_LINEAR) != 0;   // u / act hold fp8 bytes for the fp8 GEMMs
     const LayerPack& lp = m->layers[l];
     // full-row GEMM with the residual add and the FOLLOWING LayerNorm fused (gemm_fr.hip): bit 0 = cross out-proj + norm3,
@@ -220,7 +233,7 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
     const bool fr_out = lp.WcoP && (g_fr_mask & 1) && fr_outproj_ok(M, d);
     const bool fr_fc2 = !fp8 && lp.W2P && (g_fr_mask & 2) && fr_fc2_ok(M, d);
     const int fr_rot = N % 128 == 0 ? N / 128 : 0;   // tiles per utterance: the K-loop rotation period (gemm_fr.hip)
-    if (int rc = ditto::check_class_pin(M, d, fp8)) return rc;
+    if (int rc = ditto::check_class_pin(M, d, fp8, !pad)) return rc;
     // hb: `h` holds BF16 rows (the bf16 residual stream; ditto_forward decides, and only where both fused launches run)
     if (hb && (!fr_out || !fr_fc2 || dh != 64 || tap_self || tap_cross)) return fail(DITTO_ERR_ARG, "internal: bf16 stream outside its class");
         // ---- self-attention (src/components/DiT.py:103-139) ----
@@ -233,8 +246,8 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
         {
             ProfScope ps(m, s, DITTO_KC_GEMM_QKV);
             GemmArgs g{};
-            g.A = u; g.lda = d; g.W = lp.Wqkv; g.bias = lp.bqkv; g.out = qkv; g.ldo = 3 * d;
-            g.M = M; g.N = 3 * d; g.K = d;
+            g.A = u; g.lda = d; g.W = lp.Wqkv; g.bias = lp.bqkv; g.out = qkv; g.ldo = 3 * dp;
+            g.M = M; g.N = 3 * dp; g.K = d;
             g.rope_cos = rope_cos; g.rope_sin = rope_sin; g.rope_rows_per_batch = N; g.rope_cols = 2 * d;
             if (fused_rope && !(g_gemm_flags & 1024)) g.rope_freq_rev = m->invf_rev;   // flag 1024: A/B, table loads
             g.fp8 = fp8; g.wscale = fp8 ? lp.sqkv : nullptr;
@@ -243,17 +256,23 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
             HIP_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
 #else
             HIP_TRY(launch_gemm(g, fused_rope ? EPI_QKV_ROPE : EPI_BIAS_BF16, s));
-            if (!fused_rope) HIP_TRY(launch_rope_inplace(qkv, 3 * d, rope_cos, rope_sin, M, N, 2 * d, dh, s));
+            if (!fused_rope) HIP_TRY(launch_rope_inplace(qkv, 3 * dp, rope_cos, rope_sin, M, N, 2 * dp, dh, s, 1.0f, dhp));
 #endif
         }
         {
             ProfScope ps(m, s, DITTO_KC_ATTN_SELF);
             AttnArgs a{};
-            a.q = qkv; a.ldq = 3 * d; a.k = qkv + (size_t)d * 2; a.ldk = 3 * d; a.v = qkv + (size_t)2 * d * 2;
-            a.ldv = 3 * d; a.resid_f32 = h; a.ldr = d; a.B = B; a.H = H; a.Sq = N; a.Skv = N; a.dh = dh;
+            a.q = qkv; a.ldq = 3 * dp; a.k = qkv + (size_t)dp * 2; a.ldk = 3 * dp; a.v = qkv + (size_t)2 * dp * 2;
+            a.ldv = 3 * dp; a.B = B; a.H = H; a.Sq = N; a.Skv = N; a.dh = dhp;
             a.scale = scale; a.workspace = attn_ws; a.workspace_bytes = attn_ws_bytes; a.q_prescaled = (dh == 64);
-            a.resid_bf16 = hb;
-            HIP_TRY(launch_attention(a, s));
+            if (pad) {   // O at the padded stride into `act` (free here), then h[:, hd dh + c] += O[:, hd dhp + c]
+                a.out_bf16 = act; a.ldo = dp;
+                HIP_TRY(launch_attention(a, s));
+                HIP_TRY(launch_head_compact_add(act, dp, h, d, M, d, dh, dhp, s));
+            } else {
+                a.resid_f32 = h; a.ldr = d; a.resid_bf16 = hb;
+                HIP_TRY(launch_attention(a, s));
+            }
         }
         if (tap_self) HIP_TRY(hipMemcpyAsync(tap_self, h, (size_t)M * d * 4, hipMemcpyDeviceToDevice, s));
         // ---- cross-attention (src/components/DiT.py:141-148), K/V from the per-utterance cache ----
@@ -271,15 +290,15 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
             }
             ProfScope ps(m, s, DITTO_KC_GEMM_QPROJ);
             GemmArgs g{};
-            g.A = u; g.lda = d; g.W = lp.Wcq; g.bias = lp.bcq; g.out = qkv; g.ldo = d; g.M = M; g.N = d; g.K = d;
+            g.A = u; g.lda = d; g.W = lp.Wcq; g.bias = lp.bcq; g.out = qkv; g.ldo = dp; g.M = M; g.N = dp; g.K = d;
             HIP_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
         }
         {
             ProfScope ps(m, s, DITTO_KC_ATTN_CROSS);
             AttnArgs a{};
-            a.q = qkv; a.ldq = d; a.k = kv + (size_t)kv_layer * 2 * d * 2; a.ldk = kv_ld;
-            a.v = kv + ((size_t)kv_layer * 2 * d + d) * 2; a.ldv = kv_ld; a.out_bf16 = u; a.ldo = d;
-            a.B = B; a.H = H; a.Sq = N; a.Skv = T; a.dh = dh; a.scale = scale;
+            a.q = qkv; a.ldq = dp; a.k = kv + (size_t)kv_layer * 2 * dp * 2; a.ldk = kv_ld;
+            a.v = kv + ((size_t)kv_layer * 2 * dp + dp) * 2; a.ldv = kv_ld; a.out_bf16 = u; a.ldo = dp;
+            a.B = B; a.H = H; a.Sq = N; a.Skv = T; a.dh = dhp; a.scale = scale;
             a.workspace = attn_ws; a.workspace_bytes = attn_ws_bytes; a.q_prescaled = (dh == 64);
             HIP_TRY(launch_attention(a, s));
         }
@@ -294,8 +313,8 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
         } else {
             ProfScope ps(m, s, DITTO_KC_GEMM_OUTPROJ);
             GemmArgs g{};
-            g.A = u; g.lda = d; g.W = lp.Wco; g.bias = lp.bco; g.residual = h; g.ldr = d; g.out = h; g.ldo = d;
-            g.M = M; g.N = d; g.K = d;
+            g.A = u; g.lda = dp; g.W = lp.Wco; g.bias = lp.bco; g.residual = h; g.ldr = d; g.out = h; g.ldo = d;
+            g.M = M; g.N = d; g.K = dp;
             HIP_TRY(launch_gemm(g, EPI_BIAS_RES_F32, s));
         }
         if (tap_cross) HIP_TRY(hipMemcpyAsync(tap_cross, h, (size_t)M * d * 4, hipMemcpyDeviceToDevice, s));
@@ -360,8 +379,8 @@ size_t ditto_arena_bytes(const ditto_config* cfg) {
 }
 size_t ditto_cond_bytes(const ditto_config* cfg, int B, int T) {
     if (check_cfg(cfg) != DITTO_OK || B <= 0 || T <= 0) return 0;
-    const size_t d = cfg->hidden_dim;
-    return al((size_t)B * T * cfg->num_layers * 2 * d * 2) + al((size_t)B * 2 * d * 4);
+    const size_t d = cfg->hidden_dim, dp = cfg_dp(*cfg);
+    return al((size_t)B * T * cfg->num_layers * 2 * dp * 2) + al((size_t)B * 2 * d * 4);
 }
 size_t ditto_workspace_bytes(const ditto_config* cfg, int B, int N, int T) {
     if (check_cfg(cfg) != DITTO_OK || B <= 0 || N <= 0 || T <= 0) return 0;
@@ -403,6 +422,37 @@ int ditto_model_create(const ditto_config* cfg, const ditto_weights* w, void* ar
         // the q rows of the packed weights / biases here, so the attention kernel's scores are in log2 units
         const bool pre = (d / cfg->num_heads) == 64;
         const float qs = pre ? 1.4426950408889634f / sqrtf((float)(d / cfg->num_heads)) : 1.0f;
+        const int dh_ = d / cfg->num_heads, dhp = cfg_dhp(*cfg), dp = cfg_dp(*cfg);
+        const bool pad = dp != d;
+        if (pad) {
+            // padded heads: zero images, then every in-projection's rows / the out-projection's columns head by head
+            HIP_TRY(hipMemsetAsync(A + q.Wqkv, 0, (size_t)3 * dp * d * 2, s));
+            HIP_TRY(hipMemsetAsync(A + q.Wcq, 0, (size_t)dp * d * 2, s));
+            HIP_TRY(hipMemsetAsync(A + q.Wco, 0, (size_t)d * dp * 2, s));
+            HIP_TRY(hipMemsetAsync(A + q.bqkv, 0, (size_t)3 * dp * 4, s));
+            HIP_TRY(hipMemsetAsync(A + q.bcq, 0, (size_t)dp * 4, s));
+            if (l == 0) {
+                HIP_TRY(hipMemsetAsync(A + plan.Wkv, 0, (size_t)L * 2 * dp * d * 2, s));
+                HIP_TRY(hipMemsetAsync(A + plan.bkv, 0, (size_t)L * 2 * dp * 4, s));
+            }
+            for (int part = 0; part < 3; ++part) {   // q | k | v rows of attn.in_proj
+                HIP_TRY(launch_pack_bf16_headrows(lw.attn_in_proj_weight + (size_t)part * d * d, A + q.Wqkv, d, d, d, dh_, dhp,
+                                                  part * dp, s));
+                HIP_TRY(launch_pack_vec_heads(lw.attn_in_proj_bias + part * d, (float*)(A + q.bqkv), d, dh_, dhp, part * dp, s));
+            }
+            HIP_TRY(launch_pack_bf16_headrows(lw.cross_in_proj_weight, A + q.Wcq, d, d, d, dh_, dhp, 0, s));
+            HIP_TRY(launch_pack_vec_heads(lw.cross_in_proj_bias, (float*)(A + q.bcq), d, dh_, dhp, 0, s));
+            for (int part = 0; part < 2; ++part) {   // k | v rows of cross_attn.in_proj -> the all-layer K/V projection
+                HIP_TRY(launch_pack_bf16_headrows(lw.cross_in_proj_weight + (size_t)(1 + part) * d * d, A + plan.Wkv, d, d, d, dh_,
+                                                  dhp, l * 2 * dp + part * dp, s));
+                HIP_TRY(launch_pack_vec_heads(lw.cross_in_proj_bias + (1 + part) * d, (float*)(A + plan.bkv), d, dh_, dhp,
+                                              l * 2 * dp + part * dp, s));
+            }
+            HIP_TRY(launch_pack_bf16_headcols(lw.cross_out_proj_weight, A + q.Wco, d, d, dp, dh_, dhp, s));
+            HIP_TRY(launch_pack_bf16(lw.mlp_fc1_weight, A + q.W1g, 4 * d, d, d, 0, 16, 2, 0, s));
+            HIP_TRY(launch_pack_bf16(lw.gate_weight, A + q.W1g, 4 * d, d, d, 0, 16, 2, 16, s));
+            HIP_TRY(launch_pack_bf16(lw.mlp_fc2_weight, A + q.W2, d, 4 * d, 4 * d, 0, BIG, 1, 0, s));
+        } else {
         if (fp8) {
             HIP_TRY(launch_pack_fp8(lw.attn_in_proj_weight, A + q.Wqkv, (float*)(A + q.sqkv), 3 * d, d, d, BIG, 1, 0, s));
             HIP_TRY(launch_pack_fp8(lw.mlp_fc1_weight, A + q.W1g, (float*)(A + q.s1g), 4 * d, d, d, 16, 2, 0, s));
@@ -429,10 +479,12 @@ int ditto_model_create(const ditto_config* cfg, const ditto_weights* w, void* ar
         HIP_TRY(hipMemcpyAsync(A + plan.bkv + (size_t)l * 2 * d * 4, lw.cross_in_proj_bias + d, 2 * d * 4,
                                hipMemcpyDeviceToDevice, s));
         HIP_TRY(launch_pack_bf16(lw.cross_out_proj_weight, A + q.Wco, d, d, d, 0, BIG, 1, 0, s));
-        const bool fr_o = (d == 768 && !fp8) || d == 1024, fr_2 = (d == 768 || d == 1024) && !fp8;   // as plan_arena
+        }   // !pad
+        const bool fr_o = !pad && ((d == 768 && !fp8) || d == 1024), fr_2 = !pad && (d == 768 || d == 1024) && !fp8;   // as plan_arena
+        const bool lnq_w = !pad && d == 768 && !fp8;
         if (fr_o) HIP_TRY(launch_pack_bf16_stage_major(lw.cross_out_proj_weight, A + q.WcoP, d, d, s));
         if (fr_2) HIP_TRY(launch_pack_bf16_stage_major(lw.mlp_fc2_weight, A + q.W2P, d, 4 * d, s));
-        if (d == 768 && !fp8) {   // from the PACKED q-projection (it carries the folded scale * log2(e))
+        if (lnq_w) {   // from the PACKED q-projection (it carries the folded scale * log2(e))
             HIP_TRY(launch_repack_bf16_stage_major(A + q.Wcq, A + q.WcqP, d, d, s, 16));
             HIP_TRY(launch_repack_bf16_stage_major(A + q.Wcq, A + q.WcqP32, d, d, s, 32));
         }
@@ -453,7 +505,7 @@ int ditto_model_create(const ditto_config* cfg, const ditto_weights* w, void* ar
         lp.sqkv = (const float*)(A + q.sqkv); lp.s1g = (const float*)(A + q.s1g); lp.s2 = (const float*)(A + q.s2);
         if (fr_o) lp.WcoP = A + q.WcoP;
         if (fr_2) lp.W2P = A + q.W2P;
-        if (d == 768 && !fp8) { lp.WcqP = A + q.WcqP; lp.WcqP32 = A + q.WcqP32; }
+        if (lnq_w) { lp.WcqP = A + q.WcqP; lp.WcqP32 = A + q.WcqP32; }
         lp.g1 = (const float*)(A + q.g1); lp.be1 = (const float*)(A + q.be1); lp.g2 = (const float*)(A + q.g2);
         lp.be2 = (const float*)(A + q.be2); lp.g3 = (const float*)(A + q.g3); lp.be3 = (const float*)(A + q.be3);
     }
@@ -520,16 +572,16 @@ int ditto_text_precompute(ditto_model_t m, const float* text, int B, int T, void
     if (workspace_bytes < need) return fail(DITTO_ERR_SIZE, "workspace too small for text precompute: %zu < %zu",
                                             workspace_bytes, need);
     hipStream_t s = (hipStream_t)stream;
-    const int d = c.hidden_dim, L = c.num_layers;
+    const int d = c.hidden_dim, L = c.num_layers, dp = cfg_dp(c);
     char* ws = (char*)workspace;
     void* textbf = ws;
     float* pooled = (float*)(ws + al((size_t)B * T * c.text_dim * 2));
     char* kv = (char*)cond;
-    float* tmod = (float*)(kv + al((size_t)B * T * L * 2 * d * 2));
+    float* tmod = (float*)(kv + al((size_t)B * T * L * 2 * dp * 2));
     HIP_TRY(launch_cast_bf16(text, textbf, (size_t)B * T * c.text_dim, s));
     GemmArgs g{};
-    g.A = textbf; g.lda = c.text_dim; g.W = m->Wkv; g.bias = m->bkv; g.out = kv; g.ldo = L * 2 * d;
-    g.M = B * T; g.N = L * 2 * d; g.K = d;
+    g.A = textbf; g.lda = c.text_dim; g.W = m->Wkv; g.bias = m->bkv; g.out = kv; g.ldo = L * 2 * dp;
+    g.M = B * T; g.N = L * 2 * dp; g.K = d;
     HIP_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
     if (!m->blocks_only) HIP_TRY(launch_text_mod(text, m->wx, m->bx, pooled, tmod, B, T, c.text_dim, d, s));
     return DITTO_OK;
@@ -556,7 +608,7 @@ int ditto_forward(ditto_model_t m, const float* x, const void* cond, const int64
     char* xcat = ws + w.xcat;
     void* attn_ws = ws + w.attn;
     const char* kv = (const char*)cond;
-    const float* tmod = (const float*)(kv + al((size_t)B * T * L * 2 * d * 2));
+    const float* tmod = (const float*)(kv + al((size_t)B * T * L * 2 * cfg_dp(c) * 2));
 
     // fc2 on the full-row kernel also emits the NEXT block's norm1 (fr_mask bit 1): that block then skips its LayerNorm
     const bool fp8c = (c.flags & DITTO_CFG_FP8_LINEAR) != 0;
@@ -583,7 +635,7 @@ int ditto_forward(ditto_model_t m, const float* x, const void* cond, const int64
     for (int l = 0; l < L; ++l)
         if (int rc = run_block(m, l, h, u, qkv, act, l == L - 1 ? xcat : nullptr, attn_ws, w.attn_bytes,
                                (float*)(ws + w.splitk), w.splitk_bytes, kv, l,
-                               L * 2 * d, rope_cos, rope_sin, B, N, T, s, nullptr, nullptr,
+                               L * 2 * cfg_dp(c), rope_cos, rope_sin, B, N, T, s, nullptr, nullptr,
                                (chain_ln1 && l > 0) || (ln1_in_adaln && l == 0),
                                chain_ln1 && l + 1 < L ? m->layers[l + 1].g1 : nullptr,
                                chain_ln1 && l + 1 < L ? m->layers[l + 1].be1 : nullptr, hb))
@@ -626,7 +678,7 @@ int ditto_block_forward_taps(ditto_model_t m, int layer, float* h, const void* c
     if (workspace_bytes < w.total) return fail(DITTO_ERR_SIZE, "workspace too small: %zu < %zu", workspace_bytes, w.total);
     char* ws = (char*)workspace;
     return run_block(m, layer, h, ws + w.u, ws + w.qkv, ws + w.act, nullptr, ws + w.attn, w.attn_bytes,
-                     (float*)(ws + w.splitk), w.splitk_bytes, (const char*)cond, cond_layer, c.num_layers * 2 * c.hidden_dim, rope_cos, rope_sin, B, N, T,
+                     (float*)(ws + w.splitk), w.splitk_bytes, (const char*)cond, cond_layer, c.num_layers * 2 * cfg_dp(c), rope_cos, rope_sin, B, N, T,
                      (hipStream_t)stream, tap_self, tap_cross);
 }
 
@@ -1072,8 +1124,9 @@ int ditto_full_row_plan(const ditto_config* cfg, int B, int N, int* outproj, int
     if ((long long)B * N > 0x7fffffffLL) return fail(DITTO_ERR_SHAPE, "B * N exceeds 2^31 - 1 rows");
     const int d = cfg->hidden_dim, M = B * N;
     const bool fp8c = (cfg->flags & DITTO_CFG_FP8_LINEAR) != 0;          // plan_arena packs the stage-major copies for these:
-    if (int rc = check_class_pin(M, d, fp8c)) return rc;                  // what the forward itself would answer
-    const bool have_o = (d == 768 && !fp8c) || d == 1024, have_2 = (d == 768 || d == 1024) && !fp8c;
+    if (int rc = check_class_pin(M, d, fp8c, !cfg_padded(*cfg))) return rc;   // what the forward itself would answer
+    const bool padc = cfg_padded(*cfg);                                   // padded heads: the tiled path only
+    const bool have_o = !padc && ((d == 768 && !fp8c) || d == 1024), have_2 = !padc && (d == 768 || d == 1024) && !fp8c;
     *outproj = have_o && (g_fr_mask & 1) && fr_outproj_ok(M, d);
     *fc2 = have_2 && (g_fr_mask & 2) && fr_fc2_ok(M, d);
     return DITTO_OK;

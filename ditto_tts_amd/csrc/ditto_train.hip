@@ -147,6 +147,9 @@ int check_train(const ditto_model* m) {
     if (!m) return fail(DITTO_ERR_ARG, "null model");
     if (m->blocks_only) return fail(DITTO_ERR_ARG, "training needs a full model handle (not blocks-only)");
     if (m->cfg.flags & DITTO_CFG_FP8_LINEAR) return fail(DITTO_ERR_SHAPE, "training with fp8 linear layers is not supported");
+    if (cfg_padded(m->cfg))
+        return fail(DITTO_ERR_SHAPE, "training needs head_dim %% 64 == 0 (head_dim %d runs forward-only, on padded heads)",
+                    m->cfg.hidden_dim / m->cfg.num_heads);
     return DITTO_OK;
 }
 
@@ -160,15 +163,15 @@ int get_wgrad_wgs() { return g_wgrad_wgs; }
 extern "C" {
 
 size_t ditto_train_arena_bytes(const ditto_config* cfg) {
-    if (check_cfg(cfg) != DITTO_OK) return 0;
+    if (check_cfg(cfg) != DITTO_OK || cfg_padded(*cfg)) return 0;
     return plan_train_arena(*cfg).total;
 }
 size_t ditto_tape_bytes(const ditto_config* cfg, int B, int N, int T) {
-    if (check_cfg(cfg) != DITTO_OK || B <= 0 || N <= 0 || T <= 0) return 0;
+    if (check_cfg(cfg) != DITTO_OK || cfg_padded(*cfg) || B <= 0 || N <= 0 || T <= 0) return 0;
     return plan_tape(*cfg, B, N, T).total;
 }
 size_t ditto_train_workspace_bytes(const ditto_config* cfg, int B, int N, int T) {
-    if (check_cfg(cfg) != DITTO_OK || B <= 0 || N <= 0 || T <= 0) return 0;
+    if (check_cfg(cfg) != DITTO_OK || cfg_padded(*cfg) || B <= 0 || N <= 0 || T <= 0) return 0;
     return plan_train_ws(*cfg, B, N, T).total;
 }
 

@@ -55,6 +55,13 @@ hipError_t launch_rope_tables(const float* inv_freq, float* cos_out, float* sin_
 hipError_t launch_pack_bf16(const float* src, void* dst_bf16, int rows, int cols, int dst_ld, int col_off, int blk,
                             int mult, int row_off, hipStream_t s, float scale = 1.0f);
 hipError_t launch_scale_vec(float* v, int n, float f, hipStream_t s);
+// head padding (head_dim % 64 != 0): heads of width dh laid out at a stride of dhp = roundup(dh, 64), pads zero (rowwise.hip)
+hipError_t launch_pack_bf16_headrows(const float* src, void* dst, int rows, int cols, int dst_ld, int dh, int dhp,
+                                     int dst_row_off, hipStream_t s, float scale = 1.0f);
+hipError_t launch_pack_bf16_headcols(const float* src, void* dst, int rows, int cols, int dst_ld, int dh, int dhp, hipStream_t s);
+hipError_t launch_pack_vec_heads(const float* src, float* dst, int n, int dh, int dhp, int dst_off, hipStream_t s, float scale = 1.0f);
+// h fp32 [M, ldh][:, hd * dh + c] += o bf16 [M, ldo][:, hd * dhp + c]
+hipError_t launch_head_compact_add(const void* o_bf16, int ldo, float* h, int ldh, int M, int d, int dh, int dhp, hipStream_t s);
 // fp32 [N, K] -> bf16 stage-major [K/16][N][16] (the full-row GEMM's weight layout, gemm_fr.hip)
 hipError_t launch_pack_bf16_stage_major(const float* src, void* dst, int N, int K, hipStream_t s);
 hipError_t launch_repack_bf16_stage_major(const void* src_bf16, void* dst, int N, int K, hipStream_t s, int group = 16);
@@ -209,8 +216,9 @@ hipError_t launch_layernorm_dual(const float* x, const float* gamma, const float
                                  int M, int d, hipStream_t s);
 // in-place half-split RoPE on bf16 [M, ld] for `nheads` heads of width dh starting at column 0 (generic path);
 // sin_sign = -1 applies the inverse rotation (the backward of RoPE)
+// hstride > 0: heads of width dh sit at a stride of hstride columns (padded heads); ncols then counts PHYSICAL columns
 hipError_t launch_rope_inplace(void* qk_bf16, int ld, const float* cosT, const float* sinT, int M,
-                               int rows_per_batch, int ncols, int dh, hipStream_t s, float sin_sign = 1.0f);
+                               int rows_per_batch, int ncols, int dh, hipStream_t s, float sin_sign = 1.0f, int hstride = 0);
 
 // attention backward: dq/dk/dv bf16 (same head layout as q/k/v) from dO bf16; probabilities recomputed
 struct AttnBwdArgs {

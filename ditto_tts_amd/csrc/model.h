@@ -42,6 +42,12 @@ struct ArenaPlan {
 };
 ArenaPlan plan_arena(const ditto_config& c);
 
+// head_dim % 64 != 0: inside the block the heads of q / k / v sit at a stride of dhp = roundup(head_dim, 64) columns with zero
+// pads (rowwise.hip "Head padding"); dp = H * dhp is the width of the attention-side buffers.  dhp == head_dim otherwise.
+inline int cfg_dhp(const ditto_config& c) { const int dh = c.hidden_dim / c.num_heads; return (dh + 63) / 64 * 64; }
+inline int cfg_dp(const ditto_config& c) { return c.num_heads * cfg_dhp(c); }
+inline bool cfg_padded(const ditto_config& c) { return cfg_dp(c) != c.hidden_dim; }
+
 struct WsPlan { size_t h, u, qkv, act, xcat, eps, attn, attn_bytes, splitk, splitk_bytes, total; };
 // K-splits of a long-K, few-tile GEMM [M, N] x K at small batch (1 = none): ditto_api.hip
 int small_batch_k_splits(int M, int N, int K);
@@ -49,7 +55,7 @@ WsPlan plan_ws(const ditto_config& c, int B, int N, int T);
 int check_cfg(const ditto_config* c);
 void set_wgrad_wgs(int v);   // ditto_train.hip: split-K target of the wgrad GEMMs (ditto_set_option("wgrad_wgs"))
 int get_wgrad_wgs();
-int check_class_pin(int M, int d, bool fp8);   // ditto_api.hip: a pinned full-row class that this launch cannot take -> error
+int check_class_pin(int M, int d, bool fp8, bool has_fr);   // ditto_api.hip: a pinned full-row class that this launch cannot take -> error
 
 }  // namespace ditto
 

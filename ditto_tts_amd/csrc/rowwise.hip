@@ -620,6 +620,73 @@ hipError_t launch_repack_bf16_stage_major(const void* src, void* dst, int N, int
                        (bf16*)dst, N, K, group);
     return hipGetLastError();
 }
+// ------------------------------------------------------------------------------------------------
+// Head padding (head_dim % 64 != 0, e.g. the paper's XL shape 1152 / 16 = 72): the attention GEMMs need head widths that
+// are multiples of the 64-deep K tile, so inside the block the heads of q / k / v live at a stride of dhp = roundup(dh, 64)
+// columns with ZERO pads — zero weight rows and biases in the projections that produce them (q.k^T and P.V are then
+// unchanged: the pads add 0), zero weight COLUMNS in the out-projection that consumes them.  These kernels build those
+// images; the destination regions are zero-filled first.
+// ------------------------------------------------------------------------------------------------
+// dst[(r / dh) * dhp + r % dh + dst_row_off][c] = bf16(src[r][c] * scale): the rows of an in-projection, head by head
+__global__ __launch_bounds__(256) void pack_bf16_headrows_kernel(const float* __restrict__ src, bf16* __restrict__ dst,
+                                                                 int rows, int cols, int dst_ld, int dh, int dhp,
+                                                                 int dst_row_off, float scale) {
+    const size_t n = (size_t)rows * cols;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cols), c = (int)(i % cols);
+        dst[(size_t)((r / dh) * dhp + r % dh + dst_row_off) * dst_ld + c] = (bf16)(src[i] * scale);
+    }
+}
+// dst[r][(c / dh) * dhp + c % dh] = bf16(src[r][c]): the columns of an out-projection
+__global__ __launch_bounds__(256) void pack_bf16_headcols_kernel(const float* __restrict__ src, bf16* __restrict__ dst,
+                                                                 int rows, int cols, int dst_ld, int dh, int dhp) {
+    const size_t n = (size_t)rows * cols;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cols), c = (int)(i % cols);
+        dst[(size_t)r * dst_ld + (c / dh) * dhp + c % dh] = (bf16)src[i];
+    }
+}
+__global__ void pack_vec_heads_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int dh, int dhp,
+                                      int dst_off, float scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[(i / dh) * dhp + i % dh + dst_off] = src[i] * scale;
+}
+// h[row, hd * dh + c] += o[row, hd * dhp + c]: the self-attention's head merge + residual (src/components/DiT.py:137-139: no
+// out-projection) when the heads were computed at the padded stride
+__global__ __launch_bounds__(256) void head_compact_add_kernel(const bf16* __restrict__ o, int ldo, float* __restrict__ h,
+                                                               int ldh, size_t n, int d, int dh, int dhp) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / d;
+        const int c = (int)(i % d);
+        h[row * ldh + c] += (float)o[row * ldo + (c / dh) * dhp + c % dh];
+    }
+}
+static unsigned ew_blocks(size_t n) {
+    size_t g = (n + 255) / 256;
+    return (unsigned)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+hipError_t launch_pack_bf16_headrows(const float* src, void* dst, int rows, int cols, int dst_ld, int dh, int dhp,
+                                     int dst_row_off, hipStream_t s, float scale) {
+    hipLaunchKernelGGL(pack_bf16_headrows_kernel, dim3(ew_blocks((size_t)rows * cols)), dim3(256), 0, s, src, (bf16*)dst, rows,
+                       cols, dst_ld, dh, dhp, dst_row_off, scale);
+    return hipGetLastError();
+}
+hipError_t launch_pack_bf16_headcols(const float* src, void* dst, int rows, int cols, int dst_ld, int dh, int dhp,
+                                     hipStream_t s) {
+    hipLaunchKernelGGL(pack_bf16_headcols_kernel, dim3(ew_blocks((size_t)rows * cols)), dim3(256), 0, s, src, (bf16*)dst, rows,
+                       cols, dst_ld, dh, dhp);
+    return hipGetLastError();
+}
+hipError_t launch_pack_vec_heads(const float* src, float* dst, int n, int dh, int dhp, int dst_off, hipStream_t s, float scale) {
+    hipLaunchKernelGGL(pack_vec_heads_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, dst, n, dh, dhp, dst_off, scale);
+    return hipGetLastError();
+}
+hipError_t launch_head_compact_add(const void* o_bf16, int ldo, float* h, int ldh, int M, int d, int dh, int dhp, hipStream_t s) {
+    hipLaunchKernelGGL(head_compact_add_kernel, dim3(ew_blocks((size_t)M * d)), dim3(256), 0, s, (const bf16*)o_bf16, ldo, h, ldh,
+                       (size_t)M * d, d, dh, dhp);
+    return hipGetLastError();
+}
+
 __global__ void scale_vec_kernel(float* __restrict__ v, int n, float f) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) v[i] *= f;

@@ -42,7 +42,12 @@ typedef enum ditto_status {
 typedef void* ditto_stream_t;            /* hipStream_t */
 typedef struct ditto_model* ditto_model_t;
 
-/* DiTTO.__init__ keyword arguments, reference src/model/DiTTO.py:10-19 */
+/* DiTTO.__init__ keyword arguments, reference src/model/DiTTO.py:10-19.
+ * Shapes: hidden_dim % 64 == 0 and <= 2048; hidden_dim % num_heads == 0 with an EVEN head_dim (half-split RoPE).  head_dim 64
+ * runs the fused attention kernels; any other multiple of 64 (e.g. the shipped 1-head / 768 config) the GEMM-composed attention;
+ * head_dim % 64 != 0 (the reference takes it: src/components/DiT.py:78-86; e.g. 1152 / 16 = 72) runs forward-only on heads
+ * PADDED to the next multiple of 64 inside the block — zero weight rows / columns, so no result changes; the arena, cond and
+ * workspace sizes grow accordingly (always take them from the *_bytes queries); training and fp8 linears refuse such shapes. */
 typedef struct ditto_config {
     int32_t hidden_dim;        /* d        (768)  */
     int32_t num_layers;        /* L        (12)   */

@@ -28,7 +28,9 @@ static int g_fail = 0;
 static bool cfg_valid(const ditto_config& c) {
     if (c.hidden_dim <= 0 || c.num_layers <= 0 || c.num_heads <= 0 || c.time_dim <= 0 || c.diffusion_steps <= 0) return false;
     if (c.hidden_dim % c.num_heads || c.text_dim != c.hidden_dim || c.hidden_dim % 64 || c.hidden_dim > 2048) return false;
-    if ((c.hidden_dim / c.num_heads) % 64) return false;
+    const int dh = c.hidden_dim / c.num_heads, dhp = (dh + 63) / 64 * 64;   // head_dim % 64 != 0 runs on heads padded to dhp
+    if (dh % 2) return false;
+    if (dh % 64 && ((c.flags & DITTO_CFG_FP8_LINEAR) || 4 * c.hidden_dim < c.num_heads * dhp)) return false;
     if ((c.flags & DITTO_CFG_FP8_LINEAR) && c.hidden_dim % 128) return false;
     if (c.flags & ~DITTO_CFG_FP8_LINEAR) return false;
     return true;
@@ -63,7 +65,8 @@ static void size_queries() {
         // bf16 weights alone: L (3 + 1 + 1 + 8 + 4) d^2 + L 2 d^2 (cross K/V) + 2 d^2 elements of 1 (fp8: some) or 2 bytes
         EXPECT(arena >= (size_t)L * 19 * d * d, "arena smaller than its weights: %zu", arena);
         const size_t tarena = ditto_train_arena_bytes(&c);
-        EXPECT((tarena > 0) == !(fl & DITTO_CFG_FP8_LINEAR) || tarena > 0, "train arena");
+        const bool padded = (d / H) % 64 != 0;      // padded heads are forward-only: no training sizes
+        EXPECT((tarena > 0) == (!(fl & DITTO_CFG_FP8_LINEAR) && !padded) || (tarena > 0 && !padded), "train arena");
         for (int B : Bs) for (int N : Ns) for (int T : Ts) {
             const bool shape_ok = B > 0 && N > 0 && T > 0;
             const size_t ws = ditto_workspace_bytes(&c, B, N, T), cond = ditto_cond_bytes(&c, B, T);
@@ -84,7 +87,8 @@ static void size_queries() {
             EXPECT(ditto_full_row_plan(&c, B, N, &a, &b) == DITTO_OK && (a == 0 || a == 1) && (b == 0 || b == 1),
                    "full_row_plan B=%d N=%d", B, N);
             const bool f8 = (fl & DITTO_CFG_FP8_LINEAR) != 0;
-            if (d == 768) { if (f8 || M < 176 * 64 - 63) EXPECT(a == 0 && b == 0, "full-row plan where it cannot run (d = 768)"); }
+            if (padded) EXPECT(a == 0 && b == 0, "full-row plan on padded heads");
+            else if (d == 768) { if (f8 || M < 176 * 64 - 63) EXPECT(a == 0 && b == 0, "full-row plan where it cannot run (d = 768)"); }
             else if (d == 1024) {   // 64-row tiles, >= 192 of them; fc2 never under fp8
                 if (M < 192 * 64 - 63) EXPECT(a == 0 && b == 0, "full-row plan where it cannot run (d = 1024)");
                 if (f8) EXPECT(b == 0, "fp8 fc2 on the full-row kernel");

@@ -54,6 +54,19 @@ def test_size_queries_and_errors():
     assert lib.ditto_arena_bytes(C.byref(bad)) == 0
     bad = hip.Config(192, 1, 3, 64, 192, 10, hip.CFG_FP8_LINEAR)   # fp8 needs hidden_dim % 128 == 0
     assert lib.ditto_arena_bytes(C.byref(bad)) == 0
+    # head_dim % 64 != 0 (the reference takes any hidden_dim % num_heads == 0, src/components/DiT.py:78-86) runs on PADDED heads:
+    # the paper's XL shape 1152 / 16 = 72 -> heads at a stride of 128 inside the block, attention-side buffers 2048 wide
+    xl = hip.Config(1152, 2, 16, 256, 1152, 50, 0)
+    plain = hip.Config(1152, 2, 18, 256, 1152, 50, 0)          # 18 heads of 64: no padding
+    assert lib.ditto_arena_bytes(C.byref(xl)) > lib.ditto_arena_bytes(C.byref(plain)) > 0
+    assert lib.ditto_cond_bytes(C.byref(xl), 2, 64) >= 2 * 64 * 2 * 2 * 2048 * 2
+    assert lib.ditto_workspace_bytes(C.byref(xl), 2, 64, 64) > lib.ditto_workspace_bytes(C.byref(plain), 2, 64, 64)
+    bad = hip.Config(90, 1, 2, 64, 90, 10, 0)                # hidden_dim itself must stay a multiple of 64 (the GEMMs' K tile)
+    assert lib.ditto_arena_bytes(C.byref(bad)) == 0 and b"hidden_dim" in lib.ditto_last_error()
+    bad = hip.Config(192, 1, 64, 64, 192, 10, 0)             # head_dim 3: odd (no half-split rotation)
+    assert lib.ditto_arena_bytes(C.byref(bad)) == 0 and b"even" in lib.ditto_last_error()
+    bad = hip.Config(384, 1, 4, 64, 384, 10, hip.CFG_FP8_LINEAR)   # fp8 linears: no padded heads (head_dim 96)
+    assert lib.ditto_arena_bytes(C.byref(bad)) == 0 and b"fp8" in lib.ditto_last_error()
     for kc, name in enumerate(hip.KERNEL_CLASSES):
         assert lib.ditto_kernel_class_name(kc).decode() == name
     assert lib.ditto_attention_workspace_bytes(1, 1, 64, 64, 64) == 0

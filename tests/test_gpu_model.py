@@ -820,3 +820,53 @@ def test_norm2_fused_into_the_q_projection_g2_golden(golden, shape, stream16):
     print(f"G2 12L, lnq {shape}, bf16 stream {stream16}: rel-L2 {r:.3e}; vs two launches {rel_l2(out, two):.3e}")
     # (on the bf16 stream a last-bit difference of q moves bf16 roundings of h downstream: the streams' own noise, 7e-3)
     assert torch.equal(out, again) and not torch.equal(out, two) and rel_l2(out, two) < (1e-2 if stream16 else 4e-3)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# head_dim % 64 != 0: shapes the reference accepts (any hidden_dim % num_heads == 0, src/components/DiT.py:78-86) run on heads
+# PADDED to the next multiple of 64 inside the block (csrc/model.h cfg_dhp; zero weight rows / columns, so q.k^T, P.V and the
+# out-projection are unchanged); the self-attention's head merge + residual becomes a compaction pass.  Inference only.
+# ---------------------------------------------------------------------------------------------------------------
+@torch.no_grad()
+@pytest.mark.parametrize("d,L,H,B,N,T", [
+    (192, 2, 2, 2, 80, 48),        # head_dim 96 -> 128 (the GEMM-composed attention on padded heads)
+    (128, 2, 4, 2, 100, 40),       # head_dim 32 -> 64 (the fused head_dim-64 kernel on padded heads, un-prescaled q)
+    (1152, 2, 16, 1, 128, 64),     # the paper's XL head geometry: 1152 / 16 = 72 -> 128
+    (320, 1, 2, 3, 33, 17),        # head_dim 160 -> 192, ragged lengths
+])
+def test_head_dims_that_are_not_multiples_of_64_against_oracle(d, L, H, B, N, T):
+    from oracle import ditto_oracle as O
+    cfg = DiTTOConfig(d, L, H, 64, d, 20)
+    assert cfg.head_dim % 64 != 0
+    sd = synthetic_state_dict(cfg, 31)
+    m = build(cfg, 31)
+    x, text, t = synthetic_inputs(cfg, B, N, T, seed=32)
+    xd, td, tt = x.to(DEV), text.to(DEV), t.to(DEV)
+    out = m(xd, td, tt)
+    want = O.ditto_forward(sd, L, H, x, text, t)
+    r = close(out, want)
+    print(f"d={d} H={H} head_dim {cfg.head_dim}: rel-L2 {r:.3e}")
+    assert torch.equal(m(xd, td, tt), out)                                   # deterministic
+    if B > 1:                                                                # an utterance does not depend on its neighbours
+        assert torch.equal(m(xd[:1].contiguous(), td[:1].contiguous(), tt[:1].contiguous())[0], out[0])
+    # the sampler surface on top of it: one reverse-diffusion step
+    sg = SpeechGenerator(ditto_model=m, device=DEV)
+    z = hash_normal((B, N, d), "z", 5)
+    tstep = torch.full((B,), 7, dtype=torch.long)
+    x1 = sg.p_sample(xd, tstep.to(DEV), td, noise=z.to(DEV))
+    betas, alphas, acp = O.sampler_tables(20)
+    want1 = O.p_sample_update(x, O.ditto_forward(sd, L, H, x, text, tstep), tstep, betas, alphas, acp, z)
+    close(x1, want1)
+
+
+def test_padded_heads_are_forward_only():
+    """Training on a padded-head shape is refused loudly (the backward kernels need head_dim % 64 == 0)."""
+    cfg = DiTTOConfig(192, 1, 2, 64, 192, 20)
+    m = DiTTO(192, 1, 2, 64, 192, 20)
+    m.load_state_dict(synthetic_state_dict(cfg, 3))
+    m = m.to(DEV).train()
+    x, text, t = (z.to(DEV) for z in synthetic_inputs(cfg, 1, 32, 16, seed=4))
+    with pytest.raises(hip.DittoHipError, match="head_dim"):
+        m(x, text, t)
+    with torch.no_grad():
+        assert torch.isfinite(m.eval()(x, text, t)).all()
