@@ -95,9 +95,21 @@ static int g_splitk_wgs = [] { const char* e = getenv("DITTO_SPLITK_WGS"); retur
 int g_lnq = [] { const char* e = getenv("DITTO_LNQ"); return e ? atoi(e) : 32; }();
 int g_resid_bf16 = [] { const char* e = getenv("DITTO_RESIDUAL_BF16"); return e ? atoi(e) : 1; }();
 int small_batch_k_splits(int M, int N, int K) {
-    if (g_splitk_wgs <= 0) return 1;
-    const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+    if (g_splitk_wgs < 0) return 1;                        // -1: never split
     const int ktiles = K / 64;
+    if (g_splitk_wgs == 0) {
+        // Default since round 4: the LOW-LATENCY CLASS.  A batch of at most 2048 rows (1-2 utterances at N = 1024: the reference's
+        // own call pattern, Experiments.ipynb:125-132) leaves its long-K GEMMs (fc2: 48 tiles x 48 K-tiles at B = 1; the final
+        // projection) on a fifth of the chip; they run split over K with an ordered fp32 reduce (bias + residual in the reduce):
+        // fc2 40.8 -> 24.2 us, step 1.83 -> 1.63 ms at C2 B = 1.  The number of splits depends on K ONLY, so inside the class an
+        // utterance's bits do not depend on its batch neighbours; like the full-row class (kernels.h fr_rule_rows) the class is a
+        // function of the launch's rows and a caller that splits one batch pins it ("fr_class_rows"): the rows of the UNSPLIT batch.
+        const long rows = g_fr_class_rows > 0 ? g_fr_class_rows : M;
+        if (rows > 2048 || ktiles < 24) return 1;
+        const int ns = ktiles / 12;                        // K = 3072: 4, 1536: 2, 4096: 5, 2048: 2
+        return ns > 8 ? 8 : ns;
+    }
+    const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);   // > 0: the explicit rule of rounds 1-3 (a workgroup target)
     if (tiles > 256 || ktiles < 16) return 1;
     long ns = g_splitk_wgs / tiles;
     if (ns > ktiles / 4) ns = ktiles / 4;
@@ -1111,7 +1123,7 @@ int ditto_set_option(const char* name, int value) {
         return DITTO_OK;
     }
     if (!strcmp(name, "splitk_wgs")) {
-        if (value < 0 || value > 2048) return fail(DITTO_ERR_ARG, "splitk_wgs must be in [0, 2048]");
+        if (value < -1 || value > 2048) return fail(DITTO_ERR_ARG, "splitk_wgs must be in [-1, 2048] (-1 never, 0 the low-latency class rule, > 0 a workgroup target)");
         g_splitk_wgs = value;
         return DITTO_OK;
     }

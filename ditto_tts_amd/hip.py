@@ -251,8 +251,10 @@ def full_row_plan(cfg, B: int, N: int):
 
 
 def set_low_latency(on: bool = True):
-    """Single-utterance serving mode: the long-K GEMMs of batches of 1-2 utterances run split-K (step 1.87 -> 1.68 ms
-    at C2, B = 1).  Off by default: with it an utterance's bits depend on the size of the batch it is in."""
+    """The explicit split-K rule of rounds 1-3 (a workgroup target of 256) for the long-K GEMMs of 1-2 utterance batches.
+    Since round 4 the DEFAULT already splits them (the low-latency class: a rule that depends on K only, so that inside the
+    class an utterance's bits do not depend on its batch neighbours); this switch trades that invariance for one more split at
+    B = 1.  set_option("splitk_wgs", -1) turns every split off."""
     set_option("splitk_wgs", 256 if on else 0)
 
 

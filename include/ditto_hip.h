@@ -302,9 +302,12 @@ int ditto_gemm_tn_bf16(const void* X, int ldx, const void* Y, int ldy, float* ou
  * The sampler state x and eps stay fp32 either way.  (DITTO_RESIDUAL_BF16 in the environment sets the initial value.)
  * "lnq": norm2 fused into the cross-attention q-projection (csrc/gemm_lnq.hip) for launches of the full-row class at d = 768:
  * 0 = LayerNorm launch + tiled GEMM, 32 / 16 = fused, on that MFMA shape.  (DITTO_LNQ sets the initial value.)
- * "splitk_wgs": low-latency mode for batches of 1-2 utterances: workgroups the long-K GEMMs (fc2, final projection)
- * are split over (K-splits with an ordered fp32 reduce; 256 is the measured choice: -10 % step time at B = 1).
- * Default 0 = never split, which keeps an utterance's result bit-identical whatever else is in its batch. */
+ * "splitk_wgs": K-splitting of the long-K GEMMs (fc2, final projection) of small batches, with an ordered fp32 reduce.
+ * 0 (default) = the low-latency CLASS: launches of at most 2048 rows (1-2 utterances at N = 1024) split by a rule that depends
+ * on K only (K = 3072: 4 splits), so an utterance's bits are independent of its batch neighbours INSIDE the class; across the
+ * class boundary they differ in the last bits (as across the full-row class boundary), and "fr_class_rows" pins this class too
+ * (-11 % step time at C2 B = 1).  -1 = never split (rounds 1-3 default).  > 0 = the older explicit rule: a workgroup target
+ * (256 was the measured choice), under which the K partition depends on the batch size. */
 int ditto_set_option(const char* name, int value);
 /* Reads a switch back (callers that change one temporarily restore what they found: ditto_tts_amd/hip.py batch_class).
  * Also "experimental": 1 when the library contains the opt-in A/B kernels of csrc/experimental/ ("gemm_tile" 130,

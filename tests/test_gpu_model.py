@@ -233,9 +233,16 @@ def test_full_size_c2_properties():
     xd, td, tt = x.to(DEV), text.to(DEV), t.to(DEV)
     out = m(xd, td, tt)
     assert torch.isfinite(out).all() and 0.3 < float(out.std()) < 10
-    for b in (0, 3):
-        one = m(xd[b:b + 1].contiguous(), td[b:b + 1].contiguous(), tt[b:b + 1].contiguous())
-        assert torch.equal(one[0], out[b]), "utterance result depends on its batch neighbours"
+    # one utterance alone (1024 rows) is the LOW-LATENCY class since round 4 (its long-K GEMMs split over K): a caller that wants
+    # the bits it has inside a bigger batch pins that batch's class, as dist.sample_sharded does ...
+    with hip.batch_class(B * N):
+        for b in (0, 3):
+            one = m(xd[b:b + 1].contiguous(), td[b:b + 1].contiguous(), tt[b:b + 1].contiguous())
+            assert torch.equal(one[0], out[b]), "utterance result depends on its batch neighbours"
+    # ... and unpinned it is the same function in another summation order, itself independent of ITS neighbours (B = 1 vs 2)
+    alone = m(xd[:1].contiguous(), td[:1].contiguous(), tt[:1].contiguous())
+    assert not torch.equal(alone[0], out[0]) and rel_l2(alone[0], out[0]) < 4e-3
+    assert torch.equal(m(xd[:2].contiguous(), td[:2].contiguous(), tt[:2].contiguous())[0], alone[0])
     perm = torch.tensor([2, 0, 3, 1], device=DEV)
     assert torch.equal(m(xd[perm].contiguous(), td[perm].contiguous(), tt[perm].contiguous()), out[perm])
     assert torch.equal(m(xd, td.clone(), tt), out)        # new text tensor -> K/V recomputed, same bits
@@ -405,8 +412,9 @@ def test_full_size_c2_sampling_loop_properties():
     eng.denoise_steps_(one, eng.prepare_text(td, N), S - 1, 0, noises, sg.betas, sg.alphas, sg.alphas_cumprod)
     assert torch.equal(one, full), "one-call loop differs from the per-step loop"
     for lo, hi in ((0, 2), (2, 3)):
-        part = sg._SpeechGenerator__sample_latents(td[lo:hi].contiguous(), xd[lo:hi].contiguous(), cond_by_audio=True,
-                                                   noises=lambda i: noises[i, lo:hi])
+        with hip.batch_class(B * N):      # what dist.sample_sharded does: every shard decides its kernel class as the whole batch
+            part = sg._SpeechGenerator__sample_latents(td[lo:hi].contiguous(), xd[lo:hi].contiguous(), cond_by_audio=True,
+                                                       noises=lambda i: noises[i, lo:hi])
         assert torch.equal(part, full[lo:hi]), f"shard [{lo},{hi}) differs from the unsharded batch"
 
 
@@ -669,7 +677,16 @@ def test_low_latency_split_k_mode():
     finally:
         hip.set_low_latency(False)
     assert torch.equal(m(xd, td, tt), base4) and torch.equal(m(xd[:1], td[:1], tt[:1]), base1)
-    assert lib.ditto_set_option(b"splitk_wgs", -1) == hip.ERR_ARG
+    # the DEFAULT rule (0) already splits the C2 shape at B = 1 (the low-latency class: 4 splits of fc2, 2 of the final
+    # projection, a function of K only); -1 = never split
+    hip.set_option("splitk_wgs", -1)
+    try:
+        never = mb(xb.to(DEV), tb.to(DEV), ttb.to(DEV))
+    finally:
+        hip.set_option("splitk_wgs", 0)
+    assert not torch.equal(never, base_big) and rel_l2(never, base_big) < 5e-3
+    close(base_big, O.ditto_forward(synthetic_state_dict(big, 2), 12, 12, xb, tb, ttb))
+    assert lib.ditto_set_option(b"splitk_wgs", -2) == hip.ERR_ARG
 
 
 @torch.no_grad()
