@@ -90,6 +90,9 @@ static inline size_t text_scratch_bytes(const ditto_config& c, int B, int T) {
 static int g_splitk_wgs = [] { const char* e = getenv("DITTO_SPLITK_WGS"); return e ? atoi(e) : 0; }();
 // "residual_bf16": the residual stream h between the segments of a block lives in HBM as bf16 (fp32 only inside accumulators
 // and LayerNorm statistics) wherever the launch takes the full-row class at d = 768 / head_dim 64 (ditto_forward decides)
+// "ll_mask": the low-latency class's launch fusions (they change no bit): bit 0 = fc2's split-K finish also writes the NEXT
+// block's norm1, bit 1 = the cross out-projection runs as two K-splits whose finish also writes norm3
+int g_ll_mask = [] { const char* e = getenv("DITTO_LL_MASK"); return e ? atoi(e) : 3; }();
 // "lnq": norm2 fused into the cross-attention q-projection (gemm_lnq.hip) for launches of the full-row class at d = 768:
 // 0 = off (LayerNorm launch + tiled GEMM), 32 / 16 = on, with that MFMA shape (32x32x16 / 16x16x32)
 int g_lnq = [] { const char* e = getenv("DITTO_LNQ"); return e ? atoi(e) : 32; }();
@@ -115,6 +118,14 @@ int small_batch_k_splits(int M, int N, int K) {
     if (ns > ktiles / 4) ns = ktiles / 4;
     if (ns > 8) ns = 8;
     return ns < 2 ? 1 : (int)ns;
+}
+
+// The cross out-projection (K = d) in the low-latency class: two K-splits (its 48 tiles at B = 1 become 96 workgroups of half the
+// depth) whose finish also writes norm3 — the LayerNorm launch behind it disappears.  Same class rule as above, K only.
+int small_batch_k_splits_outproj(int M, int K) {
+    if (g_splitk_wgs != 0 || !(g_ll_mask & 2)) return 1;
+    const long rows = g_fr_class_rows > 0 ? g_fr_class_rows : M;
+    return (rows <= 2048 && K / 64 >= 12) ? 2 : 1;
 }
 
 WsPlan plan_ws(const ditto_config& c, int B, int N, int T) {
@@ -314,6 +325,7 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
             a.workspace = attn_ws; a.workspace_bytes = attn_ws_bytes; a.q_prescaled = (dh == 64);
             HIP_TRY(launch_attention(a, s));
         }
+        bool ln3_done = false;
         if (fr_out) {
             // out-proj + residual + norm3 in one launch.  A = the attention output in u; the LayerNorm output goes to the first
             // M x d of the qkv buffer (the cross q it held has been consumed) because u is still being read as the A operand
@@ -327,12 +339,21 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
             GemmArgs g{};
             g.A = u; g.lda = dp; g.W = lp.Wco; g.bias = lp.bco; g.residual = h; g.ldr = d; g.out = h; g.ldo = d;
             g.M = M; g.N = d; g.K = dp;
-            HIP_TRY(launch_gemm(g, EPI_BIAS_RES_F32, s));
+            const int nso = fp8 ? 1 : small_batch_k_splits_outproj(M, dp);
+            if (nso > 1 && splitk_ws && splitk_bytes >= (size_t)nso * M * d * 4) {
+                // low-latency class: K-splits + a finish that adds bias + residual AND writes norm3 (into qkv: u is the A operand)
+                g.bias = nullptr; g.residual = nullptr; g.out = splitk_ws; g.k_splits = nso; g.split_stride = (size_t)M * d;
+                HIP_TRY(launch_gemm(g, EPI_BIAS_F32, s));
+                HIP_TRY(launch_splitk_finish(splitk_ws, nso, (size_t)M * d, lp.bco, h, h, nullptr, 0, M, d, s, lp.g3, lp.be3, qkv, d));
+                ln3_done = true;
+            } else {
+                HIP_TRY(launch_gemm(g, EPI_BIAS_RES_F32, s));
+            }
         }
         if (tap_cross) HIP_TRY(hipMemcpyAsync(tap_cross, h, (size_t)M * d * 4, hipMemcpyDeviceToDevice, s));
         // ---- gated MLP (src/components/DiT.py:150-155) ----
-        const void* u3 = fr_out ? (const void*)qkv : (const void*)u;   // where norm3's output is
-        if (!fr_out) {
+        const void* u3 = (fr_out || ln3_done) ? (const void*)qkv : (const void*)u;   // where norm3's output is
+        if (!fr_out && !ln3_done) {
             ProfScope ps(m, s, DITTO_KC_LAYERNORM);
             if (fp8) HIP_TRY(launch_layernorm_fp8(h, lp.g3, lp.be3, u, d, M, d, s));
             else HIP_TRY(launch_layernorm(h, lp.g3, lp.be3, u, d, M, d, s));
@@ -364,8 +385,11 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
                 g.bias = nullptr; g.residual = nullptr; g.out = splitk_ws; g.k_splits = ns;
                 g.split_stride = (size_t)M * d;
                 HIP_TRY(launch_gemm(g, EPI_BIAS_F32, s));
-                HIP_TRY(launch_splitk_finish(splitk_ws, ns, (size_t)M * d, lp.b2, h, h, out2, 2 * d, M, d, s));
+                // (next_g1 set: the finish also writes the NEXT block's norm1 into u — ditto_forward decided it, chain_ll)
+                HIP_TRY(launch_splitk_finish(splitk_ws, ns, (size_t)M * d, lp.b2, h, h, out2, 2 * d, M, d, s, next_g1, next_be1,
+                                             next_g1 ? u : nullptr, d));
             } else {
+                if (next_g1) return fail(DITTO_ERR_ARG, "internal: norm1 chaining without a kernel that writes it");
                 if (out2) { g.out2_bf16 = out2; g.ldo2 = 2 * d; }
                 HIP_TRY(launch_gemm(g, EPI_BIAS_RES_F32, s));
             }
@@ -636,6 +660,10 @@ int ditto_forward(ditto_model_t m, const float* x, const void* cond, const int64
                                      "but this launch has %d rows: it cannot take that class.  Give every shard at least 128 rows, or "
                                      "ditto_set_option(\"residual_bf16\", 0).", g_fr_class_rows, M);
     const bool hb = hb_class;
+    // low-latency class: fc2 runs split over K and its finish launch also writes the next block's norm1 (the same bits as the
+    // LayerNorm launch it replaces); decided exactly as run_block will decide the split
+    const int ns_fc2 = fp8c ? 1 : small_batch_k_splits(M, d, 4 * d);
+    const bool chain_ll = !chain_ln1 && (g_ll_mask & 1) && ns_fc2 > 1 && w.splitk_bytes >= (size_t)ns_fc2 * M * d * 4;
     // block 0's norm1 rides in the GlobalAdaLN kernel (same statistics order as the LayerNorm kernel: the same bits)
     const bool ln1_in_adaln = !fp8c && !(g_gemm_flags & 32768);      // gemm_flags bit 15: A/B, the separate launch
     {   // GlobalAdaLN (src/components/DiT.py:25-40) + bf16 copy of the raw input for proj_in
@@ -648,9 +676,9 @@ int ditto_forward(ditto_model_t m, const float* x, const void* cond, const int64
         if (int rc = run_block(m, l, h, u, qkv, act, l == L - 1 ? xcat : nullptr, attn_ws, w.attn_bytes,
                                (float*)(ws + w.splitk), w.splitk_bytes, kv, l,
                                L * 2 * cfg_dp(c), rope_cos, rope_sin, B, N, T, s, nullptr, nullptr,
-                               (chain_ln1 && l > 0) || (ln1_in_adaln && l == 0),
-                               chain_ln1 && l + 1 < L ? m->layers[l + 1].g1 : nullptr,
-                               chain_ln1 && l + 1 < L ? m->layers[l + 1].be1 : nullptr, hb))
+                               ((chain_ln1 || chain_ll) && l > 0) || (ln1_in_adaln && l == 0),
+                               (chain_ln1 || chain_ll) && l + 1 < L ? m->layers[l + 1].g1 : nullptr,
+                               (chain_ln1 || chain_ll) && l + 1 < L ? m->layers[l + 1].be1 : nullptr, hb))
             return rc;
     {   // eps = proj_in(x_raw) + proj_out(h_L)  (src/model/DiTTO.py:83,93-94), one K = 2d GEMM
         ProfScope ps(m, s, DITTO_KC_GEMM_FINAL);
@@ -995,7 +1023,7 @@ static int* option_slot(const char* name) {
         {"pp_mask", &g_pp_mask}, {"fr_mask", &g_fr_mask}, {"fr_class_rows", &g_fr_class_rows}, {"fr_dgrad", &g_fr_dgrad},
         {"train_flags", &g_train_flags}, {"fr_u_fp8", &g_fr_u_fp8}, {"fr_tile", &g_fr_tile}, {"fr64_maxk", &g_fr64_maxk},
         {"fr_stagger", &g_fr_stagger}, {"fr_rot", &g_fr_rot}, {"pp_nb", &g_pp_nb}, {"pp_stagger", &g_pp_stagger},
-        {"splitk_wgs", &g_splitk_wgs}, {"residual_bf16", &g_resid_bf16}, {"lnq", &g_lnq}, {"lnq_ring", &g_lnq_ring}};
+        {"splitk_wgs", &g_splitk_wgs}, {"residual_bf16", &g_resid_bf16}, {"lnq", &g_lnq}, {"lnq_ring", &g_lnq_ring}, {"ll_mask", &g_ll_mask}};
     for (auto& e : tab) if (!strcmp(name, e.n)) return e.p;
     return nullptr;
 }
@@ -1105,6 +1133,11 @@ int ditto_set_option(const char* name, int value) {
     if (!strcmp(name, "pp_stagger")) {
         if (value < -1 || value > 100000) return fail(DITTO_ERR_ARG, "pp_stagger must be in [-1, 100000] (10 ns ticks; -1 = rule)");
         g_pp_stagger = value;
+        return DITTO_OK;
+    }
+    if (!strcmp(name, "ll_mask")) {
+        if (value < 0 || value > 3) return fail(DITTO_ERR_ARG, "ll_mask must be in [0, 3]");
+        g_ll_mask = value;
         return DITTO_OK;
     }
     if (!strcmp(name, "lnq_ring")) {

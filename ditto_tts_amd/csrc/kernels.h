@@ -29,9 +29,12 @@ hipError_t launch_layernorm_xbf16(const void* x_bf16, const float* gamma, const 
                                   int d, hipStream_t s);
 hipError_t launch_cast_bf16(const float* src, void* dst_bf16, size_t n, hipStream_t s);
 // out = residual + bias + sum of `nsplit` fp32 partial products (contiguous [M, N], `stride` elements apart), in order
+// gamma / beta / u_bf16 (all or none): also u bf16 [M, ldu] = LayerNorm(out) * gamma + beta in the same launch (one wave per row;
+// the same h and u bits as this launch + launch_layernorm)
 hipError_t launch_splitk_finish(const float* partial, int nsplit, size_t stride, const float* bias,
                                 const float* residual, float* out, void* out2_bf16, int ldo2, int M, int N,
-                                hipStream_t s);
+                                hipStream_t s, const float* gamma = nullptr, const float* beta = nullptr,
+                                void* u_bf16 = nullptr, int ldu = 0);
 hipError_t launch_p_sample_update(float* x, const float* eps, const float* noise, const int64_t* t,
                                   const float* betas, const float* alphas, const float* acp, int B,
                                   size_t elems_per_utt, hipStream_t s);

@@ -51,6 +51,7 @@ inline bool cfg_padded(const ditto_config& c) { return cfg_dp(c) != c.hidden_dim
 struct WsPlan { size_t h, u, qkv, act, xcat, eps, attn, attn_bytes, splitk, splitk_bytes, total; };
 // K-splits of a long-K, few-tile GEMM [M, N] x K at small batch (1 = none): ditto_api.hip
 int small_batch_k_splits(int M, int N, int K);
+int small_batch_k_splits_outproj(int M, int K);
 WsPlan plan_ws(const ditto_config& c, int B, int N, int T);
 int check_cfg(const ditto_config* c);
 void set_wgrad_wgs(int v);   // ditto_train.hip: split-K target of the wgrad GEMMs (ditto_set_option("wgrad_wgs"))

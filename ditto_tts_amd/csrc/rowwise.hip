@@ -258,10 +258,88 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
         *reinterpret_cast<u32x2*>(out2 + row * ldo2 + cv * 4) = pk;
     }
 }
+// The same finish WITH the LayerNorm that follows it (the low-latency class: fc2 -> the next block's norm1, cross out-proj ->
+// norm3): one wave per row, the row in registers.  h is summed in splitk_finish_kernel's order and normalised through ln_kernel's
+// helpers, so h and u are bit for bit what the finish launch + the LayerNorm launch give — one launch less per use.
+template <int CH>
+__global__ __launch_bounds__(256) void splitk_finish_ln_kernel(const float* __restrict__ partial, int nsplit, size_t stride,
+                                                               const float* __restrict__ bias, const float* residual, float* out,
+                                                               bf16* __restrict__ out2, int ldo2, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, bf16* __restrict__ u, int ldu,
+                                                               int M, int d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = d >> 2;
+    const size_t r0 = (size_t)row * nv;
+    f32x4 v[CH];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int i = lane + 64 * c;
+        if (i < nv) {
+            f32x4 acc = reinterpret_cast<const f32x4*>(partial)[r0 + i];
+            for (int sp = 1; sp < nsplit; ++sp) acc += reinterpret_cast<const f32x4*>(partial + (size_t)sp * stride)[r0 + i];
+            if (bias) acc += reinterpret_cast<const f32x4*>(bias)[i];
+            if (residual) acc += reinterpret_cast<const f32x4*>(residual)[r0 + i];
+            reinterpret_cast<f32x4*>(out)[r0 + i] = acc;
+            if (out2) {
+                u32x2 pk;
+                pk[0] = pack_bf16x2(acc[0], acc[1]);
+                pk[1] = pack_bf16x2(acc[2], acc[3]);
+                *reinterpret_cast<u32x2*>(out2 + (size_t)row * ldo2 + i * 4) = pk;
+            }
+            v[c] = acc;
+            s += ln_sum4(acc);
+        } else {
+            v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int i = lane + 64 * c;
+        if (i < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q = ln_sq_acc(q, v[c][e], mean);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
+    bf16* urow = u + (size_t)row * ldu;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int i = lane + 64 * c;
+        if (i < nv) {
+            const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[i], b = reinterpret_cast<const f32x4*>(beta)[i];
+            u32x2 o;
+            o[0] = pack_bf16x2(ln_norm(v[c][0], mean, rstd, g[0], b[0]), ln_norm(v[c][1], mean, rstd, g[1], b[1]));
+            o[1] = pack_bf16x2(ln_norm(v[c][2], mean, rstd, g[2], b[2]), ln_norm(v[c][3], mean, rstd, g[3], b[3]));
+            *reinterpret_cast<u32x2*>(urow + 4 * i) = o;
+        }
+    }
+}
+
 hipError_t launch_splitk_finish(const float* partial, int nsplit, size_t stride, const float* bias,
                                 const float* residual, float* out, void* out2_bf16, int ldo2, int M, int N,
-                                hipStream_t s) {
+                                hipStream_t s, const float* gamma, const float* beta, void* u_bf16, int ldu) {
     if (!partial || !out || nsplit < 1 || M <= 0 || N <= 0 || N % 4 || (out2_bf16 && ldo2 % 4)) return hipErrorInvalidValue;
+    if (u_bf16) {   // + the following LayerNorm (contiguous [M, N] rows: out ld = N)
+        if (!gamma || !beta || ldu % 4) return hipErrorInvalidValue;
+        const int ch = (N / 4 + 63) / 64;
+        dim3 grid((M + 3) / 4), block(256);
+#define FIN_CASE(C)                                                                                                        \
+    case C:                                                                                                                \
+        hipLaunchKernelGGL((splitk_finish_ln_kernel<C>), grid, block, 0, s, partial, nsplit, stride, bias, residual, out,    \
+                           (bf16*)out2_bf16, ldo2, gamma, beta, (bf16*)u_bf16, ldu, M, N);                                  \
+        break;
+        switch (ch) {
+            FIN_CASE(1) FIN_CASE(2) FIN_CASE(3) FIN_CASE(4) FIN_CASE(5) FIN_CASE(6) FIN_CASE(7) FIN_CASE(8)
+            default: return hipErrorInvalidValue;
+        }
+#undef FIN_CASE
+        return hipGetLastError();
+    }
     const size_t n4 = (size_t)M * (N / 4);
     hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, partial, nsplit, stride,
                        bias, residual, out, (bf16*)out2_bf16, ldo2, N, n4);

@@ -887,3 +887,28 @@ def test_padded_heads_are_forward_only():
         m(x, text, t)
     with torch.no_grad():
         assert torch.isfinite(m.eval()(x, text, t)).all()
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("B,N,T,L", [(1, 1024, 1024, 12), (2, 700, 96, 3), (1, 100, 40, 2)])
+def test_low_latency_class_fusions_change_no_bit(B, N, T, L):
+    """The low-latency class (<= 2048 rows) at d = 768: fc2's split-K finish also writes the next block's norm1 and the cross
+    out-projection runs as two K-splits whose finish writes norm3 (ll_mask bits 0 / 1).  The first is only a launch fusion —
+    the same h and the same LayerNorm arithmetic — so ll_mask 1 is bitwise ll_mask 0; the second changes the out-projection's
+    summation order (two K halves), so it is compared at fp32-accumulation noise; both against the oracle."""
+    from oracle import ditto_oracle as O
+    cfg = DiTTOConfig(768, L, 12, 256, 768, 50)
+    m = build(cfg, 2)
+    x, text, t = synthetic_inputs(cfg, B, N, T, seed=5)
+    xd, td, tt = x.to(DEV), text.to(DEV), t.to(DEV)
+    outs = {}
+    try:
+        for mask in (0, 1, 3):
+            hip.set_option("ll_mask", mask)
+            outs[mask] = m(xd, td, tt)
+            assert torch.equal(m(xd, td, tt), outs[mask])
+    finally:
+        hip.set_option("ll_mask", 3)
+    assert torch.equal(outs[1], outs[0]), "fc2 finish + norm1 is a launch fusion: no bit may change"
+    assert not torch.equal(outs[3], outs[0]) and rel_l2(outs[3], outs[0]) < 3e-3
+    close(outs[3][:1], O.ditto_forward(synthetic_state_dict(cfg, 2), L, 12, x[:1], text[:1], t[:1]))
