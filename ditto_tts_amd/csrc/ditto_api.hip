@@ -95,6 +95,8 @@ static int g_splitk_wgs = [] { const char* e = getenv("DITTO_SPLITK_WGS"); retur
 int g_ll_mask = [] { const char* e = getenv("DITTO_LL_MASK"); return e ? atoi(e) : 3; }();
 // "lnq": norm2 fused into the cross-attention q-projection (gemm_lnq.hip) for launches of the full-row class at d = 768:
 // 0 = off (LayerNorm launch + tiled GEMM), 32 / 16 = on, with that MFMA shape (32x32x16 / 16x16x32)
+// "lnq_min_rows": > 0: the fused norm2 + q-projection also runs BELOW the full-row class, from that many (class) rows on (A/B)
+int g_lnq_min_rows = [] { const char* e = getenv("DITTO_LNQ_MIN_ROWS"); return e ? atoi(e) : 0; }();
 int g_lnq = [] { const char* e = getenv("DITTO_LNQ"); return e ? atoi(e) : 32; }();
 int g_resid_bf16 = [] { const char* e = getenv("DITTO_RESIDUAL_BF16"); return e ? atoi(e) : 1; }();
 int small_batch_k_splits(int M, int N, int K) {
@@ -300,7 +302,8 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
         if (tap_self) HIP_TRY(hipMemcpyAsync(tap_self, h, (size_t)M * d * 4, hipMemcpyDeviceToDevice, s));
         // ---- cross-attention (src/components/DiT.py:141-148), K/V from the per-utterance cache ----
         // norm2 + q-projection in one launch (gemm_lnq.hip) for the full-row class at d = 768; else LayerNorm launch + tiled GEMM
-        const bool lnq = g_lnq && lp.WcqP && d == 768 && fr_pays(M);
+        const int rows_cls = g_fr_class_rows > 0 ? g_fr_class_rows : M;
+        const bool lnq = g_lnq && lp.WcqP && d == 768 && (fr_pays(M) || (g_lnq_min_rows > 0 && rows_cls >= g_lnq_min_rows));
         if (lnq) {
             ProfScope ps(m, s, DITTO_KC_GEMM_QPROJ);
             HIP_TRY(launch_gemm_lnq(h, d, hb, lp.g2, lp.be2, g_lnq == 16 ? lp.WcqP32 : lp.WcqP, lp.bcq, qkv, d, M, d, g_lnq,
@@ -1023,7 +1026,7 @@ static int* option_slot(const char* name) {
         {"pp_mask", &g_pp_mask}, {"fr_mask", &g_fr_mask}, {"fr_class_rows", &g_fr_class_rows}, {"fr_dgrad", &g_fr_dgrad},
         {"train_flags", &g_train_flags}, {"fr_u_fp8", &g_fr_u_fp8}, {"fr_tile", &g_fr_tile}, {"fr64_maxk", &g_fr64_maxk},
         {"fr_stagger", &g_fr_stagger}, {"fr_rot", &g_fr_rot}, {"pp_nb", &g_pp_nb}, {"pp_stagger", &g_pp_stagger},
-        {"splitk_wgs", &g_splitk_wgs}, {"residual_bf16", &g_resid_bf16}, {"lnq", &g_lnq}, {"lnq_ring", &g_lnq_ring}, {"ll_mask", &g_ll_mask}};
+        {"splitk_wgs", &g_splitk_wgs}, {"residual_bf16", &g_resid_bf16}, {"lnq", &g_lnq}, {"lnq_ring", &g_lnq_ring}, {"ll_mask", &g_ll_mask}, {"lnq_min_rows", &g_lnq_min_rows}};
     for (auto& e : tab) if (!strcmp(name, e.n)) return e.p;
     return nullptr;
 }
@@ -1133,6 +1136,11 @@ int ditto_set_option(const char* name, int value) {
     if (!strcmp(name, "pp_stagger")) {
         if (value < -1 || value > 100000) return fail(DITTO_ERR_ARG, "pp_stagger must be in [-1, 100000] (10 ns ticks; -1 = rule)");
         g_pp_stagger = value;
+        return DITTO_OK;
+    }
+    if (!strcmp(name, "lnq_min_rows")) {
+        if (value < 0) return fail(DITTO_ERR_ARG, "lnq_min_rows must be >= 0");
+        g_lnq_min_rows = value;
         return DITTO_OK;
     }
     if (!strcmp(name, "ll_mask")) {
