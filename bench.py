@@ -615,8 +615,8 @@ def main():
                 sweep.append({"batch_per_gpu": b, "ms_per_step": ms, "value": b / (ms * 1e-3),
                               "step_tflops": fl / (ms * 1e-3) / 1e12})
                 if b == 1 and b != B:
-                    # the opt-in single-utterance serving mode (hip.set_low_latency: fc2 / final projection split over K; an
-                    # utterance's bits then depend on the batch size, which is why it is not the default)
+                    # the explicit split-K rule of rounds 1-3 (hip.set_low_latency: a workgroup target, so the K partition depends
+                    # on the batch size).  The default entry above already runs the low-latency CLASS of round 4 (splits by K only)
                     from ditto_tts_amd import hip as _hip
                     _hip.set_low_latency(True)
                     try:
@@ -632,7 +632,7 @@ def main():
                         del r
                     finally:
                         _hip.set_low_latency(False)
-                    sweep.append({"batch_per_gpu": b, "mode": "low_latency (opt-in split-K)", "ms_per_step": ms_ll,
+                    sweep.append({"batch_per_gpu": b, "mode": "explicit split-K rule (hip.set_low_latency)", "ms_per_step": ms_ll,
                                   "value": b / (ms_ll * 1e-3), "step_tflops": fl / (ms_ll * 1e-3) / 1e12})
 
         # ---- C3 as a strong-scaling point: global batch on rank 0 -> scatter -> 50-step loops -> gather ----
