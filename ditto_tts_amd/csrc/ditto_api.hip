@@ -61,8 +61,8 @@ ArenaPlan plan_arena(const ditto_config& c) {
         const bool fr_o = !pad && ((d == 768 && !fp8c) || d == 1024), fr_2 = !pad && (d == 768 || d == 1024) && !fp8c;
         q.WcoP = fr_o ? take(d * d * 2) : 0; q.W2P = fr_2 ? take(4 * d * d * 2) : 0;
         // ... and of the cross q-projection for the fused norm2 + q-projection kernel (gemm_lnq.hip, d == 768): both MFMA shapes' images
-        const bool lnq = !pad && d == 768 && !fp8c;
-        q.WcqP = lnq ? take(d * d * 2) : 0; q.WcqP32 = lnq ? take(d * d * 2) : 0;
+        const bool lnq = !pad && ((d == 768 && !fp8c) || d == 1024);   // (the q-projection is a bf16 GEMM in the fp8 configuration too)
+        q.WcqP = lnq ? take(d * d * 2) : 0; q.WcqP32 = lnq && d == 768 ? take(d * d * 2) : 0;
     }
     p.Wkv = take(L * 2 * dp * d * 2); p.bkv = take(L * 2 * dp * 4);
     p.Wfin = take(d * 2 * d * 2); p.bfin = take(d * 4);
@@ -303,10 +303,14 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
         // ---- cross-attention (src/components/DiT.py:141-148), K/V from the per-utterance cache ----
         // norm2 + q-projection in one launch (gemm_lnq.hip) for the full-row class at d = 768; else LayerNorm launch + tiled GEMM
         const int rows_cls = g_fr_class_rows > 0 ? g_fr_class_rows : M;
-        const bool lnq = g_lnq && lp.WcqP && d == 768 && (fr_pays(M) || (g_lnq_min_rows > 0 && rows_cls >= g_lnq_min_rows));
+        // (d = 1024, BASELINE config C5: the same kernel at that width, 32x32x16 only, from 192 tiles of 64 rows on — the rule of
+        // its full-row GEMM)
+        const bool lnq = g_lnq && lp.WcqP && ((d == 768 && (fr_pays(M) || (g_lnq_min_rows > 0 && rows_cls >= g_lnq_min_rows))) ||
+                                              (d == 1024 && fr_pays_64(M)));
         if (lnq) {
             ProfScope ps(m, s, DITTO_KC_GEMM_QPROJ);
-            HIP_TRY(launch_gemm_lnq(h, d, hb, lp.g2, lp.be2, g_lnq == 16 ? lp.WcqP32 : lp.WcqP, lp.bcq, qkv, d, M, d, g_lnq,
+            const int shape = d == 768 ? g_lnq : 32;
+            HIP_TRY(launch_gemm_lnq(h, d, hb, lp.g2, lp.be2, shape == 16 ? lp.WcqP32 : lp.WcqP, lp.bcq, qkv, d, M, d, shape,
                                     N % 64 == 0 ? N / 64 : 0, s));
         } else {
             {
@@ -520,12 +524,12 @@ int ditto_model_create(const ditto_config* cfg, const ditto_weights* w, void* ar
         HIP_TRY(launch_pack_bf16(lw.cross_out_proj_weight, A + q.Wco, d, d, d, 0, BIG, 1, 0, s));
         }   // !pad
         const bool fr_o = !pad && ((d == 768 && !fp8) || d == 1024), fr_2 = !pad && (d == 768 || d == 1024) && !fp8;   // as plan_arena
-        const bool lnq_w = !pad && d == 768 && !fp8;
+        const bool lnq_w = !pad && ((d == 768 && !fp8) || d == 1024);
         if (fr_o) HIP_TRY(launch_pack_bf16_stage_major(lw.cross_out_proj_weight, A + q.WcoP, d, d, s));
         if (fr_2) HIP_TRY(launch_pack_bf16_stage_major(lw.mlp_fc2_weight, A + q.W2P, d, 4 * d, s));
         if (lnq_w) {   // from the PACKED q-projection (it carries the folded scale * log2(e))
             HIP_TRY(launch_repack_bf16_stage_major(A + q.Wcq, A + q.WcqP, d, d, s, 16));
-            HIP_TRY(launch_repack_bf16_stage_major(A + q.Wcq, A + q.WcqP32, d, d, s, 32));
+            if (d == 768) HIP_TRY(launch_repack_bf16_stage_major(A + q.Wcq, A + q.WcqP32, d, d, s, 32));
         }
         HIP_TRY(hipMemcpyAsync(A + q.bco, lw.cross_out_proj_bias, d * 4, hipMemcpyDeviceToDevice, s));
         // gated MLP: rows interleaved [16 x fc1 | 16 x gate] so both halves of a product meet in one lane
@@ -544,7 +548,7 @@ int ditto_model_create(const ditto_config* cfg, const ditto_weights* w, void* ar
         lp.sqkv = (const float*)(A + q.sqkv); lp.s1g = (const float*)(A + q.s1g); lp.s2 = (const float*)(A + q.s2);
         if (fr_o) lp.WcoP = A + q.WcoP;
         if (fr_2) lp.W2P = A + q.W2P;
-        if (lnq_w) { lp.WcqP = A + q.WcqP; lp.WcqP32 = A + q.WcqP32; }
+        if (lnq_w) { lp.WcqP = A + q.WcqP; lp.WcqP32 = d == 768 ? A + q.WcqP32 : nullptr; }
         lp.g1 = (const float*)(A + q.g1); lp.be1 = (const float*)(A + q.be1); lp.g2 = (const float*)(A + q.g2);
         lp.be2 = (const float*)(A + q.be2); lp.g3 = (const float*)(A + q.g3); lp.be3 = (const float*)(A + q.be3);
     }
@@ -895,15 +899,17 @@ int ditto_gemm_tn_bf16(const void* X, int ldx, const void* Y, int ldy, float* ou
 }
 
 int ditto_gemm_lnq_bf16(const void* h, int ldh, int h_is_bf16, const float* gamma, const float* beta, const void* W,
-                        const float* bias, void* out_bf16, int ldo, int M, int mfma_shape, void* w_scratch,
+                        const float* bias, void* out_bf16, int ldo, int M, int d, int mfma_shape, void* w_scratch,
                         ditto_stream_t stream) {
-    if (!h || !gamma || !beta || !W || !out_bf16 || !w_scratch || M <= 0 || ldh < 768 || ldo < 768 || ldh % 4 || ldo % 8)
+    if (d != 768 && d != 1024) return fail(DITTO_ERR_SHAPE, "ditto_gemm_lnq_bf16: d must be 768 or 1024");
+    if (!h || !gamma || !beta || !W || !out_bf16 || !w_scratch || M <= 0 || ldh < d || ldo < d || ldh % 4 || ldo % 8)
         return fail(DITTO_ERR_ARG, "bad argument to ditto_gemm_lnq_bf16");
     if (mfma_shape != 32 && mfma_shape != 16) return fail(DITTO_ERR_ARG, "mfma_shape must be 32 (32x32x16) or 16 (16x16x32)");
+    if (d == 1024 && (mfma_shape != 32 || h_is_bf16)) return fail(DITTO_ERR_SHAPE, "d = 1024: 32x32x16 and fp32 rows only");
     if ((uintptr_t)w_scratch % 256) return fail(DITTO_ERR_ARG, "w_scratch must be 256-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(launch_repack_bf16_stage_major(W, w_scratch, 768, 768, s, mfma_shape == 32 ? 16 : 32));
-    HIP_TRY(launch_gemm_lnq(h, ldh, h_is_bf16 != 0, gamma, beta, w_scratch, bias, out_bf16, ldo, M, 768, mfma_shape,
+    HIP_TRY(launch_repack_bf16_stage_major(W, w_scratch, d, d, s, mfma_shape == 32 ? 16 : 32));
+    HIP_TRY(launch_gemm_lnq(h, ldh, h_is_bf16 != 0, gamma, beta, w_scratch, bias, out_bf16, ldo, M, d, mfma_shape,
                             g_fr_rot > 1 ? g_fr_rot : 0, s));   // "fr_rot" > 1: the unit entry rotates too, with that period in tiles
     return DITTO_OK;
 }

@@ -1,4 +1,4 @@
-// gemm_lnq.hip — LayerNorm (norm2) fused INTO the cross-attention q-projection, d = 768 (gfx950).
+// gemm_lnq.hip — LayerNorm (norm2) fused INTO the cross-attention q-projection, d = 768 or 1024 (gfx950).
 //
 //     u = LayerNorm(h) * gamma + beta        (reference src/components/DiT.py:142-143; eps 1e-5, never written to HBM)
 //     q[M, 768] (bf16) = u W_q^T + b_q       (the q third of nn.MultiheadAttention's in-projection, :144-148 -> torch
@@ -33,25 +33,30 @@ namespace ditto {
 
 namespace {
 
-constexpr int QM = 64, QN = 768, QKD = 768;
-constexpr int Q_AROW = QKD * 2;            // 1536 B per A row
-constexpr int Q_A = QM * Q_AROW;           // 96 KiB: the normalised rows, later the output tile
-constexpr int Q_BIAS = Q_A;                // bias row (3 KiB) behind it
-constexpr int Q_LDS = Q_A + QN * 4;        // 99 KiB
+constexpr int QM = 64;
+// width D = N = K of the projection: 768 (DiTTO-S) or 1024 (BASELINE config C5, 32x32x16 only)
+template <int D>
+struct QW {
+    static constexpr int AROW = D * 2;             // bytes per A row (1536 / 2048: multiples of 256, the swizzle's span)
+    static constexpr int A = QM * AROW;            // 96 / 128 KiB: the normalised rows, later the output tile
+    static constexpr int BIAS = A;                 // bias row (3 / 4 KiB) behind it
+    static constexpr int LDS = A + D * 4;          // 99 / 132 KiB
+    static constexpr int CH = D / 256;             // f32x4 per lane of a row (one wave per row)
+};
 
 template <int V>
 struct QC { static constexpr int value = V; };
 
-template <int SHAPE>
+template <int SHAPE, int D>
 struct Geo;
-template <>
-struct Geo<32> {
-    static constexpr int NBW = 6, MBW = 2, KS = 16, NKT = QKD / 16, PER = 8;   // PER: stages per A-swizzle period (one 256-B span)
+template <int D>
+struct Geo<32, D> {
+    static constexpr int NBW = D / 4 / 32, MBW = 2, KS = 16, NKT = D / 16, PER = 8;   // PER: stages per A-swizzle period (one 256-B span)
     using acc_t = f32x16;
 };
-template <>
-struct Geo<16> {
-    static constexpr int NBW = 12, MBW = 4, KS = 32, NKT = QKD / 32, PER = 4;
+template <int D>
+struct Geo<16, D> {
+    static constexpr int NBW = D / 4 / 16, MBW = 4, KS = 32, NKT = D / 32, PER = 4;
     using acc_t = f32x4;
 };
 
@@ -100,12 +105,14 @@ struct LnqParams {
 // R: depth of the W register ring in stages.  What the ring holds in flight per CU (4 waves x R x NBW KiB) against the L2's
 // latency under load is what paces the loop: the weights of a 64-row tile are 1.18 MB, twice the bytes per MFMA of gemm_frd's
 // 128-row tile.
-template <int SHAPE, int R, bool XB>
+template <int SHAPE, int R, bool XB, int D = 768>
 __global__ __launch_bounds__(256, 1) void gemm_lnq_kernel(LnqParams p) {
-    using G = Geo<SHAPE>;
+    using G = Geo<SHAPE, D>;
+    constexpr int Q_AROW = QW<D>::AROW, Q_BIAS = QW<D>::BIAS, CH = QW<D>::CH, QN = D, QKD = D;
+    static_assert(G::NBW <= 12, "fragment list");
     using acc_t = typename G::acc_t;
     constexpr int NBW = G::NBW, MBW = G::MBW, NKT = G::NKT, PER = G::PER;
-    constexpr int NPER = NKT / PER;                                       // 6 periods of one 256-B span of A each
+    constexpr int NPER = NKT / PER;                                       // 6 (8 at D = 1024) periods of one 256-B span of A each
     static_assert(NKT % PER == 0 && PER % R == 0 && R * NBW - 1 <= 63, "period structure / vmcnt range");
     constexpr int W_STAGE = QN * G::KS * 2;                              // bytes of one stage of W (24 / 48 KiB)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -124,10 +131,10 @@ __global__ __launch_bounds__(256, 1) void gemm_lnq_kernel(LnqParams p) {
     if (wid == 3) {
         if (p.bias) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) glds16(p.bias + i * 256 + lane * 4, lds_base + (unsigned)(Q_BIAS + i * 1024));
+            for (int i = 0; i < CH; ++i) glds16(p.bias + i * 256 + lane * 4, lds_base + (unsigned)(Q_BIAS + i * 1024));
         } else {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) *reinterpret_cast<f32x4*>(smem + Q_BIAS + i * 1024 + lane * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < CH; ++i) *reinterpret_cast<f32x4*>(smem + Q_BIAS + i * 1024 + lane * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
 
@@ -151,30 +158,30 @@ __global__ __launch_bounds__(256, 1) void gemm_lnq_kernel(LnqParams p) {
     auto issue_stage = [&](f32x4 (&slot)[NBW]) {
         issue_w(QC<0>{}, slot[0]); issue_w(QC<1>{}, slot[1]); issue_w(QC<2>{}, slot[2]);
         issue_w(QC<3>{}, slot[3]); issue_w(QC<4>{}, slot[4]); issue_w(QC<5>{}, slot[5]);
-        if constexpr (NBW == 12) {
-            issue_w(QC<6>{}, slot[6]); issue_w(QC<7>{}, slot[7]); issue_w(QC<8>{}, slot[8]);
-            issue_w(QC<9>{}, slot[9]); issue_w(QC<10>{}, slot[10]); issue_w(QC<11>{}, slot[11]);
+        if constexpr (NBW > 6) { issue_w(QC<6>{}, slot[6]); issue_w(QC<7>{}, slot[7]); }
+        if constexpr (NBW > 8) {
+            issue_w(QC<8>{}, slot[8]); issue_w(QC<9>{}, slot[9]); issue_w(QC<10>{}, slot[10]); issue_w(QC<11>{}, slot[11]);
         }
         advance_w();
     };
 
     // ---- LayerNorm of the tile's 64 rows -> LDS (bf16, swizzled): wave w takes rows 16 w .. 16 w + 15, eight at a time ----
     {
-        f32x4 g4[3], b4[3];
+        f32x4 g4[CH], b4[CH];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < CH; ++c) {
             g4[c] = reinterpret_cast<const f32x4*>(p.gamma)[lane + 64 * c];
             b4[c] = reinterpret_cast<const f32x4*>(p.beta)[lane + 64 * c];
         }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            f32x4 v[8][3];
+            f32x4 v[8][CH];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 int gr = m0 + wid * 16 + half * 8 + r;
                 gr = gr < p.M ? gr : p.M - 1;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
+                for (int c = 0; c < CH; ++c) {
                     if constexpr (XB) {
                         const u32x2 w2 = reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16*>(p.h) + (size_t)gr * p.ldh)[lane + 64 * c];
                         v[r][c] = f32x4{bf16_lo(w2[0]), bf16_hi(w2[0]), bf16_lo(w2[1]), bf16_hi(w2[1])};
@@ -188,18 +195,18 @@ __global__ __launch_bounds__(256, 1) void gemm_lnq_kernel(LnqParams p) {
                 // ln_kernel's arithmetic (rowwise.hip) through the same helpers (common.h): the same bits for the same row
                 float s = 0.f;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) s += ln_sum4(v[r][c]);
+                for (int c = 0; c < CH; ++c) s += ln_sum4(v[r][c]);
                 const float mean = wave_sum(s) / (float)QKD;
                 float q = 0.f;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
+                for (int c = 0; c < CH; ++c) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) q = ln_sq_acc(q, v[r][c][e], mean);
                 }
                 const float rstd = rsqrtf(wave_sum(q) / (float)QKD + 1e-5f);
                 const int row = wid * 16 + half * 8 + r;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
+                for (int c = 0; c < CH; ++c) {
                     u32x2 o;
                     o[0] = pack_bf16x2(ln_norm(v[r][c][0], mean, rstd, g4[c][0], b4[c][0]), ln_norm(v[r][c][1], mean, rstd, g4[c][1], b4[c][1]));
                     o[1] = pack_bf16x2(ln_norm(v[r][c][2], mean, rstd, g4[c][2], b4[c][2]), ln_norm(v[r][c][3], mean, rstd, g4[c][3], b4[c][3]));
@@ -265,9 +272,8 @@ __global__ __launch_bounds__(256, 1) void gemm_lnq_kernel(LnqParams p) {
             if constexpr (nb == 0 && !last) read_a(ANXT, span_next, aoff[(j + 1) % PER]);
         };
         block(QC<0>{}); block(QC<1>{}); block(QC<2>{}); block(QC<3>{}); block(QC<4>{}); block(QC<5>{});
-        if constexpr (NBW == 12) {
-            block(QC<6>{}); block(QC<7>{}); block(QC<8>{}); block(QC<9>{}); block(QC<10>{}); block(QC<11>{});
-        }
+        if constexpr (NBW > 6) { block(QC<6>{}); block(QC<7>{}); }
+        if constexpr (NBW > 8) { block(QC<8>{}); block(QC<9>{}); block(QC<10>{}); block(QC<11>{}); }
         if constexpr (do_w) advance_w();
     };
     // a period = PER stages = one 256-B span of A (16 chunks); a stage reads the NEXT stage's fragments, which sit in the next
@@ -311,7 +317,7 @@ __global__ __launch_bounds__(256, 1) void gemm_lnq_kernel(LnqParams p) {
                 const int row = mb * 32 + (lane & 31);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int col = wid * 192 + nb * 32 + 8 * g + 4 * (lane >> 5);
+                    const int col = wid * (D / 4) + nb * 32 + 8 * g + 4 * (lane >> 5);
                     const f32x4 b = *reinterpret_cast<const f32x4*>(lbias + col);
                     u32x2 st;
                     st[0] = pack_bf16x2(v[4 * g] + b[0], v[4 * g + 1] + b[1]);
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(256, 1) void gemm_lnq_kernel(LnqParams p) {
                 }
             } else {
                 const int row = mb * 16 + (lane & 15);
-                const int col = wid * 192 + nb * 16 + 4 * (lane >> 4);
+                const int col = wid * (D / 4) + nb * 16 + 4 * (lane >> 4);
                 const f32x4 b = *reinterpret_cast<const f32x4*>(lbias + col);
                 u32x2 st;
                 st[0] = pack_bf16x2(v[0] + b[0], v[1] + b[1]);
@@ -331,20 +337,21 @@ __global__ __launch_bounds__(256, 1) void gemm_lnq_kernel(LnqParams p) {
     }
     __syncthreads();
     // read-back: 64 rows x 96 chunks of 16 B, chunk id = tid + 256 i: lanes walk a row's chunks, whole 128-B lines per store
+    constexpr int CPR = D / 8;                                            // 16-B chunks per output row
 #pragma unroll 4
-    for (int i = 0; i < QM * 96 / 256; ++i) {
+    for (int i = 0; i < QM * CPR / 256; ++i) {
         const int id = tid + 256 * i;
-        const int row = id / 96, c = id - row * 96;
+        const int row = id / CPR, c = id - row * CPR;
         const u32x4 val = *reinterpret_cast<const u32x4*>(smem + row * Q_AROW + ((c ^ (row & 15)) << 4));
         if (m0 + row < p.M) *reinterpret_cast<u32x4*>(p.out + (size_t)(m0 + row) * p.ldo + c * 8) = val;
     }
 }
 
-template <int SHAPE, int R, bool XB>
+template <int SHAPE, int R, bool XB, int D = 768>
 hipError_t launch_lnq_t(const LnqParams& p, hipStream_t s) {
     static DevOnce lds_once;
-    if (hipError_t e = set_max_lds_once(lds_once, {reinterpret_cast<const void*>(&gemm_lnq_kernel<SHAPE, R, XB>)}, Q_LDS)) return e;
-    hipLaunchKernelGGL((gemm_lnq_kernel<SHAPE, R, XB>), dim3((p.M + QM - 1) / QM), dim3(256), Q_LDS, s, p);
+    if (hipError_t e = set_max_lds_once(lds_once, {reinterpret_cast<const void*>(&gemm_lnq_kernel<SHAPE, R, XB, D>)}, QW<D>::LDS)) return e;
+    hipLaunchKernelGGL((gemm_lnq_kernel<SHAPE, R, XB, D>), dim3((p.M + QM - 1) / QM), dim3(256), QW<D>::LDS, s, p);
     return hipGetLastError();
 }
 
@@ -356,12 +363,15 @@ int g_lnq_ring = [] { const char* e = getenv("DITTO_LNQ_RING"); return e ? atoi(
 // rot_period: tiles (of 64 rows) per utterance when that is whole, else 0 (no K-loop rotation)
 hipError_t launch_gemm_lnq(const void* h, int ldh, bool h_bf16, const float* gamma, const float* beta, const void* Wp,
                            const float* bias, void* out_bf16, int ldo, int M, int d, int shape, int rot_period, hipStream_t s) {
-    if (d != QN || M <= 0 || !h || !gamma || !beta || !Wp || !out_bf16 || (shape != 32 && shape != 16)) return hipErrorInvalidValue;
+    if ((d != 768 && d != 1024) || M <= 0 || !h || !gamma || !beta || !Wp || !out_bf16 || (shape != 32 && shape != 16))
+        return hipErrorInvalidValue;
+    if (d == 1024 && (shape != 32 || h_bf16)) return hipErrorInvalidValue;   // C5's width: 32x32x16, fp32 rows
     if (ldh % 4 || ldo % 8) return hipErrorInvalidValue;
     LnqParams p;
     p.h = h; p.ldh = ldh; p.gamma = gamma; p.beta = beta; p.Wp = (const char*)Wp; p.bias = bias;
     p.out = (bf16*)out_bf16; p.ldo = ldo; p.M = M; p.rot_period = rot_period > 0 ? rot_period : 0;
     const int ring = g_lnq_ring;
+    if (d == 1024) return launch_lnq_t<32, 4, false, 1024>(p, s);
     // default depth = the shallow ring: in the model (tools/step_ab.py, C2 B = 32, one process) 4 stages 61.3 us against 63.2 for 8
     // (shape 32), 2 stages 70.6 against 72.2 for 4 (shape 16): the loop is not short of bytes in flight
     if (shape == 32) {

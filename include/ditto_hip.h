@@ -243,13 +243,13 @@ int ditto_gemm_ln_bf16(const void* A, int lda, const void* W, const float* bias,
                        ditto_stream_t stream);
 
 /* LayerNorm fused INTO the GEMM that consumes it (csrc/gemm_lnq.hip; the model path's norm2 + cross-attention q-projection,
- * src/components/DiT.py:142-145, d = 768):  out bf16 [M, ldo] = (LayerNorm(h) * gamma + beta) W[768, 768]^T + bias, eps 1e-5;
- * the normalised rows live in the LDS only.  h: fp32 [M, ldh] or (h_is_bf16) bf16 [M, ldh]; W: bf16, nn.Linear layout
- * [768 out, 768 in]; bias may be NULL.  mfma_shape 32 / 16 = v_mfma_f32_32x32x16_bf16 / 16x16x32 (two builds of one kernel).
- * w_scratch: 768 * 768 * 2 bytes, 256-byte aligned: receives the stage-major image of W the kernel streams (the model keeps
+ * src/components/DiT.py:142-145; d = 768, or 1024 = BASELINE config C5):  out bf16 [M, ldo] = (LayerNorm(h) * gamma + beta)
+ * W[d, d]^T + bias, eps 1e-5; the normalised rows live in the LDS only.  h: fp32 [M, ldh] or (h_is_bf16, d = 768) bf16 [M, ldh];
+ * W: bf16, nn.Linear layout [d out, d in]; bias may be NULL.  mfma_shape 32 / 16 = v_mfma_f32_32x32x16_bf16 / 16x16x32 (two
+ * builds of one kernel; d = 1024: 32 only).  w_scratch: d * d * 2 bytes, 256-byte aligned: receives the stage-major image of W the kernel streams (the model keeps
  * these images in its arena).  Any M >= 1. */
 int ditto_gemm_lnq_bf16(const void* h, int ldh, int h_is_bf16, const float* gamma, const float* beta, const void* W,
-                        const float* bias, void* out_bf16, int ldo, int M, int mfma_shape, void* w_scratch,
+                        const float* bias, void* out_bf16, int ldo, int M, int d, int mfma_shape, void* w_scratch,
                         ditto_stream_t stream);
 
 /* Weight-gradient GEMM of the backward pass (csrc/gemm_tn.hip): out fp32 [Mo, No] = X[K, Mo]^T Y[K, No], both operands

@@ -714,7 +714,7 @@ def test_layernorm_fused_into_the_q_projection(lib, lnq_variant, M, h_bf16, shap
     scratch = torch.empty(d * d * 2, dtype=torch.uint8, device=DEV)
     out = torch.full((M, d), float("nan"), dtype=torch.bfloat16, device=DEV)
     hip.check(lib.ditto_gemm_lnq_bf16(hin.data_ptr(), d, int(h_bf16), gamma.data_ptr(), beta.data_ptr(), W.data_ptr(),
-                                      bias.data_ptr(), out.data_ptr(), d, M, shape, scratch.data_ptr(), stream()))
+                                      bias.data_ptr(), out.data_ptr(), d, M, d, shape, scratch.data_ptr(), stream()))
     assert torch.isfinite(out.float()).all()
     # (b) the two launches it replaces (fp32 rows: ditto_layernorm_bf16 takes fp32)
     u = torch.empty(M, d, dtype=torch.bfloat16, device=DEV)
@@ -728,12 +728,12 @@ def test_layernorm_fused_into_the_q_projection(lib, lnq_variant, M, h_bf16, shap
     # no bias; and one row alone gives that row's bits
     out0 = torch.empty_like(out)
     hip.check(lib.ditto_gemm_lnq_bf16(hin.data_ptr(), d, int(h_bf16), gamma.data_ptr(), beta.data_ptr(), W.data_ptr(),
-                                      None, out0.data_ptr(), d, M, shape, scratch.data_ptr(), stream()))
+                                      None, out0.data_ptr(), d, M, d, shape, scratch.data_ptr(), stream()))
     assert rel_l2(out0.float(), want - bias) < 4e-3
     r = M // 2
     one = torch.empty(1, d, dtype=torch.bfloat16, device=DEV)
     hip.check(lib.ditto_gemm_lnq_bf16(hin[r:r + 1].contiguous().data_ptr(), d, int(h_bf16), gamma.data_ptr(), beta.data_ptr(),
-                                      W.data_ptr(), bias.data_ptr(), one.data_ptr(), d, 1, shape, scratch.data_ptr(), stream()))
+                                      W.data_ptr(), bias.data_ptr(), one.data_ptr(), d, 1, d, shape, scratch.data_ptr(), stream()))
     if rot <= 1 or (r // 64) % rot % 6 == 0:            # (a rotated K loop sums in another order: same phase only)
         assert torch.equal(one[0], out[r])
     else:
@@ -754,5 +754,35 @@ def test_fused_q_projection_normalises_exactly_like_the_layernorm_kernel(lib):
     for shape in (32, 16):
         out = torch.empty(M, d, dtype=torch.bfloat16, device=DEV)
         hip.check(lib.ditto_gemm_lnq_bf16(h.data_ptr(), d, 0, gamma.data_ptr(), beta.data_ptr(), W.data_ptr(), None,
-                                          out.data_ptr(), d, M, shape, scratch.data_ptr(), stream()))
+                                          out.data_ptr(), d, M, d, shape, scratch.data_ptr(), stream()))
         assert torch.equal(out, u), shape
+
+
+@pytest.mark.parametrize("M", [64, 100, 1024 + 13])
+def test_layernorm_fused_into_the_q_projection_at_width_1024(lib, M):
+    """The same kernel at d = 1024 (BASELINE config C5: 64 x 1024 tiles, 256 accumulators per lane, 32x32x16, fp32 rows):
+    against the fp32 ops on the LayerNorm kernel's own bf16 output (4e-3) and the two launches it replaces (3e-3); with an
+    identity weight its normalised rows are the LayerNorm kernel's bit for bit."""
+    d = 1024
+    h = (asym((M, d), 51) * 1.3 - 0.2).to(DEV)
+    gamma = (1 + 0.2 * asym((d,), 52)).to(DEV)
+    beta = (0.1 * asym((d,), 53)).to(DEV)
+    W = bf16((asym((d, d), 54) / math.sqrt(d)).to(DEV))
+    bias = (0.1 * asym((d,), 55)).to(DEV)
+    scratch = torch.empty(d * d * 2, dtype=torch.uint8, device=DEV)
+    out = torch.full((M, d), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.check(lib.ditto_gemm_lnq_bf16(h.data_ptr(), d, 0, gamma.data_ptr(), beta.data_ptr(), W.data_ptr(), bias.data_ptr(),
+                                      out.data_ptr(), d, M, d, 32, scratch.data_ptr(), stream()))
+    u = torch.empty(M, d, dtype=torch.bfloat16, device=DEV)
+    hip.check(lib.ditto_layernorm_bf16(h.data_ptr(), gamma.data_ptr(), beta.data_ptr(), u.data_ptr(), M, d, stream()))
+    two = torch.empty(M, d, dtype=torch.bfloat16, device=DEV)
+    hip.check(lib.ditto_gemm_bf16(u.data_ptr(), d, W.data_ptr(), bias.data_ptr(), None, two.data_ptr(), d, M, d, d, 0, stream()))
+    want = u.float() @ W.float().T + bias
+    assert torch.isfinite(out.float()).all()
+    assert rel_l2(out.float(), want) < 4e-3 and rel_l2(out.float(), two.float()) < 3e-3
+    eye = bf16(torch.eye(d, device=DEV))
+    hip.check(lib.ditto_gemm_lnq_bf16(h.data_ptr(), d, 0, gamma.data_ptr(), beta.data_ptr(), eye.data_ptr(), None,
+                                      out.data_ptr(), d, M, d, 32, scratch.data_ptr(), stream()))
+    assert torch.equal(out, u)
+    assert lib.ditto_gemm_lnq_bf16(h.data_ptr(), d, 0, gamma.data_ptr(), beta.data_ptr(), W.data_ptr(), None, out.data_ptr(), d, M,
+                                   d, 16, scratch.data_ptr(), stream()) == hip.ERR_SHAPE      # 16x16x32 exists at d = 768 only

@@ -39,7 +39,7 @@ hip.set_option("fr_rot", 16)                                          # rotate a
 def launch(shape, ring, src, is_bf16):
     hip.set_option("lnq_ring", ring)
     hip.check(lib.ditto_gemm_lnq_bf16(src.data_ptr(), d, int(is_bf16), gamma.data_ptr(), beta.data_ptr(), W.data_ptr(),
-                                      bias.data_ptr(), out.data_ptr(), d, M, shape, scratch.data_ptr(), stream))
+                                      bias.data_ptr(), out.data_ptr(), d, M, d, shape, scratch.data_ptr(), stream))
 
 
 times = {(v, s): [] for v in variants for s in ("fp32", "bf16")}
