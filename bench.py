@@ -149,7 +149,7 @@ def kernel_bytes(cfg, B, N, T, seeded=True):
 
 def floor_table(cfg, B, N, T, classes):
     """profiles/r04_floor_table.json: per kernel class the time (us) its launch takes with the removable overheads knocked out
-    in diagnostic builds (main loop without epilogue, operands L2-hot, no stores: tools/r04_run5.sh) —
+    in diagnostic builds (main loop without epilogue, operands L2-hot, no stores: tools/round4/r04_run5.sh) —
     measured OFFLINE on the timed shape, so only reported for it.  step_floor_ms = the step if every class ran at its floor
     (classes without a floor entry at their time in THIS run); step_frac_at_floor = the executed FLOPs at that time / 2.5 PF."""
     if not (B == 32 and N == 1024 and T == 1024 and cfg.hidden_dim == 768 and cfg.num_layers == 12 and not cfg.fp8_linear):
