@@ -141,6 +141,35 @@ DITTO_DEV f32x2 fast_gelu_sigmoid2(f32x2 x, f32x2 g) {
     r[0] = fast_rcp(den[0]); r[1] = fast_rcp(den[1]);
     return num * r;
 }
+// Backward of the same product for two elements (train.hip gated_bwd_elem, whose formulas these are, on 2-vectors):
+//   y = gelu(a) sigmoid(g):  da = dy sigmoid(g) (Phi(a) + a phi(a)),  dg = dy gelu(a) sigmoid(g) (1 - sigmoid(g)),
+// Phi by the rational erf above (one reciprocal), phi one v_exp, sigmoid one v_exp + one v_rcp.  The epilogue of the fc2
+// dgrad GEMM in the training backward (gemm_common.h epilogue_gated_bwd).
+DITTO_DEV void gated_bwd2(f32x2 a, f32x2 g, f32x2 dy, f32x2& da, f32x2& dg) {
+    f32x2 z = a * 0.70710678118654752440f;
+    z[0] = __builtin_amdgcn_fmed3f(z[0], -4.0f, 4.0f); z[1] = __builtin_amdgcn_fmed3f(z[1], -4.0f, 4.0f);
+    const f32x2 u = z * z;
+    f32x2 pn = u * 1.9217200275534196e-08f + (-1.990321152334218e-06f);
+    pn = pn * u + 0.00015553680714219809f;
+    pn = pn * u + 0.0042930529452860355f;
+    pn = pn * u + 0.05243346840143204f;
+    pn = pn * u + 0.2139447033405304f;
+    pn = pn * u + 1.1283786296844482f;
+    f32x2 qd = u * 0.0010980380466207862f + 0.01555109117180109f;
+    qd = qd * u + 0.12079962342977524f;
+    qd = qd * u + 0.5229312181472778f;
+    qd = qd * u + 1.0f;
+    const f32x2 ea = (a * a) * (-0.72134752044448170368f), eg = g * (-1.4426950408889634f);
+    f32x2 rq, pe, sg;
+    rq[0] = fast_rcp(qd[0]); rq[1] = fast_rcp(qd[1]);
+    pe[0] = __builtin_amdgcn_exp2f(ea[0]); pe[1] = __builtin_amdgcn_exp2f(ea[1]);
+    sg[0] = fast_rcp(1.0f + __builtin_amdgcn_exp2f(eg[0])); sg[1] = fast_rcp(1.0f + __builtin_amdgcn_exp2f(eg[1]));
+    const f32x2 cdf = (z * pn + qd) * (rq * 0.5f);                 // Phi(a)
+    const f32x2 pdf = pe * 0.39894228040143267794f;                // phi(a)
+    const f32x2 t = dy * sg;
+    da = t * (a * pdf + cdf);
+    dg = (t * (a * cdf)) * (1.0f - sg);
+}
 // Fourth form (A/B build -DDITTO_GATED_H): the whole activation in PACKED fp16, in the sigmoid form of the
 // Gaussian cdf,
 //     gelu(x) sigmoid(g) ~= x / ((1 + e^-p(x)) (1 + e^-g)),   p(x) = 2 sqrt(2/pi) x (1 + 0.044715 x^2)   (the "tanh" GELU),

@@ -131,6 +131,8 @@ TrainWsPlan plan_train_ws(const ditto_config& c, int B, int N, int T) {
     size_t red = (size_t)256 * 8 * d * 4;   // colsum: <= 256 row chunks x <= 8d columns
     const size_t r2 = ln_bwd_scratch_bytes((int)M, 1, (int)d), r3 = ln_bwd_scratch_bytes(N, B, (int)d);
     red = red > r2 ? red : r2; red = red > r3 ? red : r3;
+    const size_t r4 = (size_t)2 * ((M + 255) / 256) * 8 * d * 4;   // fused fc2 dgrad + gated backward: one partial row per 128-row half tile
+    red = red > r4 ? red : r4;
     w.red = take(red);
     w.dmod = take((size_t)B * 2 * d * 4);
     w.small = take(6 * al((size_t)B * c.time_dim * 4));
@@ -324,7 +326,9 @@ int ditto_train_forward(ditto_model_t m, const float* x, const float* text, cons
             g.A = tb + q.u3; g.lda = d; g.W = lp.W1g; g.bias = lp.b1g; g.out = tb + q.act; g.ldo = 4 * d;
             g.out2_bf16 = tb + q.pre; g.ldo2 = 8 * d;   // the gated epilogue also keeps the pre-activations
             g.M = M; g.N = 8 * d; g.K = d;
-            HIP_TRY(launch_gemm(g, EPI_GATED, s));
+            // EPI_GATED_PRE = the same epilogue as its own instantiation of the 256 x 256 kernel (straight-line code; train_flags 4: A/B off)
+            const bool pre_inst = !(g_train_flags & 4) && gemm_gated_bwd_fused_ok(M, 8 * d);
+            HIP_TRY(launch_gemm(g, pre_inst ? EPI_GATED_PRE : EPI_GATED, s));
         }
         if (fr_fc2) {
             GemmParams gp{};
@@ -454,8 +458,18 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
             HIP_TRY(launch_colsum_f32(dh, d, M, d, G.mlp_fc2_bias, red, s));
         }
         TRY_RC(wgrad(dyb, d, d, tb + q.act, 4 * d, 4 * d, M, G.mlp_fc2_weight));
-        TRY_RC(dgrad(dyb, d, lt.W2T, 4 * d, big2, false));
-        HIP_TRY(launch_gated_bwd(big2, tb + q.pre, big1, M, 4 * d, s, vtmp, red));   // + the packed fc1 | gate bias gradients
+        if (!(g_train_flags & 2) && gemm_gated_bwd_fused_ok(M, 4 * d)) {
+            // ONE launch: dact = dY W2 stays in the accumulators, the epilogue reads the pre-activations and writes [da | dg]
+            // and the bias gradients' partial rows (gemm_common.h epilogue_gated_bwd; train_flags 2: A/B off)
+            GemmArgs g{};
+            g.A = dyb; g.lda = d; g.W = lt.W2T; g.out = big1; g.ldo = 8 * d; g.M = M; g.N = 4 * d; g.K = d;
+            g.pre_bf16 = tb + q.pre; g.ldpre = 8 * d; g.colsum_partial = red;
+            HIP_TRY(launch_gemm(g, EPI_GATED_BWD, s));
+            HIP_TRY(launch_reduce_partials(red, 2 * ((M + 255) / 256), (size_t)8 * d, vtmp, s));
+        } else {
+            TRY_RC(dgrad(dyb, d, lt.W2T, 4 * d, big2, false));
+            HIP_TRY(launch_gated_bwd(big2, tb + q.pre, big1, M, 4 * d, s, vtmp, red));   // + the packed fc1 | gate bias gradients
+        }
         HIP_TRY(launch_unpack_vec(vtmp, G.mlp_fc1_bias, 4 * d, 16, 2, 0, s));
         HIP_TRY(launch_unpack_vec(vtmp, G.gate_bias, 4 * d, 16, 2, 16, s));
         TRY_RC(wgrad(big1, 8 * d, 8 * d, tb + q.u3, d, d, M, wtmp));

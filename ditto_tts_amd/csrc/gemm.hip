@@ -278,6 +278,13 @@ hipError_t launch_t(const GemmParams& p, hipStream_t s) {
 
 }  // namespace
 
+// The fused launch pays where the 256 x 256 kernel is the dgrad's kernel anyway (launch_gemm's wide-output rule below).
+bool gemm_gated_bwd_fused_ok(int M, int F) {
+    if (M <= 0 || F <= 0 || F % 256) return false;
+    const long t256 = (long)((M + 255) / 256) * (F / 256);
+    return (g_gemm_tile == 0 || g_gemm_tile == 256) && F >= 2048 && t256 >= 144;
+}
+
 hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return hipErrorInvalidValue;
     if (a.fp8) {
@@ -298,6 +305,7 @@ hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s) {
     p.batch_inner = a.batch_inner > 1 ? a.batch_inner : 1;
     for (int i = 0; i < 2; ++i) { p.sA[i] = a.sA[i]; p.sW[i] = a.sW[i]; p.sO[i] = a.sO[i]; p.sR[i] = a.sR[i]; }
     p.out_esz = (epi == EPI_BIAS_RES_F32 || epi == EPI_BIAS_F32) ? 4 : 2;
+    p.pre = (const bf16*)a.pre_bf16; p.ldpre = a.ldpre; p.colpart = a.colsum_partial;
     if (nbatch > 1 && (a.fp8 || p.k_splits > 1 || nbatch > 65535)) return hipErrorInvalidValue;
     g_batch_y = nbatch;
     if (p.k_splits > 1 && (epi != EPI_BIAS_F32 || a.bias || a.fp8)) return hipErrorInvalidValue;
@@ -310,7 +318,20 @@ hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s) {
         case EPI_GATED_FP8:
             if (a.N % 32 || !a.bias) return hipErrorInvalidValue;
             break;
+        case EPI_GATED_PRE:   // the two training epilogues exist on the 256 x 256 structure only
+            if (a.N % 256 || !a.bias || !a.out2_bf16 || a.fp8 || nbatch > 1 || p.k_splits > 1) return hipErrorInvalidValue;
+            break;
+        case EPI_GATED_BWD:
+            if (a.N % 256 || a.bias || !a.pre_bf16 || !a.colsum_partial || a.ldpre % 8 || a.ldo % 8 || a.fp8 || nbatch > 1 ||
+                p.k_splits > 1)
+                return hipErrorInvalidValue;
+            break;
         default: break;
+    }
+    if (epi == EPI_GATED_PRE || epi == EPI_GATED_BWD) {
+        p.tiles_m = (a.M + 255) / 256;
+        p.tiles_n = a.N / 256;
+        return launch_gemm256(p, epi, s);
     }
     // Structure choice (measured in-model on MI355X, tools/step_ab.py, one device): the persistent 256x256
     // eight-phase kernel wins once every CU gets >= 4 tiles (QKV: 145 vs 166 us, gated MLP: 307 vs 424 us);

@@ -274,7 +274,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     // DMA (stores; the compiler's own waits retire the loads).  vmcnt retires in order, so the tile-start wait may
     // leave these (younger) stores in flight and still guarantee the (older) prologue DMA has landed: the store
     // drain of the previous tile then overlaps the first phases instead of stalling the whole workgroup.
-    constexpr int EPI_STORES = (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_RELU_BF16) ? 16 : EPI == EPI_QKV_ROPE ? 16
+    // (EPI_GATED_PRE: 8 + 16 stores, counted as 16; EPI_GATED_BWD: 32 loads + 32 stores + 8 partial-sum stores, counted as 32 —
+    // fewer than the truth only makes the wait stricter)
+    constexpr int EPI_STORES = (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_RELU_BF16 || EPI == EPI_GATED_PRE) ? 16 : EPI == EPI_QKV_ROPE ? 16
                                : (EPI == EPI_GATED || EPI == EPI_GATED_FP8) ? 8 : 32;
     bool prev_interior = false;   // previous tile of this workgroup was interior (its store count is exact)
 
@@ -467,13 +469,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 #ifdef DITTO_DIAG_G256_STAMP
         if (!first_tile || true) { G256_ACC(0, t_top, t_loop); G256_ACC(1, t_loop, t_end); G256_ACC(2, t_end, t_epi); st_acc[4] += 1; st_acc[6] = t_epi; }
 #endif
-        prev_interior = (cur_m0 + 256 <= p.M) && (cur_n0 + 256 <= p.N) && !p.out2 &&
+        prev_interior = (cur_m0 + 256 <= p.M) && (cur_n0 + 256 <= p.N) && (!p.out2 || EPI == EPI_GATED_PRE) &&
                         !(p.flags & (GF_DIAG_NO_STORE | GF_DIAG_NO_EPILOGUE));
         if (p.flags & GF_DIAG_NO_EPILOGUE) {
 #pragma unroll
             for (int m = 0; m < 8; ++m)
 #pragma unroll
                 for (int n = 0; n < 4; ++n) asm volatile("" ::"v"(acc[m][n]));   // keep the accumulators live
+            continue;
+        }
+        if constexpr (EPI == EPI_GATED_BWD) {   // no bias; whole-wave-block epilogue with its own loads (gemm_common.h)
+            const int pr = 2 * (cur_m0 >> 8) + wm;
+            if (cur_m0 + 256 <= p.M) epilogue_gated_bwd<false>(p, cur_m0 + wm * 128, cur_n0 + wn * 64, acc, fq, frow, pr);
+            else epilogue_gated_bwd<true>(p, cur_m0 + wm * 128, cur_n0 + wn * 64, acc, fq, frow, pr);
             continue;
         }
         f32x4 bias4[4];
@@ -594,11 +602,15 @@ hipError_t launch_gemm256(const GemmParams& p_in, GemmEpilogue epi, hipStream_t 
     p.group_n = pick_group_n(p.tiles_n, p.flags);
     // quarter of the expected tile time: ~1.5 us per K-tile + ~8 us fixed, in 10 ns ticks
     p.stagger_ticks = (int)((p.K / 64 * 1.5 + 8.0) * 100.0 / 4.0);
+    // (EPI_GATED_PRE / EPI_GATED_BWD with the four CU groups of an XCD started 4 - 20 us apart: 51.7 - 52.5 ms per training
+    // step against 51.8 together, profiles/r04_train_stagger_ab.txt — their HBM-heavy epilogues do not want de-phasing either)
     switch (epi) {
         case EPI_BIAS_BF16: return launch256_t<EPI_BIAS_BF16>(p, s);
         case EPI_BIAS_RES_F32: return launch256_t<EPI_BIAS_RES_F32>(p, s);
         case EPI_QKV_ROPE: return launch256_t<EPI_QKV_ROPE>(p, s);
         case EPI_GATED: return launch256_t<EPI_GATED>(p, s);
+        case EPI_GATED_PRE: return launch256_t<EPI_GATED_PRE>(p, s);
+        case EPI_GATED_BWD: return launch256_t<EPI_GATED_BWD>(p, s);
         case EPI_BIAS_F32: return launch256_t<EPI_BIAS_F32>(p, s);
         case EPI_BIAS_RELU_BF16: return launch256_t<EPI_BIAS_RELU_BF16>(p, s);
         default: break;

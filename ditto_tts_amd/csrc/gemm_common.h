@@ -31,6 +31,8 @@ struct GemmParams {
     int batch_inner;                      // gemm128 only: blockIdx.y = zo * batch_inner + zi
     long long sA[2], sW[2], sO[2], sR[2];
     int out_esz;                          // bytes per output element (batch offset of `out`)
+    const bf16* pre; int ldpre;           // EPI_GATED_BWD
+    float* colpart;                       // EPI_GATED_BWD
 };
 
 enum { GF_RELAXED_WAIT = 1,        // tile-start wait skips over the previous tile's epilogue stores
@@ -240,7 +242,7 @@ DITTO_DEV void epilogue_row(const GemmParams& p, int row, int cbase, const f32x4
             st[0] = r[0]; st[1] = r[1];
             *reinterpret_cast<u32x2*>((unsigned char*)p.out + (size_t)row * p.ldo + c) = st;
         }
-    } else if constexpr (EPI == EPI_GATED) {
+    } else if constexpr (EPI == EPI_GATED || EPI == EPI_GATED_PRE) {
         // packed columns: 16 x fc1 | 16 x gate | 16 x fc1 | 16 x gate  (reference src/components/DiT.py:153-155)
         u32x2 pk[2];
 #pragma unroll
@@ -252,7 +254,7 @@ DITTO_DEV void epilogue_row(const GemmParams& p, int row, int cbase, const f32x4
             pk[pr][1] = pack_bf16x2(o23[0], o23[1]);
         }
         store_bf16_pair<FAST>((bf16*)p.out + (size_t)row * p.ldo, cbase / 2, pk[0], pk[1], fq, p.N / 2, p.flags, p.ldo);
-        if (!FAST && p.out2) {   // training forward: the pre-activations (bias added, interleaved packed order) for the backward
+        if ((EPI == EPI_GATED_PRE) || (!FAST && p.out2)) {   // training forward: the pre-activations (bias added, interleaved packed order) for the backward
             u32x2 pr[4];
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
@@ -261,8 +263,8 @@ DITTO_DEV void epilogue_row(const GemmParams& p, int row, int cbase, const f32x4
                 pr[n][1] = pack_bf16x2(v[2], v[3]);
             }
             bf16* rowp = p.out2 + (size_t)row * p.ldo2;
-            store_bf16_pair(rowp, cbase, pr[0], pr[1], fq, p.N, p.flags & ~GF_DIAG_LINEAR_STORE, p.ldo2);
-            store_bf16_pair(rowp, cbase + 32, pr[2], pr[3], fq, p.N, p.flags & ~GF_DIAG_LINEAR_STORE, p.ldo2);
+            store_bf16_pair<FAST>(rowp, cbase, pr[0], pr[1], fq, p.N, p.flags & ~GF_DIAG_LINEAR_STORE, p.ldo2);
+            store_bf16_pair<FAST>(rowp, cbase + 32, pr[2], pr[3], fq, p.N, p.flags & ~GF_DIAG_LINEAR_STORE, p.ldo2);
         }
     } else if constexpr (EPI == EPI_QKV_ROPE) {
         float v[4][4];
@@ -353,11 +355,115 @@ DITTO_DEV void epilogue_row(const GemmParams& p, int row, int cbase, const f32x4
     }
 }
 
+// v += the same value of the 15 other lanes of the 16-lane DPP row (the lanes that hold the other rows of a 16-row block):
+// four v_add_f32_dpp (xor 1, xor 2 by quad_perm, then the half-row and row mirrors: after the first two steps a quad holds one value)
+DITTO_DEV float dpp_row_sum16(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+    return v;
+}
+
+// EPI_GATED_BWD, one wave's 128 x 64 block of a 256 x 256 tile (training backward; reference src/components/DiT.py:152-154
+// differentiated).  acc[m][n][e] = dact[r0 + 16 m][cb + 16 n + 4 fq + e].  The pre-activations of act columns cb + 16 n .. + 15
+// sit at packed columns 2 (cb + 16 n) + {0 .. 15 fc1, 16 .. 31 gate}: the store exchange of store_bf16_pair run backwards — the
+// even-fq lane loads 8 consecutive fc1 values (its own 4 and its lane^16 partner's), the odd-fq lane 8 gate values, two
+// v_permlane16_swap hand every lane its own 4 + 4 — so a row block costs 4 16-B loads and 4 16-B stores per lane.  Column sums
+// are taken over the ROUNDED values (what the weight-gradient GEMM reads next), per lane over its 8 rows, then over the 16
+// rows of a block by DPP; lanes 0, 16, 32, 48 write the wave's partial row `part_row`.  GUARD: the tile may pass row M.
+template <bool GUARD>
+DITTO_DEV void epilogue_gated_bwd(const GemmParams& p, int urow /* wave-uniform: first row of the wave's block */, int cb,
+                                  const f32x4 (&acc)[8][4], int fq, int frow, int part_row) {
+    // dact rounded to bf16 first, as the two-launch path stored it (same bits as that path up to fp contraction), and so that
+    // 64 registers hold what 128 did: the loads of two row blocks can be in flight above the arithmetic of the previous two
+    unsigned dyp[8][4][2];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            dyp[m][n][0] = pack_bf16x2(acc[m][n][0], acc[m][n][1]);
+            dyp[m][n][1] = pack_bf16x2(acc[m][n][2], acc[m][n][3]);
+            asm volatile("" : "+v"(dyp[m][n][0]), "+v"(dyp[m][n][1]));
+        }
+    float cs[4][2][4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { cs[n][0][e] = 0.f; cs[n][1][e] = 0.f; }
+    const int odd = fq & 1;
+    const int lc = 2 * cb + odd * 16 + 4 * (fq - odd);      // this lane's 8-column piece of the first packed 32-column group
+    // addresses = wave-uniform row base (scalar registers) + ONE 32-bit lane offset per matrix: the row pointers of eight row
+    // blocks as 64-bit vector values were 32 registers this epilogue does not have
+    const unsigned pre_lane = (unsigned)(frow * p.ldpre + lc) * 2u, out_lane = (unsigned)(frow * p.ldo + lc) * 2u;
+    auto row_ok = [&](int m) { return !GUARD || urow + m * 16 + frow < p.M; };   // the same for a lane and its lane^16 partner (same row)
+    auto pre_ptr = [&](int m) {
+        if (GUARD && !row_ok(m)) return (const char*)p.pre + (size_t)(p.M - 1) * p.ldpre * 2 + (size_t)lc * 2;
+        return (const char*)p.pre + (size_t)(urow + m * 16) * p.ldpre * 2 + pre_lane;
+    };
+    // (three pairs in flight instead of two — 24 loads per wave — measured no faster: 317 vs 308 us per launch at C2, B = 32;
+    // the epilogue is as much vector arithmetic, ~3 000 instructions per wave and tile, as it is traffic)
+    u32x4 ld[2][2][4];                                      // [buffer][row block of the pair][n]
+    auto load_pair = [&](int buf, int mp) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const char* prow = pre_ptr(2 * mp + i);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) ld[buf][i][n] = *reinterpret_cast<const u32x4*>(prow + 64 * n);
+        }
+    };
+    load_pair(0, 0);
+#pragma unroll
+    for (int mp = 0; mp < 4; ++mp) {
+        if (mp < 3) load_pair((mp + 1) & 1, mp + 1);
+        asm volatile("" ::: "memory");                      // the next pair's loads stay above this pair's arithmetic and stores
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = 2 * mp + i;
+            const bool ok = row_ok(m);
+            char* drow = (char*)p.out + (size_t)(urow + m * 16) * p.ldo * 2 + out_lane;   // (not dereferenced past row M)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const u32x4 l4 = ld[mp & 1][i][n];
+                const auto t0 = __builtin_amdgcn_permlane16_swap(l4[0], l4[2], false, false);
+                const auto t1 = __builtin_amdgcn_permlane16_swap(l4[1], l4[3], false, false);
+                f32x2 da01, dg01, da23, dg23;
+                gated_bwd2(f32x2{bf16_lo(t0[0]), bf16_hi(t0[0])}, f32x2{bf16_lo(t0[1]), bf16_hi(t0[1])},
+                           f32x2{bf16_lo(dyp[m][n][0]), bf16_hi(dyp[m][n][0])}, da01, dg01);
+                gated_bwd2(f32x2{bf16_lo(t1[0]), bf16_hi(t1[0])}, f32x2{bf16_lo(t1[1]), bf16_hi(t1[1])},
+                           f32x2{bf16_lo(dyp[m][n][1]), bf16_hi(dyp[m][n][1])}, da23, dg23);
+                const unsigned pa0 = pack_bf16x2(da01[0], da01[1]), pa1 = pack_bf16x2(da23[0], da23[1]);
+                const unsigned pg0 = pack_bf16x2(dg01[0], dg01[1]), pg1 = pack_bf16x2(dg23[0], dg23[1]);
+                if (ok) {
+                    cs[n][0][0] += bf16_lo(pa0); cs[n][0][1] += bf16_hi(pa0); cs[n][0][2] += bf16_lo(pa1); cs[n][0][3] += bf16_hi(pa1);
+                    cs[n][1][0] += bf16_lo(pg0); cs[n][1][1] += bf16_hi(pg0); cs[n][1][2] += bf16_lo(pg1); cs[n][1][3] += bf16_hi(pg1);
+                }
+                const auto s0 = __builtin_amdgcn_permlane16_swap(pa0, pg0, false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(pa1, pg1, false, false);
+                u32x4 st;
+                st[0] = s0[0]; st[1] = s1[0]; st[2] = s0[1]; st[3] = s1[1];
+                if (ok) *reinterpret_cast<u32x4*>(drow + 64 * n) = st;
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+    float* prt = p.colpart + (size_t)part_row * (2 * (size_t)p.N) + 2 * cb + 4 * fq;
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = dpp_row_sum16(cs[n][t][e]);
+            if (frow == 0) *reinterpret_cast<f32x4*>(prt + 32 * n + 16 * t) = v;
+        }
+}
+
 // May the tile at (m0, n0) of extent (BM_, BN_) take the FAST epilogue?  (wave-uniform)
 template <int EPI>
 DITTO_DEV bool epilogue_fast_ok(const GemmParams& p, int m0, int n0, int BM_, int BN_) {
     constexpr int must_off = GF_DIAG_NO_STORE | GF_DIAG_NO_EPILOGUE | GF_DIAG_LINEAR_STORE | GF_DIAG_SMALL_OUT | GF_STORE_SC1;
-    if (m0 + BM_ > p.M || n0 + BN_ > p.N || p.out2 || (p.flags & must_off) || !(p.flags & GF_STORE_NT)) return false;
+    if (m0 + BM_ > p.M || n0 + BN_ > p.N || (p.out2 && EPI != EPI_GATED_PRE) || (p.flags & must_off) || !(p.flags & GF_STORE_NT)) return false;
     if ((p.flags & GF_SLOW_EPILOGUE) || !p.bias) return false;
     if constexpr (EPI == EPI_BIAS_RES_F32) return p.residual != nullptr;
     if constexpr (EPI == EPI_QKV_ROPE) return p.rope_freq_rev != nullptr;   // table-free angles (the model path)

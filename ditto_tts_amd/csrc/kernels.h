@@ -108,7 +108,7 @@ inline bool fr_pays_64(int M) {
     return (rows + 63) / 64 >= 192;
 }
 
-extern int g_train_flags;   // gemm.hip: training-step A/B switches: bit 0 = the rotation's backward as its own pass (not in the dq / dk epilogues)
+extern int g_train_flags;   // gemm.hip: training-step A/B switches: bit 0 = the rotation's backward as its own pass (not in the dq / dk epilogues), bit 1 = fc2 dgrad and gated backward as two launches, bit 2 = training forward's gated GEMM on the general epilogue
 extern int g_fr_dgrad;   // gemm.hip: training backward, long-K dgrads on the full-row kernel: bit 0 fc1|gate (K = 8d), bit 1 QKV (K = 3d)
 extern int g_fr_rot;     // gemm.hip: full-row kernel's K-loop rotation: 0 off, 1 on in the model (period = tiles per utterance), > 1 = period for ditto_gemm_ln_bf16 too
 // g_fr_tile (declared above): gemm.hip: full-row kernel's tile: 0 = rule, 64 = gemm_fr64.hip for every launch with K <= g_fr64_maxk, 128 = gemm_fr.hip
@@ -145,7 +145,15 @@ enum GemmEpilogue {
     EPI_GATED = 3,        // W rows interleaved [fc1 x16 | gate x16]; out bf16 [M, N/2] = gelu(a) * sigmoid(g)
     EPI_BIAS_F32 = 4,     // out fp32 [M, ldo] = acc + bias
     EPI_GATED_FP8 = 5,    // as EPI_GATED, out fp8 e4m3 [M, N/2] (A operand of an fp8 fc2)
-    EPI_BIAS_RELU_BF16 = 6 // out bf16 [M, ldo] = max(acc + bias, 0)  (nn.TransformerDecoderLayer linear1, slp.hip)
+    EPI_BIAS_RELU_BF16 = 6, // out bf16 [M, ldo] = max(acc + bias, 0)  (nn.TransformerDecoderLayer linear1, slp.hip)
+    // Training backward of the gated MLP (src/components/DiT.py:152-154) as the epilogue of the fc2 dgrad GEMM: acc = dact
+    // [M, N] = dY W2; out bf16 [M, 2N] = [da | dg] in the packed order of the pre-activations `pre_bf16` [M, 2N] (16 x fc1 | 16 x
+    // gate); the bf16-rounded column sums (= the fc1 | gate bias gradients) as one partial row per 128-row half tile in
+    // `colsum_partial` [2 * ceil(M / 256), 2N] fp32 (the caller sums the rows in order).  256 x 256 kernel only: N % 256 == 0.
+    EPI_GATED_BWD = 7,
+    // EPI_GATED that ALWAYS writes the pre-activations (out2_bf16 [M, N], packed order) as well: the training forward, as
+    // its own instantiation so that it takes the straight-line epilogue the inference kernel has.  256 x 256 kernel only.
+    EPI_GATED_PRE = 8
 };
 struct GemmArgs {
     const void* A; int lda;          // bf16 [M, K], row stride lda (elements)
@@ -170,7 +178,11 @@ struct GemmArgs {
     // generic-head_dim path in one launch.)
     int batch_outer, batch_inner;
     long long sA[2], sW[2], sO[2], sR[2];
+    const void* pre_bf16; int ldpre;   // EPI_GATED_BWD: the forward's pre-activations, bf16 [M, ldpre]
+    float* colsum_partial;             // EPI_GATED_BWD: fp32 [2 * ceil(M / 256), 2N]
 };
+// may the fc2 dgrad + gated backward of M rows, F = N act columns, run as ONE launch (EPI_GATED_BWD)?
+bool gemm_gated_bwd_fused_ok(int M, int F);
 hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s);
 extern int g_gemm_tile;  // 0 auto | 128 | 256
 extern int g_gemm_flags; // GF_* (gemm_common.h)

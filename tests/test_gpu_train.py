@@ -283,6 +283,41 @@ def test_rope_backward_in_the_attention_epilogue_vs_its_own_pass():
     assert torch.equal(got[0]["blocks.1.attn.in_proj_weight"][2 * d:], got[1]["blocks.1.attn.in_proj_weight"][2 * d:])
 
 
+def test_gated_mlp_backward_in_the_fc2_dgrad_epilogue():
+    """From 144 tiles of 256 x 256 on, the backward of the gated MLP (reference src/components/DiT.py:152-154 differentiated) is
+    the EPILOGUE of the fc2 dgrad GEMM (csrc/gemm_common.h epilogue_gated_bwd: dact stays in the accumulators, [da | dg] and the
+    bias gradients' partial rows leave the kernel) and the training forward's gated GEMM is its own straight-line instantiation
+    (EPI_GATED_PRE); train_flags 6 = the older two launches / general epilogue.  M = 4 x 1000 rows: the last 256-row tile is
+    partial (the guarded epilogue).  (a) every parameter gradient against fp32 autograd of the oracle, rel-L2 <= 3e-2;
+    (b) fused against unfused: the forward bit-identical, the MLP gradients within 2e-3 (same bf16 rounding of dact, the
+    bias sums in another order) — and not all equal (the switch is live)."""
+    from oracle.checks import train_grad_parity
+    shape = {"B": 4, "N": 1000, "T": 192}
+    r = train_grad_parity(DEV, train_mode=True, pin_class=False, shape=shape)
+    assert not r["unexpected"], r["unexpected"]
+    assert r["out_rel_l2"] < 2e-2 and r["worst_rel_l2"] < r["tol"], r
+    cfg = DiTTOConfig(768, 2, 12, 256, 768, 50)
+    x, text, t = (z.to(DEV) for z in synthetic_inputs(cfg, 4, 1000, 192, seed=5))
+    target = hash_normal((4, 1000, 768), "noise", 6).to(DEV)
+    res = {}
+    for flag in (0, 6):
+        hip.set_option("train_flags", flag)
+        try:
+            m = _build(cfg, 12).eval()
+            out = m(x, text, t)
+            F.mse_loss(out, target).backward()
+            res[flag] = (out.detach().clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+        finally:
+            hip.set_option("train_flags", 0)
+    assert torch.equal(res[0][0], res[6][0]), "EPI_GATED_PRE must compute what EPI_GATED computes"
+    differs = 0
+    for n, g in res[0][1].items():
+        assert torch.isfinite(g).all(), n
+        assert rel_l2(g, res[6][1][n]) < 2e-3, (n, rel_l2(g, res[6][1][n]))
+        differs += int(not torch.equal(g, res[6][1][n]))
+    assert differs > 0, "train_flags did not switch the path"
+
+
 def test_large_batch_training_step_takes_the_full_row_forward():
     """From 160 row tiles on (B >= 20 at N = 1024) the training forward runs the cross out-projection + norm3 and fc2 + the
     next block's norm1 on the full-row kernel (csrc/gemm_fr.hip), its LayerNorm outputs landing in the tape slots the
