@@ -67,7 +67,7 @@ DITTO_DEV unsigned long long g256_now() {
 #define G256_ACC(i, a, b)
 #endif
 
-// FLAT is a TEMPLATE parameter on purpose: as a run-time mode its three extra scalars (next tile origin, "a next tile
+// FLAT (the K loop runs on over the tile switch) is a TEMPLATE parameter on purpose: as a run-time mode its three extra scalars (next tile origin, "a next tile
 // exists") cost the default kernel 15 % — the main loop is at the SGPR limit, and the spills (v_writelane / v_readlane) landed
 // inside it: same-box A/B gated GEMM 275 -> 318 us, QKV 127 -> 146 us, step 11.9 -> 12.6 ms, found only against the previous
 // round's library, because an A/B of the FLAG inside the new build compares two equally slowed kernels.
@@ -89,21 +89,47 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     const int srow = lane >> 3;   // row inside a piece
     const int scpos = lane & 7;   // chunk position inside the 128-B row
     int m0 = 0, n0 = 0;           // origin of the tile whose DMA is being issued
-    // FLAT K loop (GF_FLAT_K, even K-tile counts): K-tiles nkt and nkt + 1 of a tile ARE K-tiles 0 and 1 of the workgroup's
+    // FLAT K loop (even K-tile counts; default since round 4, gemm_flags bit 16384 = GF_NO_FLAT_K turns it off): K-tiles nkt and nkt + 1 of a tile ARE K-tiles 0 and 1 of the workgroup's
     // next tile, so the DMA slots of the last iteration (empty otherwise) carry the next tile's first six half-tiles, the
     // matrix pipe covers their issue (a 1-KiB LDS-DMA piece holds its wave for 60-180 cycles, twelve of them per wave sat
     // between main loop and epilogue), and K-tile 0 of the next tile is resident before this tile's epilogue starts.
-    int nm0 = 0, nn0 = 0;         // origin of the workgroup's next tile
-    bool flat_next = false;       // flat mode and a next tile exists (wave-uniform)
+    // Second version (round 4).  The first took the decision "this K-tile index belongs to the next tile" per stage call at run
+    // time — a wave-uniform branch and a fresh address computation in front of every DMA of the hand-scheduled loop (17 % slower,
+    // DESIGN.md section 8b).  Now the per-lane source addresses of K-tile 0 are EXPLICIT values (fsrc, 16 registers), a stage call
+    // is `fsrc + kt * 128` whatever tile it belongs to, and ONE block in the last iteration (after its first two stage calls,
+    // which still belong to this tile) re-points them at the next tile minus nkt K-tiles and raises the K-tile limit by two.
+    [[maybe_unused]] const char* fsrc[4][2];
+    [[maybe_unused]] int klim = nkt;   // FLAT: K-tile indices below this are staged
+    [[maybe_unused]] auto set_bases = [&](int om, int on, int kshift) {
+#pragma unroll
+        for (int half = 0; half < 4; ++half)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = (wid * 2 + i) * 8 + srow;
+                const int c = scpos ^ ((row >> 1) & 7);
+                if (half < 2) {
+                    int gr = om + half * 128 + row;
+                    gr = gr < p.M ? gr : p.M - 1;
+                    fsrc[half][i] = (const char*)p.A + (size_t)gr * p.lda * ESZ + c * 16 - (long)kshift * 128;
+                } else {
+                    int gr = on + (half - 2) * 128 + row;
+                    gr = gr < p.w_rows ? gr : p.w_rows - 1;
+                    fsrc[half][i] = (const char*)p.W + (size_t)gr * p.ldw * ESZ + c * 16 - (long)kshift * 128;
+                }
+            }
+    };
     unsigned bias_slot = 0;       // which of the two 1 KiB bias rows (after the K-tile buffers) the last prologue filled
     auto stage = [&](int buf, auto HALF, int kt) {
         constexpr int half = decltype(HALF)::value;
-        int om = m0, on = n0;
-        if (kt >= nkt) {          // wave-uniform; the waits below account for it
-            if constexpr (!FLAT) return;
-            if (!flat_next) return;
-            kt -= nkt; om = nm0; on = nn0;
+        if constexpr (FLAT) {
+            if (kt >= klim) return;   // wave-uniform; the waits below account for it
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                glds16(fsrc[half][i] + (long)kt * 128, lds_base + (unsigned)(buf * KT_BYTES + half * HALF_BYTES + (wid * 2 + i) * 1024));
+            return;
         }
+        int om = m0, on = n0;
+        if (kt >= nkt) return;    // wave-uniform; the waits below account for it
 #ifdef DITTO_DIAG_NODMA
         if (kt > 0) return;       // timing experiment: the main loop without its global->LDS traffic (WRONG results)
 #endif
@@ -167,6 +193,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         tile_to_mn(xcd_remap(tile, ntiles), p.tiles_m, p.tiles_n, p.group_n, tm, tn);
         m0 = tm * 256;
         n0 = tn * 256;
+        if constexpr (FLAT) set_bases(m0, n0, 0);
         stage_bias(n0);
         stage(0, IC<2>{}, 0);
         stage(0, IC<3>{}, 0);
@@ -293,7 +320,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
     }
 
-    constexpr bool flat = FLAT;   // the launcher picks the instantiation (GF_FLAT_K, even K-tile count)
+    constexpr bool flat = FLAT;   // the launcher picks the instantiation (even K-tile count, not GF_NO_FLAT_K)
     bool first_tile = true;
 #ifdef DITTO_DIAG_G256_STAMP
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 1, 0, 0}, lb_acc = 0;
@@ -305,13 +332,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 #endif
         const int cur_m0 = m0, cur_n0 = n0;
         const int next = tile + p.tile_stride;
+        // flat: the next tile's origin, computed here (integer divisions) and parked in two VECTOR registers until the last
+        // iteration — the main loop is at the scalar-register limit
+        [[maybe_unused]] int nm0v = 0, nn0v = 0;
         if constexpr (flat) {
-            flat_next = next < ntiles;
-            if (flat_next) {
+            if (next < ntiles) {
                 int tm, tn;
                 tile_to_mn(xcd_remap(next, ntiles), p.tiles_m, p.tiles_n, p.group_n, tm, tn);
-                nm0 = tm * 256;
-                nn0 = tn * 256;
+                asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(nm0v), "=v"(nn0v) : "s"(tm * 256), "s"(tn * 256));
             }
         }
 #pragma unroll
@@ -350,6 +378,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
                 read_A(0, IC<0>{});
                 stage(1, IC<0>{}, to);
                 stage(1, IC<1>{}, to);
+                if constexpr (FLAT) {
+                    if (it == niter - 1 && next < ntiles) {   // wave-uniform, once per tile: from here on the stage calls feed the NEXT tile
+                        m0 = __builtin_amdgcn_readfirstlane(nm0v);
+                        n0 = __builtin_amdgcn_readfirstlane(nn0v);
+                        set_bases(m0, n0, nkt);
+                        klim = nkt + 2;
+                    }
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 DITTO_BAR();
                 mma(IC<0>{}, IC<0>{});
@@ -359,7 +395,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
                 read_A(0, IC<1>{});
                 stage(0, IC<2>{}, te + 2);
                 stage(0, IC<3>{}, te + 2);
-                wait_dma(te + 2 < nkt || (FLAT && flat_next));
+                wait_dma(te + 2 < (FLAT ? klim : nkt));
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 DITTO_BAR();
                 mma(IC<1>{}, IC<1>{});
@@ -382,7 +418,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
                 read_A(1, IC<1>{});
                 stage(1, IC<2>{}, to + 2);
                 stage(1, IC<3>{}, to + 2);
-                wait_dma(to + 2 < nkt || (FLAT && flat_next));
+                wait_dma(to + 2 < (FLAT ? klim : nkt));
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 DITTO_BAR();
                 if (odd_valid) {
@@ -460,7 +496,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
                               (!FP8 || p.wscale);
         const unsigned cur_bias_slot = bias_slot;
         if constexpr (flat) {
-            if (flat_next) { stage_bias(nn0); m0 = nm0; n0 = nn0; }
+            if (next < ntiles) {   // m0 / n0 are the next tile's since the last iteration; its K-tiles 0 and 1 (B halves) are in
+                stage_bias(n0);
+#pragma unroll
+                for (int half = 0; half < 4; ++half)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) fsrc[half][i] += (long)nkt * 128;
+                klim = nkt;
+            }
         } else if (next < ntiles) {
             prologue(next);
         }
@@ -568,7 +611,9 @@ template <int EPI>
 hipError_t launch256_t(const GemmParams& p, hipStream_t s) {
     if (!(p.flags & GF_WIDE_PHASE)) return launch256_tw<EPI, false, false>(p, s);
     const int nkt = p.K / 64;
-    if ((p.flags & GF_FLAT_K) && nkt >= 2 && (nkt & 1) == 0) return launch256_tw<EPI, true, false, true>(p, s);   // opt-in experiment
+    // flat K loop wherever the K-tile count is even (C2: gated 252.9 -> 248.7 us, QKV 117.5 -> 115.7, step -0.06 .. -0.10 ms at
+    // B = 32, -0.02 / -0.05 ms at B = 8 / 16; training step 49.7 -> 48.9 ms: profiles/r04_step_ab_flat2*.txt, r04_train_flat2_ab.txt)
+    if (!(p.flags & GF_NO_FLAT_K) && nkt >= 2 && (nkt & 1) == 0) return launch256_tw<EPI, true, false, true>(p, s);
     return launch256_tw<EPI, true, false>(p, s);
 }
 

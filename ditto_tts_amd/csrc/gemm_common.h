@@ -49,7 +49,7 @@ enum { GF_RELAXED_WAIT = 1,        // tile-start wait skips over the previous ti
        GF_TN_TWO_BUFFER = 2048,    // gemm_tn.hip A/B: the first (two-buffer) weight-gradient kernel
        GF_TN_NARROW = 4096,        // ditto_train.hip A/B: weight gradients on the 128 x 128 kernel only (no 256 x 256 tiles)
        GF_PP_PARITY = 8192,
-       GF_FLAT_K = 16384 };        // gemm256 wide-phase: the K loop runs flat over the tile switch (the next tile's first half-tiles ride the last iteration's empty DMA slots)      // gemm_pp with pp_stagger > 0: the late-starting workgroups are the odd blockIdx (default: second LDS allocation of the CU)
+       GF_NO_FLAT_K = 16384 };     // gemm256 wide-phase A/B: the round-3 tile switch (prologue DMA between the K loop and the epilogue) instead of the flat K loop
 
 // Tile order.  An XCD (private 4 MiB L2) receives a contiguous range of the linear tile index (xcd_remap); within it
 // the tiles run down M inside a SUPER-COLUMN of `G` column tiles, so the tiles an XCD works on at one time are a

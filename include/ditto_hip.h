@@ -294,7 +294,8 @@ int ditto_gemm_tn_bf16(const void* X, int ldx, const void* Y, int ldy, float* ou
  * "pp_stagger": phase offset between the two workgroups of a CU in the ping-pong GEMM, 10 ns ticks (-1 = built-in rule).
  * "gemm_flags": bit mask for kernel experiments (bit 0 = relaxed tile-start wait, default on; bits 1, 2 are
  * DIAGNOSTIC timing switches that skip stores / the epilogue and produce WRONG results — tools/ only; bit 14 = 16384: the
- * persistent 256x256 kernel runs its K loop flat over the tile switch, bit-identical results).
+ * persistent 256x256 kernel takes the round-3 tile switch instead of running its K loop flat over it — A/B, bit-identical
+ * results either way).
  * "gemm_group": forced super-column width of the GEMM tile order (A/B tool; 0 = the built-in rule, which a sweep of
  * 3 / 4 / 6 / 12 / 24 at C2 B = 32 did not beat).
  * "residual_bf16": 1 = the residual stream h between the segments of a block lives in HBM as bf16 (fp32 only inside the

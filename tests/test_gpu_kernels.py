@@ -137,8 +137,8 @@ def test_every_epilogue_on_every_structure(lib, tile, flags):
 
 @pytest.mark.parametrize("shape", [(4096, 6144, 768), (5000, 2304, 768), (8192, 768, 3072), (4096, 2304, 192)])
 def test_flat_k_loop_across_the_tile_switch_is_bitwise(lib, shape):
-    """gemm256 with GF_FLAT_K (16384): the next tile's first six half-tiles ride the empty DMA slots of the last K
-    iteration, no prologue between main loop and epilogue.  More tiles than CUs (384 / 180 / 96 / 144 tiles; the second and
+    """gemm256's flat K loop (default for even K-tile counts; gemm_flags bit 16384 = the round-3 tile switch): the next tile's first
+    six half-tiles ride the empty DMA slots of the last K iteration, no prologue between main loop and epilogue.  More tiles than CUs (384 / 180 / 96 / 144 tiles; the second and
     fourth shapes have ragged last row tiles, the fourth an ODD K-tile count that must fall back), every C-ABI epilogue:
     the arithmetic is unchanged, so the outputs must equal the default build's BIT FOR BIT."""
     M, N, K = shape
