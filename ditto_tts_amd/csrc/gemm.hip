@@ -32,7 +32,7 @@ namespace ditto {
 // GF_STAGGER_START (8) is no longer on by default: after the gated epilogue got shorter the staggered start costs more
 // than the store bursts it spreads — same-process A/B at C2 B = 32 (tools/step_ab.py, 8 rounds x 25 steps): gated GEMM
 // 291.7 -> 279.1 us per launch, step 13.06 -> 12.99 ms.
-int g_gemm_flags = GF_RELAXED_WAIT | GF_STORE_NT | GF_WIDE_PHASE;
+int g_gemm_flags = [] { const char* e = getenv("DITTO_GEMM_FLAGS"); return e ? atoi(e) : (GF_RELAXED_WAIT | GF_STORE_NT | GF_WIDE_PHASE); }();   // 321; the variable: A/B runs of whole programs (bench.py)
 int g_gemm_group = 0;
 int g_pp_stagger = -1;
 int g_pp_nb = 0;

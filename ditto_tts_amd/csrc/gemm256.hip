@@ -675,6 +675,18 @@ hipError_t launch_gemm256_fp8(const GemmParams& p_in, GemmEpilogue epi, hipStrea
     p.flags = g_gemm_flags;
     p.group_n = pick_group_n(p.tiles_n, p.flags);
     p.stagger_ticks = (int)((p.K / 128 * 1.5 + 8.0) * 100.0 / 4.0);
+    const int nkt = p.K / 128;
+    if (!(p.flags & GF_NO_FLAT_K) && nkt >= 2 && (nkt & 1) == 0) {   // flat K loop, as the bf16 launcher
+        switch (epi) {
+            case EPI_BIAS_BF16: return launch256_tw<EPI_BIAS_BF16, true, true, true>(p, s);
+            case EPI_BIAS_RES_F32: return launch256_tw<EPI_BIAS_RES_F32, true, true, true>(p, s);
+            case EPI_QKV_ROPE: return launch256_tw<EPI_QKV_ROPE, true, true, true>(p, s);
+            case EPI_BIAS_F32: return launch256_tw<EPI_BIAS_F32, true, true, true>(p, s);
+            case EPI_GATED_FP8: return launch256_tw<EPI_GATED_FP8, true, true, true>(p, s);
+            default: break;
+        }
+        return hipErrorInvalidValue;
+    }
     switch (epi) {
         case EPI_BIAS_BF16: return launch256_tw<EPI_BIAS_BF16, true, true>(p, s);
         case EPI_BIAS_RES_F32: return launch256_tw<EPI_BIAS_RES_F32, true, true>(p, s);

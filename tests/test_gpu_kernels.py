@@ -425,6 +425,35 @@ def test_fp8_gemm(lib, M, N, K, epi):
         assert max_abs(out, want) < 1e-3
 
 
+@pytest.mark.parametrize("shape", [(8192, 2304, 1024), (9000, 3072, 768)])
+def test_fp8_flat_k_loop_across_the_tile_switch_is_bitwise(lib, shape):
+    """The fp8 instantiations of gemm256 take the flat K loop as well (even K-tile counts of 128 bytes).  More tiles than CUs
+    (288 / 432, the second with a ragged last row tile): gemm_flags bit 16384 (the round-3 tile switch) gives the same bits, and
+    the fp32-output epilogue agrees with the dequantised fp32 product."""
+    M, N, K = shape
+    a32 = asym((M, K), 41).to(DEV)
+    w32 = (asym((N, K), 42) / math.sqrt(K)).to(DEV)
+    Aq = a32.to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
+    Wq, ws = _quant(lib, w32)
+    bias = (0.1 * asym((N,), 43)).to(DEV)
+    res = asym((M, N), 44).to(DEV)
+    try:
+        for epi in (0, 1, 4):
+            outs = []
+            for fl in (321, 321 + 16384):
+                hip.check(lib.ditto_set_option(b"gemm_flags", fl))
+                out = res.clone() if epi == 1 else torch.zeros(M, N, device=DEV, dtype=torch.bfloat16 if epi == 0 else torch.float32)
+                hip.check(lib.ditto_gemm_fp8(Aq.data_ptr(), K, Wq.data_ptr(), ws.data_ptr(), bias.data_ptr(),
+                                             out.data_ptr() if epi == 1 else None, out.data_ptr(), N, M, N, K, epi, stream()))
+                torch.cuda.synchronize()
+                outs.append(out)
+            assert torch.equal(outs[0], outs[1]), (shape, epi, float((outs[0].float() - outs[1].float()).abs().max()))
+            if epi == 4:
+                assert rel_l2(outs[0], _deq(Aq) @ _deq(Wq, ws).T + bias) < 5e-5
+    finally:
+        hip.check(lib.ditto_set_option(b"gemm_flags", 321))
+
+
 def test_fp8_gemm_gated(lib):
     """fp8 gated-MLP epilogue: interleaved fc1|gate rows, fp8 output."""
     M, d = 300, 256
