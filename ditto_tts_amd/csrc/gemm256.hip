@@ -360,6 +360,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         }   // flat, later tiles: K-tile 0 landed behind the counted wait of the previous tile's last phase; its B halves of K-tile
             // 1 (the newest four loads before the epilogue's stores) are covered by the first iteration's own counted wait
         first_tile = false;
+#ifdef DITTO_DIAG_G256_STAMP
+        {   // slot 7: tile top -> this wave AT the tile's first barrier (accumulators zeroed, waits done)
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) asm volatile("" : "+v"(acc[m][n]));
+            const unsigned long long t_b0 = g256_now();
+            st_acc[7] += t_b0 - t_top;
+        }
+#endif
+        // (Tried in round 4, flat loop: the stagger set up once per workgroup and kept over the tile switches — group 0's top barrier
+        // paired with group 1's last loop barrier, no balance barrier — so that group 0 need not wait for group 1's epilogue.  The
+        // wait only moved to group 0's first loop barrier: gated 273.7 -> 276.3 us, QKV 125.9 -> 132.0 in the model
+        // (profiles/r04_step_ab_flat_skew.txt).  The switch costs what the two epilogues of a SIMD's wave pair cost back to back
+        // — 5 300 + 4 600 ticks in the stamps — however the barriers around them are arranged.)
         DITTO_BAR();
         if (wm == 1) DITTO_BAR();  // stagger the second wave group by one barrier
         G256_STAMP(t_loop);
@@ -538,7 +553,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         G256_STAMP(t_bias);
 #ifdef DITTO_DIAG_G256_STAMP
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        { const unsigned long long t_b2 = g256_now(); st_acc[7] += t_b2 - t_epi; (void)t_bias; }
+        (void)t_bias;
 #endif
         if constexpr (FP8) {   // per-output-column weight scale of the fp8 quantisation
             f32x4 ws4[4];
@@ -558,6 +573,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         if (fast_epi) {
             // interior tile, production flags: straight-line epilogue, the 8 row blocks in one basic block
             const int cb = cur_n0 + wn * 64, r0 = cur_m0 + wm * 128 + frow;
+            // (The two waves of a SIMD run their epilogues at the same time and the arbiter serves the OLDER one first — the stamps
+            // have wave group 0 through in 5 300 ticks and group 1 in 9 900.  s_setprio swapped between the groups halfway through
+            // the row blocks changes nothing: gated GEMM 266.0 vs 266.0 us in the model, profiles/r04_step_ab_epi_prio.txt.)
             if constexpr (EPI == EPI_QKV_ROPE) {
                 if (cb >= p.rope_cols) {   // a v head: bias only (wave-uniform)
 #pragma unroll
@@ -623,9 +641,9 @@ hipError_t launch256_t(const GemmParams& p, hipStream_t s) {
 extern "C" int ditto_diag_g256_stamps(unsigned long long* out) {   // sums of the per-wave records of the LAST launch (diagnostic build only)
     static unsigned long long host[G256_STAMP_WAVES * 8];
     if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_g256_stamps), sizeof(host)) != hipSuccess) return 1;
-    for (int i = 0; i < 8; ++i) out[i] = 0;
+    for (int i = 0; i < 16; ++i) out[i] = 0;   // [0, 8): waves 0-3 of every workgroup (wm = 0), [8, 16): waves 4-7 (wm = 1, one barrier behind)
     for (int w = 0; w < G256_STAMP_WAVES; ++w)
-        for (int i = 0; i < 8; ++i) out[i] += host[(size_t)w * 8 + i];
+        for (int i = 0; i < 8; ++i) out[((w & 7) >> 2) * 8 + i] += host[(size_t)w * 8 + i];
     for (size_t i = 0; i < sizeof(host) / sizeof(host[0]); ++i) host[i] = 0;
     return hipMemcpyToSymbol(HIP_SYMBOL(g_g256_stamps), host, sizeof(host)) != hipSuccess;
 }

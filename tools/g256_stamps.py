@@ -20,18 +20,20 @@ for name in a.shapes.split(","):
     W = (torch.randn(N, K, device="cuda") / math.sqrt(K)).to(torch.bfloat16)
     bias = torch.randn(N, device="cuda") * 0.1
     out = torch.empty(M, N // 2 if epi == 3 else N, device="cuda", dtype=torch.bfloat16)
-    buf = (C.c_ulonglong * 8)()
+    buf = (C.c_ulonglong * 16)()
     for rep in range(3):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         hip.check(lib.ditto_gemm_bf16(A.data_ptr(), K, W.data_ptr(), bias.data_ptr(), None, out.data_ptr(), out.shape[1], M, N, K, epi, st))
         e1.record(); torch.cuda.synchronize()
         assert raw.ditto_diag_g256_stamps(buf) == 0
-        s = list(buf); tiles, waves = max(s[4], 1), max(s[5], 1)
-    print(f"{name}: N={N} epi={epi} flags={a.flags}: {e0.elapsed_time(e1) * 1e3:.1f} us, {tiles / waves:.1f} tiles per wave; per wave and tile (s_memtime ticks):")
-    for n, x in zip(("start wait + barriers", "main loop", "end barrier + prologue issue", "epilogue body (to its last store issued)",
-                     "  of which: bias row read from LDS", "loop back to the next tile's top"), (s[0], s[1], s[2], s[3], s[7], s[6])):
-        print(f"    {n:44s} {x / tiles:9.1f}")
-    tot = s[0] + s[1] + s[2] + s[3] + s[6]
-    print(f"    {'sum':44s} {tot / tiles:9.1f}   (kernel / tiles-per-wave = {e0.elapsed_time(e1) * 1e3 / (tiles / waves):.2f} us)")
+        both = list(buf)
+    for grp in (0, 1):   # waves 0-3 (wm = 0) | waves 4-7 (wm = 1: one barrier behind in the loop)
+        s = both[grp * 8:grp * 8 + 8]; tiles, waves = max(s[4], 1), max(s[5], 1)
+        print(f"{name}: N={N} epi={epi} flags={a.flags}, wave group {grp}: {e0.elapsed_time(e1) * 1e3:.1f} us, {tiles / waves:.1f} tiles per wave; per wave and tile (s_memtime ticks):")
+        for n, x in zip(("start: tile top -> main loop", "  of which: top -> AT the first barrier (zeroing, waits)", "main loop", "end barrier (+ prologue issue)",
+                         "epilogue body (to its last store issued)", "loop back to the next tile's top"), (s[0], s[7], s[1], s[2], s[3], s[6])):
+            print(f"    {n:58s} {x / tiles:9.1f}")
+        tot = s[0] + s[1] + s[2] + s[3] + s[6]
+        print(f"    {'sum':58s} {tot / tiles:9.1f}   (kernel / tiles-per-wave = {e0.elapsed_time(e1) * 1e3 / (tiles / waves):.2f} us)")
 hip.check(lib.ditto_set_option(b"gemm_tile", 0)); hip.check(lib.ditto_set_option(b"gemm_flags", 321))
