@@ -285,7 +285,10 @@ int ditto_gemm_tn_bf16(const void* X, int ldx, const void* Y, int ldy, float* ou
  * path's model forward uses for norm3.
  * "fr_dgrad": training backward, the long-K dgrads (N = d = 768) on the same kernel: bit 0 = fc1|gate (K = 8d), bit 1 = QKV.
  * "train_flags": training-step A/B switches: bit 0 = the backward of the self-attention rotation (RoPE) as its own pass over
- * dq | dk instead of inside the attention backward's dq / dk epilogues (head_dim 64; other head dims always take the pass).
+ * dq | dk instead of inside the attention backward's dq / dk epilogues (head_dim 64; other head dims always take the pass);
+ * bit 1 = the fc2 dgrad GEMM and the gated MLP's derivative as two launches instead of one (the derivative as the GEMM's
+ * epilogue, from 144 tiles of 256 x 256 on); bit 2 = the training forward's gated GEMM on the general epilogue instead of its
+ * own straight-line instantiation.
  * "fr_rot": that kernel's K-loop rotation (tiles start their k sum at different places so that the workgroups of an XCD do
  * not all ask the L2 for the same weight lines at once): 0 = off, 1 = on in the model path with period = row tiles per
  * utterance (an utterance's bits do not depend on its place in the batch), > 1 = ditto_gemm_ln_bf16 rotates too, with that
