@@ -424,15 +424,22 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
     // tile reads each dY row once (the 256 x 192 kernel re-reads the dY panel per column tile); WtP = Wt stage-major.
     // Option "fr_dgrad": bit 0 = the fc1|gate dgrad (K = 8d), bit 1 = the QKV dgrad (K = 3d).
     const bool fr_dgrad = lt0_has_fr && fr_pays(M) && gemm_fr_supports(M, d, 8 * d, (size_t)8 * d, (size_t)8 * d);
+    // du — the gradient wrt a LayerNorm's output, written by a dgrad GEMM and read once by the LayerNorm backward — travels as
+    // BF16 (train_flags 8: fp32, A/B): half the bytes on both sides; dh, the stream gradient it is folded into, stays fp32.
+    const bool du_bf16 = !(g_train_flags & 8);
+    bool du_is_bf16 = false;   // what the LAST producer of du wrote (the 64-row full-row kernel has no bf16 output)
     auto dgrad_fr = [&](const void* dY, int n_out, const void* WtP, float* out) -> int {
         GemmParams gp{};
         gp.A = (const bf16*)dY; gp.lda = n_out; gp.W = (const bf16*)WtP; gp.ldw = n_out; gp.w_rows = d;
         gp.out = out; gp.ldo = d; gp.M = M; gp.N = d; gp.K = n_out;
-        HIP_TRY(launch_gemm_fr(gp, nullptr, nullptr, nullptr, d, N % 128 == 0 ? N / 128 : 0, s));
+        // bf16 output exists on gemm_frd.hip (kernels.h fr_launch_kernel == 130: every row count the full-row dgrads run at)
+        const bool hb = du_bf16 && fr_launch_kernel(M, n_out) == 130;
+        HIP_TRY(launch_gemm_fr(gp, nullptr, nullptr, nullptr, d, N % 128 == 0 ? N / 128 : 0, s, false, hb));
+        du_is_bf16 = hb;
         return DITTO_OK;
     };
     auto ln_back = [&](const float* xin, const float* gamma, float* gw, float* gb, float* next_bias) -> int {
-        HIP_TRY(launch_ln_bwd_stream(du, xin, gamma, dh, dyb, gw, gb, next_bias, red, M, d, s));
+        HIP_TRY(launch_ln_bwd_stream(du, du_is_bf16, xin, gamma, dh, dyb, gw, gb, next_bias, red, M, d, s));
         return DITTO_OK;
     };
 #define TRY_RC(expr) do { if (int _rc = (expr)) return _rc; } while (0)
@@ -476,7 +483,7 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
         HIP_TRY(launch_unpack_rows(wtmp, G.mlp_fc1_weight, 4 * d, d, 16, 2, 0, s));
         HIP_TRY(launch_unpack_rows(wtmp, G.gate_weight, 4 * d, d, 16, 2, 16, s));
         if (fr_dgrad && (g_fr_dgrad & 1)) TRY_RC(dgrad_fr(big1, 8 * d, lt.W1gTP, du));
-        else TRY_RC(dgrad(big1, 8 * d, lt.W1gT, d, du, true));
+        else { TRY_RC(dgrad(big1, 8 * d, lt.W1gT, d, du, !du_bf16)); du_is_bf16 = du_bf16; }
         TRY_RC(ln_back(h2, lp.g3, G.norm3_weight, G.norm3_bias, G.cross_out_proj_bias));
 
         // ---- cross-attention: h2 = h1 + oc Wo^T + bo,  oc = attn(qc, Kc, Vc),  qc = u2 Wq^T + bq ----
@@ -496,7 +503,8 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
         HIP_TRY(launch_colsum_bf16(dkv, 2 * d, Mt, 2 * d, G.cross_in_proj_bias + d, red, s));
         TRY_RC(wgrad(big1, d, d, tb + q.u2, d, d, M, G.cross_in_proj_weight));
         TRY_RC(wgrad(dkv, 2 * d, 2 * d, tb + tp.text, c.text_dim, d, Mt, G.cross_in_proj_weight + (size_t)d * d));
-        TRY_RC(dgrad(big1, d, lt.WcqT, d, du, true));
+        TRY_RC(dgrad(big1, d, lt.WcqT, d, du, !du_bf16));
+        du_is_bf16 = du_bf16;
         TRY_RC(ln_back(h1, lp.g2, G.norm2_weight, G.norm2_bias, nullptr));
 
         // ---- self-attention: h1 = h0 + attn(rope(q), rope(k), v), NO out-proj (src/components/DiT.py:134-139) ----
@@ -519,7 +527,7 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
         HIP_TRY(launch_colsum_bf16(big1, 3 * d, M, 3 * d, G.attn_in_proj_bias, red, s));
         TRY_RC(wgrad(big1, 3 * d, 3 * d, tb + q.u1, d, d, M, G.attn_in_proj_weight));
         if (fr_dgrad && (g_fr_dgrad & 2)) TRY_RC(dgrad_fr(big1, 3 * d, lt.WqkvTP, du));
-        else TRY_RC(dgrad(big1, 3 * d, lt.WqkvT, d, du, true));
+        else { TRY_RC(dgrad(big1, 3 * d, lt.WqkvT, d, du, !du_bf16)); du_is_bf16 = du_bf16; }
         TRY_RC(ln_back(h0, lp.g1, G.norm1_weight, G.norm1_bias, l > 0 ? grads->layers[l - 1].mlp_fc2_bias : nullptr));
     }
 

@@ -523,8 +523,10 @@ hipError_t launch_gemm_frd(const FrParams& fp_in, hipStream_t s) {
     fp.g.tiles_m = (fp.g.M + DM - 1) / DM;
     fp.g.tiles_n = 1;
     const bool ln = fp.gamma && fp.u, res = fp.g.residual != nullptr;
-    if (fp.hb) {   // bf16 residual stream (the model path's two launches: always with a residual)
-        if (!res || fp.g.out2) return hipErrorInvalidValue;
+    if (fp.hb) {   // bf16 residual stream (the model path's two launches: always with a residual), or — no residual, no LayerNorm —
+                   // a plain product with a bf16 result (the training backward's long-K dgrads)
+        if (fp.g.out2 || (!res && ln)) return hipErrorInvalidValue;
+        if (!res) return launch_frd_t<false, false, true>(fp, fp.g.tiles_m, s);
         return ln ? launch_frd_t<true, true, true>(fp, fp.g.tiles_m, s) : launch_frd_t<false, true, true>(fp, fp.g.tiles_m, s);
     }
     if (ln) return res ? launch_frd_t<true, true>(fp, fp.g.tiles_m, s) : launch_frd_t<true, false>(fp, fp.g.tiles_m, s);

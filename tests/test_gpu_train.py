@@ -318,6 +318,39 @@ def test_gated_mlp_backward_in_the_fc2_dgrad_epilogue():
     assert differs > 0, "train_flags did not switch the path"
 
 
+@pytest.mark.parametrize("pin", [False, True])
+def test_layernorm_input_gradient_travels_as_bf16(pin):
+    """du — the gradient wrt a LayerNorm's output, written by a dgrad GEMM and read once by the LayerNorm backward — is bf16 in
+    HBM (train_flags 8 = fp32, the round-3 form); the stream gradient dh it is folded into stays fp32.  Both forms against each
+    other: every parameter gradient within 4e-3 (one more bf16 rounding per segment), and not all equal.  pin = the kernel class
+    of the timed step (32 x 1024 rows): the long-K dgrads then run on the full-row kernel, whose bf16-output instantiation
+    without residual exists for this; unpinned: the tiled dgrad GEMMs' bf16 epilogue.  (Both forms against the oracle:
+    test_parameter_gradients_at_the_timed_dimensions_vs_oracle_autograd runs the default; 3e-2.)"""
+    cfg = DiTTOConfig(768, 2, 12, 256, 768, 50)
+    B, N, T = 2, 256, 192
+    x, text, t = (z.to(DEV) for z in synthetic_inputs(cfg, B, N, T, seed=15))
+    target = hash_normal((B, N, 768), "noise", 16).to(DEV)
+    res = {}
+    if pin:
+        hip.set_option("fr_class_rows", 32 * 1024)
+    try:
+        for flag in (0, 8):
+            hip.set_option("train_flags", flag)
+            m = _build(cfg, 13).eval()
+            F.mse_loss(m(x, text, t), target).backward()
+            res[flag] = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    finally:
+        hip.set_option("train_flags", 0)
+        if pin:
+            hip.set_option("fr_class_rows", 0)
+    differs = 0
+    for n, g in res[0].items():
+        assert torch.isfinite(g).all(), n
+        assert rel_l2(g, res[8][n]) < 4e-3, (n, rel_l2(g, res[8][n]))
+        differs += int(not torch.equal(g, res[8][n]))
+    assert differs > 10, "train_flags 8 did not switch the path"
+
+
 def test_large_batch_training_step_takes_the_full_row_forward():
     """From 160 row tiles on (B >= 20 at N = 1024) the training forward runs the cross out-projection + norm3 and fc2 + the
     next block's norm1 on the full-row kernel (csrc/gemm_fr.hip), its LayerNorm outputs landing in the tape slots the

@@ -182,7 +182,7 @@ def test_frd_register_ring_is_never_copied_while_loads_are_in_flight():
     """gemm_frd's W fragments are loaded by asm `global_load_dwordx4` statements into a register ring that hipcc believes is
     written synchronously; the kernel's own counted waits make that true before each use.  What would break it silently is a
     compiler-inserted COPY (v_mov / v_accvgpr_write) or a spill of a ring register between a load's issue and its wait.  This
-    test compiles the file to ISA (device pass only, a few seconds) and checks, for all six instantiations, that from the
+    test compiles the file to ISA (device pass only, a few seconds) and checks, for all seven instantiations, that from the
     first to the last MFMA no instruction reads a ring register except MFMAs and no scratch access exists at all."""
     src = os.path.join(CSRC, "gemm_frd.hip")
     inc = os.path.join(HERE, "..", "include")
@@ -192,7 +192,8 @@ def test_frd_register_ring_is_never_copied_while_loads_are_in_flight():
                         "--cuda-device-only", "-S", src, "-o", out], check=True, capture_output=True)
         text = open(out).read()
     parts = re.split(r"\n(_ZN5ditto12_GLOBAL__N_115gemm_frd_kernel\w+): ; @", text)
-    assert len(parts) == 13, "six instantiations expected (<LN, RES> on the fp32 stream, <LN, true> on the bf16 stream)"
+    assert len(parts) == 15, ("seven instantiations expected (<LN, RES> on the fp32 stream, <LN, true> on the bf16 stream, and the "
+                              "plain product with a bf16 result of the training backward)")
     for i in range(1, len(parts), 2):
         body = parts[i + 1].split("s_endpgm")[0].split("\n")
         loads = [(n, re.match(r"\s*global_load_dwordx4 v\[(\d+):(\d+)\], v\d+, s\[", ln)) for n, ln in enumerate(body)]
