@@ -711,8 +711,8 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     if (a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Skv <= 0) return hipErrorInvalidValue;
     const float LOG2E = 1.4426950408889634f;
     if (a.causal && a.dropout_p > 0.f) return hipErrorInvalidValue;   // no caller: the decoder stack runs in eval mode
-    if (a.resid_bf16 && (a.dh != DH || a.force_generic || a.causal || a.lse_out || a.dropout_p > 0.f))
-        return hipErrorInvalidValue;                                   // the bf16 stream exists on the fused inference kernels only
+    if (a.resid_bf16 && (a.dh != DH || a.force_generic || a.causal || (g_attn_flags & 8192)))
+        return hipErrorInvalidValue;                                   // the bf16 stream exists on the fused head_dim-64 kernels only
     if (a.dh == DH && !a.force_generic && !a.causal) {
         if ((a.ldq | a.ldk | a.ldv) % 8) return hipErrorInvalidValue;
         AttnParams p;

@@ -250,6 +250,14 @@ __global__ __launch_bounds__(256, WPS) void attn64v2_kernel(AttnParams p) {
             for (int e = 0; e < 4; ++e) o[e] = ot[db][4 * g + e] * inv;
             if constexpr (RESID) {
                 attn_resid_update(p, grow, col, o);
+                if constexpr (TRAIN) {   // training on the bf16 stream: O itself for the backward (h_after - h_before of two bf16 rows is not O)
+                    if (p.out) {
+                        u32x2 st2;
+                        st2[0] = pack_bf16x2(o[0], o[1]);
+                        st2[1] = pack_bf16x2(o[2], o[3]);
+                        *reinterpret_cast<u32x2*>(p.out + grow * p.ldo + col) = st2;
+                    }
+                }
             } else {
                 u32x2 st2;
                 st2[0] = pack_bf16x2(o[0], o[1]);

@@ -1106,7 +1106,7 @@ int ditto_set_option(const char* name, int value) {
         return DITTO_OK;
     }
     if (!strcmp(name, "train_flags")) {
-        if (value < 0 || value > 15) return fail(DITTO_ERR_ARG, "train_flags must be in [0, 15]");
+        if (value < 0 || value > 31) return fail(DITTO_ERR_ARG, "train_flags must be in [0, 31]");
         g_train_flags = value;
         return DITTO_OK;
     }

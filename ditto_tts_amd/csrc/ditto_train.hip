@@ -220,6 +220,20 @@ int ditto_train_attach(ditto_model_t m, const ditto_weights* w, void* train_aren
     return DITTO_OK;
 }
 
+// The training step on the BF16 residual stream (round 4): the tape keeps h as bf16 rows — written by the AdaLN kernel, updated by
+// the self-attention epilogue, read and written by the two full-row launches, read by the LayerNorms and by the LayerNorm
+// backward — and the self-attention's output O as bf16 beside h1 (second half of its fp32-sized slot: the backward's
+// delta = rowsum(dO . O) needs O, and the difference of two bf16 rows is not it).  Exactly where the inference forward has the
+// stream (ditto_api.hip hb_class): d = 768, head_dim 64, both fused launches on gemm_frd.hip; and with du travelling as bf16.
+// One predicate for the forward and the backward of a step: the options it reads must not change between the two calls.
+static bool train_stream_bf16(ditto_model_t m, int M) {
+    const ditto_config& c = m->cfg;
+    const int d = c.hidden_dim;
+    if ((g_train_flags & (8 | 16)) || (g_attn_flags & 8192) || d != 768 || d / c.num_heads != 64) return false;
+    if (!m->layers[0].WcoP || !m->layers[0].W2P || (g_fr_mask & 3) != 3) return false;
+    return fr_outproj_ok(M, d) && fr_fc2_ok(M, d) && fr_launch_kernel(M, d) == 130 && fr_launch_kernel(M, 4 * d) == 130;
+}
+
 int ditto_train_forward(ditto_model_t m, const float* x, const float* text, const int64_t* t, int B, int N, int T,
                         const float* rope_cos, const float* rope_sin, float dropout_p, uint64_t seed, float* eps_out,
                         void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes, ditto_stream_t stream) {
@@ -257,7 +271,12 @@ int ditto_train_forward(ditto_model_t m, const float* x, const float* text, cons
         HIP_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
     }
     HIP_TRY(launch_text_mod(text, m->wx, m->bx, pooled, tmod, B, T, c.text_dim, d, s));
-    HIP_TRY(launch_adaln(x, m->ttab, tmod, t, c.diffusion_steps, hs(0), xcat, 2 * d, B, N, d, s));
+    const bool hb = train_stream_bf16(m, M);
+    if (hb)   // bf16 h0 + block 0's norm1 from the same kernel, as the inference forward
+        HIP_TRY(launch_adaln(x, m->ttab, tmod, t, c.diffusion_steps, hs(0), xcat, 2 * d, B, N, d, s, true, m->layers[0].g1,
+                             m->layers[0].be1, tb + tp.layers[0].u1));
+    else
+        HIP_TRY(launch_adaln(x, m->ttab, tmod, t, c.diffusion_steps, hs(0), xcat, 2 * d, B, N, d, s));
 
     // As in the inference forward (ditto_api.hip run_block): from 160 row tiles on, the cross out-projection + norm3 and
     // fc2 + the next block's norm1 run on the full-row kernel (fr_mask); the LayerNorm outputs land in the tape slots the
@@ -273,7 +292,7 @@ int ditto_train_forward(ditto_model_t m, const float* x, const float* text, cons
         float *h0 = hs(3 * l), *h1 = hs(3 * l + 1), *h2 = hs(3 * l + 2), *h3 = hs(3 * l + 3);
         char* qkv = tb + q.qkv;
         // ---- self-attention ----
-        if (!(fr_fc2 && l > 0)) HIP_TRY(launch_layernorm(h0, lp.g1, lp.be1, tb + q.u1, d, M, d, s));
+        if (!hb && !(fr_fc2 && l > 0)) HIP_TRY(launch_layernorm(h0, lp.g1, lp.be1, tb + q.u1, d, M, d, s));
         {
             GemmArgs g{};
             g.A = tb + q.u1; g.lda = d; g.W = lt.Wqkv_u; g.bias = lt.bqkv_u; g.out = qkv; g.ldo = 3 * d;
@@ -288,10 +307,12 @@ int ditto_train_forward(ditto_model_t m, const float* x, const float* text, cons
             a.ldv = 3 * d; a.resid_f32 = h1; a.resid_in = h0; a.ldr = d; a.B = B; a.H = H; a.Sq = N; a.Skv = N;
             a.dh = dh; a.scale = scale; a.workspace = attn_ws; a.workspace_bytes = wp.attn_bytes;
             if (dh == 64) a.lse_out = (float*)(tb + q.lse_s);
+            if (hb) { a.resid_bf16 = true; a.out_bf16 = (char*)h1 + (size_t)M * d * 2; a.ldo = d; }   // + O for the backward
             HIP_TRY(launch_attention(a, s));
         }
         // ---- cross-attention (dropout on the probabilities in train mode) ----
-        HIP_TRY(launch_layernorm(h1, lp.g2, lp.be2, tb + q.u2, d, M, d, s));
+        if (hb) HIP_TRY(launch_layernorm_xbf16(h1, lp.g2, lp.be2, tb + q.u2, d, M, d, s));
+        else HIP_TRY(launch_layernorm(h1, lp.g2, lp.be2, tb + q.u2, d, M, d, s));
         {
             GemmArgs g{};
             g.A = tb + q.u2; g.lda = d; g.W = lt.Wcq_u; g.bias = lt.bcq_u; g.out = tb + q.qc; g.ldo = d;
@@ -312,7 +333,7 @@ int ditto_train_forward(ditto_model_t m, const float* x, const float* text, cons
             GemmParams gp{};
             gp.A = (const bf16*)(tb + q.oc); gp.lda = d; gp.W = (const bf16*)lp.WcoP; gp.ldw = d; gp.w_rows = d; gp.bias = lp.bco;
             gp.residual = h1; gp.ldr = d; gp.out = h2; gp.ldo = d; gp.M = M; gp.N = d; gp.K = d;
-            HIP_TRY(launch_gemm_fr(gp, lp.g3, lp.be3, tb + q.u3, d, fr_rot, s));
+            HIP_TRY(launch_gemm_fr(gp, lp.g3, lp.be3, tb + q.u3, d, fr_rot, s, false, hb));
         } else {
             GemmArgs g{};
             g.A = tb + q.oc; g.lda = d; g.W = lp.Wco; g.bias = lp.bco; g.residual = h1; g.ldr = d; g.out = h2; g.ldo = d;
@@ -334,11 +355,15 @@ int ditto_train_forward(ditto_model_t m, const float* x, const float* text, cons
             GemmParams gp{};
             gp.A = (const bf16*)(tb + q.act); gp.lda = 4 * d; gp.W = (const bf16*)lp.W2P; gp.ldw = 4 * d; gp.w_rows = d;
             gp.bias = lp.b2; gp.residual = h2; gp.ldr = d; gp.out = h3; gp.ldo = d; gp.M = M; gp.N = d; gp.K = 4 * d;
-            if (l == L - 1) {
+            if (l == L - 1 && hb) {   // the last block's bf16 h goes straight into the final projection's operand slot
+                gp.out = xcat + (size_t)d * 2; gp.ldo = 2 * d;
+                HIP_TRY(launch_gemm_fr(gp, nullptr, nullptr, nullptr, d, fr_rot, s, false, true));
+            } else if (l == L - 1) {
                 gp.out2 = (bf16*)(xcat + (size_t)d * 2); gp.ldo2 = 2 * d;
                 HIP_TRY(launch_gemm_fr(gp, nullptr, nullptr, nullptr, d, fr_rot, s));
             } else {
-                HIP_TRY(launch_gemm_fr(gp, m->layers[l + 1].g1, m->layers[l + 1].be1, tb + tp.layers[l + 1].u1, d, fr_rot, s));
+                HIP_TRY(launch_gemm_fr(gp, m->layers[l + 1].g1, m->layers[l + 1].be1, tb + tp.layers[l + 1].u1, d, fr_rot, s,
+                                       false, hb));
             }
         } else {
             GemmArgs g{};
@@ -426,6 +451,7 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
     const bool fr_dgrad = lt0_has_fr && fr_pays(M) && gemm_fr_supports(M, d, 8 * d, (size_t)8 * d, (size_t)8 * d);
     // du — the gradient wrt a LayerNorm's output, written by a dgrad GEMM and read once by the LayerNorm backward — travels as
     // BF16 (train_flags 8: fp32, A/B): half the bytes on both sides; dh, the stream gradient it is folded into, stays fp32.
+    const bool hb = train_stream_bf16(m, M);   // the tape's h rows are bf16, the self-attention's O sits beside h1
     const bool du_bf16 = !(g_train_flags & 8);
     bool du_is_bf16 = false;   // what the LAST producer of du wrote (the 64-row full-row kernel has no bf16 output)
     auto dgrad_fr = [&](const void* dY, int n_out, const void* WtP, float* out) -> int {
@@ -439,7 +465,8 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
         return DITTO_OK;
     };
     auto ln_back = [&](const float* xin, const float* gamma, float* gw, float* gb, float* next_bias) -> int {
-        HIP_TRY(launch_ln_bwd_stream(du, du_is_bf16, xin, gamma, dh, dyb, gw, gb, next_bias, red, M, d, s));
+        if (hb && !du_is_bf16) return fail(DITTO_ERR_ARG, "internal: bf16 tape rows with an fp32 du");
+        HIP_TRY(launch_ln_bwd_stream(du, du_is_bf16, xin, hb, gamma, dh, dyb, gw, gb, next_bias, red, M, d, s));
         return DITTO_OK;
     };
 #define TRY_RC(expr) do { if (int _rc = (expr)) return _rc; } while (0)
@@ -516,7 +543,8 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
             a.dq = big1; a.lddq = 3 * d; a.dk = big1 + (size_t)d * 2; a.lddk = 3 * d; a.dv = big1 + (size_t)2 * d * 2;
             a.lddv = 3 * d; a.B = B; a.H = H; a.Sq = N; a.Skv = N; a.dh = dhd; a.scale = scale;
             a.workspace = attn_ws; a.workspace_bytes = wp.attn_bytes;
-            if (dhd == 64) { a.lse = (const float*)(tb + q.lse_s); a.h_after = h1; a.h_before = h0; a.ldh = d; }
+            if (dhd == 64 && hb) { a.lse = (const float*)(tb + q.lse_s); a.o_bf16 = (const char*)h1 + (size_t)M * d * 2; a.ldo = d; }
+            else if (dhd == 64) { a.lse = (const float*)(tb + q.lse_s); a.h_after = h1; a.h_before = h0; a.ldh = d; }
             // the rotation's backward: in the dq / dk epilogues where the kernel can (head_dim 64), else one pass in place
             a.rope_cos = rope_cos; a.rope_sin = rope_sin;
             const bool fused_rope_bwd = (g_train_flags & 1) == 0 && attention_bwd_fuses_rope(a);

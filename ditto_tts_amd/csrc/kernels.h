@@ -272,7 +272,7 @@ hipError_t launch_reduce_partials(const float* partial, int chunks, size_t n, fl
 hipError_t launch_colsum_f32(const float* x, int ld, int M, int n, float* out, float* scratch, hipStream_t s);
 hipError_t launch_colsum_bf16(const void* x, int ld, int M, int n, float* out, float* scratch, hipStream_t s);
 size_t ln_bwd_scratch_bytes(int rows_per_group, int groups, int d);
-hipError_t launch_ln_bwd_stream(const void* dy, bool dy_bf16, const float* x, const float* gamma, float* dx_accum, void* dx_bf16,
+hipError_t launch_ln_bwd_stream(const void* dy, bool dy_bf16, const void* x, bool x_bf16, const float* gamma, float* dx_accum, void* dx_bf16,
                                 float* dgamma, float* dbeta, float* colsum_or_null, float* scratch, int rows, int d,
                                 hipStream_t s);
 hipError_t launch_ln_bwd(const float* dy, const float* x, const float* gamma, float* dx_accum, float* dgb_out,

@@ -181,7 +181,8 @@ hipError_t launch_colsum_bf16(const void* x, int ld, int M, int n, float* out, f
 // added to the stream there), so that the separate cast and column-sum passes over the 100 MB stream disappear.
 // DYB (stream form only): dy is BF16 [rows, d] — the dgrad GEMM in front writes its output once, as bf16 (round 4: 50 MB
 // less written there and 50 MB less read here per LayerNorm, 36 per step at C2).
-template <int CH, bool EXT = false, bool DYB = false>
+// XB (stream form only): x, the LayerNorm's input row, is BF16 (the training forward on the bf16 residual stream).
+template <int CH, bool EXT = false, bool DYB = false, bool XB = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, float* __restrict__ dx_accum,
                                                      float* __restrict__ partial, int d, int rows_per_group,
@@ -207,13 +208,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * d);
         const f32x4* dr = reinterpret_cast<const f32x4*>(dy + row * d);
         const u32x2* drb = reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16*>(dy) + row * d);
+        const u32x2* xrb = reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16*>(x) + row * d);
         f32x4 v[CH], gy[CH];
         float s = 0.f;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const int i = lane + 64 * c;
             if (i < nv) {
-                v[c] = xr[i];
+                if constexpr (XB) {
+                    const u32x2 t = xrb[i];
+                    v[c] = f32x4{bf16_lo(t[0]), bf16_hi(t[0]), bf16_lo(t[1]), bf16_hi(t[1])};
+                } else {
+                    v[c] = xr[i];
+                }
                 if constexpr (DYB) {
                     const u32x2 t = drb[i];
                     gy[c] = f32x4{bf16_lo(t[0]), bf16_hi(t[0]), bf16_lo(t[1]), bf16_hi(t[1])};
@@ -337,22 +344,25 @@ size_t ln_bwd_scratch_bytes(int rows_per_group, int groups, int d) {
 }
 // The residual-stream form (one group): dx_accum += dx; dx_bf16 = bf16(dx_accum); dgamma / dbeta / colsum(dx_accum)
 // (the last may be null) written to their own destinations.  scratch: ln_bwd_scratch_bytes(rows, 1, d) * 3 / 2.
-hipError_t launch_ln_bwd_stream(const void* dy, bool dy_bf16, const float* x, const float* gamma, float* dx_accum, void* dx_bf16,
-                                float* dgamma, float* dbeta, float* colsum_or_null, float* scratch, int rows, int d,
-                                hipStream_t s) {
-    if (d % 4 || d > 2048 || !dx_accum || !dx_bf16 || !scratch) return hipErrorInvalidValue;
+hipError_t launch_ln_bwd_stream(const void* dy, bool dy_bf16, const void* x, bool x_bf16, const float* gamma, float* dx_accum,
+                                void* dx_bf16, float* dgamma, float* dbeta, float* colsum_or_null, float* scratch, int rows,
+                                int d, hipStream_t s) {
+    if (d % 4 || d > 2048 || !dx_accum || !dx_bf16 || !scratch || (x_bf16 && !dy_bf16)) return hipErrorInvalidValue;
     const int ch = (d / 4 + 63) / 64;
     const int chunks = ln_bwd_chunks(rows, 1);
     const int rpc = (rows + chunks - 1) / chunks;
     dim3 grid(chunks, 1), block(256);
 #define LNB_CASE(C)                                                                                              \
     case C:                                                                                                      \
-        if (dy_bf16)                                                                                             \
-            hipLaunchKernelGGL((ln_bwd_kernel<C, true, true>), grid, block, 0, s, (const float*)dy, x, gamma, dx_accum, scratch, d, \
-                               rows, rpc, chunks, (bf16*)dx_bf16);                                               \
+        if (x_bf16)                                                                                              \
+            hipLaunchKernelGGL((ln_bwd_kernel<C, true, true, true>), grid, block, 0, s, (const float*)dy, (const float*)x, gamma,  \
+                               dx_accum, scratch, d, rows, rpc, chunks, (bf16*)dx_bf16);                         \
+        else if (dy_bf16)                                                                                        \
+            hipLaunchKernelGGL((ln_bwd_kernel<C, true, true>), grid, block, 0, s, (const float*)dy, (const float*)x, gamma,       \
+                               dx_accum, scratch, d, rows, rpc, chunks, (bf16*)dx_bf16);                         \
         else                                                                                                     \
-            hipLaunchKernelGGL((ln_bwd_kernel<C, true>), grid, block, 0, s, (const float*)dy, x, gamma, dx_accum, scratch, d, rows, \
-                               rpc, chunks, (bf16*)dx_bf16);                                                     \
+            hipLaunchKernelGGL((ln_bwd_kernel<C, true>), grid, block, 0, s, (const float*)dy, (const float*)x, gamma, dx_accum,   \
+                               scratch, d, rows, rpc, chunks, (bf16*)dx_bf16);                                   \
         break;
     switch (ch) {
         LNB_CASE(1) LNB_CASE(2) LNB_CASE(3) LNB_CASE(4) LNB_CASE(5) LNB_CASE(6) LNB_CASE(7) LNB_CASE(8)

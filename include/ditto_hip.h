@@ -288,7 +288,10 @@ int ditto_gemm_tn_bf16(const void* X, int ldx, const void* Y, int ldy, float* ou
  * dq | dk instead of inside the attention backward's dq / dk epilogues (head_dim 64; other head dims always take the pass);
  * bit 1 = the fc2 dgrad GEMM and the gated MLP's derivative as two launches instead of one (the derivative as the GEMM's
  * epilogue, from 144 tiles of 256 x 256 on); bit 2 = the training forward's gated GEMM on the general epilogue instead of its
- * own straight-line instantiation.
+ * own straight-line instantiation; bit 3 = the gradient wrt a LayerNorm's output as fp32 instead of bf16 between the dgrad GEMM
+ * and the LayerNorm backward; bit 4 = the tape's residual-stream rows as fp32 instead of bf16 (the bf16 stream exists where the
+ * inference forward has it: d = 768, head_dim 64, the full-row kernel class).  The flags must not change between the forward
+ * and the backward of one step.
  * "fr_rot": that kernel's K-loop rotation (tiles start their k sum at different places so that the workgroups of an XCD do
  * not all ask the L2 for the same weight lines at once): 0 = off, 1 = on in the model path with period = row tiles per
  * utterance (an utterance's bits do not depend on its place in the batch), > 1 = ditto_gemm_ln_bf16 rotates too, with that
