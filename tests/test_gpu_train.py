@@ -237,12 +237,15 @@ def test_training_closure_like_the_reference():
     assert again < losses[-1]
 
 
-def test_gradients_are_bit_reproducible():
+@pytest.mark.parametrize("cfg,B,N,T", [(DiTTOConfig(256, 2, 4, 256, 256, 50), 4, 512, 256),
+                                       (DiTTOConfig(768, 2, 12, 256, 768, 50), 3, 1024, 128)])
+def test_gradients_are_bit_reproducible(cfg, B, N, T):
     """No atomics anywhere in the backward (split-K partials and column sums are reduced in a fixed order): the same
-    step twice gives bitwise-identical gradients, at a shape that exercises split-K wgrad and the fused attention."""
-    cfg = DiTTOConfig(256, 2, 4, 256, 256, 50)
-    x, text, t = (z.to(DEV) for z in synthetic_inputs(cfg, 4, 512, 256, seed=3))
-    target = hash_normal((4, 512, 256), "noise", 4).to(DEV)
+    step twice gives bitwise-identical gradients, at a shape that exercises split-K wgrad and the fused attention, and at one
+    (d = 768, 3 x 1024 rows) where the gated MLP's derivative runs as the fc2 dgrad's epilogue with its per-half-tile partial
+    rows of the bias gradients."""
+    x, text, t = (z.to(DEV) for z in synthetic_inputs(cfg, B, N, T, seed=3))
+    target = hash_normal((B, N, cfg.hidden_dim), "noise", 4).to(DEV)
     grads = []
     for _ in range(2):
         m = _build(cfg, 9).train()
