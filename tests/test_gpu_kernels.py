@@ -135,11 +135,12 @@ def test_every_epilogue_on_every_structure(lib, tile, flags):
         hip.check(lib.ditto_set_option(b"gemm_flags", 321))
 
 
-@pytest.mark.parametrize("shape", [(4096, 6144, 768), (5000, 2304, 768), (8192, 768, 3072), (4096, 2304, 192)])
+@pytest.mark.parametrize("shape", [(4096, 6144, 768), (5000, 2304, 768), (8192, 768, 3072), (4096, 2304, 192), (8200, 2336, 768)])
 def test_flat_k_loop_across_the_tile_switch_is_bitwise(lib, shape):
     """gemm256's flat K loop (default for even K-tile counts; gemm_flags bit 16384 = the round-3 tile switch): the next tile's first
-    six half-tiles ride the empty DMA slots of the last K iteration, no prologue between main loop and epilogue.  More tiles than CUs (384 / 180 / 96 / 144 tiles; the second and
-    fourth shapes have ragged last row tiles, the fourth an ODD K-tile count that must fall back), every C-ABI epilogue:
+    six half-tiles ride the empty DMA slots of the last K iteration, no prologue between main loop and epilogue.  More tiles than CUs (384 / 180 / 96 / 144 / 330 tiles; the second and
+    fourth shapes have ragged last row tiles, the fourth an ODD K-tile count that must fall back, the fifth ragged last row AND
+    column tiles: the re-pointed source bases clamp both), every C-ABI epilogue:
     the arithmetic is unchanged, so the outputs must equal the default build's BIT FOR BIT."""
     M, N, K = shape
     A = bf16(asym((M, K), 24).to(DEV))
