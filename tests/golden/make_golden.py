@@ -162,6 +162,43 @@ def main():
          x_step0=kept[0], x_step1=kept[1], x_step10=kept[10], x_step49=kept[49])
 
 
+G8_SHAPE = dict(layers=2, d=768, heads=12, B=2, N=128, T=96, steps=50, seed=8, keep=(0, 1, 10, 49))
+
+
+@torch.no_grad()
+def make_loop768():
+    """G8: the 50-step sampling loop at the dimensions of the TIMED kernel class — d = 768, 12 heads of 64 (the full-row
+    GEMMs with fused LayerNorms, norm2 fused into the q-projection, the bf16 residual stream all exist only at this width;
+    G5's d = 256 model can never reach them).  2 layers, N = 128, T = 96, B = 2.  Every eps comes from the imported
+    reference DiTTO.forward (src/model/DiTTO.py:66-94); loop and update are the restated SpeechGenerator lines
+    (src/model/SpeechGenerator.py:135-145,154-163: the class cannot be imported here), noise injected from hash_normal.
+    Inputs are regenerated from ditto_tts_amd.synth by the tests (fp16 copies stored as a checksum only)."""
+    _, ref_ditto = import_reference()
+    s = G8_SHAPE
+    cfg = DiTTOConfig(s["d"], s["layers"], s["heads"], 256, s["d"], s["steps"])
+    m = build_reference_ditto(ref_ditto, cfg, synthetic_state_dict(cfg, seed=s["seed"]))
+    B, N, T, S = s["B"], s["N"], s["T"], s["steps"]
+    text = hash_normal((B, T, s["d"]), "text", 88)
+    xinit = hash_normal((B, N, s["d"]), "xT", 88)
+    betas = m.cosine_beta_schedule(S)                      # SpeechGenerator.py:70
+    alphas = 1.0 - betas                                   # :71
+    ac = torch.cumprod(alphas, dim=0)                      # :72
+    x = xinit.clone()
+    kept = {}
+    for i, t_val in enumerate(reversed(range(S))):         # :161
+        tt = torch.full((B,), t_val, dtype=torch.long)     # :162
+        eps = m(x, text, tt)                               # :135
+        z = hash_normal((B, N, s["d"]), f"z{i}", 88)
+        beta_t, alpha_t, ac_t = betas[tt].view(-1, 1, 1), alphas[tt].view(-1, 1, 1), ac[tt].view(-1, 1, 1)
+        mask = (tt > 0).float().view(-1, 1, 1)
+        x = (1 / torch.sqrt(alpha_t)) * (x - (1 - alpha_t) / torch.sqrt(1 - ac_t) * eps) \
+            + mask * torch.sqrt(beta_t) * z                # :141-145
+        if i in s["keep"]:
+            kept[i] = x.clone()
+    save("G8_loop768.npz", text16=text.half(), xinit16=xinit.half(),
+         **{f"x_step{i}": kept[i] for i in s["keep"]})
+
+
 @torch.no_grad()
 def make_vq():
     """G6: the reference's VectorQuantizer on a hashed codebook / latents (indices are the fixture)."""
@@ -231,7 +268,10 @@ if __name__ == "__main__":
         make_vq()
     elif "--slp-only" in sys.argv:
         make_slp()
+    elif "--loop768-only" in sys.argv:
+        make_loop768()
     else:
         main()
         make_vq()
         make_slp()
+        make_loop768()

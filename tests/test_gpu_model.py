@@ -813,6 +813,35 @@ def test_bf16_residual_stream_sampling_loop_tracks_the_fp32_stream():
 
 
 @torch.no_grad()
+@pytest.mark.parametrize("stream16", [1, 0])
+def test_g8_sampling_loop_of_the_timed_kernel_class_against_the_reference(golden, stream16):
+    """G8 (tests/golden/make_golden.py make_loop768: the imported reference DiTTO.forward at d = 768 / 12 heads of 64
+    inside the restated 50-step loop, src/model/SpeechGenerator.py:135-163) against the kernels that bench.py TIMES: class
+    pinned to 32 x 1024 rows, so the full-row GEMMs with their fused LayerNorms, norm2 fused into the q-projection and —
+    with residual_bf16 — the bf16 residual stream run the whole trajectory.  Stated loop tolerance: rel-L2
+    <= 2e-2 at every stored step, for both streams."""
+    g = golden("G8_loop768.npz")
+    cfg = DiTTOConfig(768, 2, 12, 256, 768, 50)
+    m = build(cfg, 8)
+    sg = SpeechGenerator(ditto_model=m, device=DEV)
+    B, N, T = 2, 128, 96
+    text, xinit = hash_normal((B, T, 768), "text", 88), hash_normal((B, N, 768), "xT", 88)
+    assert torch.equal(text.half(), g["text16"]) and torch.equal(xinit.half(), g["xinit16"])
+    noises = lambda i: hash_normal((B, N, 768), f"z{i}", 88)
+    keep = {0: None, 1: None, 10: None, 49: None}
+    with hip.batch_class(32 * 1024), _stream_bf16(stream16):
+        assert hip.full_row_plan(cfg, B, N) == (True, True)
+        x = sg._SpeechGenerator__sample_latents(text.to(DEV), xinit.to(DEV), cond_by_audio=True, noises=noises, keep=keep)
+        eps = m(xinit.to(DEV), text.to(DEV), torch.full((B,), 49, device=DEV, dtype=torch.long))
+    with hip.batch_class(32 * 1024), _stream_bf16(1 - stream16):      # the switch really selects another stream
+        assert not torch.equal(eps, m(xinit.to(DEV), text.to(DEV), torch.full((B,), 49, device=DEV, dtype=torch.long)))
+    rs = {i: rel_l2(keep[i], g[f"x_step{i}"]) for i in (0, 1, 10, 49)}
+    print(f"G8 50-step loop, {'bf16' if stream16 else 'fp32'} stream, full-row class: rel-L2 per stored step {rs}")
+    assert all(r < RTOL for r in rs.values()), rs
+    assert torch.equal(x, keep[49])
+
+
+@torch.no_grad()
 @pytest.mark.parametrize("shape", [32, 16])
 @pytest.mark.parametrize("stream16", [0, 1])
 def test_norm2_fused_into_the_q_projection_g2_golden(golden, shape, stream16):

@@ -82,6 +82,21 @@ def test_g5_sampler_trajectory(golden):
         assert rel_l2(kept[i], g[f"x_step{i}"]) < 1e-4, i   # 50 chained steps of fp32 round-off
 
 
+def test_g8_sampling_loop_at_the_timed_width(golden):
+    """G8: the 50-step loop at d = 768 / 12 heads of 64 (the width of the timed kernel class), eps from the imported
+    reference DiTTO.forward — the restated loop of the oracle reproduces it, and the regenerated inputs are the stored ones."""
+    g = golden("G8_loop768.npz")
+    cfg = DiTTOConfig(768, 2, 12, 256, 768, 50)
+    sd = synthetic_state_dict(cfg, seed=8)
+    B, N, T, S = 2, 128, 96, 50
+    text, xinit = hash_normal((B, T, 768), "text", 88), hash_normal((B, N, 768), "xT", 88)
+    assert torch.equal(text.half(), g["text16"]) and torch.equal(xinit.half(), g["xinit16"])
+    noises = [hash_normal((B, N, 768), f"z{i}", 88) for i in range(S)]
+    x, kept = O.sample_latents(sd, 2, 12, xinit, text, S, noises, keep=(0, 1, 10, 49))
+    for i in (0, 1, 10, 49):
+        assert rel_l2(kept[i], g[f"x_step{i}"]) < 1e-4, i
+
+
 def _vq_inputs():
     cb = hash_normal((1024, 768), "codebook", 66) * 0.05
     lat = hash_normal((2, 2, 96, 768), "vq_latents", 66) * 0.06
