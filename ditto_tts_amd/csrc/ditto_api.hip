@@ -109,7 +109,7 @@ int small_batch_k_splits(int M, int N, int K) {
         // fc2 40.8 -> 24.2 us, step 1.83 -> 1.63 ms at C2 B = 1.  The number of splits depends on K ONLY, so inside the class an
         // utterance's bits do not depend on its batch neighbours; like the full-row class (kernels.h fr_rule_rows) the class is a
         // function of the launch's rows and a caller that splits one batch pins it ("fr_class_rows"): the rows of the UNSPLIT batch.
-        const long rows = g_fr_class_rows > 0 ? g_fr_class_rows : M;
+        const long rows = opt_class_rows() > 0 ? opt_class_rows() : M;
         if (rows > 2048 || ktiles < 24) return 1;
         const int ns = ktiles / 12;                        // K = 3072: 4, 1536: 2, 4096: 5, 2048: 2
         return ns > 8 ? 8 : ns;
@@ -126,7 +126,7 @@ int small_batch_k_splits(int M, int N, int K) {
 // depth) whose finish also writes norm3 — the LayerNorm launch behind it disappears.  Same class rule as above, K only.
 int small_batch_k_splits_outproj(int M, int K) {
     if (g_splitk_wgs != 0 || !(g_ll_mask & 2)) return 1;
-    const long rows = g_fr_class_rows > 0 ? g_fr_class_rows : M;
+    const long rows = opt_class_rows() > 0 ? opt_class_rows() : M;
     return (rows <= 2048 && K / 64 >= 12) ? 2 : 1;
 }
 
@@ -177,13 +177,23 @@ int check_cfg(const ditto_config* c) {
 // launch cannot run a full-row kernel (fewer rows than one 64-row tile) would silently take the tiled GEMMs, whose last bits
 // differ: the promise of the pin — sharding changes no bit — would be broken without a sign.  Fail instead.
 int check_class_pin(int M, int d, bool fp8, bool has_fr) {   // has_fr: the model has full-row kernels at all (not on padded heads)
-    if (!has_fr || g_fr_class_rows <= 0 || !g_fr_mask || M >= 64) return DITTO_OK;
-    const bool wants = d == 768 ? (!fp8 && fr_rule_rows(g_fr_class_rows) != 0) : (d == 1024 && fr_pays_64(M));
+    if (!has_fr || opt_class_rows() <= 0 || !opt_fr_mask() || M >= 64) return DITTO_OK;
+    const bool wants = d == 768 ? (!fp8 && fr_rule_rows(opt_class_rows()) != 0) : (d == 1024 && fr_pays_64(M));
     if (!wants) return DITTO_OK;
     return fail(DITTO_ERR_SHAPE, "kernel class pinned to a batch of %d rows (full-row GEMM + LayerNorm kernels), but this launch has "
                                  "%d rows, fewer than one 64-row tile: it cannot take that class and its bits would differ from the "
                                  "unsplit batch's.  Give every shard at least 64 rows, or run the whole batch unfused "
-                                 "(ditto_set_option(\"fr_mask\", 0)).", g_fr_class_rows, M);
+                                 "(ditto_set_option(\"fr_mask\", 0)).", opt_class_rows(), M);
+}
+
+int check_call_opts(const ditto_call_opts* o) {
+    if (!o) return DITTO_OK;
+    if (o->class_rows < -1) return fail(DITTO_ERR_ARG, "ditto_call_opts.class_rows must be >= -1 (-1 inherit, 0 the launch's own rows)");
+    if (o->residual_bf16 < -1 || o->residual_bf16 > 1) return fail(DITTO_ERR_ARG, "ditto_call_opts.residual_bf16 must be -1, 0 or 1");
+    if (o->fr_mask < -1 || o->fr_mask > 3) return fail(DITTO_ERR_ARG, "ditto_call_opts.fr_mask must be in [-1, 3]");
+    if (o->lnq != -1 && o->lnq != 0 && o->lnq != 16 && o->lnq != 32) return fail(DITTO_ERR_ARG, "ditto_call_opts.lnq must be -1, 0, 16 or 32");
+    for (int r : o->reserved) if (r) return fail(DITTO_ERR_ARG, "ditto_call_opts.reserved must be zero");
+    return DITTO_OK;
 }
 
 }  // namespace ditto
@@ -255,8 +265,8 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
     // bit 1 = fc2 + the next block's norm1 (ln1_done tells that block its norm1 output is already in u)
     // (the stage-major weight copies exist exactly where a kernel exists: d = 768 bf16, d = 1024 — there the out-projection
     // also in the fp8 configuration, with the LayerNorm output written as fp8)
-    const bool fr_out = lp.WcoP && (g_fr_mask & 1) && fr_outproj_ok(M, d);
-    const bool fr_fc2 = !fp8 && lp.W2P && (g_fr_mask & 2) && fr_fc2_ok(M, d);
+    const bool fr_out = lp.WcoP && (opt_fr_mask() & 1) && fr_outproj_ok(M, d);
+    const bool fr_fc2 = !fp8 && lp.W2P && (opt_fr_mask() & 2) && fr_fc2_ok(M, d);
     const int fr_rot = N % 128 == 0 ? N / 128 : 0;   // tiles per utterance: the K-loop rotation period (gemm_fr.hip)
     if (int rc = ditto::check_class_pin(M, d, fp8, !pad)) return rc;
     // hb: `h` holds BF16 rows (the bf16 residual stream; ditto_forward decides, and only where both fused launches run)
@@ -302,14 +312,14 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
         if (tap_self) HIP_TRY(hipMemcpyAsync(tap_self, h, (size_t)M * d * 4, hipMemcpyDeviceToDevice, s));
         // ---- cross-attention (src/components/DiT.py:141-148), K/V from the per-utterance cache ----
         // norm2 + q-projection in one launch (gemm_lnq.hip) for the full-row class at d = 768; else LayerNorm launch + tiled GEMM
-        const int rows_cls = g_fr_class_rows > 0 ? g_fr_class_rows : M;
+        const int rows_cls = opt_class_rows() > 0 ? opt_class_rows() : M;
         // (d = 1024, BASELINE config C5: the same kernel at that width, 32x32x16 only, from 192 tiles of 64 rows on — the rule of
         // its full-row GEMM)
-        const bool lnq = g_lnq && lp.WcqP && ((d == 768 && (fr_pays(M) || (g_lnq_min_rows > 0 && rows_cls >= g_lnq_min_rows))) ||
+        const bool lnq = opt_lnq() && lp.WcqP && ((d == 768 && (fr_pays(M) || (g_lnq_min_rows > 0 && rows_cls >= g_lnq_min_rows))) ||
                                               (d == 1024 && fr_pays_64(M)));
         if (lnq) {
             ProfScope ps(m, s, DITTO_KC_GEMM_QPROJ);
-            const int shape = d == 768 ? g_lnq : 32;
+            const int shape = d == 768 ? opt_lnq() : 32;
             HIP_TRY(launch_gemm_lnq(h, d, hb, lp.g2, lp.be2, shape == 16 ? lp.WcqP32 : lp.WcqP, lp.bcq, qkv, d, M, d, shape,
                                     N % 64 == 0 ? N / 64 : 0, s));
         } else {
@@ -630,6 +640,38 @@ int ditto_text_precompute(ditto_model_t m, const float* text, int B, int T, void
     return DITTO_OK;
 }
 
+// thread-scoped options: the stack of what ditto_call_opts_push found in force (kernels.h t_opts is the top)
+static thread_local CallOpts t_opt_stack[16];
+static thread_local int t_opt_depth = 0;
+
+int ditto_call_opts_push(const ditto_call_opts* opts) {
+    if (int rc = check_call_opts(opts)) return rc;
+    if (t_opt_depth >= 16) return fail(DITTO_ERR_ARG, "ditto_call_opts_push: more than 16 nested scopes on this thread");
+    t_opt_stack[t_opt_depth++] = t_opts;
+    CallScope::apply(opts);
+    return DITTO_OK;
+}
+
+int ditto_call_opts_pop(void) {
+    if (t_opt_depth <= 0) return fail(DITTO_ERR_ARG, "ditto_call_opts_pop without a matching push on this thread");
+    t_opts = t_opt_stack[--t_opt_depth];
+    return DITTO_OK;
+}
+
+int ditto_call_opts_current(ditto_call_opts* out) {
+    if (!out) return fail(DITTO_ERR_ARG, "null argument to ditto_call_opts_current");
+    *out = ditto_call_opts{opt_class_rows(), opt_resid_bf16(), opt_fr_mask(), opt_lnq(), {0, 0, 0, 0}};
+    return DITTO_OK;
+}
+
+int ditto_forward_opts(ditto_model_t m, const float* x, const void* cond, const int64_t* t, int B, int N, int T,
+                       const float* rope_cos, const float* rope_sin, float* eps_out, void* workspace,
+                       size_t workspace_bytes, ditto_stream_t stream, const ditto_call_opts* opts) {
+    if (int rc = check_call_opts(opts)) return rc;
+    CallScope scope(opts);
+    return ditto_forward(m, x, cond, t, B, N, T, rope_cos, rope_sin, eps_out, workspace, workspace_bytes, stream);
+}
+
 int ditto_forward(ditto_model_t m, const float* x, const void* cond, const int64_t* t, int B, int N, int T,
                   const float* rope_cos, const float* rope_sin, float* eps_out, void* workspace,
                   size_t workspace_bytes, ditto_stream_t stream) {
@@ -655,17 +697,17 @@ int ditto_forward(ditto_model_t m, const float* x, const void* cond, const int64
 
     // fc2 on the full-row kernel also emits the NEXT block's norm1 (fr_mask bit 1): that block then skips its LayerNorm
     const bool fp8c = (c.flags & DITTO_CFG_FP8_LINEAR) != 0;
-    const bool chain_ln1 = (g_fr_mask & 2) && !fp8c && m->layers[0].W2P && fr_fc2_ok(M, d);
+    const bool chain_ln1 = (opt_fr_mask() & 2) && !fp8c && m->layers[0].W2P && fr_fc2_ok(M, d);
     // bf16 residual stream ("residual_bf16"): only where EVERY consumer of h has the bf16 form — d = 768, head_dim 64, both fused
     // launches of a block on gemm_frd.hip (the full-row class); any other launch keeps the fp32 stream
-    const bool hb_class = g_resid_bf16 && !fp8c && d == 768 && d / c.num_heads == 64 && chain_ln1 && (g_fr_mask & 1) &&
+    const bool hb_class = opt_resid_bf16() && !fp8c && d == 768 && d / c.num_heads == 64 && chain_ln1 && (opt_fr_mask() & 1) &&
                           m->layers[0].WcoP && fr_outproj_ok(M, d) &&
-                          (g_fr_tile == 130 || (g_fr_tile == 0 && fr_rule_rows(g_fr_class_rows > 0 ? g_fr_class_rows : M) == 130));
+                          (g_fr_tile == 130 || (g_fr_tile == 0 && fr_rule_rows(opt_class_rows() > 0 ? opt_class_rows() : M) == 130));
     // (only gemm_frd.hip has the bf16 form: a launch of fewer than 128 rows under a PINNED class would run the 64-row kernel)
     if (hb_class && M < 128)
         return fail(DITTO_ERR_SHAPE, "kernel class pinned to a batch of %d rows (bf16 residual stream on the 128-row full-row kernel), "
                                      "but this launch has %d rows: it cannot take that class.  Give every shard at least 128 rows, or "
-                                     "ditto_set_option(\"residual_bf16\", 0).", g_fr_class_rows, M);
+                                     "ditto_set_option(\"residual_bf16\", 0).", opt_class_rows(), M);
     const bool hb = hb_class;
     // low-latency class: fc2 runs split over K and its finish launch also writes the next block's norm1 (the same bits as the
     // LayerNorm launch it replaces); decided exactly as run_block will decide the split
@@ -792,6 +834,16 @@ int ditto_p_sample(ditto_model_t m, float* x, const void* cond, const int64_t* t
                                  (size_t)N * m->cfg.hidden_dim, stream);
 }
 
+int ditto_p_sample_opts(ditto_model_t m, float* x, const void* cond, const int64_t* t, const float* noise,
+                        const float* betas, const float* alphas, const float* alphas_cumprod, int B, int N, int T,
+                        const float* rope_cos, const float* rope_sin, void* workspace, size_t workspace_bytes,
+                        ditto_stream_t stream, const ditto_call_opts* opts) {
+    if (int rc = check_call_opts(opts)) return rc;
+    CallScope scope(opts);
+    return ditto_p_sample(m, x, cond, t, noise, betas, alphas, alphas_cumprod, B, N, T, rope_cos, rope_sin, workspace,
+                          workspace_bytes, stream);
+}
+
 int ditto_noise_normal(float* out, const int64_t* seeds, uint32_t step, int B, size_t elems_per_utt,
                        ditto_stream_t stream) {
     if (!out || !seeds || B <= 0 || elems_per_utt == 0) return fail(DITTO_ERR_ARG, "bad argument to ditto_noise_normal");
@@ -817,6 +869,26 @@ int ditto_p_sample_seeded(ditto_model_t m, float* x, const void* cond, const int
     HIP_TRY(launch_p_sample_update_seeded(x, eps, seeds, step, t, betas, alphas, alphas_cumprod, B, per,
                                           (hipStream_t)stream));
     return DITTO_OK;
+}
+
+int ditto_p_sample_seeded_opts(ditto_model_t m, float* x, const void* cond, const int64_t* t, const int64_t* seeds,
+                               uint32_t step, const float* betas, const float* alphas, const float* alphas_cumprod, int B,
+                               int N, int T, const float* rope_cos, const float* rope_sin, void* workspace,
+                               size_t workspace_bytes, ditto_stream_t stream, const ditto_call_opts* opts) {
+    if (int rc = check_call_opts(opts)) return rc;
+    CallScope scope(opts);
+    return ditto_p_sample_seeded(m, x, cond, t, seeds, step, betas, alphas, alphas_cumprod, B, N, T, rope_cos, rope_sin, workspace,
+                                 workspace_bytes, stream);
+}
+
+int ditto_denoise_steps_opts(ditto_model_t m, float* x, const void* cond, int t_begin, int t_end, const float* noise,
+                             const float* betas, const float* alphas, const float* alphas_cumprod, int B, int N, int T,
+                             const float* rope_cos, const float* rope_sin, int64_t* t_scratch, void* workspace,
+                             size_t workspace_bytes, ditto_stream_t stream, const ditto_call_opts* opts) {
+    if (int rc = check_call_opts(opts)) return rc;
+    CallScope scope(opts);
+    return ditto_denoise_steps(m, x, cond, t_begin, t_end, noise, betas, alphas, alphas_cumprod, B, N, T, rope_cos, rope_sin,
+                               t_scratch, workspace, workspace_bytes, stream);
 }
 
 int ditto_denoise_steps(ditto_model_t m, float* x, const void* cond, int t_begin, int t_end, const float* noise,
@@ -1178,6 +1250,13 @@ int ditto_set_option(const char* name, int value) {
 }
 
 int ditto_full_row_plan(const ditto_config* cfg, int B, int N, int* outproj, int* fc2) {
+    return ditto_full_row_plan_opts(cfg, B, N, nullptr, outproj, fc2, nullptr);
+}
+
+int ditto_full_row_plan_opts(const ditto_config* cfg, int B, int N, const ditto_call_opts* opts, int* outproj, int* fc2,
+                             int* stream_bf16) {
+    if (int rc = check_call_opts(opts)) return rc;
+    CallScope scope(opts);
     if (int rc = check_cfg(cfg)) return rc;
     if (!outproj || !fc2 || B <= 0 || N <= 0) return fail(DITTO_ERR_ARG, "bad argument to ditto_full_row_plan");
     if ((long long)B * N > 0x7fffffffLL) return fail(DITTO_ERR_SHAPE, "B * N exceeds 2^31 - 1 rows");
@@ -1186,8 +1265,11 @@ int ditto_full_row_plan(const ditto_config* cfg, int B, int N, int* outproj, int
     if (int rc = check_class_pin(M, d, fp8c, !cfg_padded(*cfg))) return rc;   // what the forward itself would answer
     const bool padc = cfg_padded(*cfg);                                   // padded heads: the tiled path only
     const bool have_o = !padc && ((d == 768 && !fp8c) || d == 1024), have_2 = !padc && (d == 768 || d == 1024) && !fp8c;
-    *outproj = have_o && (g_fr_mask & 1) && fr_outproj_ok(M, d);
-    *fc2 = have_2 && (g_fr_mask & 2) && fr_fc2_ok(M, d);
+    *outproj = have_o && (opt_fr_mask() & 1) && fr_outproj_ok(M, d);
+    *fc2 = have_2 && (opt_fr_mask() & 2) && fr_fc2_ok(M, d);
+    if (stream_bf16)   // ditto_forward's hb_class
+        *stream_bf16 = opt_resid_bf16() && !fp8c && d == 768 && d / cfg->num_heads == 64 && *outproj && *fc2 && M >= 128 &&
+                       (g_fr_tile == 130 || (g_fr_tile == 0 && fr_rule_rows(opt_class_rows() > 0 ? opt_class_rows() : M) == 130));
     return DITTO_OK;
 }
 

@@ -225,18 +225,29 @@ int ditto_train_attach(ditto_model_t m, const ditto_weights* w, void* train_aren
 // backward — and the self-attention's output O as bf16 beside h1 (second half of its fp32-sized slot: the backward's
 // delta = rowsum(dO . O) needs O, and the difference of two bf16 rows is not it).  Exactly where the inference forward has the
 // stream (ditto_api.hip hb_class): d = 768, head_dim 64, both fused launches on gemm_frd.hip; and with du travelling as bf16.
-// One predicate for the forward and the backward of a step: the options it reads must not change between the two calls.
+// Decided ONCE per step, by the forward, and recorded in the handle against the tape's address (ditto_model::tapes): the backward
+// reads the tape as it was written, whatever the options say by then.
 static bool train_stream_bf16(ditto_model_t m, int M) {
     const ditto_config& c = m->cfg;
     const int d = c.hidden_dim;
     if ((g_train_flags & (8 | 16)) || (g_attn_flags & 8192) || d != 768 || d / c.num_heads != 64) return false;
-    if (!m->layers[0].WcoP || !m->layers[0].W2P || (g_fr_mask & 3) != 3) return false;
+    if (!m->layers[0].WcoP || !m->layers[0].W2P || (opt_fr_mask() & 3) != 3) return false;
     return fr_outproj_ok(M, d) && fr_fc2_ok(M, d) && fr_launch_kernel(M, d) == 130 && fr_launch_kernel(M, 4 * d) == 130;
 }
 
 int ditto_train_forward(ditto_model_t m, const float* x, const float* text, const int64_t* t, int B, int N, int T,
                         const float* rope_cos, const float* rope_sin, float dropout_p, uint64_t seed, float* eps_out,
                         void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes, ditto_stream_t stream) {
+    return ditto_train_forward_opts(m, x, text, t, B, N, T, rope_cos, rope_sin, dropout_p, seed, eps_out, tape, tape_bytes, workspace,
+                                    workspace_bytes, stream, nullptr);
+}
+
+int ditto_train_forward_opts(ditto_model_t m, const float* x, const float* text, const int64_t* t, int B, int N, int T,
+                             const float* rope_cos, const float* rope_sin, float dropout_p, uint64_t seed, float* eps_out,
+                             void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes, ditto_stream_t stream,
+                             const ditto_call_opts* opts) {
+    if (int rc = check_call_opts(opts)) return rc;
+    CallScope scope(opts);
     if (int rc = check_train(m)) return rc;
     if (!x || !text || !t || !rope_cos || !rope_sin || !eps_out || !tape || !workspace || B <= 0 || N <= 0 || T <= 0)
         return fail(DITTO_ERR_ARG, "bad argument to ditto_train_forward");
@@ -272,6 +283,10 @@ int ditto_train_forward(ditto_model_t m, const float* x, const float* text, cons
     }
     HIP_TRY(launch_text_mod(text, m->wx, m->bx, pooled, tmod, B, T, c.text_dim, d, s));
     const bool hb = train_stream_bf16(m, M);
+    {
+        std::lock_guard<std::mutex> lk(m->tape_mu);
+        m->tapes[tape] = ditto_model::TapeRec{B, N, T, hb};
+    }
     if (hb)   // bf16 h0 + block 0's norm1 from the same kernel, as the inference forward
         HIP_TRY(launch_adaln(x, m->ttab, tmod, t, c.diffusion_steps, hs(0), xcat, 2 * d, B, N, d, s, true, m->layers[0].g1,
                              m->layers[0].be1, tb + tp.layers[0].u1));
@@ -282,8 +297,8 @@ int ditto_train_forward(ditto_model_t m, const float* x, const float* text, cons
     // fc2 + the next block's norm1 run on the full-row kernel (fr_mask); the LayerNorm outputs land in the tape slots the
     // backward reads (u3, the next block's u1).
     const bool fr_have = d == 768 && m->layers[0].WcoP != nullptr && m->layers[0].W2P != nullptr;
-    const bool fr_out = fr_have && (g_fr_mask & 1) && fr_outproj_ok(M, d);
-    const bool fr_fc2 = fr_have && (g_fr_mask & 2) && fr_fc2_ok(M, d);
+    const bool fr_out = fr_have && (opt_fr_mask() & 1) && fr_outproj_ok(M, d);
+    const bool fr_fc2 = fr_have && (opt_fr_mask() & 2) && fr_fc2_ok(M, d);
     const int fr_rot = N % 128 == 0 ? N / 128 : 0;
     for (int l = 0; l < L; ++l) {
         const LayerPack& lp = m->layers[l];
@@ -386,7 +401,29 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
                          const int64_t* t, int B, int N, int T, const float* rope_cos, const float* rope_sin,
                          float dropout_p, uint64_t seed, const void* tape, size_t tape_bytes, const ditto_grads* grads,
                          void* workspace, size_t workspace_bytes, ditto_stream_t stream) {
+    return ditto_train_backward_opts(m, w, grad_eps, x, t, B, N, T, rope_cos, rope_sin, dropout_p, seed, tape, tape_bytes, grads,
+                                     workspace, workspace_bytes, stream, nullptr);
+}
+
+int ditto_train_backward_opts(ditto_model_t m, const ditto_weights* w, const float* grad_eps, const float* x,
+                              const int64_t* t, int B, int N, int T, const float* rope_cos, const float* rope_sin,
+                              float dropout_p, uint64_t seed, const void* tape, size_t tape_bytes, const ditto_grads* grads,
+                              void* workspace, size_t workspace_bytes, ditto_stream_t stream, const ditto_call_opts* opts) {
+    if (!m) return fail(DITTO_ERR_ARG, "null model");
+    return ditto_train_backward_layers(m, w, grad_eps, x, t, B, N, T, rope_cos, rope_sin, dropout_p, seed, tape, tape_bytes, grads,
+                                       workspace, workspace_bytes, stream, opts, m->cfg.num_layers - 1, 0);
+}
+
+int ditto_train_backward_layers(ditto_model_t m, const ditto_weights* w, const float* grad_eps, const float* x,
+                                const int64_t* t, int B, int N, int T, const float* rope_cos, const float* rope_sin,
+                                float dropout_p, uint64_t seed, const void* tape, size_t tape_bytes, const ditto_grads* grads,
+                                void* workspace, size_t workspace_bytes, ditto_stream_t stream, const ditto_call_opts* opts,
+                                int layer_from, int layer_to) {
+    if (int rc = check_call_opts(opts)) return rc;
+    CallScope scope(opts);
     if (int rc = check_train(m)) return rc;
+    if (layer_from >= m->cfg.num_layers || layer_to < 0 || layer_from < layer_to)
+        return fail(DITTO_ERR_ARG, "ditto_train_backward_layers: need num_layers > layer_from >= layer_to >= 0");
     if (!w || !grad_eps || !x || !t || !rope_cos || !rope_sin || !tape || !grads || !grads->layers || !workspace ||
         B <= 0 || N <= 0 || T <= 0)
         return fail(DITTO_ERR_ARG, "bad argument to ditto_train_backward");
@@ -451,7 +488,18 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
     const bool fr_dgrad = lt0_has_fr && fr_pays(M) && gemm_fr_supports(M, d, 8 * d, (size_t)8 * d, (size_t)8 * d);
     // du — the gradient wrt a LayerNorm's output, written by a dgrad GEMM and read once by the LayerNorm backward — travels as
     // BF16 (train_flags 8: fp32, A/B): half the bytes on both sides; dh, the stream gradient it is folded into, stays fp32.
-    const bool hb = train_stream_bf16(m, M);   // the tape's h rows are bf16, the self-attention's O sits beside h1
+    // the tape's h rows are bf16 and the self-attention's O sits beside h1 — IF the forward that wrote this tape decided so
+    bool hb = false;
+    {
+        std::lock_guard<std::mutex> lk(m->tape_mu);
+        const auto it = m->tapes.find(tape);
+        if (it == m->tapes.end())
+            return fail(DITTO_ERR_ARG, "ditto_train_backward: no ditto_train_forward of this handle wrote the tape at %p", tape);
+        if (it->second.B != B || it->second.N != N || it->second.T != T)
+            return fail(DITTO_ERR_SHAPE, "ditto_train_backward: the tape was written for (B, N, T) = (%d, %d, %d), not (%d, %d, %d)",
+                        it->second.B, it->second.N, it->second.T, B, N, T);
+        hb = it->second.hb;
+    }
     const bool du_bf16 = !(g_train_flags & 8);
     bool du_is_bf16 = false;   // what the LAST producer of du wrote (the 64-row full-row kernel has no bf16 output)
     auto dgrad_fr = [&](const void* dY, int n_out, const void* WtP, float* out) -> int {
@@ -472,14 +520,18 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
 #define TRY_RC(expr) do { if (int _rc = (expr)) return _rc; } while (0)
 
     // ---- eps = [bf16(x) | bf16(h_L)] Wfin^T + (b_in + b_out)   (src/model/DiTTO.py:83,93-94) ----
+    if (layer_from == L - 1) {   // the head of the backward belongs to the call that starts at the top layer
     HIP_TRY(launch_cast_bf16(grad_eps, dyb, (size_t)M * d, s));
     HIP_TRY(launch_colsum_f32(grad_eps, d, M, d, grads->proj_in_bias, red, s));
     HIP_TRY(hipMemcpyAsync(grads->proj_out_bias, grads->proj_in_bias, (size_t)d * 4, hipMemcpyDeviceToDevice, s));
     TRY_RC(wgrad(dyb, d, d, xcat, 2 * d, d, M, grads->proj_in_weight));
     TRY_RC(wgrad(dyb, d, d, xcat + (size_t)d * 2, 2 * d, d, M, grads->proj_out_weight));
     TRY_RC(dgrad(dyb, d, m->WoutT, d, dh, true));
+    }
 
-    for (int l = L - 1; l >= 0; --l) {
+    // (a call that starts below the top layer continues on the stream gradient dh / its bf16 copy dyb that the call for the layers
+    // above left in the workspace: same workspace, same stream, in order)
+    for (int l = layer_from; l >= layer_to; --l) {
         const LayerPack& lp = m->layers[l];
         const LayerPackT& lt = m->layersT[l];
         const auto& q = tp.layers[l];
@@ -559,6 +611,7 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
         TRY_RC(ln_back(h0, lp.g1, G.norm1_weight, G.norm1_bias, l > 0 ? grads->layers[l - 1].mlp_fc2_bias : nullptr));
     }
 
+    if (layer_to > 0) return DITTO_OK;   // the tail belongs to the call that ends at layer 0
     // ---- GlobalAdaLN (src/components/DiT.py:25-40): h0 = xhat (1 + s_t + s_x) + (b_t + b_x) ----
     // dmod[b] = [sum_n dh xhat | sum_n dh]: the gradient of BOTH branches' (scale, shift) vectors
     HIP_TRY(launch_ln_bwd(dh, x, nullptr, nullptr, dmod, red, N, B, d, s));

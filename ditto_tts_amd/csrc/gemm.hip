@@ -46,6 +46,7 @@ int g_fr64_maxk = [] { const char* e = getenv("DITTO_FR64_MAXK"); return e ? ato
 int g_fr_stagger = [] { const char* e = getenv("DITTO_FR_STAGGER"); return e ? atoi(e) : 0; }();   // off: worth 6 us isolated at 512 tiles, nothing in the model, and a late second workgroup is pure tail when only a few CUs get one
 int g_fr_u_fp8 = 0;
 int g_fr_class_rows = 0;   // kernels.h fr_pays: rows of the unsplit batch whose kernel class every launch takes (0 = its own)
+thread_local CallOpts t_opts = {-1, -1, -1, -1};   // kernels.h: the calling thread's per-call options (-1 = the process default)
 int g_pp_mask = [] { const char* e = getenv("DITTO_PP_MASK"); return e ? atoi(e) : -1; }();   // -1 = built-in rule
 int g_gemm_tile = [] { const char* e = getenv("DITTO_GEMM"); return e ? atoi(e) : 0; }();
 

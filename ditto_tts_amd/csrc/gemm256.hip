@@ -585,8 +585,44 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
                     for (int m = 0; m < 8; ++m) epilogue_row<EPI, true>(p, r0 + m * 16, cb, acc[m], bias4, fq);
                 }
             } else {
+#ifdef DITTO_DIAG_G256_EPI_MFMA   // tools/build_diag.sh ("progressive accumulator release"): what would it cost to run
+                                  // the NEXT tile's K-tile 0 under this epilogue?  After each row block's epilogue the 8 MFMAs that block
+                                  // would issue (4 column blocks x 2 k-steps, fragments from the K-tile 0 that the flat loop already
+                                  // has in LDS buffer 0) go into a spare accumulator block.  TIMING ONLY (the products are discarded):
+                                  // if the epilogue segment does not grow, the matrix pipe is free under it and the restructure
+                                  // could hide one K-tile of twelve; if it grows by what the MFMAs take, there is nothing to win.
+                if constexpr (!FP8) {
+                    read_B(0, IC<0>{});
+                    read_B(0, IC<1>{});
+                    f32x4 dacc[2][4];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) dacc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        epilogue_row<EPI, true>(p, r0 + m * 16, cb, acc[m], bias4, fq);
+                        const char* abase = smem + a_base + (m >> 2) * 64 * 128 + (m & 3) * 16 * 128;
+                        const u32x4 af0 = *reinterpret_cast<const u32x4*>(abase + coff0), af1 = *reinterpret_cast<const u32x4*>(abase + coff1);
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) {
+                            const auto& bf = n < 2 ? fr.b0 : fr.b1;
+                            dacc[m & 1][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf[(n & 1) * 2 + 0]),
+                                                                                   __builtin_bit_cast(bf16x8, af0), dacc[m & 1][n], 0, 0, 0);
+                            dacc[m & 1][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf[(n & 1) * 2 + 1]),
+                                                                                   __builtin_bit_cast(bf16x8, af1), dacc[m & 1][n], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) asm volatile("" ::"v"(dacc[i][n]));
+                } else
+#endif
+                {
 #pragma unroll
                 for (int m = 0; m < 8; ++m) epilogue_row<EPI, true>(p, r0 + m * 16, cb, acc[m], bias4, fq);
+                }
             }
         } else if (cur_m0 + 256 <= p.M && !(p.flags & GF_DIAG_SMALL_OUT)) {
             // interior in M: no per-row guard, so the 8 row blocks are ONE basic block and hipcc interleaves their
@@ -625,10 +661,21 @@ hipError_t launch256_tw(const GemmParams& p, hipStream_t s) {
     hipLaunchKernelGGL((gemm256_kernel<EPI, WIDE, FP8, FLAT>), dim3(p.tile_stride), dim3(512), LDS256_ALLOC, s, p);
     return hipGetLastError();
 }
+// The diagnostic builds of tools/build_diag.sh that knock out or re-route the operand traffic (no DMA, A / W rows forced hot, cache
+// policies) live in the NON-flat stage path: such a build runs the round-3 tile switch for every launch, whatever gemm_flags says,
+// so that it measures the knocked-out kernel and not the production one.
+#if defined(DITTO_DIAG_NODMA) || defined(DITTO_DIAG_G256_AHOT) || defined(DITTO_DIAG_G256_WHOT) || defined(DITTO_G256_A_POLICY) || \
+    defined(DITTO_G256_W_POLICY)
+constexpr bool G256_DIAG_NO_FLAT = true;
+#else
+constexpr bool G256_DIAG_NO_FLAT = false;
+#endif
+
 template <int EPI>
 hipError_t launch256_t(const GemmParams& p, hipStream_t s) {
     if (!(p.flags & GF_WIDE_PHASE)) return launch256_tw<EPI, false, false>(p, s);
     const int nkt = p.K / 64;
+    if constexpr (G256_DIAG_NO_FLAT) return launch256_tw<EPI, true, false>(p, s);
     // flat K loop wherever the K-tile count is even (C2: gated 252.9 -> 248.7 us, QKV 117.5 -> 115.7, step -0.06 .. -0.10 ms at
     // B = 32, -0.02 / -0.05 ms at B = 8 / 16; training step 49.7 -> 48.9 ms: profiles/r04_step_ab_flat2*.txt, r04_train_flat2_ab.txt)
     if (!(p.flags & GF_NO_FLAT_K) && nkt >= 2 && (nkt & 1) == 0) return launch256_tw<EPI, true, false, true>(p, s);
@@ -694,7 +741,7 @@ hipError_t launch_gemm256_fp8(const GemmParams& p_in, GemmEpilogue epi, hipStrea
     p.group_n = pick_group_n(p.tiles_n, p.flags);
     p.stagger_ticks = (int)((p.K / 128 * 1.5 + 8.0) * 100.0 / 4.0);
     const int nkt = p.K / 128;
-    if (!(p.flags & GF_NO_FLAT_K) && nkt >= 2 && (nkt & 1) == 0) {   // flat K loop, as the bf16 launcher
+    if (!G256_DIAG_NO_FLAT && !(p.flags & GF_NO_FLAT_K) && nkt >= 2 && (nkt & 1) == 0) {   // flat K loop, as the bf16 launcher
         switch (epi) {
             case EPI_BIAS_BF16: return launch256_tw<EPI_BIAS_BF16, true, true, true>(p, s);
             case EPI_BIAS_RES_F32: return launch256_tw<EPI_BIAS_RES_F32, true, true, true>(p, s);

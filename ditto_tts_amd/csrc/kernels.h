@@ -82,7 +82,19 @@ extern int g_lnq_ring;   // gemm_lnq.hip: depth of the W register ring in stages
 // class of the WHOLE batch for all of them: ditto_set_option("fr_class_rows", rows of the unsplit batch) makes every
 // launch decide as that batch would (dist.sample_sharded and SpeechGenerator's seeds= path do it), so that sharding
 // changes no bit; 0 (default) = decide on the launch's own rows.  fr_mask 0 gives one class outright.
-extern int g_fr_class_rows;   // gemm.hip
+extern int g_fr_class_rows;   // gemm.hip: the PROCESS default; every reader goes through opt_class_rows()
+// Per-call options (include/ditto_hip.h ditto_call_opts, ABI 9).  The class pin, the residual-stream type, the fused full-row
+// launches and the fused norm2 + q-projection decide WHICH BITS an utterance gets, so they are a property of a CALL, not of the
+// process: an entry point that takes a ditto_call_opts (or runs inside ditto_call_opts_push / _pop of its thread) sees them in this
+// THREAD-LOCAL record; -1 = "the process default" (ditto_set_option).  One C-ABI call runs entirely on its calling thread (it only
+// enqueues), so two threads with different pins do not meet.
+struct CallOpts { int class_rows, resid_bf16, fr_mask, lnq; };
+extern thread_local CallOpts t_opts;       // gemm.hip
+extern int g_fr_mask, g_resid_bf16, g_lnq;
+inline int opt_class_rows() { return t_opts.class_rows >= 0 ? t_opts.class_rows : g_fr_class_rows; }
+inline int opt_fr_mask() { return t_opts.fr_mask >= 0 ? t_opts.fr_mask : g_fr_mask; }
+inline int opt_resid_bf16() { return t_opts.resid_bf16 >= 0 ? t_opts.resid_bf16 : g_resid_bf16; }
+inline int opt_lnq() { return t_opts.lnq >= 0 ? t_opts.lnq : g_lnq; }
 // Which N = 768 full-row kernel a batch of `rows` rows takes, 0 = none (the tiled GEMMs + LayerNorm launches).  Measured in the
 // model at C2 shapes, tools/step_ab.py --batch b with the class pinned (ms per step, unfused / 64-row / 128-row direct):
 //   b = 10: 4.68 / 4.85 / 5.18   11: 5.78 / 5.34 / 5.65   12: 5.78 / 5.37   13: 6.15 / 5.73 / 6.01   14: 6.73 / 6.19 / 6.55
@@ -100,11 +112,11 @@ inline int fr_rule_rows(int rows) {
     if (t64 >= 176 && ((rows + 255) / 256) * 4 != 256) return 64;
     return 0;
 }
-inline bool fr_pays(int M) { return fr_rule_rows(g_fr_class_rows > 0 ? g_fr_class_rows : M) != 0; }
+inline bool fr_pays(int M) { return fr_rule_rows(opt_class_rows() > 0 ? opt_class_rows() : M) != 0; }
 
 // d = 1024 runs the 64-row kernel only (gemm_fr64.hip, one workgroup per CU): it needs three quarters of the CUs busy.
 inline bool fr_pays_64(int M) {
-    const int rows = g_fr_class_rows > 0 ? g_fr_class_rows : M;
+    const int rows = opt_class_rows() > 0 ? opt_class_rows() : M;
     return (rows + 63) / 64 >= 192;
 }
 
@@ -123,7 +135,7 @@ extern int g_fr64_maxk;
 inline int fr_launch_kernel(int M, int K) {
     int k = g_fr_tile;
     if (k == 0) {
-        k = fr_rule_rows(g_fr_class_rows > 0 ? g_fr_class_rows : M);
+        k = fr_rule_rows(opt_class_rows() > 0 ? opt_class_rows() : M);
         if (k == 0) k = 130;
     } else if (k == 64 && K > g_fr64_maxk) {
         k = 130;
@@ -131,7 +143,7 @@ inline int fr_launch_kernel(int M, int K) {
     if (k != 64 && M < 128) k = 64;
     return k;
 }
-extern int g_fr_mask;    // gemm.hip: 1 = cross out-proj + LayerNorm3, 2 = fc2 + next block's LayerNorm1 on the full-row kernel
+// g_fr_mask (declared above): gemm.hip: 1 = cross out-proj + LayerNorm3, 2 = fc2 + next block's LayerNorm1 on the full-row kernel
 // same row map for an fp32 vector (bias)
 hipError_t launch_pack_vec(const float* src, float* dst, int rows, int blk, int mult, int row_off, hipStream_t s);
 hipError_t launch_add_vec(const float* a, const float* b, float* dst, int n, hipStream_t s);

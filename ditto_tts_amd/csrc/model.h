@@ -2,6 +2,8 @@
 // (inference entry points) and ditto_train.hip (training entry points).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/ditto_hip.h"
@@ -58,6 +60,25 @@ void set_wgrad_wgs(int v);   // ditto_train.hip: split-K target of the wgrad GEM
 int get_wgrad_wgs();
 int check_class_pin(int M, int d, bool fp8, bool has_fr);   // ditto_api.hip: a pinned full-row class that this launch cannot take -> error
 
+// ditto_call_opts (ABI 9): validated by check_call_opts, then in force for the length of ONE call through a CallScope on the
+// calling thread (kernels.h t_opts); fields left at -1 inherit what is in force around the call (an enclosing
+// ditto_call_opts_push scope of the thread, else the process default).
+int check_call_opts(const ditto_call_opts* o);
+struct CallScope {
+    CallOpts saved;
+    explicit CallScope(const ditto_call_opts* o) : saved(t_opts) { apply(o); }
+    ~CallScope() { t_opts = saved; }
+    CallScope(const CallScope&) = delete;
+    CallScope& operator=(const CallScope&) = delete;
+    static void apply(const ditto_call_opts* o) {
+        if (!o) return;
+        if (o->class_rows >= 0) t_opts.class_rows = o->class_rows;
+        if (o->residual_bf16 >= 0) t_opts.resid_bf16 = o->residual_bf16;
+        if (o->fr_mask >= 0) t_opts.fr_mask = o->fr_mask;
+        if (o->lnq >= 0) t_opts.lnq = o->lnq;
+    }
+};
+
 }  // namespace ditto
 
 struct ditto_model {
@@ -72,6 +93,11 @@ struct ditto_model {
     // training (ditto_train_attach)
     std::vector<ditto::LayerPackT> layersT;
     const void* WoutT = nullptr;
+    // what ditto_train_forward DECIDED for the tape it wrote (keyed by the tape's address): the backward reads the tape as it was
+    // written, whatever the options say by then (a bf16 tape read as fp32 is garbage gradients without an error)
+    struct TapeRec { int B, N, T; bool hb; };
+    std::mutex tape_mu;
+    std::unordered_map<const void*, TapeRec> tapes;
     // profiling
     bool prof = false;
     struct Rec { hipEvent_t a, b; int kc; };

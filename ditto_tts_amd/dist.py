@@ -98,7 +98,8 @@ def sample_sharded(sample_fn: Callable[[torch.Tensor, torch.Tensor, int], torch.
     `sample_fn(text_full.bfloat16().float(), ...)` — still independent of the world size (every rank, root included,
     computes on the rounded values), but NOT the plain sampler's bits.  x_T and the latents always travel as fp32.
 
-    `pin_class` (GPU shards only): run `sample_fn` under `hip.batch_class(rows of the GLOBAL batch)`, so that every
+    `pin_class` (GPU shards only): run `sample_fn` under `hip.batch_class(rows of the GLOBAL batch)` — since ABI 9 a scope of
+    THIS thread's library calls (ditto_call_opts_push / _pop), not a process-wide switch — so that every
     shard's launches pick the kernel class the unsplit batch would pick (the full-row GEMM sums in another order than
     the tiled one) and the gathered latents are bit-identical at every world size.  A shard too small to take a pinned
     full-row class (fewer than 64 rows per launch) raises instead of silently running another class.
@@ -140,20 +141,142 @@ def sample_sharded(sample_fn: Callable[[torch.Tensor, torch.Tensor, int], torch.
     return full
 
 
+_TWO_PHASE = {}   # backend name -> does it have reduce_scatter_tensor + all_gather_into_tensor (probed on first use)
+
+
+def _two_phase_ok(group=None) -> bool:
+    """Capability, not backend name: RCCL has reduce_scatter_tensor / all_gather_into_tensor, and so does this torch's gloo;
+    a backend without them answers with an exception on the first (tiny) call and falls back to one all_reduce per bucket."""
+    be = dist.get_backend(group)
+    if be not in _TWO_PHASE:
+        world = dist.get_world_size(group)
+        dev = torch.device("cuda", torch.cuda.current_device()) if be == "nccl" else torch.device("cpu")
+        try:
+            flat = torch.zeros(world, dtype=torch.float32, device=dev)
+            shard = torch.empty(1, dtype=torch.float32, device=dev)
+            dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=group)
+            dist.all_gather_into_tensor(flat, shard, group=group)
+            _TWO_PHASE[be] = True
+        except (RuntimeError, NotImplementedError):
+            _TWO_PHASE[be] = False
+    return _TWO_PHASE[be]
+
+
+def _mean_flat_(flat: torch.Tensor, world: int, group=None, two_phase: bool = True):
+    """flat (fp32, numel a multiple of `world`) <- its mean over the group, in place.  two_phase: reduce-scatter (every rank sums
+    1/W of the bucket: on RCCL each peer's slice rides its own xGMI link) + scale + all-gather; else one all_reduce."""
+    if two_phase:
+        shard = torch.empty(flat.numel() // world, dtype=torch.float32, device=flat.device)
+        dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=group)
+        shard.mul_(1.0 / world)
+        dist.all_gather_into_tensor(flat, shard, group=group)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.mul_(1.0 / world)
+
+
+def _mean_bucket_(tensors: List[torch.Tensor], world: int, group=None, two_phase: bool = True):
+    """The tensors of one bucket <- their means over the group (packed into one flat fp32 buffer padded to a multiple of W)."""
+    n = sum(t.numel() for t in tensors)
+    padded = (n + world - 1) // world * world
+    flat = torch.zeros(padded, dtype=torch.float32, device=tensors[0].device)
+    off = 0
+    for t in tensors:
+        flat[off:off + t.numel()].copy_(t.reshape(-1))
+        off += t.numel()
+    _mean_flat_(flat, world, group, two_phase)
+    off = 0
+    for t in tensors:
+        t.copy_(flat[off:off + t.numel()].view_as(t))
+        off += t.numel()
+
+
+class GradSync:
+    """The data-parallel gradient mean of one training step, OVERLAPPED with the backward that produces the gradients.
+
+    The library's backward writes gradients layer by layer, top layer first (ditto_train_backward_layers); `reduce(tensors)` is
+    called with a piece's gradients as soon as that piece is ENQUEUED on the compute stream: the tensors join the open bucket,
+    and a bucket that has reached `bucket_bytes` is exchanged at once — on CUDA on a side stream that waits for an event
+    recorded on the compute stream, so that the reduce-scatter / all-gather of the upper layers runs while the lower layers
+    are still being computed (at W = 8 the 552 MB of DiTTO-S gradients are ~1 GB moved per GPU per step against a ~36 ms
+    backward).  `finish()` exchanges what is left and makes the compute stream wait for the exchange.  Bucket contents depend on
+    the ORDER of the reduce() calls only — a property of the model — so every rank forms the same buckets.  Same arithmetic as
+    allreduce_gradients (reduce-scatter + scale + all-gather per bucket): the means are identical to the un-overlapped call's
+    when the buckets are."""
+
+    def __init__(self, group=None, bucket_bytes: int = 96 << 20, overlap: bool = True, exchange_at_world1: bool = False):
+        """`exchange_at_world1`: run the collectives even in a group of one rank (the mean over one rank is the identity): the
+        whole path — events, side stream, padding, reduce-scatter + all-gather on RCCL — on a single-GPU box (tests)."""
+        self.group, self.bucket_bytes, self.overlap = group, int(bucket_bytes), overlap
+        self.world = dist.get_world_size(group)
+        self.exchange_at_world1 = exchange_at_world1
+        self.two_phase = _two_phase_ok(group) if (self.world > 1 or exchange_at_world1) else True
+        self._open: List[torch.Tensor] = []
+        self._open_bytes = 0
+        self._comm = None
+        self._keep = []            # tensors the side stream still works on
+        self.buckets = 0           # exchanged in the step in progress (reset by finish)
+        self.last_buckets = 0
+
+    def _stream(self, dev):
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(device=dev)
+        return self._comm
+
+    def _flush(self):
+        if not self._open:
+            return
+        ts, self._open, self._open_bytes = self._open, [], 0
+        self.buckets += 1
+        if self.world == 1 and not self.exchange_at_world1:
+            return
+        if ts[0].is_cuda and self.overlap:
+            cur = torch.cuda.current_stream(ts[0].device)
+            comm = self._stream(ts[0].device)
+            ev = torch.cuda.Event()
+            ev.record(cur)                       # everything enqueued so far: these gradients' producers included
+            comm.wait_event(ev)
+            with torch.cuda.stream(comm):
+                _mean_bucket_(ts, self.world, self.group, self.two_phase)
+            for t in ts:
+                t.record_stream(comm)
+            self._keep.append(ts)
+        else:
+            _mean_bucket_(ts, self.world, self.group, self.two_phase)
+
+    def reduce(self, tensors: List[torch.Tensor]):
+        for t in tensors:
+            if t is None:
+                continue
+            self._open.append(t)
+            self._open_bytes += t.numel() * 4
+        if self._open_bytes >= self.bucket_bytes:
+            self._flush()
+
+    def finish(self) -> int:
+        self._flush()
+        if self._comm is not None and self._keep:
+            torch.cuda.current_stream(self._keep[0][0].device).wait_stream(self._comm)
+        self._keep = []
+        self.last_buckets, self.buckets = self.buckets, 0
+        return self.last_buckets
+
+
 def allreduce_gradients(params, bucket_bytes: int = 256 << 20, group=None) -> int:
-    """Average `.grad` of `params` over the data-parallel group, in place; returns the number of buckets.
+    """Average `.grad` of `params` over the data-parallel group, in place, AFTER the backward; returns the number of buckets.
+    (The overlapped form is GradSync, driven from inside the backward: DiTTO.set_grad_sync.)
 
     Gradients are packed into flat fp32 buckets of about `bucket_bytes` (large on purpose: 288 GB of HBM per GPU,
     and per-link-bound xGMI favours few large transfers; the whole DiTTO-S gradient is 552 MB = 3 buckets), each
-    padded to a multiple of the world size.  On backends with reduce_scatter_tensor / all_gather_into_tensor
-    (nccl = RCCL) a bucket is reduced as reduce-scatter + all-gather; elsewhere (gloo) as one all_reduce.  Parameters
-    without a gradient (the dead `attn.out_proj`, frozen codec weights) are skipped — identically on every rank,
-    because which parameters get gradients is a property of the model, not of the data."""
+    padded to a multiple of the world size.  Where the backend has reduce_scatter_tensor / all_gather_into_tensor (RCCL, and
+    this torch's gloo: probed once, by capability) a bucket is reduced as reduce-scatter + all-gather; elsewhere as one
+    all_reduce.  Parameters without a gradient (the dead `attn.out_proj`, frozen codec weights) are skipped — identically on
+    every rank, because which parameters get gradients is a property of the model, not of the data."""
     world = dist.get_world_size(group)
     plist = [p for p in params if p.grad is not None]
     if world == 1 or not plist:
         return 0
-    two_phase = dist.get_backend(group) == "nccl"
+    two_phase = _two_phase_ok(group)
     nb, i = 0, 0
     while i < len(plist):
         chunk, size = [], 0
@@ -161,24 +284,6 @@ def allreduce_gradients(params, bucket_bytes: int = 256 << 20, group=None) -> in
             chunk.append(plist[i])
             size += plist[i].grad.numel() * 4
             i += 1
-        n = sum(p.grad.numel() for p in chunk)
-        padded = (n + world - 1) // world * world
-        flat = torch.zeros(padded, dtype=torch.float32, device=chunk[0].grad.device)
-        off = 0
-        for p in chunk:
-            flat[off:off + p.grad.numel()].copy_(p.grad.reshape(-1))
-            off += p.grad.numel()
-        if two_phase:
-            shard = torch.empty(padded // world, dtype=torch.float32, device=flat.device)
-            dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=group)
-            shard.mul_(1.0 / world)
-            dist.all_gather_into_tensor(flat, shard, group=group)
-        else:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-            flat.mul_(1.0 / world)
-        off = 0
-        for p in chunk:
-            p.grad.copy_(flat[off:off + p.grad.numel()].view_as(p.grad))
-            off += p.grad.numel()
+        _mean_bucket_([p.grad for p in chunk], world, group, two_phase)
         nb += 1
     return nb

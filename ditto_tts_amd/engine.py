@@ -164,8 +164,20 @@ class DenoiseEngine:
             raise ValueError(f"t must have shape [{B}]")
         return t.to(device=self.device, dtype=torch.int64).contiguous()
 
-    def forward(self, x: torch.Tensor, cond: TextCond, t: torch.Tensor, out: Optional[torch.Tensor] = None):
-        """DiTTO.forward(x, text_emb, t) with text_emb pre-digested into `cond` -> eps fp32 [B,N,d]."""
+    def _call(self, name, *args, opts=None):
+        """`name`_opts(*args, opts) — the entry point with this call's ditto_call_opts (None = NULL: every field inherits the
+        thread's scope / the process defaults); a frozen pre-ABI-9 library (DITTO_HIP_LIB: tools/ A/Bs) has only `name`."""
+        if hip._has_call_opts():
+            hip.check(getattr(self.lib, name + "_opts")(*args, None if opts is None else C.byref(opts)))
+        elif opts is not None:
+            raise RuntimeError("per-call options need an ABI-9 libditto_hip.so")
+        else:
+            hip.check(getattr(self.lib, name)(*args))
+
+    def forward(self, x: torch.Tensor, cond: TextCond, t: torch.Tensor, out: Optional[torch.Tensor] = None,
+                opts: Optional[hip.CallOpts] = None):
+        """DiTTO.forward(x, text_emb, t) with text_emb pre-digested into `cond` -> eps fp32 [B,N,d].  `opts`: this call's
+        hip.CallOpts (kernel class pin, residual-stream type ...: include/ditto_hip.h ditto_call_opts)."""
         xf = self._f32(x, "x")
         B, N, d = xf.shape
         if d != self.cfg.hidden_dim or B != cond.B:
@@ -175,13 +187,14 @@ class DenoiseEngine:
             out = torch.empty_like(xf)
         ws = self.workspace(B, N, cond.T)
         c, s = self.rope_tables(N)
-        hip.check(self.lib.ditto_forward(self.handle, xf.data_ptr(), cond.buf.data_ptr(), tt.data_ptr(), B, N, cond.T,
-                                         c.data_ptr(), s.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
-                                         _stream()))
+        self._call("ditto_forward", self.handle, xf.data_ptr(), cond.buf.data_ptr(), tt.data_ptr(), B, N, cond.T,
+                                              c.data_ptr(), s.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                              _stream(), opts=opts)
         return out
 
     def p_sample_(self, x: torch.Tensor, cond: TextCond, t: torch.Tensor, noise: Optional[torch.Tensor],
-                  betas: torch.Tensor, alphas: torch.Tensor, alphas_cumprod: torch.Tensor):
+                  betas: torch.Tensor, alphas: torch.Tensor, alphas_cumprod: torch.Tensor,
+                  opts: Optional[hip.CallOpts] = None):
         """One reverse-diffusion step IN PLACE on the fp32 CUDA state x [B,N,d]."""
         if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()):
             raise ValueError("p_sample_ needs a contiguous fp32 CUDA state tensor (it is updated in place)")
@@ -191,9 +204,9 @@ class DenoiseEngine:
         c, s = self.rope_tables(N)
         if noise is not None:
             noise = self._f32(noise, "noise")
-        hip.check(self.lib.ditto_p_sample(self.handle, x.data_ptr(), cond.buf.data_ptr(), tt.data_ptr(), _ptr(noise),
-                                          betas.data_ptr(), alphas.data_ptr(), alphas_cumprod.data_ptr(), B, N, cond.T,
-                                          c.data_ptr(), s.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+        self._call("ditto_p_sample", self.handle, x.data_ptr(), cond.buf.data_ptr(), tt.data_ptr(), _ptr(noise),
+                                               betas.data_ptr(), alphas.data_ptr(), alphas_cumprod.data_ptr(), B, N, cond.T,
+                                               c.data_ptr(), s.data_ptr(), ws.data_ptr(), ws.numel(), _stream(), opts=opts)
         return x
 
     def noise_normal_(self, out: torch.Tensor, seeds: torch.Tensor, step: int):
@@ -208,7 +221,8 @@ class DenoiseEngine:
         return out
 
     def p_sample_seeded_(self, x: torch.Tensor, cond: TextCond, t: torch.Tensor, seeds: torch.Tensor, step: int,
-                         betas: torch.Tensor, alphas: torch.Tensor, alphas_cumprod: torch.Tensor):
+                         betas: torch.Tensor, alphas: torch.Tensor, alphas_cumprod: torch.Tensor,
+                         opts: Optional[hip.CallOpts] = None):
         """p_sample_ with the step's noise generated inside the update kernel from per-utterance seeds
         (bit-identical to noise_normal_(z, seeds, step) + p_sample_(x, ..., z))."""
         if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()):
@@ -217,14 +231,15 @@ class DenoiseEngine:
         tt, sd = self._t64(t, B), self._t64(seeds, B)
         ws = self.workspace(B, N, cond.T)
         c, s = self.rope_tables(N)
-        hip.check(self.lib.ditto_p_sample_seeded(self.handle, x.data_ptr(), cond.buf.data_ptr(), tt.data_ptr(),
-                                                 sd.data_ptr(), int(step) & 0xFFFFFFFF, betas.data_ptr(),
-                                                 alphas.data_ptr(), alphas_cumprod.data_ptr(), B, N, cond.T, c.data_ptr(),
-                                                 s.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+        self._call("ditto_p_sample_seeded", self.handle, x.data_ptr(), cond.buf.data_ptr(), tt.data_ptr(),
+                                                      sd.data_ptr(), int(step) & 0xFFFFFFFF, betas.data_ptr(),
+                                                      alphas.data_ptr(), alphas_cumprod.data_ptr(), B, N, cond.T, c.data_ptr(),
+                                                      s.data_ptr(), ws.data_ptr(), ws.numel(), _stream(), opts=opts)
         return x
 
     def denoise_steps_(self, x: torch.Tensor, cond: TextCond, t_begin: int, t_end: int, noises: Optional[torch.Tensor],
-                       betas: torch.Tensor, alphas: torch.Tensor, alphas_cumprod: torch.Tensor):
+                       betas: torch.Tensor, alphas: torch.Tensor, alphas_cumprod: torch.Tensor,
+                       opts: Optional[hip.CallOpts] = None):
         """The sampling loop t_begin .. t_end (inclusive, descending) as ONE library call, in place on x;
         noises fp32 [t_begin - t_end + 1, B, N, d] in execution order."""
         if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()):
@@ -238,14 +253,15 @@ class DenoiseEngine:
         ws = self.workspace(B, N, cond.T)
         c, s = self.rope_tables(N)
         tt = torch.empty(B, dtype=torch.int64, device=self.device)
-        hip.check(self.lib.ditto_denoise_steps(self.handle, x.data_ptr(), cond.buf.data_ptr(), int(t_begin), int(t_end),
-                                               _ptr(noises), betas.data_ptr(), alphas.data_ptr(),
-                                               alphas_cumprod.data_ptr(), B, N, cond.T, c.data_ptr(), s.data_ptr(),
-                                               tt.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+        self._call("ditto_denoise_steps", self.handle, x.data_ptr(), cond.buf.data_ptr(), int(t_begin), int(t_end),
+                                                    _ptr(noises), betas.data_ptr(), alphas.data_ptr(),
+                                                    alphas_cumprod.data_ptr(), B, N, cond.T, c.data_ptr(), s.data_ptr(),
+                                                    tt.data_ptr(), ws.data_ptr(), ws.numel(), _stream(), opts=opts)
         return x
 
     def capture_p_sample(self, x: torch.Tensor, cond: TextCond, t: torch.Tensor, noise: torch.Tensor,
-                         betas: torch.Tensor, alphas: torch.Tensor, alphas_cumprod: torch.Tensor):
+                         betas: torch.Tensor, alphas: torch.Tensor, alphas_cumprod: torch.Tensor,
+                         opts: Optional[hip.CallOpts] = None):
         """Capture ONE reverse-diffusion step (the ~122 stream-ordered launches of ditto_p_sample) into a HIP
         graph bound to these exact tensors; returns a StepGraph (which keeps them, the workspace and the
         RoPE tables alive).  Replaying it advances `x` in place using whatever
@@ -260,11 +276,11 @@ class DenoiseEngine:
         B, N, _ = x.shape
         ws = self.workspace(B, N, cond.T)      # allocate outside the capture
         rope = self.rope_tables(N)
-        self.p_sample_(x, cond, t, noise, betas, alphas, alphas_cumprod)   # warm-up (lazy kernel attributes)
+        self.p_sample_(x, cond, t, noise, betas, alphas, alphas_cumprod, opts=opts)   # warm-up (lazy kernel attributes)
         torch.cuda.current_stream().synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self.p_sample_(x, cond, t, noise, betas, alphas, alphas_cumprod)
+            self.p_sample_(x, cond, t, noise, betas, alphas, alphas_cumprod, opts=opts)
         return StepGraph(self, g, (ws, rope, cond.buf, x, t, noise, betas, alphas, alphas_cumprod, self.arena))
 
     def block_forward_(self, layer: int, h: torch.Tensor, cond: TextCond, cond_layer: Optional[int] = None,
@@ -338,8 +354,9 @@ class DenoiseEngine:
     def release_tape(self, tape, B, N, T):
         self._tapes.setdefault((B, N, T), []).append(tape)
 
-    def train_forward(self, x, text_emb, t, dropout_p: float, seed: int):
-        """DiTTO.forward in train mode: returns (eps fp32 [B,N,d], tape)."""
+    def train_forward(self, x, text_emb, t, dropout_p: float, seed: int, opts: Optional[hip.CallOpts] = None):
+        """DiTTO.forward in train mode: returns (eps fp32 [B,N,d], tape).  The library records against the tape how it wrote it
+        (bf16 or fp32 stream rows): train_backward reads it that way whatever the options are by then."""
         if not getattr(self, "_train_attached", False):
             raise RuntimeError("train_attach() has not been called for the current weights")
         xf, text = self._f32(x, "x"), self._f32(text_emb, "text_emb")
@@ -352,14 +369,20 @@ class DenoiseEngine:
         ws = self._train_workspace(B, N, T)
         c, s = self.rope_tables(N)
         out = torch.empty_like(xf)
-        hip.check(self.lib.ditto_train_forward(self.handle, xf.data_ptr(), text.data_ptr(), tt.data_ptr(), B, N, T,
-                                               c.data_ptr(), s.data_ptr(), float(dropout_p), int(seed), out.data_ptr(),
-                                               tape.data_ptr(), tape.numel(), ws.data_ptr(), ws.numel(), _stream()))
+        self._call("ditto_train_forward", self.handle, xf.data_ptr(), text.data_ptr(), tt.data_ptr(), B, N, T,
+                                                    c.data_ptr(), s.data_ptr(), float(dropout_p), int(seed), out.data_ptr(),
+                                                    tape.data_ptr(), tape.numel(), ws.data_ptr(), ws.numel(), _stream(), opts=opts)
         return out, tape, xf, tt
 
     def train_backward(self, state: Mapping[str, torch.Tensor], grad_eps, xf, tt, T: int, tape, dropout_p: float,
-                       seed: int) -> Dict[str, torch.Tensor]:
-        """Backward of train_forward: fp32 gradients keyed by the reference state_dict names (fresh tensors)."""
+                       seed: int, opts: Optional[hip.CallOpts] = None, piece_cb=None,
+                       layers_per_piece: int = 1) -> Dict[str, torch.Tensor]:
+        """Backward of train_forward: fp32 gradients keyed by the reference state_dict names (fresh tensors).
+
+        `piece_cb` (optional): the backward runs in pieces of `layers_per_piece` layers, top layer first
+        (ditto_train_backward_layers: bit-identical to the single call), and after each piece is ENQUEUED piece_cb(list of that
+        piece's gradient tensors) is called — dist.GradSync.reduce starts their data-parallel exchange on a side stream while
+        the layers below are still being computed."""
         B, N, d = xf.shape
         g = self._f32(grad_eps, "grad_output")
         w, keep = self._weights_struct(state)
@@ -380,10 +403,24 @@ class DenoiseEngine:
         gs.layers = layers
         ws = self._train_workspace(B, N, T)
         c, s = self.rope_tables(N)
-        hip.check(self.lib.ditto_train_backward(self.handle, C.byref(w), g.data_ptr(), xf.data_ptr(), tt.data_ptr(), B,
-                                                N, T, c.data_ptr(), s.data_ptr(), float(dropout_p), int(seed),
-                                                tape.data_ptr(), tape.numel(), C.byref(gs), ws.data_ptr(), ws.numel(),
-                                                _stream()))
+        args = (self.handle, C.byref(w), g.data_ptr(), xf.data_ptr(), tt.data_ptr(), B, N, T, c.data_ptr(), s.data_ptr(),
+                float(dropout_p), int(seed), tape.data_ptr(), tape.numel(), C.byref(gs), ws.data_ptr(), ws.numel(), _stream())
+        if piece_cb is None:
+            self._call("ditto_train_backward", *args, opts=opts)
+            return grads
+        head = ("proj_in.weight", "proj_in.bias", "proj_out.weight", "proj_out.bias")     # written by the piece that starts at the top
+        tail = [k for f, k in hip.GLOBAL_KEY.items() if f != "rotary_inv_freq" and k not in head]   # ... that ends at layer 0
+        step = max(int(layers_per_piece), 1)
+        hi = L - 1
+        while hi >= 0:
+            lo = max(hi - step + 1, 0)
+            hip.check(self.lib.ditto_train_backward_layers(*args, None if opts is None else C.byref(opts), hi, lo))
+            piece = [grads[k] for k in head] if hi == L - 1 else []
+            piece += [grads[f"blocks.{l}.{k}"] for l in range(hi, lo - 1, -1) for k in hip.LAYER_KEY.values()]
+            if lo == 0:
+                piece += [grads[k] for k in tail]
+            piece_cb(piece)
+            hi = lo - 1
         return grads
 
     # ------------------------------------------------------------------ profiling (bench.py)

@@ -97,6 +97,20 @@ class SlpWeights(C.Structure):
                 ("length_predictor_bias", C.c_void_p)]
 
 
+class CallOpts(C.Structure):
+    """ditto_call_opts (ABI 9): the per-call switches that decide which bits an utterance gets.  -1 = inherit."""
+    _fields_ = [("class_rows", C.c_int32), ("residual_bf16", C.c_int32), ("fr_mask", C.c_int32), ("lnq", C.c_int32),
+                ("reserved", C.c_int32 * 4)]
+
+    def __init__(self, class_rows=None, residual_bf16=None, fr_mask=None, lnq=None):
+        super().__init__(-1 if class_rows is None else min(int(class_rows), 0x7FFFFFFF),
+                         -1 if residual_bf16 is None else int(residual_bf16),
+                         -1 if fr_mask is None else int(fr_mask), -1 if lnq is None else int(lnq))
+
+    def __repr__(self):
+        return f"CallOpts(class_rows={self.class_rows}, residual_bf16={self.residual_bf16}, fr_mask={self.fr_mask}, lnq={self.lnq})"
+
+
 # ditto_layer_grads / ditto_grads have the layout of the weight structs (one pointer per state_dict key)
 LayerGrads, Grads = LayerWeights, Weights
 
@@ -113,6 +127,10 @@ SYMBOLS = {
     "ditto_rope_tables": (_i, [_vp, _i, _vp, _vp, _vp]),
     "ditto_text_precompute": (_i, [_vp, _vp, _i, _i, _vp, _sz, _vp, _sz, _vp]),
     "ditto_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ditto_forward_opts": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp, C.POINTER(CallOpts)]),
+    "ditto_call_opts_push": (_i, [C.POINTER(CallOpts)]),
+    "ditto_call_opts_pop": (_i, []),
+    "ditto_call_opts_current": (_i, [C.POINTER(CallOpts)]),
     "ditto_block_forward": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "ditto_block_forward_taps": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ditto_global_adaln_scratch_bytes": (_sz, [_i, _i, _i, _i]),
@@ -120,9 +138,14 @@ SYMBOLS = {
     "ditto_apply_rope_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ditto_p_sample_update": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _sz, _vp]),
     "ditto_p_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "ditto_p_sample_opts": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, C.POINTER(CallOpts)]),
     "ditto_denoise_steps": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ditto_denoise_steps_opts": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp,
+                                      C.POINTER(CallOpts)]),
     "ditto_noise_normal": (_i, [_vp, _vp, C.c_uint32, _i, _sz, _vp]),
     "ditto_p_sample_seeded": (_i, [_vp, _vp, _vp, _vp, _vp, C.c_uint32, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "ditto_p_sample_seeded_opts": (_i, [_vp, _vp, _vp, _vp, _vp, C.c_uint32, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp,
+                                        C.POINTER(CallOpts)]),
     "ditto_q_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _sz, _vp]),
     "ditto_layernorm_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "ditto_gemm_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -142,6 +165,12 @@ SYMBOLS = {
     "ditto_train_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _u64, _vp, _vp, _sz, _vp, _sz, _vp]),
     "ditto_train_backward": (_i, [_vp, C.POINTER(Weights), _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _u64, _vp, _sz,
                                   C.POINTER(Grads), _vp, _sz, _vp]),
+    "ditto_train_forward_opts": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _u64, _vp, _vp, _sz, _vp, _sz, _vp,
+                                      C.POINTER(CallOpts)]),
+    "ditto_train_backward_opts": (_i, [_vp, C.POINTER(Weights), _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _u64, _vp, _sz,
+                                       C.POINTER(Grads), _vp, _sz, _vp, C.POINTER(CallOpts)]),
+    "ditto_train_backward_layers": (_i, [_vp, C.POINTER(Weights), _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _u64, _vp, _sz,
+                                         C.POINTER(Grads), _vp, _sz, _vp, C.POINTER(CallOpts), _i, _i]),
     "ditto_layernorm_bwd_scratch_bytes": (_sz, [_i, _i, _i]),
     "ditto_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
     "ditto_attention_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
@@ -164,6 +193,8 @@ SYMBOLS = {
     "ditto_set_option": (_i, [C.c_char_p, _i]),
     "ditto_get_option": (_i, [C.c_char_p, C.POINTER(C.c_int)]),
     "ditto_full_row_plan": (_i, [C.POINTER(Config), _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ditto_full_row_plan_opts": (_i, [C.POINTER(Config), _i, _i, C.POINTER(CallOpts), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                      C.POINTER(C.c_int)]),
     "ditto_profile_enable": (_i, [_vp, _i]),
     "ditto_profile_read": (_i, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     "ditto_kernel_class_name": (C.c_char_p, [_i]),
@@ -194,7 +225,7 @@ def lib() -> C.CDLL:
                     continue
                 raise
             fn.restype, fn.argtypes = res, args
-        if l.ditto_abi_version() != 8 and not (frozen and l.ditto_abi_version() == 7):
+        if l.ditto_abi_version() != 9 and not (frozen and l.ditto_abi_version() in (7, 8)):
             raise RuntimeError("libditto_hip.so ABI version mismatch")
         _lib = l
     return _lib
@@ -217,37 +248,86 @@ def get_option(name: str) -> int:
     return int(v.value)
 
 
-class batch_class:
-    """Context manager: every forward inside decides its kernel class (tiled GEMM + LayerNorm, or the full-row GEMM
-    with the LayerNorm fused: different summation orders, so different last bits) as a batch of `rows` = B x N rows
-    would.  A caller that splits one batch over several launches or GPUs wraps the pieces in
-    `batch_class(rows of the unsplit batch)`: an utterance's bits are then the same however the batch was split
-    (ditto_set_option("fr_class_rows"); dist.sample_sharded and SpeechGenerator's seeds= path use it).  PROCESS-WIDE,
-    like every ditto_set_option switch: it also governs forwards that other threads or streams of this process enqueue
-    meanwhile.  Nests: exit restores the value found on entry.  A launch that cannot take the pinned class (a full-row
-    class with fewer than 64 rows in the launch) raises DittoHipError instead of silently running another class."""
+def _has_call_opts() -> bool:
+    return hasattr(lib(), "ditto_call_opts_push") and lib().ditto_abi_version() >= 9
 
-    def __init__(self, rows: int):
-        self.rows = int(rows)
-        self._prev = 0
+
+class call_opts:
+    """Context manager: the per-call options (class_rows, residual_bf16, fr_mask, lnq) in force for every library call THIS
+    THREAD makes inside the block (ditto_call_opts_push / _pop).  Nothing process-wide changes: other threads and streams keep
+    their own options.  Nests; a field left None inherits the enclosing block, else the process default (set_option)."""
+
+    def __init__(self, class_rows=None, residual_bf16=None, fr_mask=None, lnq=None):
+        self.opts = CallOpts(class_rows, residual_bf16, fr_mask, lnq)
+        self._legacy = None
 
     def __enter__(self):
-        self._prev = get_option("fr_class_rows")
-        set_option("fr_class_rows", min(self.rows, 0x7FFFFFFF))
+        if _has_call_opts():
+            check(lib().ditto_call_opts_push(C.byref(self.opts)))
+        else:   # a frozen pre-ABI-9 library (DITTO_HIP_LIB, tools/ A/Bs): the old process-wide switches
+            names = {"fr_class_rows": self.opts.class_rows, "residual_bf16": self.opts.residual_bf16,
+                     "fr_mask": self.opts.fr_mask, "lnq": self.opts.lnq}
+            self._legacy = {k: get_option(k) for k, v in names.items() if v >= 0}
+            for k, v in names.items():
+                if v >= 0:
+                    set_option(k, v)
         return self
 
     def __exit__(self, *exc):
-        set_option("fr_class_rows", self._prev)
+        if self._legacy is None:
+            check(lib().ditto_call_opts_pop())
+        else:
+            for k, v in self._legacy.items():
+                set_option(k, v)
+            self._legacy = None
         return False
 
 
-def full_row_plan(cfg, B: int, N: int):
+class batch_class(call_opts):
+    """Context manager: every forward THIS THREAD makes inside decides its kernel class (low-latency / tiled GEMM + LayerNorm /
+    full-row GEMM with the LayerNorms fused: different summation orders, so different last bits) as a batch of `rows` = B x N
+    rows would.  A caller that splits one batch over several launches or GPUs wraps the pieces in `batch_class(rows of the
+    unsplit batch)` — or passes CallOpts(class_rows=...) to the engine call itself: an utterance's bits are then the same however
+    the batch was split (dist.sample_sharded and SpeechGenerator's seeds= path do).  Since ABI 9 this is a property of the
+    CALLS, not of the process (ditto_call_opts): no other thread's forwards are affected.  Nests.  A launch that cannot take the
+    pinned class (a full-row class with fewer than 64 rows in the launch) raises DittoHipError instead of silently running
+    another class."""
+
+    def __init__(self, rows: int):
+        super().__init__(class_rows=int(rows))
+        self.rows = int(rows)
+
+
+def current_opts() -> CallOpts:
+    """The options a call made by this thread NOW (without its own CallOpts) would run under, every field resolved."""
+    o = CallOpts()
+    if _has_call_opts():
+        check(lib().ditto_call_opts_current(C.byref(o)))
+    else:
+        o.class_rows, o.residual_bf16 = get_option("fr_class_rows"), get_option("residual_bf16")
+        o.fr_mask, o.lnq = get_option("fr_mask"), get_option("lnq")
+    return o
+
+
+def full_row_plan(cfg, B: int, N: int, opts: "CallOpts | None" = None):
     """(outproj, fc2): which of a block's two fused GEMM + LayerNorm launches a forward over B x N rows takes
-    (ditto_full_row_plan; host arithmetic, no GPU call)."""
+    (ditto_full_row_plan; host arithmetic, no GPU call) under this thread's options, or under `opts`."""
     a, b = C.c_int(0), C.c_int(0)
     c = make_config(cfg)
-    check(lib().ditto_full_row_plan(C.byref(c), B, N, C.byref(a), C.byref(b)))
+    if opts is not None:
+        check(lib().ditto_full_row_plan_opts(C.byref(c), B, N, C.byref(opts), C.byref(a), C.byref(b), None))
+    else:
+        check(lib().ditto_full_row_plan(C.byref(c), B, N, C.byref(a), C.byref(b)))
     return bool(a.value), bool(b.value)
+
+
+def stream_is_bf16(cfg, B: int, N: int, opts: "CallOpts | None" = None) -> bool:
+    """Does a forward of B x N rows carry its residual stream as bf16 (ditto_forward's rule, answered by the library)?"""
+    a, b, h = C.c_int(0), C.c_int(0), C.c_int(0)
+    c = make_config(cfg)
+    check(lib().ditto_full_row_plan_opts(C.byref(c), B, N, C.byref(opts) if opts is not None else None, C.byref(a), C.byref(b),
+                                         C.byref(h)))
+    return bool(h.value)
 
 
 def set_low_latency(on: bool = True):

@@ -51,7 +51,10 @@ class _DiTTOTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, text_emb, t, dropout_p, seed, keys, *params):
         eng = model.engine(x.device, train=True)
-        out, tape, xf, tt = eng.train_forward(x, text_emb.to(x.device), t, dropout_p, seed)
+        # the options in force where forward() is CALLED (a hip.batch_class / hip.call_opts scope of this thread) are this
+        # step's options: autograd runs backward() on its own worker thread, where no such scope exists, so they travel in ctx
+        ctx.opts = hip.current_opts() if hip._has_call_opts() else None
+        out, tape, xf, tt = eng.train_forward(x, text_emb.to(x.device), t, dropout_p, seed, opts=ctx.opts)
         ctx.model, ctx.eng, ctx.tape, ctx.xf, ctx.tt = model, eng, tape, xf, tt
         ctx.T, ctx.dropout_p, ctx.seed, ctx.keys = text_emb.shape[1], dropout_p, seed, keys
         ctx.sig = model._watch.sig
@@ -65,7 +68,12 @@ class _DiTTOTrainFn(torch.autograd.Function):
         if ctx.tape is None:
             raise RuntimeError("backward through the same DiTTO.forward twice (the activation tape was released)")
         sd = {k: v for k, v in model.state_dict(keep_vars=True).items() if not k.startswith("nac.")}
-        grads = eng.train_backward(sd, grad_out, ctx.xf, ctx.tt, ctx.T, ctx.tape, ctx.dropout_p, ctx.seed)
+        sync = getattr(model, "_grad_sync", None)      # dist.GradSync: the gradient exchange overlapped with this backward
+        grads = eng.train_backward(sd, grad_out, ctx.xf, ctx.tt, ctx.T, ctx.tape, ctx.dropout_p, ctx.seed, opts=ctx.opts,
+                                   piece_cb=sync.reduce if sync is not None else None,
+                                   layers_per_piece=getattr(model, "_grad_sync_layers", 1))
+        if sync is not None:
+            sync.finish()                              # the compute stream waits for the exchange: the gradients returned are the means
         B, N, _ = ctx.xf.shape
         eng.release_tape(ctx.tape, B, N, ctx.T)
         ctx.tape = None
@@ -297,6 +305,14 @@ class DiTTO(nn.Module):
             self._engine.train_attach({k: v for k, v in self.state_dict().items() if not k.startswith("nac.")})
             self._train_packed = True
         return self._engine
+
+    def set_grad_sync(self, sync, layers_per_piece: int = 1):
+        """Data-parallel training: `sync` (ditto_tts_amd.dist.GradSync, or None to switch off) receives every piece of the
+        backward's gradients as soon as that piece is enqueued (engine.train_backward piece_cb) and exchanges them on a side
+        stream while the layers below are computed; `loss.backward()` then returns gradients that already are the mean over the
+        data-parallel group — no allreduce_gradients call afterwards.  The reference has no distributed training
+        (src/utils/Trainer.py:16 trains on one device); this is the hook a multi-GPU Trainer would use."""
+        self._grad_sync, self._grad_sync_layers = sync, int(layers_per_piece)
 
     def text_cond(self, text_emb: torch.Tensor, N_hint: int = 1) -> TextCond:
         """Step-invariant text work, cached while the caller keeps passing the same text_emb tensor (the

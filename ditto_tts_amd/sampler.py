@@ -126,7 +126,7 @@ class SpeechGenerator:
         which sums over k in another order).  Default None = the reference's behaviour, torch.randn_like from the global
         generator;
         `batch_class` (optional int): the number of utterances of the UNSPLIT batch this call is a piece of.  The loop
-        then runs under hip.batch_class(batch_class * N), every launch picks the class that batch would pick, and an
+        then passes hip.CallOpts(class_rows = batch_class * N) to every step's call, every launch picks the class that batch would pick, and an
         utterance's latents are the same bits whatever piece or GPU it is sampled on (dist.sample_sharded pins the
         class itself: do not pass it there);
         `use_graph`: replay the step from a HIP graph (default off: measured no gain even at B = 1, the step is
@@ -154,24 +154,24 @@ class SpeechGenerator:
         use_graph = bool(use_graph)
         z = torch.empty_like(x)
         n_loop = self._loop_steps()
-        if batch_class is not None:                 # capture and loop both under the unsplit batch's kernel class
-            from .hip import batch_class as _pin
-            with _pin(int(batch_class) * x.shape[1]):
-                return self.__loop(x, cond, t_tensor, z, use_graph, n_loop, seeds, noises, keep, eng)
-        return self.__loop(x, cond, t_tensor, z, use_graph, n_loop, seeds, noises, keep, eng)
+        opts = None
+        if batch_class is not None:                 # every step of the loop is CALLED with the unsplit batch's kernel class: a
+            from .hip import CallOpts               # per-call argument (ditto_call_opts), nothing process-wide changes
+            opts = CallOpts(class_rows=int(batch_class) * x.shape[1])
+        return self.__loop(x, cond, t_tensor, z, use_graph, n_loop, seeds, noises, keep, eng, opts)
 
-    def __loop(self, x, cond, t_tensor, z, use_graph, n_loop, seeds, noises, keep, eng):
+    def __loop(self, x, cond, t_tensor, z, use_graph, n_loop, seeds, noises, keep, eng, opts=None):
         graph = None
         if use_graph:
             t_tensor.fill_(n_loop - 1)
             keep_x = x.clone()                      # capture runs one warm-up step on x: restore it afterwards
             z.zero_()
-            graph = eng.capture_p_sample(x, cond, t_tensor, z, self.betas, self.alphas, self.alphas_cumprod)
+            graph = eng.capture_p_sample(x, cond, t_tensor, z, self.betas, self.alphas, self.alphas_cumprod, opts=opts)
             x.copy_(keep_x)
         for i, t_val in enumerate(reversed(range(n_loop))):
             t_tensor.fill_(t_val)
             if seeds is not None:
-                eng.p_sample_seeded_(x, cond, t_tensor, seeds, t_val, self.betas, self.alphas, self.alphas_cumprod)
+                eng.p_sample_seeded_(x, cond, t_tensor, seeds, t_val, self.betas, self.alphas, self.alphas_cumprod, opts=opts)
                 if keep is not None and i in keep:
                     keep[i] = x.clone()
                 continue
@@ -182,7 +182,7 @@ class SpeechGenerator:
             if graph is not None:
                 graph.replay()
             else:
-                eng.p_sample_(x, cond, t_tensor, z, self.betas, self.alphas, self.alphas_cumprod)
+                eng.p_sample_(x, cond, t_tensor, z, self.betas, self.alphas, self.alphas_cumprod, opts=opts)
             if keep is not None and i in keep:
                 keep[i] = x.clone()
         return x

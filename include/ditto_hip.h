@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DITTO_ABI_VERSION 8
+#define DITTO_ABI_VERSION 9
 
 typedef enum ditto_status {
     DITTO_OK = 0,
@@ -41,6 +41,25 @@ typedef enum ditto_status {
 
 typedef void* ditto_stream_t;            /* hipStream_t */
 typedef struct ditto_model* ditto_model_t;
+
+/* Per-call options (ABI 9).  Four switches decide WHICH BITS an utterance gets — the kernel class its launch takes, the type of
+ * the residual stream, the fused full-row launches, the fused norm2 + q-projection — so they belong to a CALL, not to the
+ * process: the *_opts entry points take them as an argument, and ditto_call_opts_push / _pop put them in force for every call
+ * the CALLING THREAD makes in between.  Each field: -1 = inherit (the thread's enclosing push scope, else the process default of
+ * ditto_set_option).  A call runs entirely on its calling thread (it only enqueues), so threads with different options do not
+ * interfere; handles stay immutable.
+ *   class_rows    > 0: decide the kernel class as a batch of that many rows (B * N of the UNSPLIT batch) would — what a caller
+ *                 that splits one batch over launches or GPUs passes so that sharding changes no bit ("fr_class_rows");
+ *                 0: the launch's own rows.
+ *   residual_bf16 0 / 1 ("residual_bf16").      fr_mask 0 .. 3 ("fr_mask").      lnq 0 / 16 / 32 ("lnq").
+ *   reserved      must be zero. */
+typedef struct ditto_call_opts {
+    int32_t class_rows;
+    int32_t residual_bf16;
+    int32_t fr_mask;
+    int32_t lnq;
+    int32_t reserved[4];
+} ditto_call_opts;
 
 /* DiTTO.__init__ keyword arguments, reference src/model/DiTTO.py:10-19.
  * Shapes: hidden_dim % 64 == 0 and <= 2048; hidden_dim % num_heads == 0 with an EVEN head_dim (half-split RoPE).  head_dim 64
@@ -133,6 +152,18 @@ int ditto_text_precompute(ditto_model_t m, const float* text, int B, int T, void
 int ditto_forward(ditto_model_t m, const float* x, const void* cond, const int64_t* t, int B, int N, int T,
                   const float* rope_cos, const float* rope_sin, float* eps_out,
                   void* workspace, size_t workspace_bytes, ditto_stream_t stream);
+/* the same call with its options as an argument (opts == NULL: every field inherits) */
+int ditto_forward_opts(ditto_model_t m, const float* x, const void* cond, const int64_t* t, int B, int N, int T,
+                       const float* rope_cos, const float* rope_sin, float* eps_out,
+                       void* workspace, size_t workspace_bytes, ditto_stream_t stream, const ditto_call_opts* opts);
+/* Thread-scoped form for every other entry point (ditto_block_forward*, the unit-test kernels, a caller's own helper that
+ * makes several calls): `opts` are in force for the calls THIS THREAD makes until the matching pop.  Nests (depth <= 16);
+ * fields at -1 inherit the enclosing scope.  ditto_call_opts_pop without a push is an error. */
+int ditto_call_opts_push(const ditto_call_opts* opts);
+int ditto_call_opts_pop(void);
+/* what a call made by this thread NOW, without an opts argument, would run under: every field resolved (scope, else process
+ * default), none -1 */
+int ditto_call_opts_current(ditto_call_opts* out);
 
 /* One DiT block, DiT.forward(x, text_emb, time_emb, rotary_pos) (src/components/DiT.py:100-157), in place on the
  * fp32 residual stream h [B,N,d].  `layer` selects the packed weights, `cond_layer` the K/V slice of `cond`
@@ -176,6 +207,10 @@ int ditto_p_sample(ditto_model_t m, float* x, const void* cond, const int64_t* t
                    const float* betas, const float* alphas, const float* alphas_cumprod,
                    int B, int N, int T, const float* rope_cos, const float* rope_sin,
                    void* workspace, size_t workspace_bytes, ditto_stream_t stream);
+int ditto_p_sample_opts(ditto_model_t m, float* x, const void* cond, const int64_t* t, const float* noise,
+                        const float* betas, const float* alphas, const float* alphas_cumprod,
+                        int B, int N, int T, const float* rope_cos, const float* rope_sin,
+                        void* workspace, size_t workspace_bytes, ditto_stream_t stream, const ditto_call_opts* opts);
 
 /* The sampling loop, SpeechGenerator.__sample_latents (src/model/SpeechGenerator.py:149-164), as ONE stream-ordered
  * enqueue: for t_val = t_begin, t_begin-1, ..., t_end:  x <- p_sample(x, full(B, t_val), cond).  `noise` holds the
@@ -186,6 +221,10 @@ int ditto_denoise_steps(ditto_model_t m, float* x, const void* cond, int t_begin
                         const float* betas, const float* alphas, const float* alphas_cumprod, int B, int N, int T,
                         const float* rope_cos, const float* rope_sin, int64_t* t_scratch, void* workspace,
                         size_t workspace_bytes, ditto_stream_t stream);
+int ditto_denoise_steps_opts(ditto_model_t m, float* x, const void* cond, int t_begin, int t_end, const float* noise,
+                             const float* betas, const float* alphas, const float* alphas_cumprod, int B, int N, int T,
+                             const float* rope_cos, const float* rope_sin, int64_t* t_scratch, void* workspace,
+                             size_t workspace_bytes, ditto_stream_t stream, const ditto_call_opts* opts);
 
 /* Per-utterance counter-based N(0,1) (no reference counterpart: the reference draws `torch.randn_like` from torch's
  * global generator, src/model/SpeechGenerator.py:141,154, a stream that cannot be sharded over GPUs).
@@ -200,6 +239,10 @@ int ditto_p_sample_seeded(ditto_model_t m, float* x, const void* cond, const int
                           uint32_t step, const float* betas, const float* alphas, const float* alphas_cumprod, int B,
                           int N, int T, const float* rope_cos, const float* rope_sin, void* workspace,
                           size_t workspace_bytes, ditto_stream_t stream);
+int ditto_p_sample_seeded_opts(ditto_model_t m, float* x, const void* cond, const int64_t* t, const int64_t* seeds,
+                               uint32_t step, const float* betas, const float* alphas, const float* alphas_cumprod, int B,
+                               int N, int T, const float* rope_cos, const float* rope_sin, void* workspace,
+                               size_t workspace_bytes, ditto_stream_t stream, const ditto_call_opts* opts);
 
 /* DiTTO.q_sample (src/model/DiTTO.py:106-126), bug-for-bug: `buffer` is the module's
  * `alphas_cumprod` buffer, which holds clipped betas.  out may alias x_start. */
@@ -326,6 +369,10 @@ int ditto_get_option(const char* name, int* value);
  * arithmetic only (no GPU call): the full-row kernel addresses its operands with 32-bit byte offsets, so each launch is
  * admitted on the row stride IT reads with (fc2: 4 * hidden_dim). */
 int ditto_full_row_plan(const ditto_config* cfg, int B, int N, int* outproj, int* fc2);
+/* the same question for a call made with `opts` (NULL: as above); *stream_bf16 (may be NULL) = 1 when that forward carries its
+ * residual stream as bf16 (d = 768, head_dim 64, bf16 linears, both fused launches on the 128-row kernel) */
+int ditto_full_row_plan_opts(const ditto_config* cfg, int B, int N, const ditto_call_opts* opts, int* outproj, int* fc2,
+                             int* stream_bf16);
 
 /* ---- either side of the loop -------------------------------------------------------
  * ditto_vq_argmin: VectorQuantizer.forward (src/components/VectorQuantizer.py:22-43): idx[r] = argmin_k
@@ -396,6 +443,28 @@ int ditto_train_backward(ditto_model_t m, const ditto_weights* w, const float* g
                          const int64_t* t, int B, int N, int T, const float* rope_cos, const float* rope_sin,
                          float dropout_p, uint64_t seed, const void* tape, size_t tape_bytes, const ditto_grads* grads,
                          void* workspace, size_t workspace_bytes, ditto_stream_t stream);
+/* The same two calls with their options as an argument.  The forward RECORDS in the handle, against the tape's address, how it
+ * wrote the tape (bf16 or fp32 residual-stream rows); the backward reads the tape as it was written — whatever the options say by
+ * then — and fails (DITTO_ERR_ARG / _SHAPE) on a tape no forward of this handle wrote or one written for another (B, N, T). */
+int ditto_train_forward_opts(ditto_model_t m, const float* x, const float* text, const int64_t* t, int B, int N, int T,
+                             const float* rope_cos, const float* rope_sin, float dropout_p, uint64_t seed, float* eps_out,
+                             void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes, ditto_stream_t stream,
+                             const ditto_call_opts* opts);
+int ditto_train_backward_opts(ditto_model_t m, const ditto_weights* w, const float* grad_eps, const float* x,
+                              const int64_t* t, int B, int N, int T, const float* rope_cos, const float* rope_sin,
+                              float dropout_p, uint64_t seed, const void* tape, size_t tape_bytes, const ditto_grads* grads,
+                              void* workspace, size_t workspace_bytes, ditto_stream_t stream, const ditto_call_opts* opts);
+/* The backward in pieces, for a caller that overlaps the data-parallel gradient exchange with it (ditto_tts_amd/dist.py GradSync:
+ * the reduce-scatter / all-gather of the layers already done runs on another stream while the layers below are computed): this
+ * call runs layers layer_from, layer_from - 1, ..., layer_to (num_layers > layer_from >= layer_to >= 0) and writes THEIR gradients
+ * (grads->layers[l]); the call with layer_from == num_layers - 1 also runs the head (proj_in / proj_out gradients), the call with
+ * layer_to == 0 the tail (GlobalAdaLN, time embedding).  Successive calls, top layer first, on ONE stream with ONE workspace (it
+ * carries the stream gradient between them) are bit-identical to ditto_train_backward, which is the call (num_layers - 1, 0). */
+int ditto_train_backward_layers(ditto_model_t m, const ditto_weights* w, const float* grad_eps, const float* x,
+                                const int64_t* t, int B, int N, int T, const float* rope_cos, const float* rope_sin,
+                                float dropout_p, uint64_t seed, const void* tape, size_t tape_bytes, const ditto_grads* grads,
+                                void* workspace, size_t workspace_bytes, ditto_stream_t stream, const ditto_call_opts* opts,
+                                int layer_from, int layer_to);
 /* building blocks of the backward, exported for unit parity tests:
  * ditto_layernorm_bwd: dx_accum fp32 [M,d] += LN'(dy); dgamma_dbeta fp32 [groups, 2d] (rows_per_group * groups = M;
  *   gamma may be NULL = ones; dx_accum or dgamma_dbeta may be NULL); scratch >= ditto_layernorm_bwd_scratch_bytes.

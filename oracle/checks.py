@@ -6,7 +6,7 @@ train_grad_parity — SURVEY.md §8f row 1 at the TIMED model dimensions.  The C
 kernels which the small-shape gradient tests never reach: d = 768 / 12 heads of 64 (whole 64-row attention tiles, the fused
 attention backward with the rotation in its epilogues), the full-row forward GEMMs with the fused LayerNorms, the long-K
 dgrads on the full-row kernel and the 256 x 256 weight-gradient tiles with the XCD map.  This check builds a 2-layer model
-of exactly those widths, pins the kernel class to the timed batch (32 x 1024 rows: ditto_set_option("fr_class_rows")), runs
+of exactly those widths, pins the kernel class to the timed batch (32 x 1024 rows: hip.call_opts(class_rows=...), ditto_call_opts), runs
 the reference's training closure (src/TrainDiTTO.py:85-91: model.train() -> forward -> MSE -> backward; cross-attention
 dropout p = 0.1 active, src/components/DiT.py:90-91) and compares EVERY parameter gradient with fp32 autograd over the
 oracle, whose dropout mask is the restated counter hash (hash_dropout_mask)."""
@@ -54,17 +54,13 @@ def train_grad_parity(dev="cuda", train_mode=True, pin_class=True, seed=21, shap
     m = m.to(dev)
     m = m.train() if train_mode else m.eval()
     plan = None
-    if pin_class:
-        hip.set_option("fr_class_rows", s["class_rows"])
-    try:
+    # the class pin is a scope of THIS thread's calls; the autograd Function carries it to the backward (run on autograd's thread)
+    with hip.call_opts(class_rows=s["class_rows"] if pin_class else None):
         plan = hip.full_row_plan(cfg, B, N)
         torch.manual_seed(1000 + seed)
         out = m(x.to(dev), text.to(dev), t.to(dev))
         loss = F.mse_loss(out, target.to(dev))
-        loss.backward()
-    finally:
-        if pin_class:
-            hip.set_option("fr_class_rows", 0)
+    loss.backward()       # outside the scope on purpose
     rels, missing = [], []
     for name, prm in m.named_parameters():
         w = sd[name].grad

@@ -25,7 +25,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, n), f"{n} declared in ditto_hip.h but not exported by libditto_hip.so"
         assert n in hip.SYMBOLS, f"{n} has no ctypes prototype in ditto_tts_amd/hip.py"
     assert sorted(hip.SYMBOLS) == names
-    assert lib.ditto_abi_version() == 8
+    assert lib.ditto_abi_version() == 9
 
 
 def test_struct_layout_matches_header():
@@ -33,6 +33,7 @@ def test_struct_layout_matches_header():
     assert C.sizeof(hip.Config) == 28
     assert C.sizeof(hip.LayerWeights) == 18 * 8
     assert C.sizeof(hip.Weights) == 15 * 8
+    assert C.sizeof(hip.CallOpts) == 32
 
 
 def test_size_queries_and_errors():
@@ -133,3 +134,66 @@ def test_full_row_plan_is_judged_per_launch_and_pinnable():
     assert hip.full_row_plan(c5b, 11, 1024) == (False, False)
     with pytest.raises(hip.DittoHipError):
         hip.set_option("fr_class_rows", -1)
+
+
+def test_call_options_are_per_call_and_per_thread():
+    """ABI 9: the switches that decide which bits an utterance gets — kernel class pin, residual-stream
+    type, fused launches — are a ditto_call_opts ARGUMENT or a scope of the CALLING THREAD (ditto_call_opts_push / _pop), not
+    process state: a second thread never sees the first one's pin, nesting restores, fields at -1 inherit, bad values and an
+    unbalanced pop are errors.  Host arithmetic only (ditto_full_row_plan_opts / ditto_call_opts_current): no GPU call."""
+    import threading
+    cfg = PRESETS["C2"]["cfg"]
+    base = hip.current_opts()
+    assert (base.class_rows, base.residual_bf16, base.fr_mask, base.lnq) == (0, 1, 3, 32)
+    # per-call argument: the same question, two answers, no state in between
+    assert hip.full_row_plan(cfg, 16, 1024) == (False, False)
+    assert hip.full_row_plan(cfg, 16, 1024, hip.CallOpts(class_rows=32 * 1024)) == (True, True)
+    assert hip.full_row_plan(cfg, 32, 1024, hip.CallOpts(fr_mask=1)) == (True, False)
+    assert hip.full_row_plan(cfg, 16, 1024) == (False, False)
+    assert hip.stream_is_bf16(cfg, 32, 1024) and not hip.stream_is_bf16(cfg, 32, 1024, hip.CallOpts(residual_bf16=0))
+    assert not hip.stream_is_bf16(cfg, 16, 1024) and hip.stream_is_bf16(cfg, 16, 1024, hip.CallOpts(class_rows=32 * 1024))
+    assert not hip.stream_is_bf16(cfg, 12, 1024)      # the 64-row full-row kernel's batches keep the fp32 stream
+    # thread scope: nests, inherits, restores; another thread is untouched while this one is inside its scope
+    seen = {}
+    inside, done = threading.Event(), threading.Event()
+
+    def other():
+        inside.wait(10)
+        seen["other"] = (hip.current_opts().class_rows, hip.full_row_plan(cfg, 16, 1024))
+        with hip.batch_class(777):
+            seen["other_in"] = hip.current_opts().class_rows
+        done.set()
+
+    th = threading.Thread(target=other)
+    th.start()
+    with hip.call_opts(class_rows=32 * 1024, residual_bf16=0):
+        inside.set()
+        assert done.wait(10)
+        o = hip.current_opts()
+        assert (o.class_rows, o.residual_bf16, o.fr_mask) == (32 * 1024, 0, 3)
+        with hip.call_opts(fr_mask=2):                    # class_rows and residual_bf16 inherit the enclosing scope
+            o = hip.current_opts()
+            assert (o.class_rows, o.residual_bf16, o.fr_mask) == (32 * 1024, 0, 2)
+            assert hip.full_row_plan(cfg, 16, 1024) == (False, True)
+        assert hip.current_opts().fr_mask == 3
+        assert hip.get_option("fr_class_rows") == 0 and hip.get_option("residual_bf16") == 1   # the process defaults never moved
+    th.join()
+    assert seen == {"other": (0, (False, False)), "other_in": 777}
+    assert hip.current_opts().class_rows == 0
+    # validation
+    import ctypes as C
+    lib = hip.lib()
+    bad = hip.CallOpts(); bad.lnq = 7
+    assert lib.ditto_call_opts_push(C.byref(bad)) == hip.ERR_ARG
+    bad = hip.CallOpts(); bad.reserved[2] = 1
+    assert lib.ditto_call_opts_push(C.byref(bad)) == hip.ERR_ARG
+    bad = hip.CallOpts(); bad.class_rows = -5
+    a, b = C.c_int(), C.c_int()
+    c = hip.make_config(cfg)
+    assert lib.ditto_full_row_plan_opts(C.byref(c), 1, 64, C.byref(bad), C.byref(a), C.byref(b), None) == hip.ERR_ARG
+    assert lib.ditto_call_opts_pop() == hip.ERR_ARG and b"without a matching push" in lib.ditto_last_error()
+    for _ in range(16):
+        assert lib.ditto_call_opts_push(None) == hip.OK
+    assert lib.ditto_call_opts_push(None) == hip.ERR_ARG          # depth limit
+    for _ in range(16):
+        assert lib.ditto_call_opts_pop() == hip.OK

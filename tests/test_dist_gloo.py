@@ -13,7 +13,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from ditto_tts_amd.config import DiTTOConfig
-from ditto_tts_amd.dist import allreduce_gradients, gather_batch, sample_sharded, scatter_batch, shard_bounds
+from ditto_tts_amd.dist import (GradSync, _two_phase_ok, allreduce_gradients, gather_batch, sample_sharded, scatter_batch,
+                                 shard_bounds)
 from ditto_tts_amd.synth import hash_normal, synthetic_state_dict
 
 CFG = DiTTOConfig(64, 1, 1, 32, 64, 4)
@@ -111,9 +112,23 @@ def _grad_worker(rank, world, port, q):
         for i, p in enumerate(ps):
             if i != 3:                                   # one parameter without a gradient (like attn.out_proj)
                 p.grad = hash_normal(tuple(p.shape), f"g{i}", rank)
+        two_phase = _two_phase_ok()                      # the branch is chosen by CAPABILITY: this torch's gloo has both collectives,
         nb = allreduce_gradients(ps, bucket_bytes=160)   # tiny buckets: forces several, with world-size padding
+        # the same gradients through the OVERLAPPED form: pieces arrive in backward order (top layer first), a bucket is
+        # exchanged as soon as it is full, finish() takes the rest
+        qs = [torch.nn.Parameter(torch.zeros(s)) for s in ((7, 5), (3,), (11, 2), (4,))]
+        gs = [hash_normal(tuple(p.shape), f"g{i}", rank) if i != 3 else None for i, p in enumerate(qs)]
+        sync = GradSync(bucket_bytes=100)
+        sync.reduce([gs[2], gs[3]])                      # (a None in a piece is skipped, like a parameter without a gradient)
+        sync.reduce([gs[1]])
+        sync.reduce([gs[0]])
+        nb2 = sync.finish()
+        # the one-all_reduce fallback of a backend without the two collectives must give the same means
+        from ditto_tts_amd.dist import _mean_bucket_
+        fb = [hash_normal(tuple(p.shape), f"g{i}", rank) for i, p in enumerate(ps) if i != 3]
+        _mean_bucket_(fb, world, None, two_phase=False)
         if rank == 0:
-            q.put((nb, [None if p.grad is None else p.grad.clone() for p in ps]))
+            q.put((nb, [None if p.grad is None else p.grad.clone() for p in ps], two_phase, nb2, gs, fb))
     finally:
         dist.destroy_process_group()
 
@@ -121,8 +136,16 @@ def _grad_worker(rank, world, port, q):
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("world", [2, 4])
 def test_gradient_allreduce_is_the_mean_over_ranks(world):
-    nb, got = _spawn(_grad_worker, world)
-    assert nb >= 2 and got[3] is None
+    """allreduce_gradients (after the backward) and GradSync (overlapped with it: VERDICT r4 item 7) on the reduce-scatter +
+    all-gather branch — the one RCCL takes — at world 2 and 4: padding to a multiple of W (35 + 3 + 22 elements in buckets of
+    40 / 25 floats), bucket boundaries, the 1/W scale; and the all_reduce fallback gives the same means."""
+    nb, got, two_phase, nb2, sync_got, fb = _spawn(_grad_worker, world)
+    assert two_phase, "this torch's gloo was expected to have reduce_scatter_tensor / all_gather_into_tensor"
+    assert nb >= 2 and got[3] is None and nb2 >= 2 and sync_got[3] is None
+    k = 0
     for i, shape in enumerate(((7, 5), (3,), (11, 2))):
         want = sum(hash_normal(shape, f"g{i}", r) for r in range(world)) / world
         assert torch.allclose(got[i], want, rtol=0, atol=1e-6)
+        assert torch.allclose(sync_got[i], want, rtol=0, atol=1e-6)
+        assert torch.allclose(fb[k], want, rtol=0, atol=1e-6)
+        k += 1

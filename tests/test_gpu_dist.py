@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 
 from ditto_tts_amd.config import DiTTOConfig
-from ditto_tts_amd.dist import allreduce_gradients, gather_batch, sample_sharded, scatter_batch
+from ditto_tts_amd.dist import GradSync, allreduce_gradients, gather_batch, sample_sharded, scatter_batch
 from ditto_tts_amd.modules import DiTTO
 from ditto_tts_amd.sampler import SpeechGenerator
 from ditto_tts_amd.synth import hash_normal, synthetic_state_dict
@@ -60,15 +60,17 @@ def test_sharded_sampling_on_rccl_equals_direct(rccl_world1):
 
 @torch.no_grad()
 def test_pinned_class_restores_and_refuses_what_it_cannot_honour(rccl_world1):
-    """hip.batch_class nests (exit restores the value found on entry) and a launch that cannot take a pinned full-row class —
-    fewer rows than one 64-row tile — raises instead of silently running the tiled kernels (whose bits differ)."""
+    """hip.batch_class nests (exit restores what was in force on entry) WITHOUT touching the process-wide switch (ABI 9: the
+    pin is a property of this thread's calls), and a launch that cannot take a pinned full-row class — fewer rows than one
+    64-row tile — raises instead of silently running the tiled kernels (whose bits differ)."""
     from ditto_tts_amd import hip
-    assert hip.get_option("fr_class_rows") == 0
+    assert hip.get_option("fr_class_rows") == 0 and hip.current_opts().class_rows == 0
     with hip.batch_class(32768):
         with hip.batch_class(512):
-            assert hip.get_option("fr_class_rows") == 512
-        assert hip.get_option("fr_class_rows") == 32768
-    assert hip.get_option("fr_class_rows") == 0
+            assert hip.current_opts().class_rows == 512
+        assert hip.current_opts().class_rows == 32768
+        assert hip.get_option("fr_class_rows") == 0       # nothing process-wide moved
+    assert hip.current_opts().class_rows == 0
     cfg = DiTTOConfig(768, 1, 12, 64, 768, 6)
     m = DiTTO(768, 1, 12, 64, 768, 6)
     m.load_state_dict(synthetic_state_dict(cfg, 3))
@@ -96,6 +98,46 @@ def test_gradient_bucket_path_on_rccl(rccl_world1):
     out = torch.empty(8, device=DEV)
     dist.all_gather_into_tensor(out, shard)
     assert torch.equal(out, flat)
+
+
+def test_overlapped_gradient_exchange_on_rccl(rccl_world1):
+    """dist.GradSync through DiTTO.set_grad_sync on the real backend (the reduce-scatter + all-gather branch had
+    never executed on RCCL): the backward runs in layer pieces, each piece's bucket is exchanged on a side stream behind an event
+    while the next piece computes, finish() joins the streams.  World size 1, `exchange_at_world1` — the mean over one rank is the
+    identity, so every gradient must equal the plain backward's BIT FOR BIT, through padding (buckets of 1 MiB over tensors of
+    odd sizes), the 1/W scale and the copy back."""
+    import torch.nn.functional as F
+    from ditto_tts_amd.synth import synthetic_inputs
+    cfg = DiTTOConfig(256, 4, 4, 64, 256, 20)
+    x, text, t = (z.to(DEV) for z in synthetic_inputs(cfg, 2, 128, 48, seed=41))
+    target = hash_normal((2, 128, 256), "noise", 42).to(DEV)
+
+    def grads(sync, per_piece=1):
+        m = DiTTO(256, 4, 4, 64, 256, 20)
+        m.load_state_dict(synthetic_state_dict(cfg, 5))
+        m = m.to(DEV).eval()
+        m.set_grad_sync(sync, layers_per_piece=per_piece)
+        F.mse_loss(m(x, text, t), target).backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    plain = grads(None)
+    for per_piece, bucket in ((1, 1 << 20), (2, 3 << 20), (4, 1 << 30)):
+        sync = GradSync(bucket_bytes=bucket, exchange_at_world1=True)
+        assert sync.two_phase
+        got = grads(sync, per_piece)
+        assert sync.last_buckets >= 1 and (bucket > (1 << 20) or sync.last_buckets >= 3)
+        assert got.keys() == plain.keys()
+        for n, g in plain.items():
+            assert torch.equal(got[n], g), (per_piece, bucket, n)
+    # the post-hoc form on the same backend: a forced exchange at world 1 leaves the gradients untouched too
+    ps = [torch.nn.Parameter(torch.zeros(5, 7, device=DEV)), torch.nn.Parameter(torch.zeros(3, device=DEV))]
+    for i, p in enumerate(ps):
+        p.grad = hash_normal(tuple(p.shape), f"g{i}", 1).to(DEV)
+    before = [p.grad.clone() for p in ps]
+    s2 = GradSync(bucket_bytes=64, overlap=False, exchange_at_world1=True)
+    s2.reduce([ps[0].grad]); s2.reduce([ps[1].grad])
+    assert s2.finish() == 2 and all(torch.equal(p.grad, b) for p, b in zip(ps, before))
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -449,3 +449,81 @@ def test_training_surface_contract():
     m3 = _build(cfg, 1).eval()
     m3(x * 0.5, text, t).square().mean().backward()
     assert torch.allclose(m2.proj_out.weight.grad, g1 + m3.proj_out.weight.grad, rtol=1e-5, atol=1e-7)
+
+
+def test_backward_reads_the_tape_as_the_forward_wrote_it():
+    """the tape's residual-stream rows are bf16 or fp32 by a decision the FORWARD takes from the options in
+    force around it; the backward used to take the same decision again from whatever the options were by then, and a change in
+    between (`with hip.batch_class(rows): out = m(x)` ... `loss.backward()` outside, on autograd's own thread) read a bf16 tape
+    as fp32: garbage gradients, no error.  Now the forward records its decision against the tape (ditto_model::tapes) and the
+    autograd Function carries the forward's options to the backward: the gradients are the SAME BITS whether the scope is
+    still open at backward time or not, whether process-wide switches moved in between or not."""
+    cfg = DiTTOConfig(768, 2, 12, 256, 768, 50)
+    B, N, T = 2, 256, 192
+    x, text, t = (z.to(DEV) for z in synthetic_inputs(cfg, B, N, T, seed=21))
+    target = hash_normal((B, N, 768), "noise", 22).to(DEV)
+
+    def run(close_scope_first, meddle):
+        m = _build(cfg, 15).eval()
+        scope = hip.batch_class(32 * 1024)
+        scope.__enter__()
+        try:
+            assert hip.stream_is_bf16(cfg, B, N)                  # the pinned class carries the bf16 stream (and tape)
+            loss = F.mse_loss(m(x, text, t), target)
+        finally:
+            if close_scope_first:
+                scope.__exit__(None, None, None)
+        try:
+            if meddle:                                            # process-wide switches that used to re-decide the tape's type
+                hip.set_option("train_flags", 16)
+                hip.set_option("residual_bf16", 0)
+            loss.backward()
+        finally:
+            hip.set_option("train_flags", 0)
+            hip.set_option("residual_bf16", 1)
+            if not close_scope_first:
+                scope.__exit__(None, None, None)
+        return {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    ref = run(False, False)
+    for variant in ((True, False), (True, True)):
+        got = run(*variant)
+        assert got.keys() == ref.keys()
+        for n, g in ref.items():
+            assert torch.isfinite(got[n]).all(), (variant, n)
+            assert torch.equal(got[n], g), (variant, n, rel_l2(got[n], g))
+    # ... and the C-ABI refuses a tape no forward of the handle wrote, or one written for another shape
+    m = _build(cfg, 15).eval()
+    eng = m.engine(DEV, train=True)
+    sd = {k: v for k, v in m.state_dict(keep_vars=True).items() if not k.startswith("nac.")}
+    out, tape, xf, tt = eng.train_forward(x, text, t, 0.0, 0)
+    stray = torch.empty_like(tape)
+    with pytest.raises(hip.DittoHipError, match="no ditto_train_forward of this handle wrote the tape"):
+        eng.train_backward(sd, torch.ones_like(out), xf, tt, T, stray, 0.0, 0)
+    with pytest.raises(hip.DittoHipError, match="written for"):
+        eng.train_backward(sd, torch.ones_like(out)[:1], xf[:1].contiguous(), tt[:1].contiguous(), T, tape, 0.0, 0)
+
+
+@pytest.mark.parametrize("per_piece", [1, 2, 5])
+def test_backward_in_layer_pieces_is_bitwise_the_single_call(per_piece):
+    """ditto_train_backward_layers (the backward as successive calls over layer ranges, top first: what lets the data-parallel
+    gradient exchange of the upper layers overlap the computation of the lower ones, dist.GradSync) == ditto_train_backward, bit
+    for bit, for every piece size; the callback sees every gradient tensor exactly once, in backward order."""
+    cfg = DiTTOConfig(256, 5, 4, 64, 256, 20)
+    B, N, T = 2, 96, 40
+    x, text, t = (z.to(DEV) for z in synthetic_inputs(cfg, B, N, T, seed=31))
+    m = _build(cfg, 17).train()
+    eng = m.engine(DEV, train=True)
+    sd = {k: v for k, v in m.state_dict(keep_vars=True).items() if not k.startswith("nac.")}
+    gout = hash_normal((B, N, 256), "gout", 32).to(DEV)
+    out, tape, xf, tt = eng.train_forward(x, text, t, 0.1, 1234)
+    whole = eng.train_backward(sd, gout, xf, tt, T, tape, 0.1, 1234)
+    seen = []
+    pieces = eng.train_backward(sd, gout, xf, tt, T, tape, 0.1, 1234, piece_cb=lambda ts: seen.append([z.data_ptr() for z in ts]),
+                                layers_per_piece=per_piece)
+    assert len(seen) == -(-5 // per_piece)
+    flat = [p for piece in seen for p in piece]
+    assert sorted(flat) == sorted(g.data_ptr() for g in pieces.values()) and len(set(flat)) == len(flat)
+    assert seen[0][0] == pieces["proj_in.weight"].data_ptr() and seen[-1][-1] == pieces["ada_ln.text_mlp.1.bias"].data_ptr()
+    for k, g in whole.items():
+        assert torch.equal(pieces[k], g), k
