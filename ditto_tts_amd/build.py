@@ -22,13 +22,15 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # instructions occupy the matrix pipe (a lone wave showed zero MFMA / vector overlap: removing the 24 MFMAs of a tile saved
 # exactly 24 x 32 cycles); scalar v_sub / v_mul issue beside the MFMAs.
 EXTRA = {"attention.hip": ["-fno-honor-nans"], "attention_v4.hip": ["-fno-honor-nans"],
-         "attention_bwd.hip": ["-fno-slp-vectorize"], "attention_train.hip": ["-fno-honor-nans", "-fno-slp-vectorize"]}
+         "attention_bwd.hip": ["-fno-slp-vectorize"], "attention_train.hip": ["-fno-honor-nans", "-fno-slp-vectorize"],
+         "attention_w4.hip": ["-fno-honor-nans", "-fno-slp-vectorize"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC,
          "-Wall", "-Wno-unused-function"]
 
 
 # csrc/experimental/: opt-in A/B kernels that no dispatch rule selects (attention_v4.hip: attention at one wave per SIMD;
-# gemm_o3.hip: three GEMM workgroups per CU — both measured slower than the shipped kernels).  They are
+# attention_w4.hip: at four; gemm_o3.hip: three GEMM workgroups per CU; gemm_fr128.hip: the full-row GEMM with its weights through
+# an LDS ring — all measured slower than or equal to the shipped kernels).  They are
 # compiled only with DITTO_EXPERIMENTAL=1 in the environment (every file then sees -DDITTO_EXPERIMENTAL and the dispatchers
 # accept gemm_tile 130 / attn_flags 4096); the default library neither contains nor pays for them.
 EXPERIMENTAL = os.environ.get("DITTO_EXPERIMENTAL", "0") not in ("", "0")

@@ -37,7 +37,8 @@ namespace ditto {
 // on small grids; bit 8 (256): never attn64v3 (the software-pipelined kernel), bit 9 (512): attn64v3 wherever Skv % 128 == 0; bit 10 (1024): its 8-wave (256 queries per
 // workgroup) form always, bit 11 (2048): never; bit 12 (4096): attn64v4 (attention_v4.hip: one wave per SIMD, 64 queries per wave)
 // wherever Skv % 64 == 0; bit 13 (8192): the training forward on the older kernel (attn64_kernel<.., TRAIN>) instead of attn64v2's
-// TRAIN instantiations (attention_train.hip) — A/B only.
+// TRAIN instantiations (attention_train.hip) — A/B only; bit 14 (16384): attn64w4 (four waves per SIMD, attention_w4.hip) on large
+// grids, bit 15 (32768): attn64w4 whatever the grid (unit tests).
 // ditto_set_option("attn_flags")
 int g_attn_flags = 3;
 
@@ -707,12 +708,28 @@ hipError_t launch_rope_inplace(void* x, int ld, const float* cs, const float* sn
     return hipGetLastError();
 }
 
+#ifdef DITTO_DIAG_A2_STAMP
+}  // namespace ditto
+extern "C" int ditto_diag_a2_stamps(unsigned long long* out) {   // out[8]: sums over the waves of the LAST launches (diagnostic build only)
+    static unsigned long long host[ditto::A2_STAMP_WAVES * 8];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(ditto::g_a2_stamps), sizeof(host)) != hipSuccess) return 1;
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    for (int w = 0; w < ditto::A2_STAMP_WAVES; ++w)
+        for (int i = 0; i < 8; ++i) out[i] += host[(size_t)w * 8 + i];
+    return 0;
+}
+namespace ditto {
+#endif
+
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     if (a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Skv <= 0) return hipErrorInvalidValue;
     const float LOG2E = 1.4426950408889634f;
     if (a.causal && a.dropout_p > 0.f) return hipErrorInvalidValue;   // no caller: the decoder stack runs in eval mode
-    if (a.resid_bf16 && (a.dh != DH || a.force_generic || a.causal || (g_attn_flags & 8192)))
-        return hipErrorInvalidValue;                                   // the bf16 stream exists on the fused head_dim-64 kernels only
+    // the bf16 stream exists on the fused head_dim-64 kernels only; attn_flags 8192 (the older TRAINING-forward kernel, an A/B bit)
+    // concerns the training forward alone: it must not make the default inference forward fail
+    const bool train_fwd = a.lse_out != nullptr || a.dropout_p > 0.f;
+    if (a.resid_bf16 && (a.dh != DH || a.force_generic || a.causal || (train_fwd && (g_attn_flags & 8192))))
+        return hipErrorInvalidValue;
     if (a.dh == DH && !a.force_generic && !a.causal) {
         if ((a.ldq | a.ldk | a.ldv) % 8) return hipErrorInvalidValue;
         AttnParams p;
@@ -772,6 +789,13 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
             // tools/step_ab.py): 138 / 127 us (self / cross) against 159 / 141 us at 2 waves per SIMD with the
             // prefetch, and 150 / 140 us for attn64 — the kernel is latency-bound (SQ counters: VALU issue 53 %,
             // MFMA 28 %, both idle 34 % of the time at 2 waves), so occupancy pays more than the prefetch.
+            // four waves per SIMD (attn64w4, round 5; csrc/experimental/attention_w4.hip, DITTO_EXPERIMENTAL builds): attn_flags
+            // 16384 = wherever the grid is large, 32768 = always (unit tests).  Measured equal to attn64v2 (134.2 / 136.6 us isolated,
+            // 128.4 / 127.6 self and 124.7 / 125.4 cross in the model, profiles/r05_w4_ab.txt): no rule selects it.
+#ifdef DITTO_EXPERIMENTAL
+            if (((g_attn_flags & 16384) && (int)gridv.x > 320) || (g_attn_flags & 32768))
+                return launch_attn64w4(p, a.resid_f32 != nullptr, s);
+#endif
             if (!(g_attn_flags & 64)) {
                 // small grid (at most ~1 workgroup per CU): the deep-prefetch instantiation (attn_flags 128 disables)
                 if ((int)gridv.x <= 320 && !(g_attn_flags & 128)) {

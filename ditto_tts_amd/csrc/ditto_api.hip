@@ -1127,8 +1127,9 @@ int ditto_get_option(const char* name, int* value) {
 int ditto_set_option(const char* name, int value) {
     if (!name) return fail(DITTO_ERR_ARG, "null option name");
 #ifndef DITTO_EXPERIMENTAL
-    if ((!strcmp(name, "gemm_tile") && value == 130) || (!strcmp(name, "attn_flags") && (value & 4096)))
-        return fail(DITTO_ERR_ARG, "%s = %d selects a kernel of csrc/experimental/ (gemm_o3.hip / attention_v4.hip: opt-in A/B "
+    if ((!strcmp(name, "gemm_tile") && value == 130) || (!strcmp(name, "attn_flags") && (value & (4096 | 16384 | 32768))) ||
+        (!strcmp(name, "fr_tile") && value == 128))
+        return fail(DITTO_ERR_ARG, "%s = %d selects a kernel of csrc/experimental/ (gemm_o3.hip / attention_v4.hip / attention_w4.hip / gemm_fr128.hip: opt-in A/B "
                                    "kernels no rule selects), which this library was built without (DITTO_EXPERIMENTAL=1 python -m "
                                    "ditto_tts_amd.build --force)", name, value);
 #endif

@@ -75,7 +75,12 @@ DITTO_DEV void q_mfma_last(f32x4& c, const f32x4& w, const bf16x8& a) {
 }
 template <int IMM>
 DITTO_DEV void q_wload(f32x4& dst, unsigned voff, const char* base) {
+#ifdef DITTO_DIAG_LNQ_NOW   // tools/build_diag.sh: the kernel WITHOUT its weight stream (the registers keep whatever they
+                            // hold; TIMING ONLY) — LayerNorm, LDS fragment reads, MFMAs and the epilogue alone
+    asm volatile("" : "+v"(dst) : "v"(voff), "s"(base), "n"(IMM) : "memory");
+#else
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(base), "n"(IMM) : "memory");
+#endif
 }
 template <int VM>
 DITTO_DEV void q_wait(f32x4& frag) {   // counted wait that ties the fragment's registers: no use moves above it

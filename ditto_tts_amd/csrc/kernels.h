@@ -102,9 +102,20 @@ inline int opt_lnq() { return t_opts.lnq >= 0 ? t_opts.lnq : g_lnq; }
 // i.e. the 128-row kernel (gemm_frd.hip) from 136 of its tiles on; below that the 64-row kernel (gemm_fr64.hip, two workgroups
 // per CU) from 176 of ITS tiles on — except where the unfused N = d GEMMs' 256 x 192 tiles make exactly one round of the 256
 // CUs (16 x 1024 rows; the rule below excludes every row count that rounds up to those 64 tiles of 256 rows, 16129 .. 16384),
-// which is the one place in that range where they are not quantised away.  The two full-row kernels
-// produce the same h bits (u within a bf16 rounding tie), the unfused path differs in the last bits: the CLASS boundary that
-// callers pin (fr_class_rows) is "full-row or not".
+// which is the one place in that range where they are not quantised away.
+// THREE kernel classes result (what "an utterance's bits do not depend on its batch" is relative to):
+//   low-latency  <= 2048 rows: tiled GEMMs, fc2 / final projection / cross out-projection split over K by a K-only rule, fp32 stream
+//                (ll_mask bit 0 — fc2's finish also writes the next norm1 — changes no bit; bit 1 — the out-projection as TWO
+//                K-splits — changes the summation order of that GEMM: it is part of what defines the class)
+//   tiled        up to 17 407 rows: tiled GEMMs + LayerNorm launches, fp32 stream; inside it 11 264 .. 17 407 rows (176 .. 271 tiles
+//                of 64 rows, except the exact 256-row rounds) take the 64-row full-row kernel — same fp32 h bits as the 128-row
+//                kernel's fp32 form (u within a bf16 rounding tie), still the fp32 stream
+//   full-row     >= 17 408 rows (136 tiles of 128 rows): gemm_frd.hip for both fused launches, norm2 fused into the q-projection and,
+//                with "residual_bf16" (default), the BF16 residual stream — h is rounded to bf16 three times per block, the fused
+//                LayerNorms (and the AdaLN kernel's block-0 norm1) normalise the UNROUNDED fp32 row they hold in registers, while
+//                the A/B path of gemm_flags 32768 (norm1 as its own launch) reads the bf16-rounded h: a bf16 tie apart
+// A caller pins a class through the rows it passes (ditto_call_opts.class_rows / "fr_class_rows"): "full-row or not", and inside
+// the full-row range also WHICH full-row kernel and with it the stream type.
 extern int g_fr_tile;
 inline int fr_rule_rows(int rows) {
     const int t128 = (rows + 127) / 128, t64 = (rows + 63) / 64;

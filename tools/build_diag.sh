@@ -12,7 +12,7 @@ mkdir -p /tmp/diag_objs
 for f in *.hip ${DITTO_EXPERIMENTAL:+experimental/*.hip}; do
   extra=""; { [ "$f" = attention.hip ] || [ "$f" = experimental/attention_v4.hip ]; } && extra="-fno-honor-nans"
   [ "$f" = attention_bwd.hip ] && extra="-fno-slp-vectorize"
-  [ "$f" = attention_train.hip ] && extra="-fno-honor-nans -fno-slp-vectorize"
+  { [ "$f" = attention_train.hip ] || [ "$f" = attention_w4.hip ]; } && extra="-fno-honor-nans -fno-slp-vectorize"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I ../../include -I . -Wno-unused-function $extra "$@" ${DITTO_EXPERIMENTAL:+-DDITTO_EXPERIMENTAL} -c $f -o /tmp/diag_objs/$(basename ${f%.hip}).o &
 done
 wait
