@@ -794,13 +794,18 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
             // 128.4 / 127.6 self and 124.7 / 125.4 cross in the model, profiles/r05_w4_ab.txt): no rule selects it.
 #ifdef DITTO_EXPERIMENTAL
             if (((g_attn_flags & 16384) && (int)gridv.x > 320) || (g_attn_flags & 32768))
-                return launch_attn64w4(p, a.resid_f32 != nullptr, s);
+                return launch_attn64w4(p, a.resid_f32 != nullptr, s, (g_attn_flags & 131072) != 0);   // + 131072: 256 queries per workgroup
 #endif
             if (!(g_attn_flags & 64)) {
                 // small grid (at most ~1 workgroup per CU): the deep-prefetch instantiation (attn_flags 128 disables)
                 if ((int)gridv.x <= 320 && !(g_attn_flags & 128)) {
                     if (a.resid_f32) hipLaunchKernelGGL((attn64v2_kernel<true, 2, 4>), gridv, dim3(256), 0, s, p);
                     else hipLaunchKernelGGL((attn64v2_kernel<false, 2, 4>), gridv, dim3(256), 0, s, p);
+                    return hipGetLastError();
+                }
+                if (g_attn_flags & 65536) {   // K fragments prefetched together (KPF): A/B bit of round 5, same bits
+                    if (a.resid_f32) hipLaunchKernelGGL((attn64v2_kernel<true, 3, 2, false, false, true>), gridv, dim3(256), 0, s, p);
+                    else hipLaunchKernelGGL((attn64v2_kernel<false, 3, 2, false, false, true>), gridv, dim3(256), 0, s, p);
                     return hipGetLastError();
                 }
                 if (a.resid_f32) hipLaunchKernelGGL((attn64v2_kernel<true, 3>), gridv, dim3(256), 0, s, p);

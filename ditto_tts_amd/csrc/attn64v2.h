@@ -47,7 +47,13 @@ DITTO_DEV unsigned long long a2_now() {
 #define A2_STAMP(i)
 #endif
 
-template <bool RESID, int WPS = 2, int NBUF = 2, bool TRAIN = false, bool DROP = false>
+// KPF (round 5): the eight K fragments of a tile are requested TOGETHER, ahead of the first S MFMA.  Left to itself hipcc, at
+// the 168-register budget of three waves per SIMD, reads them one at a time into ONE register quad per chain — ds_read, wait,
+// MFMA, ds_read into the same registers, wait, MFMA ... — so each of a chain's four MFMAs pays a full LDS round trip (the stamp
+// build has this segment at 1 267 of a wave-tile's 3 278 ticks, profiles/r05_a2_stamps.txt).  The registers exist: the 16 of P
+// and the V fragments' are dead while S is computed, and chain 1's accumulator may take over chain 0's fragments.  Same products
+// in the same order: bit-identical to the kernel without it.
+template <bool RESID, int WPS = 2, int NBUF = 2, bool TRAIN = false, bool DROP = false, bool KPF = false>
 __global__ __launch_bounds__(256, WPS) void attn64v2_kernel(AttnParams p) {
     constexpr bool PFV = WPS <= 2;   // V fragments prefetched ahead of the softmax only when 256 registers are available
     __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * KV_TILE_BYTES];  // [buf][K|V]
@@ -128,6 +134,9 @@ __global__ __launch_bounds__(256, WPS) void attn64v2_kernel(AttnParams p) {
 
     if constexpr (NBUF == 2) {
         dma_kv(0, 0);
+#ifdef DITTO_DIAG_A2_NODMA   // both buffers hold tile 0: every later tile computes on VALID data (no NaN garbage that would speed the
+        dma_kv(0, 1);        // whole step up through the clock), only the traffic is gone
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     } else {
@@ -159,6 +168,20 @@ __global__ __launch_bounds__(256, WPS) void attn64v2_kernel(AttnParams p) {
 
         // ---- S'^T[key][query] = K Q'^T - m  (log2 units) ----
         f32x16 st[2];
+        if constexpr (KPF) {
+            bf16x8 kfr[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                kfr[i] = *reinterpret_cast<const bf16x8*>(kb + (i >> 2) * 32 * 128 + k_row_off + (((2 * (i & 3) + hh) ^ k_swz) << 4));
+            __builtin_amdgcn_sched_barrier(0);   // all eight requests ahead of the first MFMA
+#pragma unroll
+            for (int kb2 = 0; kb2 < 2; ++kb2) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    st[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb2 * 4 + ks], qf[ks], ks == 0 ? cneg : st[kb2], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
 #pragma unroll
         for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
@@ -167,6 +190,7 @@ __global__ __launch_bounds__(256, WPS) void attn64v2_kernel(AttnParams p) {
                                                                    (((2 * ks + hh) ^ k_swz) << 4));
                 st[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? cneg : st[kb2], 0, 0, 0);
             }
+        }
         A2_STAMP(0);   // next tile's DMA issued, K fragments read, the 8 S MFMAs issued
         if constexpr (decltype(MASKED)::value) {
             const int kbase_idx = kt * KBLK + 4 * hh;
@@ -333,8 +357,13 @@ __global__ __launch_bounds__(256, WPS) void attn64v2_kernel(AttnParams p) {
 // live instead of 16).  The row sum is that of the fp32 probabilities (attn64v2 sums the bf16-rounded ones): another
 // association, the same tolerance (tests/test_gpu_kernels.py).  Pre-scaled q, inference only (no TRAIN / DROP forms).
 // ------------------------------------------------------------------------------------------------
-template <bool RESID>
-__global__ __launch_bounds__(256, 4) void attn64w4_kernel(AttnParams p) {
+// NW = waves per workgroup: 4 (128 queries) or 8 (256 queries share every K/V tile: half the LDS-DMA pieces and barriers per query;
+// two workgroups per CU keep the four waves per SIMD) — the clean no-DMA knock-out of round 5 prices the K/V traffic at 10-13 % of
+// the C2 launch (profiles/r05_floor_diag2.txt).
+template <bool RESID, int NW = 4>
+__global__ __launch_bounds__(NW * 64, 4) void attn64w4_kernel(AttnParams p) {
+    static_assert(NW == 4 || NW == 8, "waves per workgroup");
+    constexpr int QB = NW * 32;                                   // queries per workgroup (p.nqb counts blocks of this size)
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KV_TILE_BYTES];  // [buf][K|V]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -343,7 +372,7 @@ __global__ __launch_bounds__(256, 4) void attn64w4_kernel(AttnParams p) {
     const int qb = id % p.nqb, bh = id / p.nqb;
     const int h = bh % p.H, b = bh / p.H;
     const int ql = lane & 31, hh = lane >> 5;
-    int qrow = qb * QBLK + wid * 32 + ql;
+    int qrow = qb * QB + wid * 32 + ql;
     const bool qvalid = qrow < p.Sq;
     qrow = qvalid ? qrow : p.Sq - 1;
 
@@ -358,8 +387,8 @@ __global__ __launch_bounds__(256, 4) void attn64w4_kernel(AttnParams p) {
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
     auto dma_kv = [&](int kt, int buf) {   // rows past Skv are clamped (never read out of bounds), masked in the tile
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int piece = wid * 2 + i;
+        for (int i = 0; i < 8 / NW; ++i) {
+            const int piece = wid * (8 / NW) + i;
             const int row = piece * 8 + (lane >> 3), cpos = lane & 7;
             int key = kt * KBLK + row;
             key = key < p.Skv ? key : p.Skv - 1;

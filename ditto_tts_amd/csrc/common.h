@@ -39,15 +39,37 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 constexpr int WAVE = 64;
 
+// Wave-wide sum / maximum, the total in every lane.  Round 5: on the cross-lane paths of the VECTOR pipe (DPP quad permutes and row
+// mirrors, two row broadcasts, one v_readlane) instead of six ds_bpermute round trips through the LDS: the fused norm2 + q-projection
+// kernel normalises its 64 rows at ONE wave per SIMD, where each of its 32 reductions per wave was a chain of six ~120-cycle LDS
+// latencies — 42 % of the kernel (profiles/r05_lnq_stamps.txt).  Association: the near-to-far butterfly x_i + x_{i^1}, then ^2, ^4, ^8,
+// ^16, ^32 — after the quad steps all lanes of a quad hold the same value, so the half-row mirror pairs the same VALUES as lane i ^ 4
+// would (likewise the row mirror for i ^ 8), and (R1 + R0), then (R3 + R2) + (R1 + R0) across the four rows is the butterfly's
+// (R0 + R1) + (R2 + R3) by commutativity: every kernel that normalises rows through these helpers (ln_kernel, the AdaLN kernel's
+// norm1, the split-K finish, gemm_lnq) still produces the SAME bits as the others.
+template <int CTRL, int ROW_MASK = 0xF>
+DITTO_DEV float dpp_f32(float v, float masked = 0.0f) {   // lanes of masked-off rows read `masked`
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, masked), __builtin_bit_cast(int, v), CTRL,
+                                                                 ROW_MASK, 0xF, false));
+}
 DITTO_DEV float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_f32<0xB1>(v);            // quad_perm [1,0,3,2]: lane i ^ 1
+    v += dpp_f32<0x4E>(v);            // quad_perm [2,3,0,1]: lane i ^ 2
+    v += dpp_f32<0x141>(v);           // row_half_mirror: the other quad of the 8-lane group
+    v += dpp_f32<0x140>(v);           // row_mirror: the other half of the 16-lane row
+    v += dpp_f32<0x142, 0xA>(v);      // row_bcast:15 into rows 1 and 3: R1 + R0, R3 + R2
+    v += dpp_f32<0x143, 0xC>(v);      // row_bcast:31 into rows 2 and 3: lane 63 = (R3 + R2) + (R1 + R0)
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 DITTO_DEV float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    const float ninf = -__builtin_huge_valf();
+    v = fmaxf(v, dpp_f32<0xB1>(v));
+    v = fmaxf(v, dpp_f32<0x4E>(v));
+    v = fmaxf(v, dpp_f32<0x141>(v));
+    v = fmaxf(v, dpp_f32<0x140>(v));
+    v = fmaxf(v, dpp_f32<0x142, 0xA>(v, ninf));
+    v = fmaxf(v, dpp_f32<0x143, 0xC>(v, ninf));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // LayerNorm row arithmetic shared by ln_kernel (rowwise.hip) and the fused norm2 + q-projection kernel (gemm_lnq.hip), with

@@ -13,7 +13,15 @@ namespace {
 #include "attn64v2.h"
 }
 
-hipError_t launch_attn64w4(const AttnParams& p, bool resid, hipStream_t s) {
+hipError_t launch_attn64w4(const AttnParams& p_in, bool resid, hipStream_t s, bool wide) {
+    AttnParams p = p_in;
+    if (wide) {                                      // 256 queries per workgroup, eight waves
+        p.nqb = (p.Sq + 255) / 256;
+        const dim3 grid(p.nqb * p.H * p.B);
+        if (resid) hipLaunchKernelGGL((attn64w4_kernel<true, 8>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((attn64w4_kernel<false, 8>), grid, dim3(512), 0, s, p);
+        return hipGetLastError();
+    }
     const dim3 grid(p.nqb * p.H * p.B);
     if (resid) hipLaunchKernelGGL((attn64w4_kernel<true>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((attn64w4_kernel<false>), grid, dim3(256), 0, s, p);

@@ -47,6 +47,20 @@ struct QW {
 template <int V>
 struct QC { static constexpr int value = V; };
 
+#ifdef DITTO_DIAG_LNQ_STAMP   // tools/build_diag_one.sh ... gemm_lnq.hip -DDITTO_DIAG_LNQ_STAMP: s_memtime stamps around the kernel's phases
+__device__ unsigned long long g_lnq_stamps[2048 * 4 * 8];
+DITTO_DEV unsigned long long lnq_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define LNQ_STAMP(i) const unsigned long long lnq_t##i = lnq_now()
+#else
+#define LNQ_STAMP(i)
+#endif
+
 template <int SHAPE, int D>
 struct Geo;
 template <int D>
@@ -73,14 +87,14 @@ DITTO_DEV void q_mfma_last(f32x16& c, const f32x4& w, const bf16x8& a) {
 DITTO_DEV void q_mfma_last(f32x4& c, const f32x4& w, const bf16x8& a) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 9" : "+a"(c) : "v"(w), "v"(a));
 }
-template <int IMM>
+template <int IMM, bool PROLOGUE = false>
 DITTO_DEV void q_wload(f32x4& dst, unsigned voff, const char* base) {
-#ifdef DITTO_DIAG_LNQ_NOW   // tools/build_diag.sh: the kernel WITHOUT its weight stream (the registers keep whatever they
-                            // hold; TIMING ONLY) — LayerNorm, LDS fragment reads, MFMAs and the epilogue alone
-    asm volatile("" : "+v"(dst) : "v"(voff), "s"(base), "n"(IMM) : "memory");
-#else
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(base), "n"(IMM) : "memory");
+#ifdef DITTO_DIAG_LNQ_NOW   // tools/build_diag_one.sh: the kernel WITHOUT its weight stream — only the ring's prologue
+                            // loads happen, every later stage multiplies the fragments the registers already hold (valid weights, so
+                            // no NaN garbage speeds the rest of the step up).  TIMING ONLY: LayerNorm, LDS reads, MFMAs, epilogue alone
+    if constexpr (!PROLOGUE) { asm volatile("" : "+v"(dst) : "v"(voff), "s"(base), "n"(IMM) : "memory"); return; }
 #endif
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(base), "n"(IMM) : "memory");
 }
 template <int VM>
 DITTO_DEV void q_wait(f32x4& frag) {   // counted wait that ties the fragment's registers: no use moves above it
@@ -123,6 +137,7 @@ __global__ __launch_bounds__(256, 1) void gemm_lnq_kernel(LnqParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    LNQ_STAMP(0);
     // XCD-contiguous tiles (blocks b and b + 8 share an XCD: neighbouring tiles, i.e. neighbouring K-loop phases, on one L2)
     const int ntile = gridDim.x;
     const int tile = (ntile & 7) == 0 ? (int)(blockIdx.x & 7) * (ntile >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
@@ -160,12 +175,16 @@ __global__ __launch_bounds__(256, 1) void gemm_lnq_kernel(LnqParams p) {
         constexpr int nb = decltype(NB)::value;
         q_wload<(nb & 3) * 1024>(dst, vw + (unsigned)((nb >> 2) * 4096), wbase);
     };
+    auto issue_wp = [&](auto NB, f32x4& dst) {   // the ring prologue's loads (the no-weight-stream diagnostic keeps exactly these)
+        constexpr int nb = decltype(NB)::value;
+        q_wload<(nb & 3) * 1024, true>(dst, vw + (unsigned)((nb >> 2) * 4096), wbase);
+    };
     auto issue_stage = [&](f32x4 (&slot)[NBW]) {
-        issue_w(QC<0>{}, slot[0]); issue_w(QC<1>{}, slot[1]); issue_w(QC<2>{}, slot[2]);
-        issue_w(QC<3>{}, slot[3]); issue_w(QC<4>{}, slot[4]); issue_w(QC<5>{}, slot[5]);
-        if constexpr (NBW > 6) { issue_w(QC<6>{}, slot[6]); issue_w(QC<7>{}, slot[7]); }
+        issue_wp(QC<0>{}, slot[0]); issue_wp(QC<1>{}, slot[1]); issue_wp(QC<2>{}, slot[2]);
+        issue_wp(QC<3>{}, slot[3]); issue_wp(QC<4>{}, slot[4]); issue_wp(QC<5>{}, slot[5]);
+        if constexpr (NBW > 6) { issue_wp(QC<6>{}, slot[6]); issue_wp(QC<7>{}, slot[7]); }
         if constexpr (NBW > 8) {
-            issue_w(QC<8>{}, slot[8]); issue_w(QC<9>{}, slot[9]); issue_w(QC<10>{}, slot[10]); issue_w(QC<11>{}, slot[11]);
+            issue_wp(QC<8>{}, slot[8]); issue_wp(QC<9>{}, slot[9]); issue_wp(QC<10>{}, slot[10]); issue_wp(QC<11>{}, slot[11]);
         }
         advance_w();
     };
@@ -178,43 +197,49 @@ __global__ __launch_bounds__(256, 1) void gemm_lnq_kernel(LnqParams p) {
             g4[c] = reinterpret_cast<const f32x4*>(p.gamma)[lane + 64 * c];
             b4[c] = reinterpret_cast<const f32x4*>(p.beta)[lane + 64 * c];
         }
+        // all 16 rows of the wave are requested at once (round 5: the first version fetched them in two batches of eight, two memory
+        // round trips per tile with the matrix pipe idle); bf16 rows stay packed until their row is normalised
+        using raw_t = typename std::conditional<XB, u32x2, f32x4>::type;
+        constexpr int RB = XB ? 16 : 8;                                  // rows in flight (fp32 rows: 8, the register file's share)
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            f32x4 v[8][CH];
+        for (int half = 0; half < 16 / RB; ++half) {
+            raw_t raw[RB][CH];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                int gr = m0 + wid * 16 + half * 8 + r;
+            for (int r = 0; r < RB; ++r) {
+                int gr = m0 + wid * 16 + half * RB + r;
                 gr = gr < p.M ? gr : p.M - 1;
 #pragma unroll
                 for (int c = 0; c < CH; ++c) {
-                    if constexpr (XB) {
-                        const u32x2 w2 = reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16*>(p.h) + (size_t)gr * p.ldh)[lane + 64 * c];
-                        v[r][c] = f32x4{bf16_lo(w2[0]), bf16_hi(w2[0]), bf16_lo(w2[1]), bf16_hi(w2[1])};
-                    } else {
-                        v[r][c] = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.h) + (size_t)gr * p.ldh)[lane + 64 * c];
-                    }
+                    if constexpr (XB) raw[r][c] = reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16*>(p.h) + (size_t)gr * p.ldh)[lane + 64 * c];
+                    else raw[r][c] = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.h) + (size_t)gr * p.ldh)[lane + 64 * c];
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
+            for (int r = 0; r < RB; ++r) {
+                f32x4 v[CH];
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    if constexpr (XB) v[c] = f32x4{bf16_lo(raw[r][c][0]), bf16_hi(raw[r][c][0]), bf16_lo(raw[r][c][1]), bf16_hi(raw[r][c][1])};
+                    else v[c] = raw[r][c];
+                }
                 // ln_kernel's arithmetic (rowwise.hip) through the same helpers (common.h): the same bits for the same row
                 float s = 0.f;
 #pragma unroll
-                for (int c = 0; c < CH; ++c) s += ln_sum4(v[r][c]);
+                for (int c = 0; c < CH; ++c) s += ln_sum4(v[c]);
                 const float mean = wave_sum(s) / (float)QKD;
                 float q = 0.f;
 #pragma unroll
                 for (int c = 0; c < CH; ++c) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) q = ln_sq_acc(q, v[r][c][e], mean);
+                    for (int e = 0; e < 4; ++e) q = ln_sq_acc(q, v[c][e], mean);
                 }
                 const float rstd = rsqrtf(wave_sum(q) / (float)QKD + 1e-5f);
-                const int row = wid * 16 + half * 8 + r;
+                const int row = wid * 16 + half * RB + r;
 #pragma unroll
                 for (int c = 0; c < CH; ++c) {
                     u32x2 o;
-                    o[0] = pack_bf16x2(ln_norm(v[r][c][0], mean, rstd, g4[c][0], b4[c][0]), ln_norm(v[r][c][1], mean, rstd, g4[c][1], b4[c][1]));
-                    o[1] = pack_bf16x2(ln_norm(v[r][c][2], mean, rstd, g4[c][2], b4[c][2]), ln_norm(v[r][c][3], mean, rstd, g4[c][3], b4[c][3]));
+                    o[0] = pack_bf16x2(ln_norm(v[c][0], mean, rstd, g4[c][0], b4[c][0]), ln_norm(v[c][1], mean, rstd, g4[c][1], b4[c][1]));
+                    o[1] = pack_bf16x2(ln_norm(v[c][2], mean, rstd, g4[c][2], b4[c][2]), ln_norm(v[c][3], mean, rstd, g4[c][3], b4[c][3]));
                     const int chunk = (lane + 64 * c) >> 1;                // 16-B chunk of the row holding k = 4 (lane + 64 c) ..
                     *reinterpret_cast<u32x2*>(smem + row * Q_AROW + ((chunk ^ (row & 15)) << 4) + (lane & 1) * 8) = o;
                 }
@@ -223,10 +248,14 @@ __global__ __launch_bounds__(256, 1) void gemm_lnq_kernel(LnqParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // (wave 3: the bias pieces)
     __syncthreads();
+    LNQ_STAMP(1);
 
     // ring prologue: from here on the W loads are the ONLY vector-memory operations until the epilogue's stores
 #pragma unroll
     for (int r = 0; r < R; ++r) issue_stage(wr[r]);
+#ifdef DITTO_DIAG_LNQ_NOW
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the only loads of the diagnostic: landed before any MFMA reads a fragment
+#endif
 
     // ---- accumulators: zero, pinned in AGPRs ----
     acc_t acc[NBW][MBW];
@@ -307,6 +336,7 @@ __global__ __launch_bounds__(256, 1) void gemm_lnq_kernel(LnqParams p) {
         pcur = pnext;
     }
     period(QC<1>{}, pcur * 256, 0);
+    LNQ_STAMP(2);
 
     // ---------------- epilogue: q = acc + bias -> bf16, staged through the A region (every wave is done reading it) ----------------
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -350,6 +380,17 @@ __global__ __launch_bounds__(256, 1) void gemm_lnq_kernel(LnqParams p) {
         const u32x4 val = *reinterpret_cast<const u32x4*>(smem + row * Q_AROW + ((c ^ (row & 15)) << 4));
         if (m0 + row < p.M) *reinterpret_cast<u32x4*>(p.out + (size_t)(m0 + row) * p.ldo + c * 8) = val;
     }
+#ifdef DITTO_DIAG_LNQ_STAMP
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        LNQ_STAMP(3);
+        const int w = blockIdx.x * 4 + wid;
+        if (lane == 0 && w < 2048 * 4) {
+            g_lnq_stamps[w * 8 + 0] = lnq_t1 - lnq_t0; g_lnq_stamps[w * 8 + 1] = lnq_t2 - lnq_t1; g_lnq_stamps[w * 8 + 2] = lnq_t3 - lnq_t2;
+            g_lnq_stamps[w * 8 + 3] = 1; g_lnq_stamps[w * 8 + 4] = lnq_t0; g_lnq_stamps[w * 8 + 5] = lnq_t3;
+        }
+    }
+#endif
 }
 
 template <int SHAPE, int R, bool XB, int D = 768>
@@ -361,6 +402,15 @@ hipError_t launch_lnq_t(const LnqParams& p, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef DITTO_DIAG_LNQ_STAMP
+}  // namespace ditto
+extern "C" int ditto_diag_lnq_stamps(unsigned long long* out, int n) {   // raw per-wave records of the LAST launch (diagnostic build only)
+    if (n > 2048 * 4 * 8) n = 2048 * 4 * 8;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ditto::g_lnq_stamps), (size_t)n * 8) != hipSuccess;
+}
+namespace ditto {
+#endif
 
 int g_lnq_ring = [] { const char* e = getenv("DITTO_LNQ_RING"); return e ? atoi(e) : 0; }();   // 0 = the shape's default depth
 
