@@ -124,12 +124,12 @@ def kernel_flops(cfg, B, N, T):
 
 
 def stream_is_bf16(cfg, B, N):
-    """Does a forward of B x N rows carry its residual stream as bf16 (csrc/ditto_api.hip ditto_forward's rule: option
-    "residual_bf16" on, d = 768, head_dim 64, bf16 linears, both fused full-row launches = the full-row class)?"""
+    """Does a forward of B x N rows carry its residual stream as bf16?  Answered by the library itself (ditto_full_row_plan_opts:
+    csrc/ditto_api.hip ditto_forward's rule — "residual_bf16" on, d = 768, head_dim 64, bf16 linears, both fused launches on the
+    128-row full-row kernel = the full-row class)."""
     from ditto_tts_amd import hip
     try:
-        return bool(hip.get_option("residual_bf16")) and cfg.hidden_dim == 768 and cfg.hidden_dim // cfg.num_heads == 64 \
-            and not cfg.fp8_linear and hip.full_row_plan(cfg, B, N) == (True, True)
+        return hip.stream_is_bf16(cfg, B, N)
     except Exception:  # noqa: BLE001 - an older library selected with DITTO_HIP_LIB
         return False
 
@@ -148,14 +148,14 @@ def kernel_bytes(cfg, B, N, T, seeded=True):
 
 
 def floor_table(cfg, B, N, T, classes):
-    """profiles/r04_floor_table.json: per kernel class the time (us) its launch takes with the removable overheads knocked out
+    """profiles/r05_floor_table.json: per kernel class the time (us) its launch takes with the removable overheads knocked out
     in diagnostic builds (main loop without epilogue, operands L2-hot, no stores: tools/round4/r04_run5.sh) —
     measured OFFLINE on the timed shape, so only reported for it.  step_floor_ms = the step if every class ran at its floor
     (classes without a floor entry at their time in THIS run); step_frac_at_floor = the executed FLOPs at that time / 2.5 PF."""
     if not (B == 32 and N == 1024 and T == 1024 and cfg.hidden_dim == 768 and cfg.num_layers == 12 and not cfg.fp8_linear):
         return None
     try:
-        tab = json.load(open(os.path.join(ROOT, "profiles", "r04_floor_table.json")))
+        tab = json.load(open(os.path.join(ROOT, "profiles", "r05_floor_table.json")))
     except (OSError, ValueError):
         return None
     us = 0.0
@@ -166,7 +166,7 @@ def floor_table(cfg, B, N, T, classes):
     fl = B * (cfg.flops_per_utt_step(N, T, cached_kv=True) + one_off)
     return {"step_floor_ms": us * 1e-3, "step_frac_at_floor": fl / (us * 1e-6) / 1e12 / PEAK_BF16_TFLOPS,
             "per_class_floor_us": {k: v.get("floor_us") for k, v in tab.items() if isinstance(v, dict)},
-            "source": "profiles/r04_floor_table.json (offline diagnostic builds on this shape; DESIGN.md section 9)"}
+            "source": "profiles/r05_floor_table.json (offline diagnostic builds on this shape; DESIGN.md section 9)"}
 
 
 def class_peak(cfg, name):
@@ -525,11 +525,14 @@ def train_step_line(dev, state_cache, steps=3):
     del m, opt, x, text, noise, loss
     torch.cuda.empty_cache()
     # the line validates itself: every parameter gradient of a 2-layer model of the SAME widths, kernel class pinned to this
-    # batch, train mode with dropout, against fp32 autograd of the CPU oracle (oracle/checks.py; after the timed region)
+    # batch, train mode with dropout, against fp32 autograd of the CPU oracle (oracle/checks.py; after the timed region).
+    # B = 4, N = 768 = 3 072 rows: 12 x 12 = 144 tiles of 256 x 256 in the fc2 dgrad, the fewest that take the FUSED gated-MLP
+    # backward (EPI_GATED_BWD) and the training forward's own gated instantiation (EPI_GATED_PRE) the timed step runs — at the
+    # 512 rows of the round-4 check those two kernels were not in the self-check
     try:
         from oracle.checks import train_grad_parity
         torch.set_num_threads(usable_cores())
-        gp = train_grad_parity(dev)
+        gp = train_grad_parity(dev, shape=dict(B=4, N=768, T=192))
         out["grad_parity"] = {k: gp[k] for k in ("worst_rel_l2", "tensor", "median_rel_l2", "loss_rel", "n_tensors", "tol",
                                                  "ok", "what")}
     except Exception as e:  # noqa: BLE001 - a checker failure must not lose the timed numbers; it is reported instead

@@ -115,9 +115,24 @@ static_assert(frd_vm(0, 3, true) == 11 && frd_vm(2, 0, true) == 11 && frd_vm(2, 
 
 // HB: the residual stream is bf16 in HBM (fp.hb): residual read and h written as bf16 (fp32 only in the accumulators and the
 // LayerNorm, which still sees the UNROUNDED fp32 row); p.residual / p.out point to bf16, ldr / ldo in bf16 elements.
+#ifdef DITTO_DIAG_FRD_STAMP   // tools/build_diag_one.sh ... gemm_frd.hip -DDITTO_DIAG_FRD_STAMP: s_memtime stamps around the kernel's phases
+__device__ unsigned long long g_frd_stamps[1024 * 4 * 8];
+DITTO_DEV unsigned long long frd_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define FRD_STAMP(i) const unsigned long long frd_t##i = frd_now()
+#else
+#define FRD_STAMP(i)
+#endif
+
 template <bool LN, bool RES, bool HB = false>
 __global__ __launch_bounds__(256, 1) void gemm_frd_kernel(FrParams fp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    FRD_STAMP(0);
     const GemmParams& p = fp.g;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);       // = the wave's column quarter
@@ -278,6 +293,7 @@ __global__ __launch_bounds__(256, 1) void gemm_frd_kernel(FrParams fp) {
     // A slab 0 has landed for this wave (older than the residual loads); for everyone:
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     FD_BAR();
+    FRD_STAMP(1);
     // W stages 0 and 1 -> the register ring (twelve loads, nothing else behind them: the wait counts of frd_vm start here)
     issue_w(DC<0>{}, wr[0][0]); issue_w(DC<1>{}, wr[0][1]); issue_w(DC<2>{}, wr[0][2]);
     issue_w(DC<3>{}, wr[0][3]); issue_w(DC<4>{}, wr[0][4]); issue_w(DC<5>{}, wr[0][5]);
@@ -361,6 +377,7 @@ __global__ __launch_bounds__(256, 1) void gemm_frd_kernel(FrParams fp) {
     // ---------------- epilogue: the accumulators hold h = residual + bias + A W^T; they are only READ from here on ----------------
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     FD_BAR();                                                       // every wave is out of the main loop: the A slabs are idle
+    FRD_STAMP(2);
     float mean[4] = {0.f, 0.f, 0.f, 0.f}, rstd[4] = {1.f, 1.f, 1.f, 1.f};
     if constexpr (LN) {
         if (wid < 2) {   // gamma and beta rows -> LDS (3 pieces of 1 KiB each), landed by the first exchange below
@@ -415,6 +432,7 @@ __global__ __launch_bounds__(256, 1) void gemm_frd_kernel(FrParams fp) {
             rstd[mb] = rsqrtf(fmaf((red[r] + red[DM + r]) + (red[2 * DM + r] + red[3 * DM + r]), 1.0f / DN, 1e-5f));
         }
     }
+    FRD_STAMP(3);
     // stores (gemm_fr.hip): every output row leaves through a wave-private LDS stage so that the stores are whole 128-B lines:
     // h fp32 (nt), u = LN(h) bf16, optional bf16 copy of h.
     const int cl = wid * 192 + 4 * hh;                             // this lane's column origin; + nb * 32 + 8 g
@@ -505,6 +523,18 @@ __global__ __launch_bounds__(256, 1) void gemm_frd_kernel(FrParams fp) {
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     }
+#ifdef DITTO_DIAG_FRD_STAMP
+    {
+        FRD_STAMP(4);                                                // (stores issued)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        FRD_STAMP(5);                                                // (stores drained)
+        const int w = blockIdx.x * 4 + wid;
+        if (lane == 0 && w < 1024 * 4) {
+            g_frd_stamps[w * 8 + 0] = frd_t1 - frd_t0; g_frd_stamps[w * 8 + 1] = frd_t2 - frd_t1; g_frd_stamps[w * 8 + 2] = frd_t3 - frd_t2;
+            g_frd_stamps[w * 8 + 3] = frd_t4 - frd_t3; g_frd_stamps[w * 8 + 4] = frd_t5 - frd_t4; g_frd_stamps[w * 8 + 5] = 1;
+        }
+    }
+#endif
 }
 
 template <bool LN, bool RES, bool HB = false>
@@ -532,5 +562,14 @@ hipError_t launch_gemm_frd(const FrParams& fp_in, hipStream_t s) {
     if (ln) return res ? launch_frd_t<true, true>(fp, fp.g.tiles_m, s) : launch_frd_t<true, false>(fp, fp.g.tiles_m, s);
     return res ? launch_frd_t<false, true>(fp, fp.g.tiles_m, s) : launch_frd_t<false, false>(fp, fp.g.tiles_m, s);
 }
+
+#ifdef DITTO_DIAG_FRD_STAMP
+}  // namespace ditto
+extern "C" int ditto_diag_frd_stamps(unsigned long long* out, int n) {   // raw per-wave records of the LAST launch (diagnostic build only)
+    if (n > 1024 * 4 * 8) n = 1024 * 4 * 8;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ditto::g_frd_stamps), (size_t)n * 8) != hipSuccess;
+}
+namespace ditto {
+#endif
 
 }  // namespace ditto

@@ -61,16 +61,17 @@ DITTO_DEV unsigned long long lnq_now() {
 #define LNQ_STAMP(i)
 #endif
 
-template <int SHAPE, int D>
+// NW = waves per workgroup, side by side in N: 4 (one per SIMD, the whole register file each) or 8 (two per SIMD, round 5)
+template <int SHAPE, int D, int NW>
 struct Geo;
-template <int D>
-struct Geo<32, D> {
-    static constexpr int NBW = D / 4 / 32, MBW = 2, KS = 16, NKT = D / 16, PER = 8;   // PER: stages per A-swizzle period (one 256-B span)
+template <int D, int NW>
+struct Geo<32, D, NW> {
+    static constexpr int NBW = D / NW / 32, MBW = 2, KS = 16, NKT = D / 16, PER = 8;   // PER: stages per A-swizzle period (one 256-B span)
     using acc_t = f32x16;
 };
-template <int D>
-struct Geo<16, D> {
-    static constexpr int NBW = D / 4 / 16, MBW = 4, KS = 32, NKT = D / 32, PER = 4;
+template <int D, int NW>
+struct Geo<16, D, NW> {
+    static constexpr int NBW = D / NW / 16, MBW = 4, KS = 32, NKT = D / 32, PER = 4;
     using acc_t = f32x4;
 };
 
@@ -124,9 +125,17 @@ struct LnqParams {
 // R: depth of the W register ring in stages.  What the ring holds in flight per CU (4 waves x R x NBW KiB) against the L2's
 // latency under load is what paces the loop: the weights of a 64-row tile are 1.18 MB, twice the bytes per MFMA of gemm_frd's
 // 128-row tile.
-template <int SHAPE, int R, bool XB, int D = 768>
-__global__ __launch_bounds__(256, 1) void gemm_lnq_kernel(LnqParams p) {
-    using G = Geo<SHAPE, D>;
+// NW = 8 (round 5): two waves per SIMD.  The stamp timeline (profiles/r05_lnq_stamps_final.txt) has the 4-wave kernel spend 37 % of
+// a tile normalising its 64 rows and 21 % in its epilogue — both vector work that ONE wave per SIMD issues at 4+ cycles per
+// instruction with every latency exposed — against 42 % in the MFMA loop (82 % of it MFMA issue), and the no-weight-stream
+// knock-out prices the W stream at 7 % (profiles/r05_floor_diag2.txt): not the bound round 4 took it for.  Eight waves split N
+// eight ways (96 columns, 96 accumulators each), so no weight byte is fetched twice and every output element is the same K-ordered
+// chain (bit-identical to NW = 4); each wave normalises 8 rows instead of 16 and two waves share a SIMD's vector pipe.
+template <int SHAPE, int R, bool XB, int D = 768, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW / 4) void gemm_lnq_kernel(LnqParams p) {
+    static_assert(NW == 4 || NW == 8, "waves per workgroup");
+    constexpr int RPW = QM / NW;                                         // rows a wave normalises (16 / 8)
+    using G = Geo<SHAPE, D, NW>;
     constexpr int Q_AROW = QW<D>::AROW, Q_BIAS = QW<D>::BIAS, CH = QW<D>::CH, QN = D, QKD = D;
     static_assert(G::NBW <= 12, "fragment list");
     using acc_t = typename G::acc_t;
@@ -181,7 +190,8 @@ __global__ __launch_bounds__(256, 1) void gemm_lnq_kernel(LnqParams p) {
     };
     auto issue_stage = [&](f32x4 (&slot)[NBW]) {
         issue_wp(QC<0>{}, slot[0]); issue_wp(QC<1>{}, slot[1]); issue_wp(QC<2>{}, slot[2]);
-        issue_wp(QC<3>{}, slot[3]); issue_wp(QC<4>{}, slot[4]); issue_wp(QC<5>{}, slot[5]);
+        if constexpr (NBW > 3) issue_wp(QC<3>{}, slot[3]);
+        if constexpr (NBW > 4) { issue_wp(QC<4>{}, slot[4]); issue_wp(QC<5>{}, slot[5]); }
         if constexpr (NBW > 6) { issue_wp(QC<6>{}, slot[6]); issue_wp(QC<7>{}, slot[7]); }
         if constexpr (NBW > 8) {
             issue_wp(QC<8>{}, slot[8]); issue_wp(QC<9>{}, slot[9]); issue_wp(QC<10>{}, slot[10]); issue_wp(QC<11>{}, slot[11]);
@@ -200,13 +210,13 @@ __global__ __launch_bounds__(256, 1) void gemm_lnq_kernel(LnqParams p) {
         // all 16 rows of the wave are requested at once (round 5: the first version fetched them in two batches of eight, two memory
         // round trips per tile with the matrix pipe idle); bf16 rows stay packed until their row is normalised
         using raw_t = typename std::conditional<XB, u32x2, f32x4>::type;
-        constexpr int RB = XB ? 16 : 8;                                  // rows in flight (fp32 rows: 8, the register file's share)
+        constexpr int RB = XB ? RPW : 8;                                 // rows in flight (fp32 rows: 8, the register file's share)
 #pragma unroll
-        for (int half = 0; half < 16 / RB; ++half) {
+        for (int half = 0; half < RPW / RB; ++half) {
             raw_t raw[RB][CH];
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
-                int gr = m0 + wid * 16 + half * RB + r;
+                int gr = m0 + wid * RPW + half * RB + r;
                 gr = gr < p.M ? gr : p.M - 1;
 #pragma unroll
                 for (int c = 0; c < CH; ++c) {
@@ -234,7 +244,7 @@ __global__ __launch_bounds__(256, 1) void gemm_lnq_kernel(LnqParams p) {
                     for (int e = 0; e < 4; ++e) q = ln_sq_acc(q, v[c][e], mean);
                 }
                 const float rstd = rsqrtf(wave_sum(q) / (float)QKD + 1e-5f);
-                const int row = wid * 16 + half * RB + r;
+                const int row = wid * RPW + half * RB + r;
 #pragma unroll
                 for (int c = 0; c < CH; ++c) {
                     u32x2 o;
@@ -305,7 +315,9 @@ __global__ __launch_bounds__(256, 1) void gemm_lnq_kernel(LnqParams p) {
             if constexpr (do_w) issue_w(NB, slot[nb]);
             if constexpr (nb == 0 && !last) read_a(ANXT, span_next, aoff[(j + 1) % PER]);
         };
-        block(QC<0>{}); block(QC<1>{}); block(QC<2>{}); block(QC<3>{}); block(QC<4>{}); block(QC<5>{});
+        block(QC<0>{}); block(QC<1>{}); block(QC<2>{});
+        if constexpr (NBW > 3) block(QC<3>{});
+        if constexpr (NBW > 4) { block(QC<4>{}); block(QC<5>{}); }
         if constexpr (NBW > 6) { block(QC<6>{}); block(QC<7>{}); }
         if constexpr (NBW > 8) { block(QC<8>{}); block(QC<9>{}); block(QC<10>{}); block(QC<11>{}); }
         if constexpr (do_w) advance_w();
@@ -352,7 +364,7 @@ __global__ __launch_bounds__(256, 1) void gemm_lnq_kernel(LnqParams p) {
                 const int row = mb * 32 + (lane & 31);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int col = wid * (D / 4) + nb * 32 + 8 * g + 4 * (lane >> 5);
+                    const int col = wid * (D / NW) + nb * 32 + 8 * g + 4 * (lane >> 5);
                     const f32x4 b = *reinterpret_cast<const f32x4*>(lbias + col);
                     u32x2 st;
                     st[0] = pack_bf16x2(v[4 * g] + b[0], v[4 * g + 1] + b[1]);
@@ -361,7 +373,7 @@ __global__ __launch_bounds__(256, 1) void gemm_lnq_kernel(LnqParams p) {
                 }
             } else {
                 const int row = mb * 16 + (lane & 15);
-                const int col = wid * (D / 4) + nb * 16 + 4 * (lane >> 4);
+                const int col = wid * (D / NW) + nb * 16 + 4 * (lane >> 4);
                 const f32x4 b = *reinterpret_cast<const f32x4*>(lbias + col);
                 u32x2 st;
                 st[0] = pack_bf16x2(v[0] + b[0], v[1] + b[1]);
@@ -374,8 +386,8 @@ __global__ __launch_bounds__(256, 1) void gemm_lnq_kernel(LnqParams p) {
     // read-back: 64 rows x 96 chunks of 16 B, chunk id = tid + 256 i: lanes walk a row's chunks, whole 128-B lines per store
     constexpr int CPR = D / 8;                                            // 16-B chunks per output row
 #pragma unroll 4
-    for (int i = 0; i < QM * CPR / 256; ++i) {
-        const int id = tid + 256 * i;
+    for (int i = 0; i < QM * CPR / (NW * 64); ++i) {
+        const int id = tid + NW * 64 * i;
         const int row = id / CPR, c = id - row * CPR;
         const u32x4 val = *reinterpret_cast<const u32x4*>(smem + row * Q_AROW + ((c ^ (row & 15)) << 4));
         if (m0 + row < p.M) *reinterpret_cast<u32x4*>(p.out + (size_t)(m0 + row) * p.ldo + c * 8) = val;
@@ -393,11 +405,11 @@ __global__ __launch_bounds__(256, 1) void gemm_lnq_kernel(LnqParams p) {
 #endif
 }
 
-template <int SHAPE, int R, bool XB, int D = 768>
+template <int SHAPE, int R, bool XB, int D = 768, int NW = 4>
 hipError_t launch_lnq_t(const LnqParams& p, hipStream_t s) {
     static DevOnce lds_once;
-    if (hipError_t e = set_max_lds_once(lds_once, {reinterpret_cast<const void*>(&gemm_lnq_kernel<SHAPE, R, XB, D>)}, QW<D>::LDS)) return e;
-    hipLaunchKernelGGL((gemm_lnq_kernel<SHAPE, R, XB, D>), dim3((p.M + QM - 1) / QM), dim3(256), QW<D>::LDS, s, p);
+    if (hipError_t e = set_max_lds_once(lds_once, {reinterpret_cast<const void*>(&gemm_lnq_kernel<SHAPE, R, XB, D, NW>)}, QW<D>::LDS)) return e;
+    hipLaunchKernelGGL((gemm_lnq_kernel<SHAPE, R, XB, D, NW>), dim3((p.M + QM - 1) / QM), dim3(NW * 64), QW<D>::LDS, s, p);
     return hipGetLastError();
 }
 
@@ -412,6 +424,8 @@ extern "C" int ditto_diag_lnq_stamps(unsigned long long* out, int n) {   // raw 
 namespace ditto {
 #endif
 
+// 8 (default since round 5) = two waves per SIMD, 4 = one (the round-4 form): bit-identical outputs; shape 32 only (the 16x16x32 twin stays at 4)
+int g_lnq_waves = [] { const char* e = getenv("DITTO_LNQ_WAVES"); return e ? atoi(e) : 8; }();
 int g_lnq_ring = [] { const char* e = getenv("DITTO_LNQ_RING"); return e ? atoi(e) : 0; }();   // 0 = the shape's default depth
 
 // h: fp32 [M, ldh] (h_bf16 false) or bf16 [M, ldh]; Wp: the stage-major image of W_q for `shape` (32: group 16, 16: group 32);
@@ -426,7 +440,9 @@ hipError_t launch_gemm_lnq(const void* h, int ldh, bool h_bf16, const float* gam
     p.h = h; p.ldh = ldh; p.gamma = gamma; p.beta = beta; p.Wp = (const char*)Wp; p.bias = bias;
     p.out = (bf16*)out_bf16; p.ldo = ldo; p.M = M; p.rot_period = rot_period > 0 ? rot_period : 0;
     const int ring = g_lnq_ring;
-    if (d == 1024) return launch_lnq_t<32, 4, false, 1024>(p, s);
+    if (d == 1024) return g_lnq_waves == 8 ? launch_lnq_t<32, 4, false, 1024, 8>(p, s) : launch_lnq_t<32, 4, false, 1024>(p, s);
+    if (g_lnq_waves == 8 && shape == 32)   // two waves per SIMD (round 5, default): "lnq_waves" 8; in the model 60.8 -> 53.2 us per launch
+        return h_bf16 ? launch_lnq_t<32, 4, true, 768, 8>(p, s) : launch_lnq_t<32, 4, false, 768, 8>(p, s);
     // default depth = the shallow ring: in the model (tools/step_ab.py, C2 B = 32, one process) 4 stages 61.3 us against 63.2 for 8
     // (shape 32), 2 stages 70.6 against 72.2 for 4 (shape 16): the loop is not short of bytes in flight
     if (shape == 32) {

@@ -796,6 +796,40 @@ def test_fused_q_projection_normalises_exactly_like_the_layernorm_kernel(lib):
         assert torch.equal(out, u), shape
 
 
+@pytest.mark.parametrize("h_bf16", [False, True])
+@pytest.mark.parametrize("M,rot", [(64, 0), (1, 0), (63, 5), (200, 0), (1024, 16), (2048 + 37, 5)])
+def test_fused_q_projection_on_two_waves_per_simd_is_bitwise_the_four_wave_kernel(lib, M, rot, h_bf16):
+    """ditto_set_option("lnq_waves", 8): the fused norm2 + q-projection with EIGHT waves per workgroup (two per SIMD; each wave
+    owns 96 of the 768 columns and normalises 8 of the 64 rows) against the four-wave kernel: no weight byte is fetched twice,
+    every output element is the same K-ordered MFMA chain and every row is normalised by the same one-wave-per-row arithmetic —
+    so the outputs must agree BIT FOR BIT, ragged M and rotated K loops included."""
+    d = 768
+    h = (asym((M, d), 51) * 1.9 - 0.3).to(DEV)
+    hin = bf16(h) if h_bf16 else h
+    gamma = (1 + 0.2 * asym((d,), 52)).to(DEV)
+    beta = (0.1 * asym((d,), 53)).to(DEV)
+    W = bf16((asym((d, d), 54) / math.sqrt(d)).to(DEV))
+    bias = (0.1 * asym((d,), 55)).to(DEV)
+    scratch = torch.empty(d * d * 2, dtype=torch.uint8, device=DEV)
+    outs = {}
+    try:
+        hip.set_option("fr_rot", rot if rot else 1)
+        for waves in (4, 8, 8):
+            hip.set_option("lnq_waves", waves)
+            out = torch.full((M, d), float("nan"), dtype=torch.bfloat16, device=DEV)
+            hip.check(lib.ditto_gemm_lnq_bf16(hin.data_ptr(), d, int(h_bf16), gamma.data_ptr(), beta.data_ptr(), W.data_ptr(),
+                                              bias.data_ptr(), out.data_ptr(), d, M, d, 32, scratch.data_ptr(), stream()))
+            torch.cuda.synchronize()
+            if waves in outs:
+                assert torch.equal(out, outs[waves])                    # run to run
+            outs[waves] = out
+    finally:
+        hip.set_option("lnq_waves", 8)
+        hip.set_option("fr_rot", 1)
+    assert torch.isfinite(outs[4].float()).all()
+    assert torch.equal(outs[8], outs[4]), float((outs[8].float() - outs[4].float()).abs().max())
+
+
 @pytest.mark.parametrize("M", [64, 100, 1024 + 13])
 def test_layernorm_fused_into_the_q_projection_at_width_1024(lib, M):
     """The same kernel at d = 1024 (BASELINE config C5: 64 x 1024 tiles, 256 accumulators per lane, 32x32x16, fp32 rows):
@@ -824,3 +858,15 @@ def test_layernorm_fused_into_the_q_projection_at_width_1024(lib, M):
     assert torch.equal(out, u)
     assert lib.ditto_gemm_lnq_bf16(h.data_ptr(), d, 0, gamma.data_ptr(), beta.data_ptr(), W.data_ptr(), None, out.data_ptr(), d, M,
                                    d, 16, scratch.data_ptr(), stream()) == hip.ERR_SHAPE      # 16x16x32 exists at d = 768 only
+    # two waves per SIMD (the default since round 5) against one: the same bits
+    res = {}
+    try:
+        for waves in (8, 4):
+            hip.set_option("lnq_waves", waves)
+            o = torch.empty_like(out)
+            hip.check(lib.ditto_gemm_lnq_bf16(h.data_ptr(), d, 0, gamma.data_ptr(), beta.data_ptr(), W.data_ptr(), bias.data_ptr(),
+                                              o.data_ptr(), d, M, d, 32, scratch.data_ptr(), stream()))
+            res[waves] = o
+    finally:
+        hip.set_option("lnq_waves", 8)
+    assert torch.equal(res[8], res[4])

@@ -43,16 +43,17 @@ acc = {v: {} for v in variants}
 wall = {v: [] for v in variants}
 
 
-GENERIC_OPTS = set()
+GENERIC_OPTS = {}   # name -> the value found when a variant first named it (restored for variants without it)
 
 
 def select(v):
     v, _, kv = v.partition(":")          # ...:name.value[,name.value] arbitrary ditto_set_option pairs (reset to 0 by variants without them)
-    for name in GENERIC_OPTS:
-        hip.check(lib.ditto_set_option(name.encode(), 0))
+    for name, dflt in GENERIC_OPTS.items():
+        hip.check(lib.ditto_set_option(name.encode(), dflt))
     for pair in [x for x in kv.split(";") if x]:
         name, _, val = pair.partition(".")
-        GENERIC_OPTS.add(name)
+        if name not in GENERIC_OPTS:
+            GENERIC_OPTS[name] = hip.get_option(name)
         hip.check(lib.ditto_set_option(name.encode(), int(val)))
     v, _, cr = v.partition("=")          # ...=fr_class_rows (pin the full-row kernel class: rows of the batch to decide as)
     if cr or not os.environ.get("DITTO_HIP_LIB"):
