@@ -98,6 +98,10 @@ int g_ll_mask = [] { const char* e = getenv("DITTO_LL_MASK"); return e ? atoi(e)
 // "lnq_min_rows": > 0: the fused norm2 + q-projection also runs BELOW the full-row class, from that many (class) rows on (A/B)
 int g_lnq_min_rows = [] { const char* e = getenv("DITTO_LNQ_MIN_ROWS"); return e ? atoi(e) : 0; }();
 int g_lnq = [] { const char* e = getenv("DITTO_LNQ"); return e ? atoi(e) : 32; }();
+// "frq" (round 5, DITTO_EXPERIMENTAL builds; default 0): the cross out-projection + residual + norm3 of launches on the bf16 residual
+// stream on the fused q-projection kernel's skeleton (gemm_lnq.hip MODE 1: 64-row tiles, A resident in the LDS, two waves per SIMD)
+// instead of gemm_frd.hip's 128-row tile.  Measured slower in the model (74.0 against 65.8 us per launch): an A/B switch, no rule selects it.
+int g_frq = [] { const char* e = getenv("DITTO_FRQ"); return e ? atoi(e) : 0; }();
 int g_resid_bf16 = [] { const char* e = getenv("DITTO_RESIDUAL_BF16"); return e ? atoi(e) : 1; }();
 int small_batch_k_splits(int M, int N, int K) {
     if (g_splitk_wgs < 0) return 1;                        // -1: never split
@@ -350,7 +354,10 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
             GemmParams gp{};
             gp.A = (const bf16*)u; gp.lda = d; gp.W = (const bf16*)lp.WcoP; gp.ldw = d; gp.w_rows = d; gp.bias = lp.bco;
             gp.residual = h; gp.ldr = d; gp.out = h; gp.ldo = d; gp.M = M; gp.N = d; gp.K = d;
-            HIP_TRY(launch_gemm_fr(gp, lp.g3, lp.be3, qkv, d, fr_rot, s, fp8, hb));
+            if (hb && g_frq && d == 768 && !fp8)   // bf16 stream: the 64-row, two-waves-per-SIMD form (gemm_lnq.hip MODE 1)
+                HIP_TRY(launch_gemm_frq(u, d, lp.WcoP, lp.bco, h, h, d, lp.g3, lp.be3, qkv, d, M, N % 64 == 0 ? N / 64 : 0, s));
+            else
+                HIP_TRY(launch_gemm_fr(gp, lp.g3, lp.be3, qkv, d, fr_rot, s, fp8, hb));
         } else {
             ProfScope ps(m, s, DITTO_KC_GEMM_OUTPROJ);
             GemmArgs g{};
@@ -986,6 +993,23 @@ int ditto_gemm_lnq_bf16(const void* h, int ldh, int h_is_bf16, const float* gamm
     return DITTO_OK;
 }
 
+int ditto_gemm_resln_bf16(const void* A, int lda, const void* W, const float* bias, void* h_bf16, int ldh, const float* gamma,
+                          const float* beta, void* u_bf16, int ldu, int M, int rot_period_tiles, void* w_scratch, ditto_stream_t stream) {
+    if (!A || !W || !h_bf16 || !w_scratch || M <= 0 || lda < 768 || ldh < 768 || lda % 8 || ldh % 8 || (gamma == nullptr) != (beta == nullptr) ||
+        (gamma == nullptr) != (u_bf16 == nullptr) || (u_bf16 && (ldu < 768 || ldu % 8)) || rot_period_tiles < 0)
+        return fail(DITTO_ERR_ARG, "bad argument to ditto_gemm_resln_bf16");
+    if ((uintptr_t)w_scratch % 256) return fail(DITTO_ERR_ARG, "w_scratch must be 256-byte aligned");
+#ifndef DITTO_EXPERIMENTAL
+    return fail(DITTO_ERR_ARG, "ditto_gemm_resln_bf16 is an opt-in A/B kernel (csrc/gemm_lnq.hip, out-projection form: measured slower than "
+                               "csrc/gemm_frd.hip in the model); build with DITTO_EXPERIMENTAL=1");
+#else
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(launch_repack_bf16_stage_major(W, w_scratch, 768, 768, s, 16));
+    HIP_TRY(launch_gemm_frq(A, lda, w_scratch, bias, h_bf16, h_bf16, ldh, gamma, beta, u_bf16, ldu, M, rot_period_tiles, s));
+    return DITTO_OK;
+#endif
+}
+
 int ditto_gemm_ln_bf16(const void* A, int lda, const void* W, const float* bias, const float* residual, float* out,
                        int ldo, const float* gamma, const float* beta, void* u_bf16, int ldu, int M, int N, int K,
                        ditto_stream_t stream) {
@@ -1104,7 +1128,7 @@ static int* option_slot(const char* name) {
         {"pp_mask", &g_pp_mask}, {"fr_mask", &g_fr_mask}, {"fr_class_rows", &g_fr_class_rows}, {"fr_dgrad", &g_fr_dgrad},
         {"train_flags", &g_train_flags}, {"fr_u_fp8", &g_fr_u_fp8}, {"fr_tile", &g_fr_tile}, {"fr64_maxk", &g_fr64_maxk},
         {"fr_stagger", &g_fr_stagger}, {"fr_rot", &g_fr_rot}, {"pp_nb", &g_pp_nb}, {"pp_stagger", &g_pp_stagger},
-        {"splitk_wgs", &g_splitk_wgs}, {"residual_bf16", &g_resid_bf16}, {"lnq", &g_lnq}, {"lnq_ring", &g_lnq_ring}, {"lnq_waves", &g_lnq_waves}, {"ll_mask", &g_ll_mask}, {"lnq_min_rows", &g_lnq_min_rows}};
+        {"splitk_wgs", &g_splitk_wgs}, {"residual_bf16", &g_resid_bf16}, {"lnq", &g_lnq}, {"lnq_ring", &g_lnq_ring}, {"lnq_waves", &g_lnq_waves}, {"frq", &g_frq}, {"ll_mask", &g_ll_mask}, {"lnq_min_rows", &g_lnq_min_rows}};
     for (auto& e : tab) if (!strcmp(name, e.n)) return e.p;
     return nullptr;
 }
@@ -1225,6 +1249,15 @@ int ditto_set_option(const char* name, int value) {
     if (!strcmp(name, "ll_mask")) {
         if (value < 0 || value > 3) return fail(DITTO_ERR_ARG, "ll_mask must be in [0, 3]");
         g_ll_mask = value;
+        return DITTO_OK;
+    }
+    if (!strcmp(name, "frq")) {
+        if (value < 0 || value > 1) return fail(DITTO_ERR_ARG, "frq must be 0 or 1");
+#ifndef DITTO_EXPERIMENTAL
+        if (value) return fail(DITTO_ERR_ARG, "frq = 1 selects an opt-in A/B kernel (gemm_lnq.hip, out-projection form) which this library was "
+                                              "built without (DITTO_EXPERIMENTAL=1 python -m ditto_tts_amd.build --force)");
+#endif
+        g_frq = value;
         return DITTO_OK;
     }
     if (!strcmp(name, "lnq_waves")) {

@@ -190,6 +190,7 @@ SYMBOLS = {
     "ditto_attention_causal_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
     "ditto_layernorm_dual": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "ditto_gemm_lnq_bf16": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "ditto_gemm_resln_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "ditto_set_option": (_i, [C.c_char_p, _i]),
     "ditto_get_option": (_i, [C.c_char_p, C.POINTER(C.c_int)]),
     "ditto_full_row_plan": (_i, [C.POINTER(Config), _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -295,6 +295,18 @@ int ditto_gemm_lnq_bf16(const void* h, int ldh, int h_is_bf16, const float* gamm
                         const float* bias, void* out_bf16, int ldo, int M, int d, int mfma_shape, void* w_scratch,
                         ditto_stream_t stream);
 
+/* OPT-IN A/B KERNEL (DITTO_EXPERIMENTAL builds; otherwise DITTO_ERR_ARG): the cross out-projection + residual + the LayerNorm behind it
+ * ON THE BF16 RESIDUAL STREAM on the fused q-projection kernel's skeleton (csrc/gemm_lnq.hip, out-projection form; src/components/
+ * DiT.py:148 + :152; "frq" selects it in the model).  Measured slower than csrc/gemm_frd.hip in the model (74.0 / 65.8 us): not a default.
+ *   h bf16 [M, ldh] (in place) = h + A[M, 768] (bf16) W[768, 768]^T + bias;  u bf16 [M, ldu] = LayerNorm(h) * gamma + beta (eps 1e-5,
+ *   on the UNROUNDED fp32 row; gamma = beta = u = NULL: no LayerNorm output).  64-row tiles whose A rows stay in the LDS, eight
+ *   waves (two per SIMD) side by side in N, W streamed straight into registers.  W: bf16, nn.Linear layout [768 out, 768 in];
+ * w_scratch: 768 * 768 * 2 bytes, 256-byte aligned (receives the stage-major image; the model keeps it in its arena).
+ * rot_period_tiles > 0: tiles t and t + period start their K loop at the same place (the model passes the 64-row tiles per utterance). */
+int ditto_gemm_resln_bf16(const void* A, int lda, const void* W, const float* bias, void* h_bf16, int ldh, const float* gamma,
+                          const float* beta, void* u_bf16, int ldu, int M, int rot_period_tiles, void* w_scratch,
+                          ditto_stream_t stream);
+
 /* Weight-gradient GEMM of the backward pass (csrc/gemm_tn.hip): out fp32 [Mo, No] = X[K, Mo]^T Y[K, No], both operands
  * K-major bf16 (rows = the contraction index, as activations and their gradients lie in memory), i.e. dW = dY^T X of
  * nn.Linear (what autograd computes for reference src/TrainDiTTO.py:90).  tile = 128 (128x128, two workgroups per CU) or
@@ -350,6 +362,9 @@ int ditto_gemm_tn_bf16(const void* X, int ldx, const void* Y, int ldy, float* ou
  * "residual_bf16": 1 = the residual stream h between the segments of a block lives in HBM as bf16 (fp32 only inside the
  * accumulators and the LayerNorm statistics) for launches of the full-row class at d = 768 / head_dim 64; 0 = fp32 stream.
  * The sampler state x and eps stay fp32 either way.  (DITTO_RESIDUAL_BF16 in the environment sets the initial value.)
+ * "frq": 1 (DITTO_EXPERIMENTAL builds only; default 0) = the cross out-projection + residual + norm3 of launches on the bf16 residual
+ * stream on the fused q-projection kernel's skeleton (csrc/gemm_lnq.hip: 64-row tiles, two waves per SIMD) instead of csrc/gemm_frd.hip's
+ * 128-row tile — measured slower, an A/B switch.  "lnq_waves": 8 (default) / 4 = waves per workgroup of the fused norm2 + q-projection (bit-identical).
  * "lnq": norm2 fused into the cross-attention q-projection (csrc/gemm_lnq.hip) for launches of the full-row class at d = 768:
  * 0 = LayerNorm launch + tiled GEMM, 32 / 16 = fused, on that MFMA shape.  (DITTO_LNQ sets the initial value.)
  * "splitk_wgs": K-splitting of the long-K GEMMs (fc2, final projection) of small batches, with an ordered fp32 reduce.

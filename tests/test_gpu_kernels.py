@@ -830,6 +830,57 @@ def test_fused_q_projection_on_two_waves_per_simd_is_bitwise_the_four_wave_kerne
     assert torch.equal(outs[8], outs[4]), float((outs[8].float() - outs[4].float()).abs().max())
 
 
+@pytest.mark.parametrize("ln", [True, False])
+@pytest.mark.parametrize("M,rot", [(64, 0), (1, 0), (63, 0), (65, 3), (200, 0), (1024, 16), (2048 + 37, 5), (4096, 16)])
+def test_out_projection_residual_layernorm_on_the_bf16_stream(lib, M, rot, ln):
+    """ditto_gemm_resln_bf16 (csrc/gemm_lnq.hip, out-projection form: an opt-in A/B kernel of DITTO_EXPERIMENTAL builds — measured
+    slower than csrc/gemm_frd.hip in the model; reference src/components/DiT.py:148 + :152): h <- h + A W^T + bias in place, u =
+    LayerNorm(h) from the UNROUNDED fp32 row.  Against the fp32 ops on the same bf16 operands: h within a bf16 rounding of the
+    fp32 result (rel-L2 < 3e-3), u against LayerNorm of the fp32 row (4e-3); ragged M (a partial last 64-row tile, one row),
+    rotated K loops, with and without the LayerNorm output; rows do not depend on what else is in the launch (bitwise against a
+    launch of that row alone, same rotation phase); run-to-run determinism; rows past M untouched."""
+    d = 768
+    if not experimental():
+        assert lib.ditto_gemm_resln_bf16(None, d, None, None, None, d, None, None, None, d, M, 0, None, stream()) == hip.ERR_ARG
+        pytest.skip("needs the csrc/experimental/ kernels (DITTO_EXPERIMENTAL=1 build)")
+    A = bf16(asym((M, d), 61).to(DEV))
+    W = bf16((asym((d, d), 62) / math.sqrt(d)).to(DEV))
+    bias = (0.1 * asym((d,), 63)).to(DEV)
+    h0 = bf16((asym((M + 3, d), 64) * 1.5 + 0.2).to(DEV))              # three guard rows behind M
+    g = (1 + 0.2 * asym((d,), 65)).to(DEV)
+    b = (0.1 * asym((d,), 66)).to(DEV)
+    scratch = torch.empty(d * d * 2, dtype=torch.uint8, device=DEV)
+    want_h = h0[:M].float() + A.float() @ W.float().T + bias
+    want_u = torch.nn.functional.layer_norm(want_h, (d,), g, b, 1e-5)
+    first = None
+    for rep in range(2):
+        h = h0.clone()
+        u = torch.full((M + 3, d), 7.0, dtype=torch.bfloat16, device=DEV)
+        hip.check(lib.ditto_gemm_resln_bf16(A.data_ptr(), d, W.data_ptr(), bias.data_ptr(), h.data_ptr(), d, g.data_ptr() if ln else None,
+                                            b.data_ptr() if ln else None, u.data_ptr() if ln else None, d, M, rot, scratch.data_ptr(), stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(h[M:], h0[M:]) and bool((u[M:].float() == 7.0).all())
+        assert rel_l2(h[:M].float(), want_h) < 3e-3 and max_abs(h[:M].float(), want_h) < 0.05 * (1 + float(want_h.abs().max()) / 8)
+        if ln:
+            assert rel_l2(u[:M].float(), want_u) < 4e-3 and max_abs(u[:M].float(), want_u) < 4e-2
+        if first is None:
+            first = (h.clone(), u.clone())
+        else:
+            assert torch.equal(h, first[0]) and torch.equal(u, first[1])
+    r = M // 2
+    if rot == 0 or (r // 64) % rot % 6 == 0:                             # a row alone: the same bits when its K loop starts at the same place
+        h1 = h0[r:r + 1].clone()
+        u1 = torch.empty(1, d, dtype=torch.bfloat16, device=DEV)
+        hip.check(lib.ditto_gemm_resln_bf16(A[r:r + 1].contiguous().data_ptr(), d, W.data_ptr(), bias.data_ptr(), h1.data_ptr(), d,
+                                            g.data_ptr() if ln else None, b.data_ptr() if ln else None, u1.data_ptr() if ln else None, d, 1,
+                                            rot, scratch.data_ptr(), stream()))
+        assert torch.equal(h1[0], first[0][r])
+        if ln:
+            assert torch.equal(u1[0], first[1][r])
+    assert lib.ditto_gemm_resln_bf16(A.data_ptr(), d, W.data_ptr(), bias.data_ptr(), None, d, None, None, None, d, M, 0, scratch.data_ptr(),
+                                     stream()) == hip.ERR_ARG
+
+
 @pytest.mark.parametrize("M", [64, 100, 1024 + 13])
 def test_layernorm_fused_into_the_q_projection_at_width_1024(lib, M):
     """The same kernel at d = 1024 (BASELINE config C5: 64 x 1024 tiles, 256 accumulators per lane, 32x32x16, fp32 rows):
