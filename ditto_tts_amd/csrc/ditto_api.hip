@@ -96,7 +96,9 @@ int g_ll_mask = [] { const char* e = getenv("DITTO_LL_MASK"); return e ? atoi(e)
 // "lnq": norm2 fused into the cross-attention q-projection (gemm_lnq.hip) for launches of the full-row class at d = 768:
 // 0 = off (LayerNorm launch + tiled GEMM), 32 / 16 = on, with that MFMA shape (32x32x16 / 16x16x32)
 // "lnq_min_rows": > 0: the fused norm2 + q-projection also runs BELOW the full-row class, from that many (class) rows on (A/B)
-int g_lnq_min_rows = [] { const char* e = getenv("DITTO_LNQ_MIN_ROWS"); return e ? atoi(e) : 0; }();
+// Default 8192 since round 5: with the kernel on two waves per SIMD the fused launch wins from 128 of its 64-row tiles on
+// (profiles/r05_small_batch_lnq8.txt, same process: B = 8 4.02 -> 3.95 ms, B = 16 6.63 -> 6.47; B = 4 2.61 -> 2.63, hence not lower).
+int g_lnq_min_rows = [] { const char* e = getenv("DITTO_LNQ_MIN_ROWS"); return e ? atoi(e) : 8192; }();
 int g_lnq = [] { const char* e = getenv("DITTO_LNQ"); return e ? atoi(e) : 32; }();
 // "frq" (round 5, DITTO_EXPERIMENTAL builds; default 0): the cross out-projection + residual + norm3 of launches on the bf16 residual
 // stream on the fused q-projection kernel's skeleton (gemm_lnq.hip MODE 1: 64-row tiles, A resident in the LDS, two waves per SIMD)

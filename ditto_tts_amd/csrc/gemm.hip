@@ -378,7 +378,12 @@ hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s) {
     // B = 16; gated 51.5 -> 48.3 (B = 4), 99.0 -> 78.3 (B = 8).  Narrow outputs (N = d) keep the 4-round rule: at B = 4
     // the d x d GEMMs take 33 us on it against 18.
     const bool wide256 = a.N >= 2048 && t256 >= 144;
-    if (forced == 256 || (forced == 0 && (t256 >= 4 * 256 || wide256))) {
+    // Narrow outputs whose 256 x 256 tiles make WHOLE rounds of the 256 CUs (d = 1024 at M = 16384: 64 x 4 tiles, one per CU): no
+    // tile quantisation to lose.  Round 5, C5 bf16 in-model (profiles/r05_c5_tile256.txt): fc2 147.5 (256 x 128 ring) -> 116.9 us,
+    // the K = 1024 out-projection 57.4 -> 48.4, the final projection 78.5 -> 64.4.  Widths that are multiples of 192 keep the rule
+    // below (their 256 x 192 tiles were measured against this kernel in round 1).
+    const bool rounds256 = gemm256_whole_rounds(a.M, a.N, a.K);
+    if (forced == 256 || (forced == 0 && (t256 >= 4 * 256 || wide256 || rounds256))) {
         p.tiles_m = (a.M + 255) / 256;
         p.tiles_n = (a.N + 255) / 256;
         return launch_gemm256(p, epi, s);

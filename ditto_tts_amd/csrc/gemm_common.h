@@ -510,7 +510,9 @@ inline bool fr_outproj_ok(int M, int d) {
     return fr_pays(M) && gemm_fr_supports(M, d, d, (size_t)d, (size_t)d);
 }
 inline bool fr_fc2_ok(int M, int d) {
-    if (d == 1024) return fr_pays_64(M) && gemm_fr64_supports(M, d, 4 * d, (size_t)4 * d, (size_t)4 * d);
+    if (d == 1024)   // (not where the tiled fc2 runs whole rounds of 256 x 256 tiles: kernels.h gemm256_whole_rounds; by CLASS rows)
+        return fr_pays_64(M) && !gemm256_whole_rounds(opt_class_rows() > 0 ? opt_class_rows() : M, d, 4 * d) &&
+               gemm_fr64_supports(M, d, 4 * d, (size_t)4 * d, (size_t)4 * d);
     return fr_pays(M) && gemm_fr_supports(M, d, 4 * d, (size_t)4 * d, (size_t)4 * d);
 }
 // gemm_pp.hip

@@ -529,6 +529,9 @@ __global__ __launch_bounds__(256, 1) void gemm_frd_kernel(FrParams fp) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         FRD_STAMP(5);                                                // (stores drained)
         const int w = blockIdx.x * 4 + wid;
+#ifdef DITTO_DIAG_FRD_STAMP_K   // record only the launches of this depth WITH a LayerNorm (in-model stamps: tools/frd_stamps_model.py)
+        if (p.K == DITTO_DIAG_FRD_STAMP_K && LN)
+#endif
         if (lane == 0 && w < 1024 * 4) {
             g_frd_stamps[w * 8 + 0] = frd_t1 - frd_t0; g_frd_stamps[w * 8 + 1] = frd_t2 - frd_t1; g_frd_stamps[w * 8 + 2] = frd_t3 - frd_t2;
             g_frd_stamps[w * 8 + 3] = frd_t4 - frd_t3; g_frd_stamps[w * 8 + 4] = frd_t5 - frd_t4; g_frd_stamps[w * 8 + 5] = 1;

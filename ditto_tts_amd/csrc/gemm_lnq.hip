@@ -266,6 +266,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_lnq_kernel(LnqParams p) 
                     else raw[r][c] = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.h) + (size_t)gr * p.ldh)[lane + 64 * c];
                 }
             }
+#ifdef DITTO_DIAG_LNQ_STAMP
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (half == 0) { const unsigned long long tl = lnq_now(); if (lane == 0 && blockIdx.x * NW + wid < 2048 * 4) g_lnq_stamps[(blockIdx.x * NW + wid) * 8 + 7] = tl - lnq_t0; }
+#endif
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
                 f32x4 v[CH];
@@ -298,6 +302,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_lnq_kernel(LnqParams p) 
             }
         }
     }
+#ifdef DITTO_DIAG_LNQ_STAMP
+    { const unsigned long long tv = lnq_now(); if (lane == 0 && blockIdx.x * NW + wid < 2048 * 4) g_lnq_stamps[(blockIdx.x * NW + wid) * 8 + 6] = tv - lnq_t0; }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // (wave 3: the bias pieces)
     __syncthreads();
     LNQ_STAMP(1);
@@ -344,7 +351,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_lnq_kernel(LnqParams p) 
 
 #ifdef DITTO_DIAG_LNQ_STAMP
     const unsigned long long lnq_tinit = lnq_now();   // (MODE 1: the residual has become the accumulators)
-    if (lane == 0 && blockIdx.x * NW + wid < 2048 * 4) g_lnq_stamps[(blockIdx.x * NW + wid) * 8 + 6] = lnq_tinit - lnq_t1;
+    if (MODE == 1 && lane == 0 && blockIdx.x * NW + wid < 2048 * 4) g_lnq_stamps[(blockIdx.x * NW + wid) * 8 + 6] = lnq_tinit - lnq_t1;
 #endif
     // ring prologue: from here on the W loads are the ONLY vector-memory operations until the epilogue's stores
 #pragma unroll

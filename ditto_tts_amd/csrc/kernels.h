@@ -112,7 +112,8 @@ inline int opt_lnq() { return t_opts.lnq >= 0 ? t_opts.lnq : g_lnq; }
 //   low-latency  <= 2048 rows: tiled GEMMs, fc2 / final projection / cross out-projection split over K by a K-only rule, fp32 stream
 //                (ll_mask bit 0 — fc2's finish also writes the next norm1 — changes no bit; bit 1 — the out-projection as TWO
 //                K-splits — changes the summation order of that GEMM: it is part of what defines the class)
-//   tiled        up to 17 407 rows: tiled GEMMs + LayerNorm launches, fp32 stream; inside it 11 264 .. 17 407 rows (176 .. 271 tiles
+//   tiled        up to 17 407 rows: tiled GEMMs + LayerNorm launches, fp32 stream; from 8 192 rows on (round 5, "lnq_min_rows")
+//                norm2 is fused into the q-projection (gemm_lnq.hip, two waves per SIMD); inside it 11 264 .. 17 407 rows (176 .. 271 tiles
 //                of 64 rows, except the exact 256-row rounds) take the 64-row full-row kernel — same fp32 h bits as the 128-row
 //                kernel's fp32 form (u within a bf16 rounding tie), still the fp32 stream
 //   full-row     >= 17 408 rows (136 tiles of 128 rows): gemm_frd.hip for both fused launches, norm2 fused into the q-projection and,
@@ -129,6 +130,15 @@ inline int fr_rule_rows(int rows) {
     return 0;
 }
 inline bool fr_pays(int M) { return fr_rule_rows(opt_class_rows() > 0 ? opt_class_rows() : M) != 0; }
+
+// gemm.hip's tile rule for narrow outputs (N < 2048, not a multiple of 192): the 256 x 256 persistent kernel where its tiles make
+// whole rounds of the 256 CUs.  Also read by fr_fc2_ok (gemm_common.h): at d = 1024 that GEMM + a LayerNorm launch beats the
+// 64-row full-row fc2 (116.9 + 18 against 157.7 us at M = 16384: the full-row kernel re-streams all 8 MiB of W per 64 rows).
+inline bool gemm256_whole_rounds(int M, int N, int K) {
+    if (N >= 2048 || N % 256 || N % 192 == 0 || K < 1024) return false;
+    const long t256 = (long)((M + 255) / 256) * (N / 256);
+    return t256 >= 256 && t256 % 256 == 0;
+}
 
 // d = 1024 runs the 64-row kernel only (gemm_fr64.hip, one workgroup per CU): it needs three quarters of the CUs busy.
 inline bool fr_pays_64(int M) {

@@ -130,7 +130,12 @@ def test_full_row_plan_is_judged_per_launch_and_pinnable():
     assert hip.full_row_plan(c5, 16, 1024) == (True, False)
     assert hip.full_row_plan(c5, 8, 1024) == (False, False)
     c5b = PRESETS["C5_bf16"]["cfg"]
-    assert hip.full_row_plan(c5b, 16, 1024) == (True, True)
+    # round 5: at 16 x 1024 rows the tiled fc2 makes ONE whole round of 256 x 256 tiles (kernels.h gemm256_whole_rounds) and, with
+    # a LayerNorm launch, beats the 64-row full-row fc2 (which re-streams all of W per 64 rows); other row counts keep the fusion
+    assert hip.full_row_plan(c5b, 16, 1024) == (True, False)
+    assert hip.full_row_plan(c5b, 14, 1024) == (True, True)
+    with hip.batch_class(14 * 1024):
+        assert hip.full_row_plan(c5b, 16, 1024) == (True, True)        # (decided on the CLASS rows)
     assert hip.full_row_plan(c5b, 11, 1024) == (False, False)
     with pytest.raises(hip.DittoHipError):
         hip.set_option("fr_class_rows", -1)

@@ -578,7 +578,9 @@ def test_c5_width_takes_the_full_row_path_against_oracle():
         m = m.to(DEV).eval()
         plain = m(x.to(DEV), text.to(DEV), t.to(DEV))
         assert hip.full_row_plan(cfg, 2, 256) == (False, False)
-        with hip.batch_class(16 * 1024):
+        with hip.batch_class(16 * 1024):      # C5's own class: fc2 on whole rounds of 256 x 256 tiles since round 5, not full-row
+            assert hip.full_row_plan(cfg, 2, 256) == (True, False)
+        with hip.batch_class(14 * 1024):
             assert hip.full_row_plan(cfg, 2, 256) == (True, not fp8)
             fused = m(x.to(DEV), text.to(DEV), t.to(DEV))
             assert torch.equal(fused, m(x.to(DEV), text.to(DEV).clone(), t.to(DEV)))
@@ -594,7 +596,8 @@ def test_c5_width_takes_the_full_row_path_against_oracle():
 def test_c5_full_shape_against_oracle():
     """BASELINE configs[4] at its FULL shape — 24 layers, d = 1024, h = 16, N = T = 1024 — one utterance against the fp32
     oracle, kernel class pinned to C5's batch of 16 so that the launches are the ones bench.py times (full-row kernel for
-    the cross out-projection + norm3 in both configurations, for fc2 + the next norm1 in the bf16 one).  Stated tolerances:
+    the cross out-projection + norm3 in both configurations; fc2 on one whole round of 256 x 256 tiles + a LayerNorm launch since
+    round 5 — the full-row fc2 + next norm1 of d = 1024 is covered by the test above, class 14 x 1024).  Stated tolerances:
     bf16 2e-2, fp8 6e-2 (the N = 1024 shape had only ever run in the bench)."""
     from oracle import ditto_oracle as O
     p = PRESETS["C5"]
@@ -611,7 +614,7 @@ def test_c5_full_shape_against_oracle():
         m.load_state_dict(sd)
         m = m.to(DEV).eval()
         with hip.batch_class(p["B"] * N):
-            assert hip.full_row_plan(cfg, 1, N) == (True, not cfg.fp8_linear)
+            assert hip.full_row_plan(cfg, 1, N) == (True, False)
             res[cfg.fp8_linear] = rel_l2(m(x.to(DEV), text.to(DEV), t.to(DEV)), want)
         del m
     print(f"C5 full shape 24L N=T=1024: bf16 rel-L2 {res[False]:.3e}, fp8 rel-L2 {res[True]:.3e}")

@@ -28,7 +28,7 @@ p = PRESETS[a.config]
 cfg, N, T = p["cfg"], p["N"], p["T"]
 B = a.batch or p["B"]
 dev = torch.device("cuda")
-m = DiTTO(cfg.hidden_dim, cfg.num_layers, cfg.num_heads, cfg.time_dim, cfg.text_dim, cfg.diffusion_steps)
+m = DiTTO(cfg.hidden_dim, cfg.num_layers, cfg.num_heads, cfg.time_dim, cfg.text_dim, cfg.diffusion_steps, fp8_linear=cfg.fp8_linear)
 m.load_state_dict(synthetic_state_dict(cfg, seed=1234))
 m = m.to(dev).eval()
 sg = SpeechGenerator(ditto_model=m, device=dev)
