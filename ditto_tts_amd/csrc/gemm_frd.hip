@@ -129,6 +129,22 @@ DITTO_DEV unsigned long long frd_now() {
 #define FRD_STAMP(i)
 #endif
 
+// accumulator-init group gi of 24 -> its (nb, mb) block (see the kernel's prologue)
+constexpr int frd_group_nb(int gi) {
+#if defined(FRD_PAIRED) && FRD_PAIRED
+    return 2 * (gi >> 3) + (gi & 1);
+#else
+    return gi >> 2;
+#endif
+}
+constexpr int frd_group_mb(int gi) {
+#if defined(FRD_PAIRED) && FRD_PAIRED
+    return (gi >> 1) & 3;
+#else
+    return gi & 3;
+#endif
+}
+
 template <bool LN, bool RES, bool HB = false>
 __global__ __launch_bounds__(256, 1) void gemm_frd_kernel(FrParams fp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -225,11 +241,20 @@ __global__ __launch_bounds__(256, 1) void gemm_frd_kernel(FrParams fp) {
                 else rp[mb] = reinterpret_cast<const char*>(p.residual + (size_t)gr * p.ldr + wid * 192 + 4 * hh);
             }
         }
-        constexpr int WD = 4, NG = 24;                               // window depth; groups = (nb, mb) blocks, mb fastest
+#ifndef FRD_WD
+#define FRD_WD 4
+#endif
+#ifndef FRD_PAIRED
+#define FRD_PAIRED 0
+#endif
+        // window depth (groups of four loads in flight per wave); 24 groups = (nb, mb) blocks.  Order: mb fastest (FRD_PAIRED 0),
+        // or the two column blocks that share a row's 128-byte line back to back (bf16 stream: 2 x 64 B; FRD_PAIRED 1)
+        constexpr int WD = HB ? FRD_WD : 4, NG = 24;                 // (the fp32 form: 16-byte loads, twice the window registers)
+        static_assert(WD == 4 || WD == 8 || WD == 12, "window depth");
         using res_t = typename std::conditional<HB, u32x2, f32x4>::type;   // four columns of one row: bf16 x 4 or fp32 x 4
         res_t T[WD][4];
         auto issue_group = [&](auto GI, res_t (&t)[4]) {
-            constexpr int nb = decltype(GI)::value >> 2, mb = decltype(GI)::value & 3;
+            constexpr int nb = frd_group_nb(decltype(GI)::value), mb = frd_group_mb(decltype(GI)::value);
             if constexpr (RES && HB) {
                 const char* ptr = rp[mb];
                 asm volatile("global_load_dwordx2 %0, %4, off offset:%5\n\t"
@@ -254,7 +279,7 @@ __global__ __launch_bounds__(256, 1) void gemm_frd_kernel(FrParams fp) {
             }
         };
         auto finish_group = [&](auto GI, res_t (&t)[4]) {
-            constexpr int gi = decltype(GI)::value, nb = gi >> 2, mb = gi & 3;
+            constexpr int gi = decltype(GI)::value, nb = frd_group_nb(gi), mb = frd_group_mb(gi);
             constexpr int younger = NG - 1 - gi < WD - 1 ? NG - 1 - gi : WD - 1;
             if constexpr (RES)
                 asm volatile("s_waitcnt vmcnt(%4)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]) : "n"(4 * younger) : "memory");
@@ -284,6 +309,8 @@ __global__ __launch_bounds__(256, 1) void gemm_frd_kernel(FrParams fp) {
             if constexpr (gi + WD < NG) issue_group(DC<gi + WD>{}, T[gi % WD]);
         };
         issue_group(DC<0>{}, T[0]); issue_group(DC<1>{}, T[1]); issue_group(DC<2>{}, T[2]); issue_group(DC<3>{}, T[3]);
+        if constexpr (WD > 4) { issue_group(DC<4>{}, T[4 % WD]); issue_group(DC<5>{}, T[5 % WD]); issue_group(DC<6>{}, T[6 % WD]); issue_group(DC<7>{}, T[7 % WD]); }
+        if constexpr (WD > 8) { issue_group(DC<8>{}, T[8 % WD]); issue_group(DC<9>{}, T[9 % WD]); issue_group(DC<10>{}, T[10 % WD]); issue_group(DC<11>{}, T[11 % WD]); }
         init_step(DC<0>{}); init_step(DC<1>{}); init_step(DC<2>{}); init_step(DC<3>{}); init_step(DC<4>{}); init_step(DC<5>{});
         init_step(DC<6>{}); init_step(DC<7>{}); init_step(DC<8>{}); init_step(DC<9>{}); init_step(DC<10>{}); init_step(DC<11>{});
         init_step(DC<12>{}); init_step(DC<13>{}); init_step(DC<14>{}); init_step(DC<15>{}); init_step(DC<16>{}); init_step(DC<17>{});
