@@ -248,7 +248,9 @@ __global__ __launch_bounds__(256, 1) void gemm_frd_kernel(FrParams fp) {
 #define FRD_PAIRED 0
 #endif
         // window depth (groups of four loads in flight per wave); 24 groups = (nb, mb) blocks.  Order: mb fastest (FRD_PAIRED 0),
-        // or the two column blocks that share a row's 128-byte line back to back (bf16 stream: 2 x 64 B; FRD_PAIRED 1)
+        // or the two column blocks that share a row's 128-byte line back to back (bf16 stream: 2 x 64 B; FRD_PAIRED 1).
+        // Round 5 A/B (-DFRD_WD=8|12 -DFRD_PAIRED=1, profiles/r05_frd_window_ab.txt): out-proj 65.6 -> 64.2 .. 65.4 us, fc2 137.5 ->
+        // 136.2 .. 137.0: inside the noise — the 17 us of this phase are not a too-small load window; defaults kept.
         constexpr int WD = HB ? FRD_WD : 4, NG = 24;                 // (the fp32 form: 16-byte loads, twice the window registers)
         static_assert(WD == 4 || WD == 8 || WD == 12, "window depth");
         using res_t = typename std::conditional<HB, u32x2, f32x4>::type;   // four columns of one row: bf16 x 4 or fp32 x 4

@@ -8,7 +8,7 @@ TAG=$1
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-BENCH="python3 bench.py --no-cpu-baseline --profile-steps 0 --loops 0 --no-sweep --no-c3 --no-other-configs"
+BENCH="python3 bench.py --no-cpu-baseline --profile-steps 0 --loops 0 --no-sweep --no-c3 --no-other-configs --no-parity"   # (--no-parity since round 5: the parity leg now runs 12 more B = 32 steps between seconds of CPU work, whose cold-clock launches do not belong in the average)
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $BENCH --steps 10 --warmup 2 > $OUT/kt.log 2>&1
 DITTO_ROCTX=1 timeout 600 rocprofv3 --kernel-trace --marker-trace --output-format csv -d $OUT/mk -o mk -- $BENCH --steps 2 --warmup 1 > $OUT/mk.log 2>&1
