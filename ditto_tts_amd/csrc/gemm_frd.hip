@@ -257,6 +257,12 @@ __global__ __launch_bounds__(256, 1) void gemm_frd_kernel(FrParams fp) {
         res_t T[WD][4];
         auto issue_group = [&](auto GI, res_t (&t)[4]) {
             constexpr int nb = frd_group_nb(decltype(GI)::value), mb = frd_group_mb(decltype(GI)::value);
+#ifdef DITTO_DIAG_FRD_NORES   // stamps only: the accumulators start from the bias alone (valid numbers, WRONG results) — what do the residual loads cost?
+            if constexpr (true) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t[i] = res_t{};
+            } else
+#endif
             if constexpr (RES && HB) {
                 const char* ptr = rp[mb];
                 asm volatile("global_load_dwordx2 %0, %4, off offset:%5\n\t"
@@ -283,8 +289,12 @@ __global__ __launch_bounds__(256, 1) void gemm_frd_kernel(FrParams fp) {
         auto finish_group = [&](auto GI, res_t (&t)[4]) {
             constexpr int gi = decltype(GI)::value, nb = frd_group_nb(gi), mb = frd_group_mb(gi);
             constexpr int younger = NG - 1 - gi < WD - 1 ? NG - 1 - gi : WD - 1;
+#ifndef DITTO_DIAG_FRD_NORES
             if constexpr (RES)
                 asm volatile("s_waitcnt vmcnt(%4)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]) : "n"(4 * younger) : "memory");
+#else
+            if constexpr (gi == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             if constexpr (gi == 0) {
                 if constexpr (!RES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 FD_BAR();      // every wave is past a wait that covers wave 0's bias row (the oldest load): visible to all
