@@ -369,6 +369,31 @@ def test_shards_straddling_the_full_row_threshold_agree_when_the_class_is_pinned
 
 
 @torch.no_grad()
+def test_shards_straddling_the_fused_q_projection_threshold_agree_when_the_class_is_pinned():
+    """Round 5: inside the tiled class, launches of 8 192 rows and more run norm2 + the cross-attention q-projection as ONE
+    kernel (csrc/gemm_lnq.hip on two waves per SIMD; "lnq_min_rows"), smaller ones as a LayerNorm launch + a tiled GEMM — another
+    MFMA shape, so the last bits differ.  The decision is taken on the CLASS rows like the full-row one: a batch of 9 utterances
+    (9 216 rows) split 5 + 4 reproduces the unsplit forward bit for bit when pinned, and differs (within noise) when not."""
+    from ditto_tts_amd import hip
+    cfg = DiTTOConfig(768, 2, 12, 256, 768, 4)
+    m = build(cfg, 6)
+    B, N, T = 9, 1024, 64
+    x, text, t = synthetic_inputs(cfg, B, N, T, seed=14)
+    xd, td, tt = x.to(DEV), text.to(DEV), t.to(DEV)
+    assert hip.get_option("lnq_min_rows") == 8192 and hip.full_row_plan(cfg, B, N) == (False, False)
+    whole = m(xd, td, tt)
+    parts = [(0, 5), (5, 9)]
+    free = torch.cat([m(xd[a:b].contiguous(), td[a:b].contiguous(), tt[a:b].contiguous()) for a, b in parts])
+    assert not torch.equal(free, whole), "the shards were expected to take the unfused q-projection on their own"
+    assert rel_l2(free, whole) < 4e-3
+    with hip.batch_class(B * N):
+        pinned = torch.cat([m(xd[a:b].contiguous(), td[a:b].contiguous(), tt[a:b].contiguous()) for a, b in parts])
+    assert torch.equal(pinned, whole), "pinned to the unsplit batch's class, a shard must reproduce its bits"
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(2)).to(DEV)
+    assert torch.equal(m(xd[perm].contiguous(), td[perm].contiguous(), tt[perm].contiguous()), whole[perm])
+
+
+@torch.no_grad()
 def test_full_row_path_on_ragged_rows():
     """The fused full-row path where nothing is aligned: N = 1000 latent frames (not a multiple of the 128-row tile: tiles
     straddle utterances, no K-loop rotation, a partial last tile at M = 21 x 1000), T = 96: fused against unfused within
