@@ -21,6 +21,9 @@ struct AttnParams {
     // training forward (TRAIN instantiations only)
     float* lse;                    // [B, H, Sq] log2-domain log-sum-exp: m * scale_log2 + log2(l)
     unsigned drop_thr; float keep_scale; unsigned seed_lo, seed_hi; int layer;
+    // split-KV (attn64v3 <SPLIT>: the low-latency class): `ksplit` workgroups per (query block, head), each over Skv / ksplit keys;
+    // unnormalised partial outputs po fp32 [ksplit][B Sq][H 64] and (running maximum, row sum) pml fp32 [ksplit][B Sq][H][2]
+    int ksplit; float* po; float* pml;
 };
 
 hipError_t launch_attention_train64(const AttnParams& p, bool resid, hipStream_t s);   // attention_train.hip

@@ -92,6 +92,11 @@ static int g_splitk_wgs = [] { const char* e = getenv("DITTO_SPLITK_WGS"); retur
 // and LayerNorm statistics) wherever the launch takes the full-row class at d = 768 / head_dim 64 (ditto_forward decides)
 // "ll_mask": the low-latency class's launch fusions (they change no bit): bit 0 = fc2's split-K finish also writes the NEXT
 // block's norm1, bit 1 = the cross out-projection runs as two K-splits whose finish also writes norm3
+// bit 2 (round 5, OFF by default): the fused head_dim-64 attention of the class split over the keys + an ordered merge launch, which
+// for the self-attention also writes norm2 (attention.hip attention_kv_splits).  Built for VERDICT r4 item 6 and measured SLOWER
+// (profiles/r05_attn_split_bench.txt, r05_splitkv_ab.txt): at B = 1 the unsplit kernel takes 16.6 us, the 4-way split one 15.0 us —
+// its time is not the 16-tile loop but the fixed cost of a launch on 96 .. 384 workgroups, and the split writes 12.6 MB of fp32
+// partials instead of 1.5 MB of output — plus 7.5 us of merge: step 1.59 -> 1.72 ms.  Kept as an A/B switch with its tests.
 int g_ll_mask = [] { const char* e = getenv("DITTO_LL_MASK"); return e ? atoi(e) : 3; }();
 // "lnq": norm2 fused into the cross-attention q-projection (gemm_lnq.hip) for launches of the full-row class at d = 768:
 // 0 = off (LayerNorm launch + tiled GEMM), 32 / 16 = on, with that MFMA shape (32x32x16 / 16x16x32)
@@ -300,6 +305,14 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
             if (!fused_rope) HIP_TRY(launch_rope_inplace(qkv, 3 * dp, rope_cos, rope_sin, M, N, 2 * dp, dh, s, 1.0f, dhp));
 #endif
         }
+        // norm2 + q-projection in one launch (gemm_lnq.hip) for the full-row class at d = 768; else LayerNorm launch + tiled GEMM
+        const int rows_cls = opt_class_rows() > 0 ? opt_class_rows() : M;
+        // (d = 1024, BASELINE config C5: the same kernel at that width, 32x32x16 only, from 192 tiles of 64 rows on — the rule of
+        // its full-row GEMM)
+        const bool lnq = opt_lnq() && lp.WcqP && ((d == 768 && (fr_pays(M) || (g_lnq_min_rows > 0 && rows_cls >= g_lnq_min_rows))) ||
+                                              (d == 1024 && fr_pays_64(M)));
+        const bool lnq_here = lnq;
+        bool ln2_done = false;
         {
             ProfScope ps(m, s, DITTO_KC_ATTN_SELF);
             AttnArgs a{};
@@ -312,24 +325,20 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
                 HIP_TRY(launch_head_compact_add(act, dp, h, d, M, d, dh, dhp, s));
             } else {
                 a.resid_f32 = h; a.ldr = d; a.resid_bf16 = hb;
+                // low-latency class: split over the keys, and the merge launch also writes norm2 (the LayerNorm launch below goes)
+                if (!lnq_here && attention_kv_splits(a) > 1) { a.ln_gamma = lp.g2; a.ln_beta = lp.be2; a.ln_out = u; a.ld_ln = d; ln2_done = true; }
                 HIP_TRY(launch_attention(a, s));
             }
         }
         if (tap_self) HIP_TRY(hipMemcpyAsync(tap_self, h, (size_t)M * d * 4, hipMemcpyDeviceToDevice, s));
         // ---- cross-attention (src/components/DiT.py:141-148), K/V from the per-utterance cache ----
-        // norm2 + q-projection in one launch (gemm_lnq.hip) for the full-row class at d = 768; else LayerNorm launch + tiled GEMM
-        const int rows_cls = opt_class_rows() > 0 ? opt_class_rows() : M;
-        // (d = 1024, BASELINE config C5: the same kernel at that width, 32x32x16 only, from 192 tiles of 64 rows on — the rule of
-        // its full-row GEMM)
-        const bool lnq = opt_lnq() && lp.WcqP && ((d == 768 && (fr_pays(M) || (g_lnq_min_rows > 0 && rows_cls >= g_lnq_min_rows))) ||
-                                              (d == 1024 && fr_pays_64(M)));
         if (lnq) {
             ProfScope ps(m, s, DITTO_KC_GEMM_QPROJ);
             const int shape = d == 768 ? opt_lnq() : 32;
             HIP_TRY(launch_gemm_lnq(h, d, hb, lp.g2, lp.be2, shape == 16 ? lp.WcqP32 : lp.WcqP, lp.bcq, qkv, d, M, d, shape,
                                     N % 64 == 0 ? N / 64 : 0, s));
         } else {
-            {
+            if (!ln2_done) {   // (low-latency class: the split self-attention's merge launch wrote norm2 already)
                 ProfScope ps(m, s, DITTO_KC_LAYERNORM);
                 if (hb) HIP_TRY(launch_layernorm_xbf16(h, lp.g2, lp.be2, u, d, M, d, s));
                 else HIP_TRY(launch_layernorm(h, lp.g2, lp.be2, u, d, M, d, s));
@@ -1033,7 +1042,8 @@ int ditto_attention_bf16(const void* q, int ldq, const void* k, int ldk, const v
                          ditto_stream_t stream) {
     if (!q || !k || !v || !out) return fail(DITTO_ERR_ARG, "null pointer to ditto_attention_bf16");
     if (dh % 64) return fail(DITTO_ERR_SHAPE, "head_dim must be a multiple of 64");
-    if (workspace_bytes < attention_workspace_bytes(B, H, Sq, Skv, dh))
+    // (head_dim 64: the scratch is OPTIONAL — the split-KV partials of the low-latency class; without it the launch is not split)
+    if (dh != 64 && workspace_bytes < attention_workspace_bytes(B, H, Sq, Skv, dh))
         return fail(DITTO_ERR_SIZE, "attention workspace too small");
     AttnArgs a{};
     a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.out_bf16 = out; a.ldo = ldo;
@@ -1249,7 +1259,7 @@ int ditto_set_option(const char* name, int value) {
         return DITTO_OK;
     }
     if (!strcmp(name, "ll_mask")) {
-        if (value < 0 || value > 3) return fail(DITTO_ERR_ARG, "ll_mask must be in [0, 3]");
+        if (value < 0 || value > 7) return fail(DITTO_ERR_ARG, "ll_mask must be in [0, 7]");
         g_ll_mask = value;
         return DITTO_OK;
     }

@@ -259,8 +259,14 @@ struct AttnArgs {
     float* lse_out;                  // fused (dh == 64) path: fp32 [B, H, Sq] log2-domain log-sum-exp for the backward
     bool q_prescaled;                // q already multiplied by scale * log2(e) (packed weights, dh == 64): `scale` unused
     bool causal;                     // key j visible to query i only if j <= i + (Skv - Sq); GEMM-composed path only
+    // split-KV path only (attention_kv_splits(a) > 1; the low-latency class): the merge launch also writes
+    // ln_out bf16 [B Sq, ld_ln] = LayerNorm(resid row after the update) * ln_gamma + ln_beta (the self-attention's norm2) if set
+    const float* ln_gamma; const float* ln_beta; void* ln_out; int ld_ln;
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+// > 1: launch_attention(a) will run the key sequence in that many splits + an ordered merge launch (and fuse the LayerNorm asked for
+// by a.ln_*); 1: one launch, a.ln_* ignored — the caller runs its LayerNorm.  A K-only rule inside the low-latency class.
+int attention_kv_splits(const AttnArgs& a);
 size_t attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh);
 // the GEMM-composed path's scratch at any head_dim (force_generic / causal)
 size_t attention_generic_workspace_bytes(int B, int H, int Sq, int Skv, int dh);

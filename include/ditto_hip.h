@@ -270,7 +270,8 @@ int ditto_gemm_bf16(const void* A, int lda, const void* W, const float* bias, co
 int ditto_attention_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
                          void* out, int ldo, int B, int H, int Sq, int Skv, int dh, float scale,
                          void* workspace, size_t workspace_bytes, ditto_stream_t stream);
-/* scratch bytes ditto_attention_bf16 needs (0 for the fused dh = 64 kernel) */
+/* scratch bytes ditto_attention_bf16 needs (dh != 64), or can use (dh = 64: the split-KV partials of launches of at most 2048
+ * query rows over >= 512 keys — "ll_mask" bit 2; with less the launch simply is not split) */
 size_t ditto_attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh);
 
 /* Full-row GEMM with the residual add and the FOLLOWING LayerNorm fused (N = 768: csrc/gemm_frd.hip, or csrc/gemm_fr.hip / its
@@ -372,7 +373,12 @@ int ditto_gemm_tn_bf16(const void* X, int ldx, const void* Y, int ldy, float* ou
  * on K only (K = 3072: 4 splits), so an utterance's bits are independent of its batch neighbours INSIDE the class; across the
  * class boundary they differ in the last bits (as across the full-row class boundary), and "fr_class_rows" pins this class too
  * (-11 % step time at C2 B = 1).  -1 = never split (rounds 1-3 default).  > 0 = the older explicit rule: a workgroup target
- * (256 was the measured choice), under which the K partition depends on the batch size. */
+ * (256 was the measured choice), under which the K partition depends on the batch size.
+ * "ll_mask" (default 3): the other launch forms of the low-latency class, each a function of the class and of K / Skv only:
+ * bit 0 = fc2's split-K finish also writes the next block's norm1 (no bit changes), bit 1 = the cross out-projection as two
+ * K-splits whose finish writes norm3, bit 2 (round 5; off by default: measured slower, an A/B switch) = the fused head_dim-64 attention split over the keys (Skv a multiple of
+ * 512 and >= 1024: 4 splits; of 256 and >= 512: 2) with an ordered merge launch that for the self-attention also writes norm2.
+ * Bits 1 and 2 change a summation order: they are part of what defines the class (pin it with class_rows as usual). */
 int ditto_set_option(const char* name, int value);
 /* Reads a switch back (callers that change one temporarily restore what they found: ditto_tts_amd/hip.py batch_class).
  * Also "experimental": 1 when the library contains the opt-in A/B kernels of csrc/experimental/ ("gemm_tile" 130,

@@ -288,6 +288,59 @@ def test_attention_pipelined_kernel_is_bitwise_the_tile_loop_kernel(lib, B, H, S
         assert torch.equal(outs[0], outs[3]), "attn64v4 (one wave per SIMD, two query blocks per wave) differs from attn64v2"
 
 
+@pytest.mark.parametrize("B,H,Sq,Skv,ns", [(1, 12, 1024, 1024, 4), (2, 3, 1000, 512, 2), (1, 2, 333, 2048, 4), (2, 4, 64, 768, 2),
+                                         (1, 16, 128, 1536, 4), (1, 2, 100, 320, 1), (3, 12, 1024, 1024, 1)])
+def test_attention_split_over_the_keys_in_the_low_latency_class(lib, B, H, Sq, Skv, ns):
+    """Round 5, "ll_mask" bit 2 (an A/B switch, off by default: measured slower at B = 1, profiles/r05_attn_split_bench.txt):
+    launches of at most 2048 query rows (the low-latency class) run the fused head_dim-64 attention split over the keys — 4 ranges when Skv is a multiple of 512 (>= 1024), 2 when a multiple of 256 (>= 512): a function of Skv
+    only — and an ordered merge launch (csrc/attention.hip attn64v3 <SPLIT>, attn_merge_kernel).  Against torch on the same
+    operands, against the unsplit launch (same kernel, one range) within bf16-output noise, with rows whose running maximum is
+    raised late (a dominating key in the LAST range and one in the first), repeatable; shapes the rule leaves alone (ns = 1: too
+    few keys, or more than 2048 rows) give the unsplit bits."""
+    dh, d = 64, H * 64
+    q = asym((B * Sq, d), 41) * 0.7
+    k = asym((B * Skv, d), 42) * 0.7
+    v = asym((B * Skv, d), 43)
+    k[Skv - 3, :dh] = q[5, :dh] * 40.0      # a late dominating key for one row: its partial dominates the merge
+    k[70, :dh] = q[9, :dh] * 30.0           # and an early one
+    scale = 1.0 / math.sqrt(dh)
+    qs = bf16((q * (1.4426950408889634 * scale)).to(DEV))
+    q_ref = qs.float() / (1.4426950408889634 * scale)
+    k, v = bf16(k.to(DEV)), bf16(v.to(DEV))
+    nws = lib.ditto_attention_workspace_bytes(B, H, Sq, Skv, dh)
+    assert (nws > 0) == (B * Sq <= 2048 and Skv >= 512)
+    ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=DEV)
+    hip.check(lib.ditto_set_option(b"attn_flags", 16))
+    outs = {}
+    try:
+        for mask in (7, 3):
+            hip.set_option("ll_mask", mask)
+            out = torch.full((B * Sq, d), float("nan"), dtype=torch.bfloat16, device=DEV)
+            hip.check(lib.ditto_attention_bf16(qs.data_ptr(), d, k.data_ptr(), d, v.data_ptr(), d, out.data_ptr(), d, B, H, Sq,
+                                               Skv, dh, scale, ws.data_ptr(), ws.numel(), stream()))
+            outs[mask] = out
+        again = torch.empty_like(outs[7])
+        hip.set_option("ll_mask", 7)
+        hip.check(lib.ditto_attention_bf16(qs.data_ptr(), d, k.data_ptr(), d, v.data_ptr(), d, again.data_ptr(), d, B, H, Sq,
+                                           Skv, dh, scale, ws.data_ptr(), ws.numel(), stream()))
+        none = torch.empty_like(outs[7])      # no scratch: the same call is simply not split
+        hip.check(lib.ditto_attention_bf16(qs.data_ptr(), d, k.data_ptr(), d, v.data_ptr(), d, none.data_ptr(), d, B, H, Sq,
+                                           Skv, dh, scale, None, 0, stream()))
+    finally:
+        hip.set_option("ll_mask", 3)
+        hip.check(lib.ditto_set_option(b"attn_flags", 3))
+    want = _attn_ref(q_ref, k, v, B, H, Sq, Skv, dh, scale)
+    for o in outs.values():
+        assert torch.isfinite(o.float()).all()
+        assert rel_l2(o.float(), want) < 1.5e-2 and max_abs(o.float(), want) < 6e-2
+    assert torch.equal(again, outs[7]) and torch.equal(none, outs[3])
+    if ns > 1:
+        assert not torch.equal(outs[7], outs[3]), "the launch was expected to run split"
+        assert rel_l2(outs[7].float(), outs[3].float()) < 4e-3
+    else:
+        assert torch.equal(outs[7], outs[3])
+
+
 @pytest.mark.parametrize("attn_flags", [3, 16, 16 + 64, 16 + 128, 16 + 256, 16 + 512, 16 + 4096, 16 + 32768])
 def test_attention_forced_rescale(lib, attn_flags):
     """Rule 26: force the online-softmax rescale branch — one key in the LAST tile dominates one query row."""
