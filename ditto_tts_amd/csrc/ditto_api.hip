@@ -1140,7 +1140,7 @@ static int* option_slot(const char* name) {
         {"pp_mask", &g_pp_mask}, {"fr_mask", &g_fr_mask}, {"fr_class_rows", &g_fr_class_rows}, {"fr_dgrad", &g_fr_dgrad},
         {"train_flags", &g_train_flags}, {"fr_u_fp8", &g_fr_u_fp8}, {"fr_tile", &g_fr_tile}, {"fr64_maxk", &g_fr64_maxk},
         {"fr_stagger", &g_fr_stagger}, {"fr_rot", &g_fr_rot}, {"pp_nb", &g_pp_nb}, {"pp_stagger", &g_pp_stagger},
-        {"splitk_wgs", &g_splitk_wgs}, {"residual_bf16", &g_resid_bf16}, {"lnq", &g_lnq}, {"lnq_ring", &g_lnq_ring}, {"lnq_waves", &g_lnq_waves}, {"lnq_persist", &g_lnq_persist}, {"frq", &g_frq}, {"ll_mask", &g_ll_mask}, {"lnq_min_rows", &g_lnq_min_rows}};
+        {"splitk_wgs", &g_splitk_wgs}, {"residual_bf16", &g_resid_bf16}, {"lnq", &g_lnq}, {"lnq_ring", &g_lnq_ring}, {"lnq_waves", &g_lnq_waves}, {"frq", &g_frq}, {"ll_mask", &g_ll_mask}, {"lnq_min_rows", &g_lnq_min_rows}};
     for (auto& e : tab) if (!strcmp(name, e.n)) return e.p;
     return nullptr;
 }
@@ -1275,11 +1275,6 @@ int ditto_set_option(const char* name, int value) {
     if (!strcmp(name, "lnq_waves")) {
         if (value != 4 && value != 8) return fail(DITTO_ERR_ARG, "lnq_waves must be 4 (one wave per SIMD) or 8 (two)");
         g_lnq_waves = value;
-        return DITTO_OK;
-    }
-    if (!strcmp(name, "lnq_persist")) {
-        if (value != 0 && value != 1) return fail(DITTO_ERR_ARG, "lnq_persist must be 0 or 1");
-        g_lnq_persist = value;
         return DITTO_OK;
     }
     if (!strcmp(name, "lnq_ring")) {

@@ -46,11 +46,6 @@ struct QW {
     static constexpr int RED = LDS;                // fp32 [8 waves][64 rows]
     static constexpr int GB = RED + 8 * QM * 4;    // gamma row | beta row
     static constexpr int LDS1 = GB + 2 * D * 4;    // 107 KiB at D = 768
-    // persistent MODE 0 form (D = 768, bf16 rows, eight waves): the first PF rows of each wave's eight of the NEXT tile, raw bf16,
-    // brought in by LDS-DMA under the current tile's epilogue
-    static constexpr int PF = 4;
-    static constexpr int NEXT = LDS;               // [8 waves][PF rows][AROW bytes] = 48 KiB
-    static constexpr int LDSP = NEXT + 8 * PF * AROW;   // 147 KiB
 };
 
 template <int V>
@@ -129,7 +124,6 @@ struct LnqParams {
     bf16* out; int ldo;                     // MODE 0: the product.  MODE 1: u = LayerNorm(h') bf16 (may be null: no LayerNorm output)
     int M;
     int rot_period;                         // > 0: tiles t and t + rot_period start their K loop at the same place (tiles per utterance)
-    int ntiles;                             // row tiles of the launch (the persistent form walks blockIdx, blockIdx + gridDim, ...)
     // MODE 1 (out-projection + residual + LayerNorm): h' = resid + A W^T + bias, written to hout (may alias resid); XB = both are bf16
     const void* resid; void* hout; int ldr;
 };
@@ -166,27 +160,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_lnq_kernel(LnqParams p) 
     static_assert(NKT % PER == 0 && PER % R == 0 && R * NBW - 1 <= 63, "period structure / vmcnt range");
     constexpr int W_STAGE = QN * G::KS * 2;                              // bytes of one stage of W (24 / 48 KiB)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     LNQ_STAMP(0);
-    // PERSISTENT form (round 5; the bf16-stream, eight-wave kernel of the model path): one workgroup per CU walks tiles b, b + grid,
-    // ... and before the epilogue of the current tile each wave brings the first PF of its eight rows of the NEXT tile into a spare
-    // 48 KiB of the LDS by LDS-DMA (no registers): from the second tile on the LayerNorm phase normalises those while the other
-    // rows' loads land, instead of starting with a memory round trip (profiles/r05_lnq_stamps_fine.txt: 8 600 of a tile's 49 000
-    // ticks).  Same arithmetic per tile: bit-identical to the one-tile-per-workgroup launch (tests).
-    constexpr bool PERSIST = MODE == 0 && NW == 8 && XB && D == 768;
-    constexpr int PF = QW<D>::PF;
-    const int ntile = PERSIST ? p.ntiles : (int)gridDim.x;
-    auto tile_of = [&](int vb) { return (ntile & 7) == 0 ? (vb & 7) * (ntile >> 3) + (vb >> 3) : vb; };
-    const int tid0 = tid;
-    for (int vb = blockIdx.x, it = 0; vb < ntile; vb += gridDim.x, ++it) {
-    // (the lane-derived addressing is recomputed per tile: hoisted out of the tile loop it would stay live across the whole kernel,
-    // past what two waves per SIMD leave a wave in vector registers)
-    int tid = tid0;
-    if constexpr (PERSIST) asm volatile("" : "+v"(tid));
-    const int lane = tid & 63;
     // XCD-contiguous tiles (blocks b and b + 8 share an XCD: neighbouring tiles, i.e. neighbouring K-loop phases, on one L2)
-    const int tile = tile_of(vb);
+    const int ntile = gridDim.x;
+    const int tile = (ntile & 7) == 0 ? (int)(blockIdx.x & 7) * (ntile >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int m0 = tile * QM;
     // K-loop rotation by whole periods: the workgroups of an XCD do not all ask their L2 for the same weight lines at once.
     // A function of the tile's place INSIDE its utterance, so an utterance's bits do not depend on its place in the batch.
@@ -194,7 +173,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_lnq_kernel(LnqParams p) 
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;
 
     // bias row -> LDS (3 pieces of 1 KiB), wave 3; landed and visible behind the barrier that ends the LayerNorm
-    if (wid == 3 && it == 0) {
+    if (wid == 3) {
         if (p.bias) {
 #pragma unroll
             for (int i = 0; i < CH; ++i) glds16(p.bias + i * 256 + lane * 4, lds_base + (unsigned)(Q_BIAS + i * 1024));
@@ -264,9 +243,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_lnq_kernel(LnqParams p) 
     } else
     // ---- LayerNorm of the tile's 64 rows -> LDS (bf16, swizzled): wave w takes rows 16 w .. 16 w + 15, eight at a time ----
     {
-        if constexpr (PERSIST) {
-            if (it > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the tile (its own LDS-DMA: no barrier needed)
-        }
         f32x4 g4[CH], b4[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -286,10 +262,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_lnq_kernel(LnqParams p) 
                 gr = gr < p.M ? gr : p.M - 1;
 #pragma unroll
                 for (int c = 0; c < CH; ++c) {
-                    if constexpr (PERSIST) {
-                        if (it > 0 && r < PF) raw[r][c] = reinterpret_cast<const u32x2*>(smem + QW<D>::NEXT + (wid * PF + r) * Q_AROW)[lane + 64 * c];
-                        else raw[r][c] = reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16*>(p.h) + (size_t)gr * p.ldh)[lane + 64 * c];
-                    } else if constexpr (XB) raw[r][c] = reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16*>(p.h) + (size_t)gr * p.ldh)[lane + 64 * c];
+                    if constexpr (XB) raw[r][c] = reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16*>(p.h) + (size_t)gr * p.ldh)[lane + 64 * c];
                     else raw[r][c] = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.h) + (size_t)gr * p.ldh)[lane + 64 * c];
                 }
             }
@@ -458,20 +431,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_lnq_kernel(LnqParams p) 
     }
     period(QC<1>{}, pcur * 256, 0);
     LNQ_STAMP(2);
-    if constexpr (PERSIST) {   // (every load of the W ring has been waited for)
-        if (vb + (int)gridDim.x < ntile) {
-            // PF rows x 1536 B = 6 pieces of 1 KiB per wave: byte o = 1024 i + 16 lane of the wave's block is row o / 1536, offset o % 1536
-            const int mn = tile_of(vb + (int)gridDim.x) * QM;
-#pragma unroll
-            for (int i = 0; i < PF * Q_AROW / 1024; ++i) {
-                const int o = 1024 * i + 16 * lane, r = o / Q_AROW, c = o - r * Q_AROW;
-                int gr = mn + wid * RPW + r;
-                gr = gr < p.M ? gr : p.M - 1;
-                glds16(reinterpret_cast<const char*>(p.h) + ((size_t)gr * p.ldh) * 2 + c,
-                       lds_base + (unsigned)(QW<D>::NEXT + wid * PF * Q_AROW + 1024 * i));
-            }
-        }
-    }
 
     // ---------------- epilogue: q = acc + bias -> bf16, staged through the A region (every wave is done reading it) ----------------
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -617,7 +576,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_lnq_kernel(LnqParams p) 
         if (m0 + row < p.M) *reinterpret_cast<u32x4*>(p.out + (size_t)(m0 + row) * p.ldo + c * 8) = val;
     }
 #ifdef DITTO_DIAG_LNQ_STAMP
-    if (it == 0) {
+    {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         LNQ_STAMP(3);
         const int w = blockIdx.x * NW + wid;
@@ -627,25 +586,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_lnq_kernel(LnqParams p) 
         }
     }
 #endif
-    if constexpr (PERSIST) __syncthreads();   // the staging rows have been read back: the next tile's LayerNorm may overwrite them
-    }   // tiles of this workgroup
 }
 
 template <int SHAPE, int R, bool XB, int D = 768, int NW = 4>
-hipError_t launch_lnq_t(const LnqParams& p_in, hipStream_t s) {
+hipError_t launch_lnq_t(const LnqParams& p, hipStream_t s) {
     static DevOnce lds_once;
-    constexpr int LDSZ = (NW == 8 && XB && D == 768) ? QW<D>::LDSP : QW<D>::LDS;
-    if (hipError_t e = set_max_lds_once(lds_once, {reinterpret_cast<const void*>(&gemm_lnq_kernel<SHAPE, R, XB, D, NW>)}, LDSZ)) return e;
-    static int n_cu = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return n;
-    }();
-    LnqParams p = p_in;
-    p.ntiles = (p.M + QM - 1) / QM;
-    // the persistent form (eight waves, bf16 rows): one workgroup per CU; "lnq_persist" 0 = one tile per workgroup (A/B, same bits)
-    const int grid = (NW == 8 && XB && D == 768 && g_lnq_persist && p.ntiles > n_cu) ? n_cu : p.ntiles;
-    hipLaunchKernelGGL((gemm_lnq_kernel<SHAPE, R, XB, D, NW>), dim3(grid), dim3(NW * 64), LDSZ, s, p);
+    if (hipError_t e = set_max_lds_once(lds_once, {reinterpret_cast<const void*>(&gemm_lnq_kernel<SHAPE, R, XB, D, NW>)}, QW<D>::LDS)) return e;
+    hipLaunchKernelGGL((gemm_lnq_kernel<SHAPE, R, XB, D, NW>), dim3((p.M + QM - 1) / QM), dim3(NW * 64), QW<D>::LDS, s, p);
     return hipGetLastError();
 }
 
@@ -677,7 +624,6 @@ namespace ditto {
 // 8 (default since round 5) = two waves per SIMD, 4 = one (the round-4 form): bit-identical outputs; shape 32 only (the 16x16x32 twin stays at 4)
 int g_lnq_waves = [] { const char* e = getenv("DITTO_LNQ_WAVES"); return e ? atoi(e) : 8; }();
 int g_lnq_ring = [] { const char* e = getenv("DITTO_LNQ_RING"); return e ? atoi(e) : 0; }();   // 0 = the shape's default depth
-int g_lnq_persist = [] { const char* e = getenv("DITTO_LNQ_PERSIST"); return e ? atoi(e) : 1; }();   // 1 = the eight-wave bf16-row kernel as a persistent grid (round 5)
 
 // The out-projection form (MODE 1): h' bf16 [M, ldr] = resid + A[M, 768] (bf16) W^T + bias (hout may alias resid), u bf16 [M, ldu] =
 // LayerNorm(h') * gamma + beta (u null: no LayerNorm output).  Wp: stage-major image Wp[768 / 16][768][16] (the full-row kernels').

@@ -76,7 +76,6 @@ hipError_t launch_gemm_lnq(const void* h, int ldh, bool h_bf16, const float* gam
 // the fused q-projection kernel's skeleton (64-row tiles, A resident in the LDS, two waves per SIMD); d = 768, K = 768 only
 hipError_t launch_gemm_frq(const void* A, int lda, const void* Wp, const float* bias, const void* resid_bf16, void* hout_bf16, int ldr,
                            const float* gamma, const float* beta, void* u_bf16, int ldu, int M, int rot_period, hipStream_t s);
-extern int g_lnq_persist;   // gemm_lnq.hip: 1 = the eight-wave bf16-row kernel as a persistent grid with the next tile's rows requested a tile ahead
 extern int g_lnq_waves;  // gemm_lnq.hip: waves per workgroup of the d = 768 / shape-32 kernel: 4 (one per SIMD) or 8 (two per SIMD)
 extern int g_lnq_ring;   // gemm_lnq.hip: depth of the W register ring in stages (0 = default: 4 for shape 32, 2 for shape 16; 8 / 4 = the deep rings)
 // The full-row kernel runs ONE 128-row tile per workgroup, so it needs enough rows to fill the chip: measured in the

@@ -366,8 +366,6 @@ int ditto_gemm_tn_bf16(const void* X, int ldx, const void* Y, int ldy, float* ou
  * "frq": 1 (DITTO_EXPERIMENTAL builds only; default 0) = the cross out-projection + residual + norm3 of launches on the bf16 residual
  * stream on the fused q-projection kernel's skeleton (csrc/gemm_lnq.hip: 64-row tiles, two waves per SIMD) instead of csrc/gemm_frd.hip's
  * 128-row tile — measured slower, an A/B switch.  "lnq_waves": 8 (default) / 4 = waves per workgroup of the fused norm2 + q-projection (bit-identical).
- * "lnq_persist": 1 (default) / 0 = that kernel (eight waves, bf16 rows) as a persistent grid of one workgroup per CU that requests
- * the next tile's rows a tile ahead, or one tile per workgroup (bit-identical).
  * "lnq": norm2 fused into the cross-attention q-projection (csrc/gemm_lnq.hip) for launches of the full-row class at d = 768:
  * 0 = LayerNorm launch + tiled GEMM, 32 / 16 = fused, on that MFMA shape.  (DITTO_LNQ sets the initial value.)
  * "splitk_wgs": K-splitting of the long-K GEMMs (fc2, final projection) of small batches, with an ordered fp32 reduce.

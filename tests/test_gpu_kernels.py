@@ -849,42 +849,6 @@ def test_fused_q_projection_normalises_exactly_like_the_layernorm_kernel(lib):
         assert torch.equal(out, u), shape
 
 
-@pytest.mark.parametrize("M,rot", [(32768, 16), (32768 + 64 * 100 + 13, 5), (16384 + 64, 0), (64 * 1000, 16)])
-def test_fused_q_projection_as_a_persistent_grid_is_bitwise_one_tile_per_workgroup(lib, M, rot):
-    """ditto_set_option("lnq_persist", 1) (default; round 5): with more 64-row tiles than CUs the eight-wave, bf16-row kernel runs
-    one workgroup per CU that walks tiles b, b + grid, ... and brings the first four of each wave's eight rows of its NEXT tile into
-    the LDS by LDS-DMA under the current tile's epilogue.  Per tile nothing else changes: the outputs equal those of one tile per
-    workgroup ("lnq_persist" 0) and of the four-wave kernel BIT FOR BIT — two whole rounds (the model's 512 tiles), a ragged
-    number of tiles with a partial last one, one tile more than CUs, and nearly four rounds."""
-    d = 768
-    hin = bf16((asym((M, d), 61) * 1.7 - 0.2).to(DEV))
-    gamma = (1 + 0.2 * asym((d,), 62)).to(DEV)
-    beta = (0.1 * asym((d,), 63)).to(DEV)
-    W = bf16((asym((d, d), 64) / math.sqrt(d)).to(DEV))
-    bias = (0.1 * asym((d,), 65)).to(DEV)
-    scratch = torch.empty(d * d * 2, dtype=torch.uint8, device=DEV)
-    outs = {}
-    try:
-        hip.set_option("fr_rot", rot if rot else 1)
-        for waves, persist in ((8, 1), (8, 0), (4, 1), (8, 1)):
-            hip.set_option("lnq_waves", waves)
-            hip.set_option("lnq_persist", persist)
-            out = torch.full((M, d), float("nan"), dtype=torch.bfloat16, device=DEV)
-            hip.check(lib.ditto_gemm_lnq_bf16(hin.data_ptr(), d, 1, gamma.data_ptr(), beta.data_ptr(), W.data_ptr(),
-                                              bias.data_ptr(), out.data_ptr(), d, M, d, 32, scratch.data_ptr(), stream()))
-            torch.cuda.synchronize()
-            if (waves, persist) in outs:
-                assert torch.equal(out, outs[(waves, persist)])         # run to run
-            outs[(waves, persist)] = out
-    finally:
-        hip.set_option("lnq_waves", 8)
-        hip.set_option("lnq_persist", 1)
-        hip.set_option("fr_rot", 1)
-    assert torch.isfinite(outs[(8, 1)].float()).all()
-    assert torch.equal(outs[(8, 1)], outs[(8, 0)]), float((outs[(8, 1)].float() - outs[(8, 0)].float()).abs().max())
-    assert torch.equal(outs[(8, 1)], outs[(4, 1)])
-
-
 @pytest.mark.parametrize("h_bf16", [False, True])
 @pytest.mark.parametrize("M,rot", [(64, 0), (1, 0), (63, 5), (200, 0), (1024, 16), (2048 + 37, 5)])
 def test_fused_q_projection_on_two_waves_per_simd_is_bitwise_the_four_wave_kernel(lib, M, rot, h_bf16):
