@@ -110,6 +110,11 @@ int g_lnq = [] { const char* e = getenv("DITTO_LNQ"); return e ? atoi(e) : 32; }
 // instead of gemm_frd.hip's 128-row tile.  Measured slower in the model (74.0 against 65.8 us per launch): an A/B switch, no rule selects it.
 int g_frq = [] { const char* e = getenv("DITTO_FRQ"); return e ? atoi(e) : 0; }();
 int g_resid_bf16 = [] { const char* e = getenv("DITTO_RESIDUAL_BF16"); return e ? atoi(e) : 1; }();
+// "qkv_split" (round 5): 0 = off; n > 0 = the QKV GEMM's last 256 columns as a second launch where that leaves whole rounds of
+// 256 x 256 tiles (run_block), for launches of at most n rounds of such tiles.  Default 3 = B = 8 and B = 16 at N = 1024
+// (profiles/r05_qkv_split_ab.txt, same process: QKV 48.6 -> 44.4 us / 75.6 -> 72.3, step 3.87 -> 3.83 / 6.44 -> 6.42 ms; B = 24 and
+// B = 32 — 3.4 and 4.5 rounds — do not gain: the small-tile tail launch costs what the half round did).  Bit-identical either way.
+int g_qkv_split = [] { const char* e = getenv("DITTO_QKV_SPLIT"); return e ? atoi(e) : 3; }();
 int small_batch_k_splits(int M, int N, int K) {
     if (g_splitk_wgs < 0) return 1;                        // -1: never split
     const int ktiles = K / 64;
@@ -301,8 +306,26 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
                               // would the 256 x 192 kernel (whole tile rounds at M = 32768; gemm_tile 192) buy this class?
             HIP_TRY(launch_gemm(g, EPI_BIAS_BF16, s));
 #else
+            // Whole rounds (round 5, "qkv_split"): where the 256 x 256 tiles of the QKV GEMM leave a fractional round of the CUs but
+            // the tiles of all but its LAST 256 columns make whole rounds (d = 768: 9 column tiles, M a multiple of 8192 rows:
+            // B = 8 is 288 tiles = 1.125 rounds, i.e. two rounds' time), those last columns — all of them v columns, plain bias
+            // epilogue — run as a second launch on the small-tile kernel.  Every tiled kernel multiplies with the same MFMA in
+            // the same K order: the same bits as the single launch (test).
+            const int q_tm = (M + 255) / 256, q_tn = (3 * dp) / 256;
+            const bool q_split = g_qkv_split && !fp8 && fused_rope && g_gemm_tile == 0 && (3 * dp) % 256 == 0 && 3 * dp >= 2048 + 256 &&
+                                 2 * d <= 3 * dp - 256 && (long)q_tm * q_tn >= 144 && ((long)q_tm * q_tn) % 256 != 0 &&
+                                 ((long)q_tm * (q_tn - 1)) % 256 == 0 && (long)q_tm * q_tn <= (long)g_qkv_split * 256;
+            if (q_split) {
+                GemmArgs gm = g, gt = g;
+                gm.N = 3 * dp - 256;
+                HIP_TRY(launch_gemm(gm, EPI_QKV_ROPE, s));
+                gt.N = 256; gt.W = (const char*)lp.Wqkv + (size_t)gm.N * d * 2; gt.bias = lp.bqkv + gm.N;
+                gt.out = qkv + (size_t)gm.N * 2; gt.rope_cols = 0; gt.rope_freq_rev = nullptr;
+                HIP_TRY(launch_gemm(gt, EPI_BIAS_BF16, s));
+            } else {
             HIP_TRY(launch_gemm(g, fused_rope ? EPI_QKV_ROPE : EPI_BIAS_BF16, s));
             if (!fused_rope) HIP_TRY(launch_rope_inplace(qkv, 3 * dp, rope_cos, rope_sin, M, N, 2 * dp, dh, s, 1.0f, dhp));
+            }
 #endif
         }
         // norm2 + q-projection in one launch (gemm_lnq.hip) for the full-row class at d = 768; else LayerNorm launch + tiled GEMM
@@ -1140,7 +1163,7 @@ static int* option_slot(const char* name) {
         {"pp_mask", &g_pp_mask}, {"fr_mask", &g_fr_mask}, {"fr_class_rows", &g_fr_class_rows}, {"fr_dgrad", &g_fr_dgrad},
         {"train_flags", &g_train_flags}, {"fr_u_fp8", &g_fr_u_fp8}, {"fr_tile", &g_fr_tile}, {"fr64_maxk", &g_fr64_maxk},
         {"fr_stagger", &g_fr_stagger}, {"fr_rot", &g_fr_rot}, {"pp_nb", &g_pp_nb}, {"pp_stagger", &g_pp_stagger},
-        {"splitk_wgs", &g_splitk_wgs}, {"residual_bf16", &g_resid_bf16}, {"lnq", &g_lnq}, {"lnq_ring", &g_lnq_ring}, {"lnq_waves", &g_lnq_waves}, {"frq", &g_frq}, {"ll_mask", &g_ll_mask}, {"lnq_min_rows", &g_lnq_min_rows}};
+        {"splitk_wgs", &g_splitk_wgs}, {"residual_bf16", &g_resid_bf16}, {"lnq", &g_lnq}, {"lnq_ring", &g_lnq_ring}, {"lnq_waves", &g_lnq_waves}, {"qkv_split", &g_qkv_split}, {"frq", &g_frq}, {"ll_mask", &g_ll_mask}, {"lnq_min_rows", &g_lnq_min_rows}};
     for (auto& e : tab) if (!strcmp(name, e.n)) return e.p;
     return nullptr;
 }
@@ -1275,6 +1298,11 @@ int ditto_set_option(const char* name, int value) {
     if (!strcmp(name, "lnq_waves")) {
         if (value != 4 && value != 8) return fail(DITTO_ERR_ARG, "lnq_waves must be 4 (one wave per SIMD) or 8 (two)");
         g_lnq_waves = value;
+        return DITTO_OK;
+    }
+    if (!strcmp(name, "qkv_split")) {
+        if (value < 0 || value > 64) return fail(DITTO_ERR_ARG, "qkv_split must be in [0, 64]");
+        g_qkv_split = value;
         return DITTO_OK;
     }
     if (!strcmp(name, "lnq_ring")) {

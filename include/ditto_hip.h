@@ -374,6 +374,8 @@ int ditto_gemm_tn_bf16(const void* X, int ldx, const void* Y, int ldy, float* ou
  * class boundary they differ in the last bits (as across the full-row class boundary), and "fr_class_rows" pins this class too
  * (-11 % step time at C2 B = 1).  -1 = never split (rounds 1-3 default).  > 0 = the older explicit rule: a workgroup target
  * (256 was the measured choice), under which the K partition depends on the batch size.
+ * "qkv_split" (default 3; 0 = off): the QKV GEMM's last 256 columns (v columns) as a second launch where the rest makes whole
+ * rounds of 256 x 256 tiles on the CUs, for launches of at most that many rounds (d = 768: B = 8, 16 at N = 1024); bit-identical.
  * "ll_mask" (default 3): the other launch forms of the low-latency class, each a function of the class and of K / Skv only:
  * bit 0 = fc2's split-K finish also writes the next block's norm1 (no bit changes), bit 1 = the cross out-projection as two
  * K-splits whose finish writes norm3, bit 2 (round 5; off by default: measured slower, an A/B switch) = the fused head_dim-64 attention split over the keys (Skv a multiple of

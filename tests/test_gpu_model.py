@@ -394,6 +394,31 @@ def test_shards_straddling_the_fused_q_projection_threshold_agree_when_the_class
 
 
 @torch.no_grad()
+@pytest.mark.parametrize("B", [8, 16])
+def test_qkv_gemm_split_into_whole_rounds_plus_a_tail_changes_no_bit(B):
+    """ditto_set_option("qkv_split", n): where the 256 x 256 tiles of the QKV GEMM make a fractional round of the CUs but all
+    except its last 256 columns make whole rounds (d = 768, M a multiple of 8192 rows), those last columns (v columns: plain bias
+    epilogue) run as a second launch on the small-tile kernel.  Every tiled GEMM kernel uses the same MFMA in the same K order,
+    so the forward must be BIT-IDENTICAL with and without the split."""
+    from ditto_tts_amd import hip
+    cfg = DiTTOConfig(768, 2, 12, 256, 768, 4)
+    m = build(cfg, 6)
+    N, T = 1024, 64
+    x, text, t = synthetic_inputs(cfg, B, N, T, seed=15)
+    xd, td, tt = x.to(DEV), text.to(DEV), t.to(DEV)
+    prev = hip.get_option("qkv_split")
+    outs = {}
+    try:
+        for v in (0, 64):
+            hip.set_option("qkv_split", v)
+            outs[v] = m(xd, td, tt)
+    finally:
+        hip.set_option("qkv_split", prev)
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[64], outs[0])
+
+
+@torch.no_grad()
 def test_full_row_path_on_ragged_rows():
     """The fused full-row path where nothing is aligned: N = 1000 latent frames (not a multiple of the 128-row tile: tiles
     straddle utterances, no K-loop rotation, a partial last tile at M = 21 x 1000), T = 96: fused against unfused within
