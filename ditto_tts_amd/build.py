@@ -21,28 +21,14 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # attention_bwd.hip: the SLP vectoriser pairs the P / dS arithmetic into v_pk_add_f32 / v_pk_mul_f32, and packed fp32
 # instructions occupy the matrix pipe (a lone wave showed zero MFMA / vector overlap: removing the 24 MFMAs of a tile saved
 # exactly 24 x 32 cycles); scalar v_sub / v_mul issue beside the MFMAs.
-EXTRA = {"attention.hip": ["-fno-honor-nans"], "attention_v4.hip": ["-fno-honor-nans"],
-         "attention_bwd.hip": ["-fno-slp-vectorize"], "attention_train.hip": ["-fno-honor-nans", "-fno-slp-vectorize"],
-         "attention_w4.hip": ["-fno-honor-nans", "-fno-slp-vectorize"]}
+EXTRA = {"attention.hip": ["-fno-honor-nans"], "attention_p.hip": ["-fno-honor-nans", "-fno-slp-vectorize"],
+         "attention_bwd.hip": ["-fno-slp-vectorize"], "attention_train.hip": ["-fno-honor-nans", "-fno-slp-vectorize"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC,
          "-Wall", "-Wno-unused-function"]
 
 
-# csrc/experimental/: opt-in A/B kernels that no dispatch rule selects (attention_v4.hip: attention at one wave per SIMD;
-# attention_w4.hip: at four; gemm_o3.hip: three GEMM workgroups per CU; gemm_fr128.hip: the full-row GEMM with its weights through
-# an LDS ring — all measured slower than or equal to the shipped kernels).  They are
-# compiled only with DITTO_EXPERIMENTAL=1 in the environment (every file then sees -DDITTO_EXPERIMENTAL and the dispatchers
-# accept gemm_tile 130 / attn_flags 4096); the default library neither contains nor pays for them.
-EXPERIMENTAL = os.environ.get("DITTO_EXPERIMENTAL", "0") not in ("", "0")
-STAMP = os.path.join(CSRC, ".experimental_on" if EXPERIMENTAL else ".experimental_off")
-
-
 def _sources():
-    srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
-    if EXPERIMENTAL:
-        exp = os.path.join(CSRC, "experimental")
-        srcs += sorted(os.path.join(exp, f) for f in os.listdir(exp) if f.endswith(".hip"))
-    return srcs
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
 def _deps():
@@ -60,12 +46,7 @@ def _stale(target, deps):
 
 def build(force: bool = False, verbose: bool = True) -> str:
     srcs, hdrs = _sources(), _deps()
-    if not os.path.exists(STAMP):           # the experimental switch changed since the last build: everything is stale
-        force = True
-        for f in (".experimental_on", ".experimental_off"):
-            if os.path.exists(os.path.join(CSRC, f)):
-                os.remove(os.path.join(CSRC, f))
-    flags = FLAGS + (["-DDITTO_EXPERIMENTAL"] if EXPERIMENTAL else [])
+    flags = FLAGS
     objs, jobs = [], []
     for s in srcs:
         o = s[:-4] + ".o"
@@ -86,7 +67,6 @@ def build(force: bool = False, verbose: bool = True) -> str:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
-    open(STAMP, "w").close()
     return LIB
 
 

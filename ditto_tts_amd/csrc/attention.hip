@@ -35,12 +35,15 @@ namespace ditto {
 // (unit tests of attn64v2); bit 5 (32): run the kernels above on pre-scaled q instead of attn64v2 (A/B); bit 6 (64):
 // attn64v2 at 2 waves per SIMD with the V prefetch instead of 3 without; bit 7 (128): no deep-prefetch instantiation
 // on small grids; bit 8 (256): never attn64v3 (the software-pipelined kernel), bit 9 (512): attn64v3 wherever Skv % 128 == 0; bit 10 (1024): its 8-wave (256 queries per
-// workgroup) form always, bit 11 (2048): never; bit 12 (4096): attn64v4 (attention_v4.hip: one wave per SIMD, 64 queries per wave)
-// wherever Skv % 64 == 0; bit 13 (8192): the training forward on the older kernel (attn64_kernel<.., TRAIN>) instead of attn64v2's
-// TRAIN instantiations (attention_train.hip) — A/B only; bit 14 (16384): attn64w4 (four waves per SIMD, attention_w4.hip) on large
-// grids, bit 15 (32768): attn64w4 whatever the grid (unit tests).
+// workgroup) form always, bit 11 (2048): never; bit 13 (8192): the training forward on the older kernel (attn64_kernel<.., TRAIN>)
+// instead of attn64v2's TRAIN instantiations (attention_train.hip) — A/B only; bit 17 (131072): never attn64p (attention_p.hip, the
+// 64-queries-per-wave kernel of round 6), bit 18 (262144): attn64p whatever the grid.  (Bits 12, 14, 15, 16 selected the round-3 /
+// round-5 experiments attn64v4 / attn64w4 / KPF, measured equal or slower and deleted in round 6: DESIGN.md "tried".)
 // ditto_set_option("attn_flags")
 int g_attn_flags = 3;
+// attn64p from this many of its 256-query workgroups on (by class rows): 768 = three per CU, i.e. B >= 16 at N = 1024, 12 heads (in-model
+// A/B, profiles/r06_attn_ab.txt: B = 12 loses 3 % of its attention time, B = 16 gains 9 %).  ditto_set_option("attn64p_min_wgs")
+int g_attn64p_min_wgs = [] { const char* e = getenv("DITTO_ATTN64P_MIN_WGS"); const int v = e ? atoi(e) : 768; return v > 0 ? v : 768; }();
 
 namespace {
 
@@ -318,20 +321,14 @@ constexpr int V3_LDS = (V3_KSLOTS + V3_VSLOTS) * KV_TILE_BYTES;   // 72 KiB
 
 // NW = waves per workgroup = 32-query blocks sharing the K/V tiles: 4 (128 queries, two workgroups per CU) or 8 (256
 // queries, one workgroup per CU: half the K/V LDS-DMA bytes and ring writes per FLOP; p.nqb counts blocks of 32 NW).
-// SPLIT: blockIdx also enumerates p.ksplit ranges of the key sequence; the workgroup writes its UNNORMALISED output, running
-// maximum and row sum (p.po / p.pml) and attn_merge_kernel adds the ranges in order (the low-latency class: 96 workgroups of 16
-// tiles each at B = 1 become 384 of 4).
-template <bool RESID, int NW = 4, bool SPLIT = false>
+template <bool RESID, int NW = 4>
 __global__ __launch_bounds__(64 * NW, 2) void attn64v3_kernel(AttnParams p) {
     constexpr int PW = 8 / NW;                                      // 1-KiB DMA pieces per wave per tile image (2 or 1)
     extern __shared__ __attribute__((aligned(16))) char smem[];    // [4 K tiles][5 V tiles]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nsp = SPLIT ? p.ksplit : 1;
-    const int nwg = p.nqb * p.H * p.B * nsp;
-    int id = xcd_remap(blockIdx.x, nwg);
-    const int sp = SPLIT ? id % nsp : 0;
-    if constexpr (SPLIT) id /= nsp;
+    const int nwg = p.nqb * p.H * p.B;
+    const int id = xcd_remap(blockIdx.x, nwg);
     const int qb = id % p.nqb, bh = id / p.nqb;
     const int h = bh % p.H, b = bh / p.H;
     const int ql = lane & 31, hh = lane >> 5;
@@ -345,16 +342,15 @@ __global__ __launch_bounds__(64 * NW, 2) void attn64v3_kernel(AttnParams p) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
     }
-    const int nkt = p.Skv / KBLK / nsp;                            // even, >= 2 (per split)
-    const int key0 = sp * nkt * KBLK;                              // first key row of this split
+    const int nkt = p.Skv / KBLK;                                  // even, >= 2
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
     // this lane's two (row, chunk) DMA sources of tile 0; tile kt is + kt * 64 rows (LDS swizzles applied on the source)
     const bf16 *ksrc[2], *vsrc[2];
 #pragma unroll
     for (int i = 0; i < PW; ++i) {
         const int row = (wid * PW + i) * 8 + (lane >> 3), cpos = lane & 7;
-        ksrc[i] = p.k + ((size_t)b * p.Skv + key0 + row) * p.ldk + h * DH + (cpos ^ ((row >> 1) & 7)) * 8;
-        vsrc[i] = p.v + ((size_t)b * p.Skv + key0 + row) * p.ldv + h * DH + (cpos ^ (((row >> 1) & 1) << 2)) * 8;
+        ksrc[i] = p.k + ((size_t)b * p.Skv + row) * p.ldk + h * DH + (cpos ^ ((row >> 1) & 7)) * 8;
+        vsrc[i] = p.v + ((size_t)b * p.Skv + row) * p.ldv + h * DH + (cpos ^ (((row >> 1) & 1) << 2)) * 8;
     }
     const size_t kstep = (size_t)KBLK * p.ldk, vstep = (size_t)KBLK * p.ldv;
     int issued = 0;                                               // tiles whose DMA has been issued
@@ -589,21 +585,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attn64v3_kernel(AttnParams p) {
     const float inv = 1.0f / lsum[0];
     if (!qvalid) return;
     const size_t grow = (size_t)b * p.Sq + qrow;
-    if constexpr (SPLIT) {   // the partial: O unnormalised, relative to the running maximum m = -cneg (log2 domain); merged in order later
-        const size_t prow = ((size_t)sp * p.B * p.Sq + grow) * p.H + h;
-        float* po = p.po + prow * DH;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = ot[db][4 * g + e];
-                *reinterpret_cast<f32x4*>(po + 32 * db + 8 * g + 4 * hh) = o;
-            }
-        if (hh == 0) { p.pml[prow * 2] = -cneg[0]; p.pml[prow * 2 + 1] = lsum[0]; }
-        return;
-    }
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -621,83 +602,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attn64v3_kernel(AttnParams p) {
                 *reinterpret_cast<u32x2*>(p.out + grow * p.ldo + col) = st2;
             }
         }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Split-KV merge (the low-latency class).  One wave per query row, lane l holds columns 4 l + 256 c: for every head the partials
-// of the splits are added IN ORDER, each scaled by 2^(m_s - M), M = max_s m_s (the running maxima are whole numbers of octaves
-// apart or not — either way a plain exp2), and the sum divided by the likewise merged row sum.  Then, as the unsplit kernels do:
-//   RESID: resid[row] = resid_in[row] + o (fp32 stream; src/components/DiT.py:139), and — LN — the row's LayerNorm written as
-//          bf16 (norm2, DiT.py:142): ln_kernel's arithmetic through the same helpers, so the SAME bits as the launch it replaces;
-//   else:  out bf16 [row] = o.
-// CH = ceil(d / 256) chunks per lane (d = H * 64 <= 1024).
-// ------------------------------------------------------------------------------------------------
-template <bool RESID, bool LN, int CH>
-__global__ __launch_bounds__(256) void attn_merge_kernel(AttnParams p, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         bf16* __restrict__ ln_out, int ld_ln) {
-    const int lane = threadIdx.x & 63;
-    const size_t rows = (size_t)p.B * p.Sq;
-    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const int d = p.H * DH, ns = p.ksplit;
-    f32x4 v[CH];
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-        const int col = 4 * lane + 256 * c;
-        v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (col < d) {
-            const int h = col >> 6;
-            float M = -3.0e38f;
-            for (int sp = 0; sp < ns; ++sp) M = fmaxf(M, p.pml[(((size_t)sp * rows + row) * p.H + h) * 2]);
-            f32x4 o = {0.f, 0.f, 0.f, 0.f};
-            float l = 0.f;
-            for (int sp = 0; sp < ns; ++sp) {
-                const size_t pr = ((size_t)sp * rows + row) * p.H + h;
-                const float w = __builtin_amdgcn_exp2f(p.pml[pr * 2] - M);
-                const f32x4 x = *reinterpret_cast<const f32x4*>(p.po + pr * DH + (col & 63));
-                o += x * w;
-                l = __builtin_fmaf(p.pml[pr * 2 + 1], w, l);
-            }
-            const float inv = 1.0f / l;
-            o *= inv;
-            if constexpr (RESID) {
-                f32x4 r = *reinterpret_cast<const f32x4*>(p.resid_in + row * p.ldr + col);
-                r += o;
-                *reinterpret_cast<f32x4*>(p.resid + row * p.ldr + col) = r;
-                v[c] = r;
-            } else {
-                u32x2 st;
-                st[0] = pack_bf16x2(o[0], o[1]); st[1] = pack_bf16x2(o[2], o[3]);
-                *reinterpret_cast<u32x2*>(p.out + row * p.ldo + col) = st;
-            }
-        }
-    }
-    if constexpr (RESID && LN) {
-        float s = 0.f;
-#pragma unroll
-        for (int c = 0; c < CH; ++c) s += ln_sum4(v[c]);              // (columns past d hold zeros)
-        const float mean = wave_sum(s) / (float)d;
-        float q = 0.f;
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            if (4 * lane + 256 * c < d) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) q = ln_sq_acc(q, v[c][e], mean);
-            }
-        }
-        const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            const int col = 4 * lane + 256 * c;
-            if (col < d) {
-                const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + col), b4 = *reinterpret_cast<const f32x4*>(beta + col);
-                u32x2 st;
-                st[0] = pack_bf16x2(ln_norm(v[c][0], mean, rstd, g4[0], b4[0]), ln_norm(v[c][1], mean, rstd, g4[1], b4[1]));
-                st[1] = pack_bf16x2(ln_norm(v[c][2], mean, rstd, g4[2], b4[2]), ln_norm(v[c][3], mean, rstd, g4[3], b4[3]));
-                *reinterpret_cast<u32x2*>(ln_out + row * ld_ln + col) = st;
-            }
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -791,27 +695,9 @@ static int generic_chunk(int B, int H, int Sq, int Skv, int dh) {
 size_t attention_generic_workspace_bytes(int B, int H, int Sq, int Skv, int dh) {
     return (size_t)generic_chunk(B, H, Sq, Skv, dh) * generic_fwd_bytes(Sq, Skv, dh);
 }
-// split-KV partials (the low-latency class, at most 2048 query rows): 4 splits x rows x H x (64 + 2) fp32
-static size_t split_ws_bytes(int ns, size_t rows, int H) { return align256((size_t)ns * rows * H * DH * 4) + align256((size_t)ns * rows * H * 2 * 4); }
 size_t attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh) {
-    if (dh == DH) return (size_t)B * Sq <= 2048 && Skv >= 512 ? split_ws_bytes(4, (size_t)B * Sq, H) : 0;
+    if (dh == DH) return 0;   // the fused head_dim-64 kernels need no scratch
     return attention_generic_workspace_bytes(B, H, Sq, Skv, dh);
-}
-
-// Split-KV rule: inside the low-latency class (at most 2048 rows, decided on the CLASS rows like the K-splits of the GEMMs there:
-// ditto_api.hip small_batch_k_splits) the fused head_dim-64 attention of the inference forward runs its key sequence in 4 splits
-// (Skv a multiple of 512, >= 1024) or 2 (a multiple of 256, >= 512) — a function of Skv ONLY, so an utterance's bits do not
-// depend on its batch neighbours inside the class.  ll_mask bit 2 (default on) switches it; it changes the summation order, i.e.
-// it is part of what defines the class.
-extern int g_ll_mask;   // ditto_api.hip
-int attention_kv_splits(const AttnArgs& a) {
-    if (a.dh != DH || !a.q_prescaled || a.lse_out || a.dropout_p > 0.f || a.force_generic || a.causal || a.resid_bf16) return 1;
-    if (!(g_ll_mask & 4) || (g_attn_flags & (32 | 256 | 4096 | 32768))) return 1;
-    const long rows = opt_class_rows() > 0 ? opt_class_rows() : (long)a.B * a.Sq;
-    if (rows > 2048 || (long)a.B * a.Sq > 2048 || a.H * DH > 1024) return 1;
-    const int ns = (a.Skv >= 1024 && a.Skv % 512 == 0) ? 4 : ((a.Skv >= 512 && a.Skv % 256 == 0) ? 2 : 1);
-    if (ns == 1 || !a.workspace || a.workspace_bytes < split_ws_bytes(ns, (size_t)a.B * a.Sq, a.H)) return 1;
-    return ns;
 }
 
 hipError_t launch_rope_inplace(void* x, int ld, const float* cs, const float* sn, int M, int rpb, int ncols, int dh,
@@ -855,7 +741,6 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
         p.v = (const bf16*)a.v; p.ldv = a.ldv; p.out = (bf16*)a.out_bf16; p.ldo = a.ldo;
         p.resid = a.resid_f32; p.ldr = a.ldr; p.resid_in = a.resid_in ? a.resid_in : a.resid_f32; p.resid_bf16 = a.resid_bf16 ? 1 : 0; p.B = a.B; p.H = a.H; p.Sq = a.Sq; p.Skv = a.Skv;
         p.nqb = (a.Sq + QBLK - 1) / QBLK;
-        p.ksplit = 1; p.po = nullptr; p.pml = nullptr;
         p.scale_log2 = a.scale * LOG2E;
         p.lse = a.lse_out; p.drop_thr = dropout_threshold(a.dropout_p);
         p.keep_scale = p.drop_thr ? 1.0f / (1.0f - a.dropout_p) : 1.0f;
@@ -870,30 +755,16 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
             return launch_attention_train64(p, a.resid_f32 != nullptr, s);   // attention_train.hip: attn64v2 <TRAIN [, DROP]>
         }
         if (a.q_prescaled && !(g_attn_flags & 32)) {   // q already carries scale * log2(e): the reduced-VALU kernel
-            // one wave per SIMD, 64 queries per wave (attention_v4.hip): attn_flags 4096 = wherever the shape allows
-#ifdef DITTO_EXPERIMENTAL
-            if ((g_attn_flags & 4096) && attn64v4_supports(p) && !a.resid_bf16) return launch_attn64v4(p, a.resid_f32 != nullptr, s);
-#endif
-            if (const int ns = attention_kv_splits(a); ns > 1) {   // the low-latency class: split-KV + ordered merge (+ norm2)
-                static DevOnce lds_split;
-                if (hipError_t e = set_max_lds_once(lds_split, {reinterpret_cast<const void*>(&attn64v3_kernel<false, 4, true>)}, V3_LDS))
-                    return e;
-                const size_t rows = (size_t)a.B * a.Sq;
-                p.ksplit = ns;
-                p.po = (float*)a.workspace;
-                p.pml = (float*)((char*)a.workspace + align256((size_t)ns * rows * a.H * DH * 4));
-                hipLaunchKernelGGL((attn64v3_kernel<false, 4, true>), dim3(p.nqb * a.H * a.B * ns), dim3(256), V3_LDS, s, p);
-                const dim3 gm((unsigned)((rows + 3) / 4));
-                const int ch = (a.H * DH + 255) / 256;
-                const bool ln = a.resid_f32 && a.ln_gamma && a.ln_beta && a.ln_out;
-#define DITTO_MERGE(R, L, C) hipLaunchKernelGGL((attn_merge_kernel<R, L, C>), gm, dim3(256), 0, s, p, a.ln_gamma, a.ln_beta, (bf16*)a.ln_out, a.ld_ln)
-#define DITTO_MERGE_CH(R, L) do { if (ch == 1) DITTO_MERGE(R, L, 1); else if (ch == 2) DITTO_MERGE(R, L, 2); else if (ch == 3) DITTO_MERGE(R, L, 3); else DITTO_MERGE(R, L, 4); } while (0)
-                if (!a.resid_f32) DITTO_MERGE_CH(false, false);
-                else if (ln) DITTO_MERGE_CH(true, true);
-                else DITTO_MERGE_CH(true, false);
-#undef DITTO_MERGE_CH
-#undef DITTO_MERGE
-                return hipGetLastError();
+            // attn64p (attention_p.hip, round 6: 64 queries per wave, 256 per workgroup, two workgroups per CU) from three workgroups per
+            // CU on — decided on the CLASS rows, like every rule that changes an utterance's bits (its row sum is the fp32 sum of the
+            // probabilities, attn64v2's that of their bf16 roundings): C2 B = 32 112 against 127 us in isolation (-12 %), Sq = Skv =
+            // 4096 397 against 463 (profiles/r06_attn_probe.txt).  attn_flags 131072 = never, 262144 = wherever the strides allow.
+            {
+                const long rows_cls = opt_class_rows() > 0 ? opt_class_rows() : (long)a.B * a.Sq;
+                const long wgs = (rows_cls / 256) * a.H;
+                const bool wide_ok = a.ldo % 8 == 0 && (!a.resid_f32 || a.ldr % 8 == 0);   // 16-byte row pieces in the epilogue
+                if (wide_ok && !(g_attn_flags & 131072) && (wgs >= g_attn64p_min_wgs || (g_attn_flags & 262144)))
+                    return launch_attn64p(p, a.resid_f32 != nullptr, s);
             }
             const dim3 gridv(p.nqb * a.H * a.B);
             // whole pairs of key tiles: the software-pipelined, hand-interleaved kernel where it measures faster — small grids
@@ -929,23 +800,11 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
             // tools/step_ab.py): 138 / 127 us (self / cross) against 159 / 141 us at 2 waves per SIMD with the
             // prefetch, and 150 / 140 us for attn64 — the kernel is latency-bound (SQ counters: VALU issue 53 %,
             // MFMA 28 %, both idle 34 % of the time at 2 waves), so occupancy pays more than the prefetch.
-            // four waves per SIMD (attn64w4, round 5; csrc/experimental/attention_w4.hip, DITTO_EXPERIMENTAL builds): attn_flags
-            // 16384 = wherever the grid is large, 32768 = always (unit tests).  Measured equal to attn64v2 (134.2 / 136.6 us isolated,
-            // 128.4 / 127.6 self and 124.7 / 125.4 cross in the model, profiles/r05_w4_ab.txt): no rule selects it.
-#ifdef DITTO_EXPERIMENTAL
-            if (((g_attn_flags & 16384) && (int)gridv.x > 320) || (g_attn_flags & 32768))
-                return launch_attn64w4(p, a.resid_f32 != nullptr, s, (g_attn_flags & 131072) != 0);   // + 131072: 256 queries per workgroup
-#endif
             if (!(g_attn_flags & 64)) {
                 // small grid (at most ~1 workgroup per CU): the deep-prefetch instantiation (attn_flags 128 disables)
                 if ((int)gridv.x <= 320 && !(g_attn_flags & 128)) {
                     if (a.resid_f32) hipLaunchKernelGGL((attn64v2_kernel<true, 2, 4>), gridv, dim3(256), 0, s, p);
                     else hipLaunchKernelGGL((attn64v2_kernel<false, 2, 4>), gridv, dim3(256), 0, s, p);
-                    return hipGetLastError();
-                }
-                if (g_attn_flags & 65536) {   // K fragments prefetched together (KPF): A/B bit of round 5, same bits
-                    if (a.resid_f32) hipLaunchKernelGGL((attn64v2_kernel<true, 3, 2, false, false, true>), gridv, dim3(256), 0, s, p);
-                    else hipLaunchKernelGGL((attn64v2_kernel<false, 3, 2, false, false, true>), gridv, dim3(256), 0, s, p);
                     return hipGetLastError();
                 }
                 if (a.resid_f32) hipLaunchKernelGGL((attn64v2_kernel<true, 3>), gridv, dim3(256), 0, s, p);

@@ -1,0 +1,26 @@
+// attention_p.hip — the translation unit of attn64p (attn64p.h): the head_dim-64 attention forward of the inference path at 64
+// queries per wave (reference src/components/DiT.py:131-139 self-attention, :144-148 cross-attention).  Its own file because it is
+// compiled without the SLP vectoriser (build.py EXTRA: -fno-honor-nans -fno-slp-vectorize; packed fp32 adds cost it 40 registers)
+// and because co-compiled kernel templates perturb one another's register allocation (guide rule 19).
+#include <type_traits>
+
+#include "attn_common.h"
+
+namespace ditto {
+
+namespace {
+#include "attn64v2.h"   // the tile constants (the kernel itself is instantiated in attention.hip / attention_train.hip)
+#include "attn64p.h"
+}  // namespace
+
+// p.nqb is set here: blocks of 256 queries
+hipError_t launch_attn64p(const AttnParams& p_in, bool resid, hipStream_t s) {
+    AttnParams p = p_in;
+    p.nqb = (p.Sq + 255) / 256;
+    const dim3 grid(p.nqb * p.H * p.B), block(256);
+    if (resid) hipLaunchKernelGGL((attn64p_kernel<true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((attn64p_kernel<false>), grid, block, 0, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace ditto

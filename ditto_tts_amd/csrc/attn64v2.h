@@ -47,13 +47,7 @@ DITTO_DEV unsigned long long a2_now() {
 #define A2_STAMP(i)
 #endif
 
-// KPF (round 5): the eight K fragments of a tile are requested TOGETHER, ahead of the first S MFMA.  Left to itself hipcc, at
-// the 168-register budget of three waves per SIMD, reads them one at a time into ONE register quad per chain — ds_read, wait,
-// MFMA, ds_read into the same registers, wait, MFMA ... — so each of a chain's four MFMAs pays a full LDS round trip (the stamp
-// build has this segment at 1 267 of a wave-tile's 3 278 ticks, profiles/r05_a2_stamps.txt).  The registers exist: the 16 of P
-// and the V fragments' are dead while S is computed, and chain 1's accumulator may take over chain 0's fragments.  Same products
-// in the same order: bit-identical to the kernel without it.
-template <bool RESID, int WPS = 2, int NBUF = 2, bool TRAIN = false, bool DROP = false, bool KPF = false>
+template <bool RESID, int WPS = 2, int NBUF = 2, bool TRAIN = false, bool DROP = false>
 __global__ __launch_bounds__(256, WPS) void attn64v2_kernel(AttnParams p) {
     constexpr bool PFV = WPS <= 2;   // V fragments prefetched ahead of the softmax only when 256 registers are available
     __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * KV_TILE_BYTES];  // [buf][K|V]
@@ -168,20 +162,6 @@ __global__ __launch_bounds__(256, WPS) void attn64v2_kernel(AttnParams p) {
 
         // ---- S'^T[key][query] = K Q'^T - m  (log2 units) ----
         f32x16 st[2];
-        if constexpr (KPF) {
-            bf16x8 kfr[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                kfr[i] = *reinterpret_cast<const bf16x8*>(kb + (i >> 2) * 32 * 128 + k_row_off + (((2 * (i & 3) + hh) ^ k_swz) << 4));
-            __builtin_amdgcn_sched_barrier(0);   // all eight requests ahead of the first MFMA
-#pragma unroll
-            for (int kb2 = 0; kb2 < 2; ++kb2) {
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    st[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb2 * 4 + ks], qf[ks], ks == 0 ? cneg : st[kb2], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        } else {
 #pragma unroll
         for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
@@ -190,7 +170,6 @@ __global__ __launch_bounds__(256, WPS) void attn64v2_kernel(AttnParams p) {
                                                                    (((2 * ks + hh) ^ k_swz) << 4));
                 st[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? cneg : st[kb2], 0, 0, 0);
             }
-        }
         A2_STAMP(0);   // next tile's DMA issued, K fragments read, the 8 S MFMAs issued
         if constexpr (decltype(MASKED)::value) {
             const int kbase_idx = kt * KBLK + 4 * hh;
@@ -334,169 +313,6 @@ __global__ __launch_bounds__(256, WPS) void attn64v2_kernel(AttnParams p) {
                         *reinterpret_cast<u32x2*>(p.out + grow * p.ldo + col) = st2;
                     }
                 }
-            } else {
-                u32x2 st2;
-                st2[0] = pack_bf16x2(o[0], o[1]);
-                st2[1] = pack_bf16x2(o[2], o[3]);
-                *reinterpret_cast<u32x2*>(p.out + grow * p.ldo + col) = st2;
-            }
-        }
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// attn64w4 (round 5): attn64v2's tile loop at FOUR waves per SIMD (<= 128 registers).  Round 5's knock-out builds say what
-// the kernel is NOT bound by — without the whole softmax (no maximum, no exponentials) the C2 launch drops 8 %, without its
-// K/V DMA nothing beyond what the garbage data gives every kernel of the step — and round 2 found 2 -> 3 waves per SIMD
-// worth 8 %: a wave's tile is a chain of latencies (barrier -> fragment reads -> MFMA chain -> row maximum -> lane exchange
-// -> branch -> exponentials -> second MFMA chain), and what hides a chain is another wave.  To fit a fourth wave the two
-// 16-register constant blocks of attn64v2 go: the running maximum is ONE register subtracted in front of the exponential (32
-// more vector instructions per tile, which the kernel has room for) instead of the MFMA chains' initial accumulator, and the row
-// sum is 32 fp32 adds instead of four MFMAs with an all-ones operand — the matrix pipe does 16 MFMAs per tile instead of 20.
-// P for the O += V P product is produced 8 values at a time right in front of the two MFMAs that consume it (4 registers
-// live instead of 16).  The row sum is that of the fp32 probabilities (attn64v2 sums the bf16-rounded ones): another
-// association, the same tolerance (tests/test_gpu_kernels.py).  Pre-scaled q, inference only (no TRAIN / DROP forms).
-// ------------------------------------------------------------------------------------------------
-// NW = waves per workgroup: 4 (128 queries) or 8 (256 queries share every K/V tile: half the LDS-DMA pieces and barriers per query;
-// two workgroups per CU keep the four waves per SIMD) — the clean no-DMA knock-out of round 5 prices the K/V traffic at 10-13 % of
-// the C2 launch (profiles/r05_floor_diag2.txt).
-template <bool RESID, int NW = 4>
-__global__ __launch_bounds__(NW * 64, 4) void attn64w4_kernel(AttnParams p) {
-    static_assert(NW == 4 || NW == 8, "waves per workgroup");
-    constexpr int QB = NW * 32;                                   // queries per workgroup (p.nqb counts blocks of this size)
-    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KV_TILE_BYTES];  // [buf][K|V]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nwg = p.nqb * p.H * p.B;
-    const int id = xcd_remap(blockIdx.x, nwg);
-    const int qb = id % p.nqb, bh = id / p.nqb;
-    const int h = bh % p.H, b = bh / p.H;
-    const int ql = lane & 31, hh = lane >> 5;
-    int qrow = qb * QB + wid * 32 + ql;
-    const bool qvalid = qrow < p.Sq;
-    qrow = qvalid ? qrow : p.Sq - 1;
-
-    bf16x8 qf[4];
-    {
-        const bf16* qp = p.q + ((size_t)b * p.Sq + qrow) * p.ldq + h * DH + 8 * hh;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
-    }
-    const int nkt = (p.Skv + KBLK - 1) / KBLK;
-    const bool ragged = (p.Skv & (KBLK - 1)) != 0;
-    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
-    auto dma_kv = [&](int kt, int buf) {   // rows past Skv are clamped (never read out of bounds), masked in the tile
-#pragma unroll
-        for (int i = 0; i < 8 / NW; ++i) {
-            const int piece = wid * (8 / NW) + i;
-            const int row = piece * 8 + (lane >> 3), cpos = lane & 7;
-            int key = kt * KBLK + row;
-            key = key < p.Skv ? key : p.Skv - 1;
-            const int ck = cpos ^ ((row >> 1) & 7), cv = cpos ^ (((row >> 1) & 1) << 2);
-            glds16(p.k + ((size_t)b * p.Skv + key) * p.ldk + h * DH + ck * 8, lds_base + (unsigned)(buf * 2 * KV_TILE_BYTES + piece * 1024));
-            glds16(p.v + ((size_t)b * p.Skv + key) * p.ldv + h * DH + cv * 8,
-                   lds_base + (unsigned)(buf * 2 * KV_TILE_BYTES + KV_TILE_BYTES + piece * 1024));
-        }
-    };
-
-    const int k_row_off = ql * 128, k_swz = (ql >> 1) & 7;
-    const int tr_q = (lane & 15) >> 2, tr_p = lane & 3;
-    const int tr_colbyte = (16 * ((lane >> 4) & 1) + 4 * tr_p) * 2;
-    const int tr_row0 = 4 * hh + tr_q;
-    const int tr_swz = ((tr_q >> 1) & 1) << 6;
-
-    f32x16 ot[2];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { ot[0][i] = 0.f; ot[1][i] = 0.f; }
-    float m_run = 0.f, l0 = 0.f, l1 = 0.f;   // running maximum (whole octaves); this lane's share of the row sum, two chains
-
-    dma_kv(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    auto tile_body = [&](int kt, auto MASKED) {
-        const char* kb = smem + (kt & 1) * 2 * KV_TILE_BYTES;
-        const char* vb = kb + KV_TILE_BYTES;
-        if (kt + 1 < nkt) dma_kv(kt + 1, (kt + 1) & 1);
-
-        // ---- S^T[key][query] = K Q'^T  (log2 units; the chains start from the inline constant 0) ----
-        f32x16 st[2];
-#pragma unroll
-        for (int kb2 = 0; kb2 < 2; ++kb2) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) st[kb2][i] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + kb2 * 32 * 128 + k_row_off + (((2 * ks + hh) ^ k_swz) << 4));
-                st[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb2], 0, 0, 0);
-            }
-        }
-        if constexpr (decltype(MASKED)::value) {
-            const int kbase_idx = kt * KBLK + 4 * hh;
-#pragma unroll
-            for (int kb2 = 0; kb2 < 2; ++kb2)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kbase_idx + kb2 * 32 + (r & 3) + 8 * (r >> 2);
-                    if (key >= p.Skv) st[kb2][r] = -1e30f;
-                }
-        }
-        // ---- row maximum; raise the running one (rarely, by whole octaves) ----
-        float tm = fmaxf(st[0][0], st[1][0]);
-#pragma unroll
-        for (int r = 1; r < 16; ++r) tm = fmaxf(tm, fmaxf(st[0][r], st[1][r]));
-        tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
-        if (kt == 0 || !__all(tm - m_run <= RESCALE_THR_LOG2)) {
-            const float up = ceilf(kt == 0 ? tm : fmaxf(tm - m_run, 0.f));
-            const float alpha = __builtin_amdgcn_exp2f(-up);   // (first tile: O and l are zero, alpha is irrelevant but finite or 0)
-            m_run += up;
-            if (kt > 0) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { ot[0][i] *= alpha; ot[1][i] *= alpha; }
-                l0 *= alpha; l1 *= alpha;
-            }
-        }
-        // ---- P = exp2(S - m) eight at a time, O^T += V^T P^T right behind; l += P in fp32 ----
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) {
-            bf16x8 pf;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float e = __builtin_amdgcn_exp2f(st[s2 >> 1][8 * (s2 & 1) + j] - m_run);
-                if (j & 1) l1 += e; else l0 += e;
-                pf[j] = (bf16)e;
-            }
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                const int colb = (tr_colbyte + 64 * db) ^ tr_swz;
-                const char* a0 = vb + (16 * s2 + tr_row0) * 128 + colb;
-                const bf16x8 vfr = cat4(__builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0)),
-                                        __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0 + 8 * 128)));
-                ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr, pf, ot[db], 0, 0, 0);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    };
-    const int nfull = ragged ? nkt - 1 : nkt;
-    for (int kt = 0; kt < nfull; ++kt) tile_body(kt, std::false_type{});
-    if (ragged) tile_body(nkt - 1, std::true_type{});
-
-    float l = l0 + l1;
-    l += __shfl_xor(l, 32, 64);
-    const float inv = 1.0f / l;
-    if (!qvalid) return;
-    const size_t grow = (size_t)b * p.Sq + qrow;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int col = h * DH + 32 * db + 8 * g + 4 * hh;
-            f32x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = ot[db][4 * g + e] * inv;
-            if constexpr (RESID) {
-                attn_resid_update(p, grow, col, o);
             } else {
                 u32x2 st2;
                 st2[0] = pack_bf16x2(o[0], o[1]);

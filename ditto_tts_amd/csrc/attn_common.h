@@ -1,4 +1,4 @@
-// attn_common.h — what the fused head_dim-64 attention kernels (attention.hip, attention_v4.hip) share: the kernel
+// attn_common.h — what the fused head_dim-64 attention kernels (attention.hip, attention_train.hip) share: the kernel
 // parameter block, tile constants and two fragment helpers.
 #pragma once
 #include "gemm_common.h"
@@ -21,13 +21,10 @@ struct AttnParams {
     // training forward (TRAIN instantiations only)
     float* lse;                    // [B, H, Sq] log2-domain log-sum-exp: m * scale_log2 + log2(l)
     unsigned drop_thr; float keep_scale; unsigned seed_lo, seed_hi; int layer;
-    // split-KV (attn64v3 <SPLIT>: the low-latency class): `ksplit` workgroups per (query block, head), each over Skv / ksplit keys;
-    // unnormalised partial outputs po fp32 [ksplit][B Sq][H 64] and (running maximum, row sum) pml fp32 [ksplit][B Sq][H][2]
-    int ksplit; float* po; float* pml;
 };
 
 hipError_t launch_attention_train64(const AttnParams& p, bool resid, hipStream_t s);   // attention_train.hip
-hipError_t launch_attn64w4(const AttnParams& p, bool resid, hipStream_t s, bool wide = false);   // experimental/attention_w4.hip (four waves per SIMD; wide: 256 queries per workgroup)
+hipError_t launch_attn64p(const AttnParams& p, bool resid, hipStream_t s);              // attention_p.hip: 64 queries per wave (round 6)
 
 // the self-attention epilogue's stream update  h[row, col .. col+3] = h_in[...] + o  (src/components/DiT.py:139: no out-proj),
 // on an fp32 stream or a bf16 one (wave-uniform branch, outside every loop)
@@ -59,9 +56,5 @@ DITTO_DEV bf16x8 cat4(bf16x4 a, bf16x4 b) {
 // (and O^T / l rescaled) when some row's new maximum exceeds it by more than this, so P stays <= 2^8 — exact in
 // bf16's exponent range, accumulated in fp32 — and the 32-register O^T rescale is skipped on most tiles.
 constexpr float ATT_RESCALE_THR_LOG2 = 8.0f;
-
-// attention_v4.hip: one wave per SIMD, 64 queries per wave (pre-scaled q, whole 64-key tiles: Skv % 64 == 0, Skv >= 64)
-bool attn64v4_supports(const AttnParams& p);
-hipError_t launch_attn64v4(const AttnParams& p, bool resid, hipStream_t s);
 
 }  // namespace ditto

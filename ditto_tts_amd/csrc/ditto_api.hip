@@ -92,24 +92,16 @@ static int g_splitk_wgs = [] { const char* e = getenv("DITTO_SPLITK_WGS"); retur
 // and LayerNorm statistics) wherever the launch takes the full-row class at d = 768 / head_dim 64 (ditto_forward decides)
 // "ll_mask": the low-latency class's launch fusions (they change no bit): bit 0 = fc2's split-K finish also writes the NEXT
 // block's norm1, bit 1 = the cross out-projection runs as two K-splits whose finish also writes norm3
-// bit 2 (round 5, OFF by default): the fused head_dim-64 attention of the class split over the keys + an ordered merge launch, which
-// for the self-attention also writes norm2 (attention.hip attention_kv_splits).  Built for VERDICT r4 item 6 and measured SLOWER
-// (profiles/r05_attn_split_bench.txt, r05_splitkv_ab.txt): at B = 1 the unsplit kernel takes 16.6 us, the 4-way split one 15.0 us —
-// its time is not the 16-tile loop but the fixed cost of a launch on 96 .. 384 workgroups, and the split writes 12.6 MB of fp32
-// partials instead of 1.5 MB of output — plus 7.5 us of merge: step 1.59 -> 1.72 ms.  Kept as an A/B switch with its tests.
-int g_ll_mask = [] { const char* e = getenv("DITTO_LL_MASK"); return e ? atoi(e) : 3; }();
+// (bit 2, round 5: split-KV attention + ordered merge — measured slower at B = 1, 1.59 -> 1.72 ms, profiles/r05_splitkv_ab.txt — was deleted in round 6)
+int g_ll_mask = [] { const char* e = getenv("DITTO_LL_MASK"); const int v = e ? atoi(e) : 3; return v < 0 || v > 3 ? 3 : v; }();
 // "lnq": norm2 fused into the cross-attention q-projection (gemm_lnq.hip) for launches of the full-row class at d = 768:
 // 0 = off (LayerNorm launch + tiled GEMM), 32 / 16 = on, with that MFMA shape (32x32x16 / 16x16x32)
 // "lnq_min_rows": > 0: the fused norm2 + q-projection also runs BELOW the full-row class, from that many (class) rows on (A/B)
 // Default 8192 since round 5: with the kernel on two waves per SIMD the fused launch wins from 128 of its 64-row tiles on
 // (profiles/r05_small_batch_lnq8.txt, same process: B = 8 4.02 -> 3.95 ms, B = 16 6.63 -> 6.47; B = 4 2.61 -> 2.63, hence not lower).
 int g_lnq_min_rows = [] { const char* e = getenv("DITTO_LNQ_MIN_ROWS"); return e ? atoi(e) : 8192; }();
-int g_lnq = [] { const char* e = getenv("DITTO_LNQ"); return e ? atoi(e) : 32; }();
-// "frq" (round 5, DITTO_EXPERIMENTAL builds; default 0): the cross out-projection + residual + norm3 of launches on the bf16 residual
-// stream on the fused q-projection kernel's skeleton (gemm_lnq.hip MODE 1: 64-row tiles, A resident in the LDS, two waves per SIMD)
-// instead of gemm_frd.hip's 128-row tile.  Measured slower in the model (74.0 against 65.8 us per launch): an A/B switch, no rule selects it.
-int g_frq = [] { const char* e = getenv("DITTO_FRQ"); return e ? atoi(e) : 0; }();
-int g_resid_bf16 = [] { const char* e = getenv("DITTO_RESIDUAL_BF16"); return e ? atoi(e) : 1; }();
+int g_lnq = [] { const char* e = getenv("DITTO_LNQ"); const int v = e ? atoi(e) : 32; return v == 0 || v == 16 || v == 32 ? v : 32; }();   // validated like ditto_set_option
+int g_resid_bf16 = [] { const char* e = getenv("DITTO_RESIDUAL_BF16"); return e ? (atoi(e) != 0) : 1; }();   // normalised to 0 / 1
 // "qkv_split" (round 5): 0 = off; n > 0 = the QKV GEMM's last 256 columns as a second launch where that leaves whole rounds of
 // 256 x 256 tiles (run_block), for launches of at most n rounds of such tiles.  Default 3 = B = 8 and B = 16 at N = 1024
 // (profiles/r05_qkv_split_ab.txt, same process: QKV 48.6 -> 44.4 us / 75.6 -> 72.3, step 3.87 -> 3.83 / 6.44 -> 6.42 ms; B = 24 and
@@ -334,8 +326,6 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
         // its full-row GEMM)
         const bool lnq = opt_lnq() && lp.WcqP && ((d == 768 && (fr_pays(M) || (g_lnq_min_rows > 0 && rows_cls >= g_lnq_min_rows))) ||
                                               (d == 1024 && fr_pays_64(M)));
-        const bool lnq_here = lnq;
-        bool ln2_done = false;
         {
             ProfScope ps(m, s, DITTO_KC_ATTN_SELF);
             AttnArgs a{};
@@ -348,8 +338,6 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
                 HIP_TRY(launch_head_compact_add(act, dp, h, d, M, d, dh, dhp, s));
             } else {
                 a.resid_f32 = h; a.ldr = d; a.resid_bf16 = hb;
-                // low-latency class: split over the keys, and the merge launch also writes norm2 (the LayerNorm launch below goes)
-                if (!lnq_here && attention_kv_splits(a) > 1) { a.ln_gamma = lp.g2; a.ln_beta = lp.be2; a.ln_out = u; a.ld_ln = d; ln2_done = true; }
                 HIP_TRY(launch_attention(a, s));
             }
         }
@@ -361,7 +349,7 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
             HIP_TRY(launch_gemm_lnq(h, d, hb, lp.g2, lp.be2, shape == 16 ? lp.WcqP32 : lp.WcqP, lp.bcq, qkv, d, M, d, shape,
                                     N % 64 == 0 ? N / 64 : 0, s));
         } else {
-            if (!ln2_done) {   // (low-latency class: the split self-attention's merge launch wrote norm2 already)
+            {
                 ProfScope ps(m, s, DITTO_KC_LAYERNORM);
                 if (hb) HIP_TRY(launch_layernorm_xbf16(h, lp.g2, lp.be2, u, d, M, d, s));
                 else HIP_TRY(launch_layernorm(h, lp.g2, lp.be2, u, d, M, d, s));
@@ -388,10 +376,7 @@ static int run_block(ditto_model* m, int l, float* h, void* u, char* qkv, void* 
             GemmParams gp{};
             gp.A = (const bf16*)u; gp.lda = d; gp.W = (const bf16*)lp.WcoP; gp.ldw = d; gp.w_rows = d; gp.bias = lp.bco;
             gp.residual = h; gp.ldr = d; gp.out = h; gp.ldo = d; gp.M = M; gp.N = d; gp.K = d;
-            if (hb && g_frq && d == 768 && !fp8)   // bf16 stream: the 64-row, two-waves-per-SIMD form (gemm_lnq.hip MODE 1)
-                HIP_TRY(launch_gemm_frq(u, d, lp.WcoP, lp.bco, h, h, d, lp.g3, lp.be3, qkv, d, M, N % 64 == 0 ? N / 64 : 0, s));
-            else
-                HIP_TRY(launch_gemm_fr(gp, lp.g3, lp.be3, qkv, d, fr_rot, s, fp8, hb));
+            HIP_TRY(launch_gemm_fr(gp, lp.g3, lp.be3, qkv, d, fr_rot, s, fp8, hb));
         } else {
             ProfScope ps(m, s, DITTO_KC_GEMM_OUTPROJ);
             GemmArgs g{};
@@ -1027,23 +1012,6 @@ int ditto_gemm_lnq_bf16(const void* h, int ldh, int h_is_bf16, const float* gamm
     return DITTO_OK;
 }
 
-int ditto_gemm_resln_bf16(const void* A, int lda, const void* W, const float* bias, void* h_bf16, int ldh, const float* gamma,
-                          const float* beta, void* u_bf16, int ldu, int M, int rot_period_tiles, void* w_scratch, ditto_stream_t stream) {
-    if (!A || !W || !h_bf16 || !w_scratch || M <= 0 || lda < 768 || ldh < 768 || lda % 8 || ldh % 8 || (gamma == nullptr) != (beta == nullptr) ||
-        (gamma == nullptr) != (u_bf16 == nullptr) || (u_bf16 && (ldu < 768 || ldu % 8)) || rot_period_tiles < 0)
-        return fail(DITTO_ERR_ARG, "bad argument to ditto_gemm_resln_bf16");
-    if ((uintptr_t)w_scratch % 256) return fail(DITTO_ERR_ARG, "w_scratch must be 256-byte aligned");
-#ifndef DITTO_EXPERIMENTAL
-    return fail(DITTO_ERR_ARG, "ditto_gemm_resln_bf16 is an opt-in A/B kernel (csrc/gemm_lnq.hip, out-projection form: measured slower than "
-                               "csrc/gemm_frd.hip in the model); build with DITTO_EXPERIMENTAL=1");
-#else
-    hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(launch_repack_bf16_stage_major(W, w_scratch, 768, 768, s, 16));
-    HIP_TRY(launch_gemm_frq(A, lda, w_scratch, bias, h_bf16, h_bf16, ldh, gamma, beta, u_bf16, ldu, M, rot_period_tiles, s));
-    return DITTO_OK;
-#endif
-}
-
 int ditto_gemm_ln_bf16(const void* A, int lda, const void* W, const float* bias, const float* residual, float* out,
                        int ldo, const float* gamma, const float* beta, void* u_bf16, int ldu, int M, int N, int K,
                        ditto_stream_t stream) {
@@ -1163,21 +1131,13 @@ static int* option_slot(const char* name) {
         {"pp_mask", &g_pp_mask}, {"fr_mask", &g_fr_mask}, {"fr_class_rows", &g_fr_class_rows}, {"fr_dgrad", &g_fr_dgrad},
         {"train_flags", &g_train_flags}, {"fr_u_fp8", &g_fr_u_fp8}, {"fr_tile", &g_fr_tile}, {"fr64_maxk", &g_fr64_maxk},
         {"fr_stagger", &g_fr_stagger}, {"fr_rot", &g_fr_rot}, {"pp_nb", &g_pp_nb}, {"pp_stagger", &g_pp_stagger},
-        {"splitk_wgs", &g_splitk_wgs}, {"residual_bf16", &g_resid_bf16}, {"lnq", &g_lnq}, {"lnq_ring", &g_lnq_ring}, {"lnq_waves", &g_lnq_waves}, {"qkv_split", &g_qkv_split}, {"frq", &g_frq}, {"ll_mask", &g_ll_mask}, {"lnq_min_rows", &g_lnq_min_rows}};
+        {"splitk_wgs", &g_splitk_wgs}, {"residual_bf16", &g_resid_bf16}, {"lnq", &g_lnq}, {"lnq_ring", &g_lnq_ring}, {"lnq_waves", &g_lnq_waves}, {"qkv_split", &g_qkv_split}, {"ll_mask", &g_ll_mask}, {"lnq_min_rows", &g_lnq_min_rows}, {"attn64p_min_wgs", &g_attn64p_min_wgs}};
     for (auto& e : tab) if (!strcmp(name, e.n)) return e.p;
     return nullptr;
 }
 
 int ditto_get_option(const char* name, int* value) {
     if (!name || !value) return fail(DITTO_ERR_ARG, "null argument to ditto_get_option");
-    if (!strcmp(name, "experimental")) {   // 1: built with the opt-in A/B kernels of csrc/experimental/ (DITTO_EXPERIMENTAL=1)
-#ifdef DITTO_EXPERIMENTAL
-        *value = 1;
-#else
-        *value = 0;
-#endif
-        return DITTO_OK;
-    }
     if (!strcmp(name, "wgrad_wgs")) { *value = get_wgrad_wgs(); return DITTO_OK; }
     if (const int* p = option_slot(name)) { *value = *p; return DITTO_OK; }
     return fail(DITTO_ERR_ARG, "unknown option '%s'", name);
@@ -1185,16 +1145,9 @@ int ditto_get_option(const char* name, int* value) {
 
 int ditto_set_option(const char* name, int value) {
     if (!name) return fail(DITTO_ERR_ARG, "null option name");
-#ifndef DITTO_EXPERIMENTAL
-    if ((!strcmp(name, "gemm_tile") && value == 130) || (!strcmp(name, "attn_flags") && (value & (4096 | 16384 | 32768))) ||
-        (!strcmp(name, "fr_tile") && value == 128))
-        return fail(DITTO_ERR_ARG, "%s = %d selects a kernel of csrc/experimental/ (gemm_o3.hip / attention_v4.hip / attention_w4.hip / gemm_fr128.hip: opt-in A/B "
-                                   "kernels no rule selects), which this library was built without (DITTO_EXPERIMENTAL=1 python -m "
-                                   "ditto_tts_amd.build --force)", name, value);
-#endif
     if (!strcmp(name, "gemm_tile")) {
-        if (value != 0 && value != 127 && value != 128 && value != 256 && value != 129 && value != 130 && value != 131 && value != 192)
-            return fail(DITTO_ERR_ARG, "gemm_tile must be 0, 127 (128x128 deep prefetch), 128, 129 (256x128 ring), 130 (128x256, 3 workgroups/CU), "
+        if (value != 0 && value != 127 && value != 128 && value != 256 && value != 129 && value != 131 && value != 192)
+            return fail(DITTO_ERR_ARG, "gemm_tile must be 0, 127 (128x128 deep prefetch), 128, 129 (256x128 ring), "
                                        "131 (128x256 ping-pong, 2 workgroups/CU), 192 (256x192 where the epilogue allows) or 256");
         g_gemm_tile = value;
         return DITTO_OK;
@@ -1247,7 +1200,7 @@ int ditto_set_option(const char* name, int value) {
         return DITTO_OK;
     }
     if (!strcmp(name, "fr_tile")) {
-        if (value != 0 && value != 64 && value != 128 && value != 130) return fail(DITTO_ERR_ARG, "fr_tile must be 0 (rule), 64, 128 or 130 (128 rows, W straight into registers)");
+        if (value != 0 && value != 64 && value != 130) return fail(DITTO_ERR_ARG, "fr_tile must be 0 (rule), 64 or 130 (128 rows, W straight into registers)");
         g_fr_tile = value;
         return DITTO_OK;
     }
@@ -1281,18 +1234,14 @@ int ditto_set_option(const char* name, int value) {
         g_lnq_min_rows = value;
         return DITTO_OK;
     }
-    if (!strcmp(name, "ll_mask")) {
-        if (value < 0 || value > 7) return fail(DITTO_ERR_ARG, "ll_mask must be in [0, 7]");
-        g_ll_mask = value;
+    if (!strcmp(name, "attn64p_min_wgs")) {
+        if (value < 1) return fail(DITTO_ERR_ARG, "attn64p_min_wgs must be >= 1");
+        g_attn64p_min_wgs = value;
         return DITTO_OK;
     }
-    if (!strcmp(name, "frq")) {
-        if (value < 0 || value > 1) return fail(DITTO_ERR_ARG, "frq must be 0 or 1");
-#ifndef DITTO_EXPERIMENTAL
-        if (value) return fail(DITTO_ERR_ARG, "frq = 1 selects an opt-in A/B kernel (gemm_lnq.hip, out-projection form) which this library was "
-                                              "built without (DITTO_EXPERIMENTAL=1 python -m ditto_tts_amd.build --force)");
-#endif
-        g_frq = value;
+    if (!strcmp(name, "ll_mask")) {
+        if (value < 0 || value > 3) return fail(DITTO_ERR_ARG, "ll_mask must be in [0, 3]");
+        g_ll_mask = value;
         return DITTO_OK;
     }
     if (!strcmp(name, "lnq_waves")) {

@@ -41,7 +41,7 @@ int g_fr_mask = [] { const char* e = getenv("DITTO_FR_MASK"); return e ? atoi(e)
 int g_fr_dgrad = [] { const char* e = getenv("DITTO_FR_DGRAD"); return e ? atoi(e) : 3; }();
 int g_train_flags = [] { const char* e = getenv("DITTO_TRAIN_FLAGS"); return e ? atoi(e) : 0; }();
 int g_fr_rot = [] { const char* e = getenv("DITTO_FR_ROT"); return e ? atoi(e) : 1; }();
-int g_fr_tile = [] { const char* e = getenv("DITTO_FR_TILE"); return e ? atoi(e) : 0; }();
+int g_fr_tile = [] { const char* e = getenv("DITTO_FR_TILE"); const int v = e ? atoi(e) : 0; return v == 64 || v == 130 ? v : 0; }();   // validated like ditto_set_option
 int g_fr64_maxk = [] { const char* e = getenv("DITTO_FR64_MAXK"); return e ? atoi(e) : 1 << 30; }();
 int g_fr_stagger = [] { const char* e = getenv("DITTO_FR_STAGGER"); return e ? atoi(e) : 0; }();   // off: worth 6 us isolated at 512 tiles, nothing in the model, and a late second workgroup is pure tail when only a few CUs get one
 int g_fr_u_fp8 = 0;
@@ -349,9 +349,6 @@ hipError_t launch_gemm(const GemmArgs& a, GemmEpilogue epi, hipStream_t s) {
     // the ReLU epilogue is built for the 128x128 and 256x256 structures only
     if (epi == EPI_BIAS_RELU_BF16 && forced != 128 && forced != 127 && forced != 256)
         forced = (long)((a.M + 255) / 256) * ((a.N + 255) / 256) >= 4 * 256 ? 256 : 128;
-#ifdef DITTO_EXPERIMENTAL
-    if (forced == 130) return launch_gemm_o3(p, epi, s);   // csrc/experimental/gemm_o3.hip (ditto_set_option refuses 130 otherwise)
-#endif
     if (forced == 131 && gemm_pp_supports(p, epi)) return launch_gemm_pp(p, epi, s);
     // Ping-pong 128x256 tiles (gemm_pp.hip) by GEMM class.  pp_mask bits: 1 narrow bf16 output (cross q-proj), 2 narrow
     // fp32 in-place residual with K <= 1024 (cross out-proj), 4 narrow fp32 output (final projection), 8 narrow residual

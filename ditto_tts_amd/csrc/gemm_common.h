@@ -478,8 +478,6 @@ hipError_t launch_gemm_p128(const GemmParams& p, GemmEpilogue epi, hipStream_t s
 // gemm192.hip
 bool gemm192_supports(GemmEpilogue epi);
 hipError_t launch_gemm192(const GemmParams& p, GemmEpilogue epi, hipStream_t s);
-// gemm_o3.hip
-hipError_t launch_gemm_o3(const GemmParams& p, GemmEpilogue epi, hipStream_t s);
 // gemm_fr.hip / gemm_fr64.hip: full-row N = 768 GEMM, fp32 residual in place, fused LayerNorm -> u bf16 (gamma/u null: none)
 struct FrParams {
     GemmParams g;
@@ -497,8 +495,6 @@ hipError_t launch_gemm_fr(const GemmParams& p, const float* gamma, const float* 
 // The two full-row launches of a DiT block over M rows of width d, each judged on the operand strides IT runs with (the
 // kernel builds 32-bit byte offsets from M * lda: fc2 reads A at lda = 4d).  One predicate for the inference forward, the
 // LayerNorm chaining decision and the training forward, so that the three cannot disagree.
-// experimental/gemm_fr128.hip (DITTO_EXPERIMENTAL builds): the rounds-2-3 form, 128-row tiles with the weights through an LDS ring
-hipError_t launch_gemm_fr128(const FrParams& fp, hipStream_t s);
 // gemm_fr64.hip: the same contract and the SAME BITS on 64-row tiles, two workgroups per CU (called by launch_gemm_fr)
 hipError_t launch_gemm_fr64(const FrParams& fp, hipStream_t s);
 // gemm_frd.hip: the same contract at N = 768 with W fetched straight from L2 into registers (128-row tiles, wave-private W)

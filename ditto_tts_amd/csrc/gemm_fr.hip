@@ -8,7 +8,7 @@
 // LayerNorm launches of a step are gone.  Kernels (kernels.h fr_launch_kernel picks; all N = 768 forms give the same fp32 h bits):
 //   gemm_frd.hip    128 x 768 tiles, one wave per SIMD, W straight from L2 into registers; the bf16 residual stream (default)
 //   gemm_fr64.hip   64 x 768 tiles, two workgroups per CU (batches of 11 .. 15 utterances), and 64 x 1024 tiles (BASELINE C5)
-//   experimental/gemm_fr128.hip   128 x 768 tiles with the weights through an LDS ring (rounds 2-3; "fr_tile" 128, opt-in build)
+//   (rounds 2-3 ran 128 x 768 tiles with the weights through an LDS ring, gemm_fr128: superseded by gemm_frd, deleted in round 6)
 #include "gemm_common.h"
 
 namespace ditto {
@@ -45,11 +45,7 @@ hipError_t launch_gemm_fr(const GemmParams& p_in, const float* gamma, const floa
         fp.stagger_ticks = g_fr_stagger;
         return launch_gemm_fr64(fp, s);
     }
-#ifdef DITTO_EXPERIMENTAL
-    return launch_gemm_fr128(fp, s);                             // "fr_tile" 128 (ditto_set_option refuses it otherwise)
-#else
     return hipErrorInvalidValue;
-#endif
 }
 
 }  // namespace ditto

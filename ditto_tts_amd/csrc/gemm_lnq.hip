@@ -42,10 +42,6 @@ struct QW {
     static constexpr int BIAS = A;                 // bias row (3 / 4 KiB) behind it
     static constexpr int LDS = A + D * 4;          // 99 / 132 KiB
     static constexpr int CH = D / 256;             // f32x4 per lane of a row (one wave per row)
-    // MODE 1 (out-projection + residual + LayerNorm): behind the bias row, the row statistics of the 8 waves and the gamma | beta rows
-    static constexpr int RED = LDS;                // fp32 [8 waves][64 rows]
-    static constexpr int GB = RED + 8 * QM * 4;    // gamma row | beta row
-    static constexpr int LDS1 = GB + 2 * D * 4;    // 107 KiB at D = 768
 };
 
 template <int V>
@@ -117,15 +113,13 @@ static_assert(lnq_vm(6, 4, 0, 47) == 23 && lnq_vm(6, 4, 5, 10) == 23 && lnq_vm(6
               lnq_vm(12, 2, 11, 0) == 0, "wait counts");
 
 struct LnqParams {
-    const void* h; int ldh;                 // MODE 0: the rows to normalise, fp32 or bf16 (XB).  MODE 1: the A operand, bf16 rows
-    const float* gamma; const float* beta;  // MODE 0: of the LayerNorm in FRONT of the product; MODE 1: of the one BEHIND it
+    const void* h; int ldh;                 // the rows to normalise, fp32 or bf16 (XB)
+    const float* gamma; const float* beta;  // of the LayerNorm in FRONT of the product
     const char* Wp;                         // stage-major weight image of the SHAPE
     const float* bias;
-    bf16* out; int ldo;                     // MODE 0: the product.  MODE 1: u = LayerNorm(h') bf16 (may be null: no LayerNorm output)
+    bf16* out; int ldo;                     // the product
     int M;
     int rot_period;                         // > 0: tiles t and t + rot_period start their K loop at the same place (tiles per utterance)
-    // MODE 1 (out-projection + residual + LayerNorm): h' = resid + A W^T + bias, written to hout (may alias resid); XB = both are bf16
-    const void* resid; void* hout; int ldr;
 };
 
 // R: depth of the W register ring in stages.  What the ring holds in flight per CU (4 waves x R x NBW KiB) against the L2's
@@ -137,19 +131,11 @@ struct LnqParams {
 // knock-out prices the W stream at 7 % (profiles/r05_floor_diag2.txt): not the bound round 4 took it for.  Eight waves split N
 // eight ways (96 columns, 96 accumulators each), so no weight byte is fetched twice and every output element is the same K-ordered
 // chain (bit-identical to NW = 4); each wave normalises 8 rows instead of 16 and two waves share a SIMD's vector pipe.
-// MODE 1 (round 5): the SAME tile loop as the out-projection + residual + LayerNorm behind it (reference src/components/DiT.py:148
-// + :152): h' = resid + A W_o^T + b_o in place on the residual stream, u = LayerNorm(h') * gamma + beta for the gated MLP.  Why here
-// and not on gemm_frd.hip's 128-row tile: that kernel runs ONE tile per CU at one wave per SIMD — residual read, K loop, LayerNorm
-// and stores of all 256 workgroups in lockstep, none overlapping (stamps: profiles/r05_frd_stamps.txt) — where this skeleton keeps A
-// resident in the LDS (no A traffic in the loop), runs two waves per SIMD through the vector-heavy ends and two tiles per CU that
-// de-phase on their own; its K = 768 loop for two 64-row tiles takes less time than gemm_frd's for one 128-row tile although every
-// tile streams all of W (the weight stream is 7 % of this loop: profiles/r05_floor_diag2.txt).  The accumulators START as
-// residual + bias (gemm_frd's trick: the epilogue only reads them); row statistics: per wave over its 96 columns (lane + lane ^ 32),
-// then across the eight waves through the LDS in a fixed order; two passes like nn.LayerNorm.
-template <int SHAPE, int R, bool XB, int D = 768, int NW = 4, int MODE = 0>
+// (Round 5 also ran this tile loop as the cross out-projection + residual + LayerNorm, "MODE 1": 74.0 us against gemm_frd.hip's 65.8 in
+// the model, profiles/r05_step_ab_frq.txt; deleted in round 6.)
+template <int SHAPE, int R, bool XB, int D = 768, int NW = 4>
 __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_lnq_kernel(LnqParams p) {
     static_assert(NW == 4 || NW == 8, "waves per workgroup");
-    static_assert(MODE == 0 || (SHAPE == 32 && NW == 8 && D == 768), "out-projection form: 32x32x16, eight waves, d = 768");
     constexpr int RPW = QM / NW;                                         // rows a wave normalises (16 / 8)
     using G = Geo<SHAPE, D, NW>;
     constexpr int Q_AROW = QW<D>::AROW, Q_BIAS = QW<D>::BIAS, CH = QW<D>::CH, QN = D, QKD = D;
@@ -180,14 +166,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_lnq_kernel(LnqParams p) 
         } else {
 #pragma unroll
             for (int i = 0; i < CH; ++i) *reinterpret_cast<f32x4*>(smem + Q_BIAS + i * 1024 + lane * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
-
-    if constexpr (MODE == 1) {
-        if ((wid == 4 || wid == 5) && p.out) {   // gamma / beta of the LayerNorm BEHIND the product -> LDS, landed by the first barrier
-            const float* src = wid == 4 ? p.gamma : p.beta;
-#pragma unroll
-            for (int i = 0; i < CH; ++i) glds16(src + i * 256 + lane * 4, lds_base + (unsigned)(QW<D>::GB + (wid - 4) * D * 4 + i * 1024));
         }
     }
 
@@ -223,24 +201,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_lnq_kernel(LnqParams p) 
         advance_w();
     };
 
-    if constexpr (MODE == 1) {
-        // ---- A (the attention output, bf16 rows) -> the LDS image, same swizzle: wave w copies rows 8 w .. 8 w + 7, 16 bytes per lane
-        //      (a row is 96 chunks: 1.5 wave-loads; 12 loads per lane, all in flight) ----
-        constexpr int CPRW = D / 8;                                   // 16-B chunks per row
-        u32x4 t[RPW * CPRW / 64];
-#pragma unroll
-        for (int i = 0; i < RPW * CPRW / 64; ++i) {
-            const int id = i * 64 + lane, rr = id / CPRW, c = id - rr * CPRW;
-            int gr = m0 + wid * RPW + rr;
-            gr = gr < p.M ? gr : p.M - 1;
-            t[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16*>(p.h) + (size_t)gr * p.ldh + c * 8);
-        }
-#pragma unroll
-        for (int i = 0; i < RPW * CPRW / 64; ++i) {
-            const int id = i * 64 + lane, rr = id / CPRW, c = id - rr * CPRW, row = wid * RPW + rr;
-            *reinterpret_cast<u32x4*>(smem + row * Q_AROW + ((c ^ (row & 15)) << 4)) = t[i];
-        }
-    } else
     // ---- LayerNorm of the tile's 64 rows -> LDS (bf16, swizzled): wave w takes rows 16 w .. 16 w + 15, eight at a time ----
     {
         f32x4 g4[CH], b4[CH];
@@ -309,36 +269,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_lnq_kernel(LnqParams p) 
     __syncthreads();
     LNQ_STAMP(1);
 
-    // ---- accumulators: zero (MODE 1: residual + bias, so that the epilogue only READS them), pinned in AGPRs ----
+    // ---- accumulators: zero, pinned in AGPRs ----
     acc_t acc[NBW][MBW];
-    if constexpr (MODE == 1) {
-        // lane (r32 = lane & 31, hh = lane >> 5) of block (nb, mb) holds row 32 mb + r32, columns 96 wid + 32 nb + 8 g + 4 hh + e
-        // (g = 0..3, e = 0..3) in register 4 g + e.  The loads below are compiler-visible and WAITED for before the ring prologue.
-        const float* lb = reinterpret_cast<const float*>(smem + Q_BIAS);
-#pragma unroll
-        for (int mb = 0; mb < MBW; ++mb) {
-            int gr = m0 + mb * 32 + (lane & 31);
-            gr = gr < p.M ? gr : p.M - 1;
-#pragma unroll
-            for (int nb = 0; nb < NBW; ++nb) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int col = wid * (D / NW) + nb * 32 + 8 * g + 4 * (lane >> 5);
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(lb + col);
-                    f32x4 r4;
-                    if constexpr (XB) {
-                        const u32x2 w2 = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16*>(p.resid) + (size_t)gr * p.ldr + col);
-                        r4 = f32x4{bf16_lo(w2[0]), bf16_hi(w2[0]), bf16_lo(w2[1]), bf16_hi(w2[1])};
-                    } else {
-                        r4 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.resid) + (size_t)gr * p.ldr + col);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[nb][mb][4 * g + e] = r4[e] + b[e];
-                }
-                asm volatile("" : "+a"(acc[nb][mb]));
-            }
-        }
-    } else {
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
@@ -347,11 +279,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_lnq_kernel(LnqParams p) 
             for (int e = 0; e < (int)(sizeof(acc_t) / 4); ++e) acc[nb][mb][e] = 0.f;
             asm volatile("" : "+a"(acc[nb][mb]));
         }
-    }
-
+    
 #ifdef DITTO_DIAG_LNQ_STAMP
-    const unsigned long long lnq_tinit = lnq_now();   // (MODE 1: the residual has become the accumulators)
-    if (MODE == 1 && lane == 0 && blockIdx.x * NW + wid < 2048 * 4) g_lnq_stamps[(blockIdx.x * NW + wid) * 8 + 6] = lnq_tinit - lnq_t1;
+    const unsigned long long lnq_tinit = lnq_now();
 #endif
     // ring prologue: from here on the W loads are the ONLY vector-memory operations until the epilogue's stores
 #pragma unroll
@@ -436,107 +366,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gemm_lnq_kernel(LnqParams p) 
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     __syncthreads();
     constexpr int CPR = D / 8;                                            // 16-B chunks per output row
-    if constexpr (MODE == 1) {
-        // ---- h' = the accumulators (residual + bias + A W^T).  Row statistics, two passes like nn.LayerNorm: a lane's 48 values of
-        //      one row per row block, + lane ^ 32, then the eight waves' parts through the LDS, summed in a fixed order. ----
-        const int r32 = lane & 31, hh = lane >> 5;
-        float* red = reinterpret_cast<float*>(smem + QW<D>::RED);         // [wave][row]
-        float mean[MBW], rstd[MBW], rsum[MBW];
-        const bool ln = p.out != nullptr;
-        auto row_pass = [&](auto PASS, float (&c2)[MBW]) {
-#pragma unroll
-            for (int mb = 0; mb < MBW; ++mb) {
-                float c = 0.f;
-#pragma unroll
-                for (int nb = 0; nb < NBW; ++nb) {
-                    asm volatile("" : "+a"(acc[nb][mb]));                 // re-pin: the copy below is a NEW value, never hoisted
-                    const acc_t v = acc[nb][mb];
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        if constexpr (decltype(PASS)::value == 0) c += v[e];
-                        else { const float dl = fmaf(rsum[mb], -(1.0f / D), v[e]); c = fmaf(dl, dl, c); }
-                    }
-                }
-                c += __shfl_xor(c, 32, 64);
-                if (hh == 0) red[wid * QM + mb * 32 + r32] = c;
-                c2[mb] = c;
-            }
-        };
-        auto total = [&](int row) {
-            return ((red[row] + red[QM + row]) + (red[2 * QM + row] + red[3 * QM + row])) +
-                   ((red[4 * QM + row] + red[5 * QM + row]) + (red[6 * QM + row] + red[7 * QM + row]));
-        };
-        if (ln) {
-            float c2[MBW];
-            row_pass(QC<0>{}, c2);
-            __syncthreads();
-#pragma unroll
-            for (int mb = 0; mb < MBW; ++mb) {
-                rsum[mb] = total(mb * 32 + r32);
-                mean[mb] = rsum[mb] * (1.0f / D);
-                asm volatile("" : "+v"(mean[mb]));                        // the ROUNDED mean, never re-fused into a consumer
-            }
-            __syncthreads();                                              // everyone has read the sums before the next pass overwrites them
-            row_pass(QC<1>{}, c2);
-            __syncthreads();
-#pragma unroll
-            for (int mb = 0; mb < MBW; ++mb) rstd[mb] = rsqrtf(fmaf(total(mb * 32 + r32), 1.0f / D, 1e-5f));
-        }
-        // ---- two outputs, each staged through the A region as whole rows: h' (bf16, the residual stream) and u = LayerNorm(h') ----
-        const float* lg = reinterpret_cast<const float*>(smem + QW<D>::GB);
-        const float* lbe = lg + D;
-#pragma unroll
-        for (int which = 0; which < 2; ++which) {
-            if (which == 1 && !ln) break;
-#pragma unroll
-            for (int nb = 0; nb < NBW; ++nb)
-#pragma unroll
-                for (int mb = 0; mb < MBW; ++mb) {
-                    asm volatile("" : "+a"(acc[nb][mb]));
-                    const acc_t v = acc[nb][mb];
-                    const int row = mb * 32 + r32;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int col = wid * (D / NW) + nb * 32 + 8 * g + 4 * hh;
-                        f32x4 y;
-                        if (which == 0) {
-                            y = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
-                        } else {
-                            const f32x4 g4 = *reinterpret_cast<const f32x4*>(lg + col), b4 = *reinterpret_cast<const f32x4*>(lbe + col);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) y[e] = (v[4 * g + e] - mean[mb]) * rstd[mb] * g4[e] + b4[e];
-                        }
-                        u32x2 st;
-                        st[0] = pack_bf16x2(y[0], y[1]);
-                        st[1] = pack_bf16x2(y[2], y[3]);
-                        *reinterpret_cast<u32x2*>(smem + row * Q_AROW + (((col >> 3) ^ (row & 15)) << 4) + (col & 7) * 2) = st;
-                    }
-                }
-            __syncthreads();
-            bf16* dst = which == 0 ? reinterpret_cast<bf16*>(p.hout) : p.out;
-            const int ldd = which == 0 ? p.ldr : p.ldo;
-#pragma unroll 4
-            for (int i = 0; i < QM * CPR / (NW * 64); ++i) {
-                const int id = tid + NW * 64 * i;
-                const int row = id / CPR, c = id - row * CPR;
-                const u32x4 val = *reinterpret_cast<const u32x4*>(smem + row * Q_AROW + ((c ^ (row & 15)) << 4));
-                if (m0 + row < p.M) *reinterpret_cast<u32x4*>(dst + (size_t)(m0 + row) * ldd + c * 8) = val;
-            }
-            if (which == 0 && ln) __syncthreads();                        // the staging rows are free again
-        }
-#ifdef DITTO_DIAG_LNQ_STAMP
-        {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            LNQ_STAMP(3);
-            const int w = blockIdx.x * NW + wid;
-            if (lane == 0 && w < 2048 * 4) {
-                g_lnq_stamps[w * 8 + 0] = lnq_t1 - lnq_t0; g_lnq_stamps[w * 8 + 1] = lnq_t2 - lnq_t1; g_lnq_stamps[w * 8 + 2] = lnq_t3 - lnq_t2;
-                g_lnq_stamps[w * 8 + 3] = 1; g_lnq_stamps[w * 8 + 4] = lnq_t0; g_lnq_stamps[w * 8 + 5] = lnq_t3;
-            }
-        }
-#endif
-        return;
-    }
     const float* lbias = reinterpret_cast<const float*>(smem + Q_BIAS);
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
@@ -596,20 +425,6 @@ hipError_t launch_lnq_t(const LnqParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
-#ifdef DITTO_EXPERIMENTAL   // the out-projection form is an opt-in A/B kernel (measured SLOWER than gemm_frd.hip in the model: 74.0 against 65.8 us,
-                            // profiles/r05_step_ab_frq.txt; stamps: the residual read into the accumulator layout and the two staged outputs
-                            // cost as much as the loop saves, profiles/r05_frq_stamps.txt): instantiated in DITTO_EXPERIMENTAL builds only
-template <bool LNOUT_UNUSED = false>
-hipError_t launch_frq_t(const LnqParams& p, hipStream_t s) {
-    using K = void (*)(LnqParams);
-    K k = &gemm_lnq_kernel<32, 4, true, 768, 8, 1>;
-    static DevOnce lds_once;
-    if (hipError_t e = set_max_lds_once(lds_once, {reinterpret_cast<const void*>(k)}, QW<768>::LDS1)) return e;
-    hipLaunchKernelGGL(k, dim3((p.M + QM - 1) / QM), dim3(512), QW<768>::LDS1, s, p);
-    return hipGetLastError();
-}
-#endif
-
 }  // namespace
 
 #ifdef DITTO_DIAG_LNQ_STAMP
@@ -624,24 +439,6 @@ namespace ditto {
 // 8 (default since round 5) = two waves per SIMD, 4 = one (the round-4 form): bit-identical outputs; shape 32 only (the 16x16x32 twin stays at 4)
 int g_lnq_waves = [] { const char* e = getenv("DITTO_LNQ_WAVES"); return e ? atoi(e) : 8; }();
 int g_lnq_ring = [] { const char* e = getenv("DITTO_LNQ_RING"); return e ? atoi(e) : 0; }();   // 0 = the shape's default depth
-
-// The out-projection form (MODE 1): h' bf16 [M, ldr] = resid + A[M, 768] (bf16) W^T + bias (hout may alias resid), u bf16 [M, ldu] =
-// LayerNorm(h') * gamma + beta (u null: no LayerNorm output).  Wp: stage-major image Wp[768 / 16][768][16] (the full-row kernels').
-hipError_t launch_gemm_frq(const void* A, int lda, const void* Wp, const float* bias, const void* resid_bf16, void* hout_bf16, int ldr,
-                           const float* gamma, const float* beta, void* u_bf16, int ldu, int M, int rot_period, hipStream_t s) {
-    if (M <= 0 || !A || !Wp || !resid_bf16 || !hout_bf16 || lda % 8 || ldr % 8 || (u_bf16 && (!gamma || !beta || ldu % 8)))
-        return hipErrorInvalidValue;
-    LnqParams p{};
-    p.h = A; p.ldh = lda; p.gamma = gamma; p.beta = beta; p.Wp = (const char*)Wp; p.bias = bias;
-    p.out = (bf16*)u_bf16; p.ldo = ldu; p.M = M; p.rot_period = rot_period > 0 ? rot_period : 0;
-    p.resid = resid_bf16; p.hout = hout_bf16; p.ldr = ldr;
-#ifdef DITTO_EXPERIMENTAL
-    return launch_frq_t<>(p, s);
-#else
-    (void)s;
-    return hipErrorNotSupported;
-#endif
-}
 
 // h: fp32 [M, ldh] (h_bf16 false) or bf16 [M, ldh]; Wp: the stage-major image of W_q for `shape` (32: group 16, 16: group 32);
 // rot_period: tiles (of 64 rows) per utterance when that is whole, else 0 (no K-loop rotation)

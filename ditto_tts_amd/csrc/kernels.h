@@ -72,10 +72,7 @@ hipError_t launch_repack_bf16_stage_major(const void* src_bf16, void* dst, int N
 // reaches HBM).  h fp32 or bf16 rows; Wp = stage-major image of W_q for the MFMA `shape`: 32 -> group 16, 16 -> group 32.
 hipError_t launch_gemm_lnq(const void* h, int ldh, bool h_bf16, const float* gamma, const float* beta, const void* Wp,
                            const float* bias, void* out_bf16, int ldo, int M, int d, int shape, int rot_period, hipStream_t s);
-// gemm_lnq.hip, out-projection form (round 5): h' bf16 = resid + A W^T + bias in place on the bf16 residual stream and u = LayerNorm(h') on
-// the fused q-projection kernel's skeleton (64-row tiles, A resident in the LDS, two waves per SIMD); d = 768, K = 768 only
-hipError_t launch_gemm_frq(const void* A, int lda, const void* Wp, const float* bias, const void* resid_bf16, void* hout_bf16, int ldr,
-                           const float* gamma, const float* beta, void* u_bf16, int ldu, int M, int rot_period, hipStream_t s);
+extern int g_attn64p_min_wgs;   // attention.hip
 extern int g_lnq_waves;  // gemm_lnq.hip: waves per workgroup of the d = 768 / shape-32 kernel: 4 (one per SIMD) or 8 (two per SIMD)
 extern int g_lnq_ring;   // gemm_lnq.hip: depth of the W register ring in stages (0 = default: 4 for shape 32, 2 for shape 16; 8 / 4 = the deep rings)
 // The full-row kernel runs ONE 128-row tile per workgroup, so it needs enough rows to fill the chip: measured in the
@@ -259,14 +256,8 @@ struct AttnArgs {
     float* lse_out;                  // fused (dh == 64) path: fp32 [B, H, Sq] log2-domain log-sum-exp for the backward
     bool q_prescaled;                // q already multiplied by scale * log2(e) (packed weights, dh == 64): `scale` unused
     bool causal;                     // key j visible to query i only if j <= i + (Skv - Sq); GEMM-composed path only
-    // split-KV path only (attention_kv_splits(a) > 1; the low-latency class): the merge launch also writes
-    // ln_out bf16 [B Sq, ld_ln] = LayerNorm(resid row after the update) * ln_gamma + ln_beta (the self-attention's norm2) if set
-    const float* ln_gamma; const float* ln_beta; void* ln_out; int ld_ln;
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
-// > 1: launch_attention(a) will run the key sequence in that many splits + an ordered merge launch (and fuse the LayerNorm asked for
-// by a.ln_*); 1: one launch, a.ln_* ignored — the caller runs its LayerNorm.  A K-only rule inside the low-latency class.
-int attention_kv_splits(const AttnArgs& a);
 size_t attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh);
 // the GEMM-composed path's scratch at any head_dim (force_generic / causal)
 size_t attention_generic_workspace_bytes(int B, int H, int Sq, int Skv, int dh);

@@ -190,7 +190,6 @@ SYMBOLS = {
     "ditto_attention_causal_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
     "ditto_layernorm_dual": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "ditto_gemm_lnq_bf16": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "ditto_gemm_resln_bf16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "ditto_set_option": (_i, [C.c_char_p, _i]),
     "ditto_get_option": (_i, [C.c_char_p, C.POINTER(C.c_int)]),
     "ditto_full_row_plan": (_i, [C.POINTER(Config), _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -226,7 +225,7 @@ def lib() -> C.CDLL:
                     continue
                 raise
             fn.restype, fn.argtypes = res, args
-        if l.ditto_abi_version() != 9 and not (frozen and l.ditto_abi_version() in (7, 8)):
+        if l.ditto_abi_version() != 10 and not (frozen and l.ditto_abi_version() in (7, 8, 9)):
             raise RuntimeError("libditto_hip.so ABI version mismatch")
         _lib = l
     return _lib
@@ -243,7 +242,7 @@ def set_option(name: str, value: int):
 
 
 def get_option(name: str) -> int:
-    """ditto_get_option: the current value of a switch ("experimental": 1 if the csrc/experimental/ kernels are built in)."""
+    """ditto_get_option: the current value of a switch."""
     v = C.c_int(0)
     check(lib().ditto_get_option(name.encode(), C.byref(v)))
     return int(v.value)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DITTO_ABI_VERSION 9
+#define DITTO_ABI_VERSION 10
 
 typedef enum ditto_status {
     DITTO_OK = 0,
@@ -270,12 +270,12 @@ int ditto_gemm_bf16(const void* A, int lda, const void* W, const float* bias, co
 int ditto_attention_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
                          void* out, int ldo, int B, int H, int Sq, int Skv, int dh, float scale,
                          void* workspace, size_t workspace_bytes, ditto_stream_t stream);
-/* scratch bytes ditto_attention_bf16 needs (dh != 64), or can use (dh = 64: the split-KV partials of launches of at most 2048
- * query rows over >= 512 keys — "ll_mask" bit 2; with less the launch simply is not split) */
+/* scratch bytes ditto_attention_bf16 needs: 0 at dh = 64 (the fused kernels), the chunked score / probability / V^T arrays of the
+ * GEMM-composed path otherwise */
 size_t ditto_attention_workspace_bytes(int B, int H, int Sq, int Skv, int dh);
 
-/* Full-row GEMM with the residual add and the FOLLOWING LayerNorm fused (N = 768: csrc/gemm_frd.hip, or csrc/gemm_fr.hip / its
- * 64-row twin csrc/gemm_fr64.hip under "fr_tile" 128 / 64 — 64 <= M < 128 always runs the 64-row twin, same fp32 bits;
+/* Full-row GEMM with the residual add and the FOLLOWING LayerNorm fused (N = 768: csrc/gemm_frd.hip, or its 64-row twin
+ * csrc/gemm_fr64.hip under "fr_tile" 64 — 64 <= M < 128 always runs the 64-row twin, same fp32 bits;
  * N = 1024: csrc/gemm_fr64.hip; M >= 64 everywhere):
  *   out fp32 [M,N] = residual + A[M,K] W[N,K]^T + bias   (residual may alias out: the in-place stream update of
  *   src/components/DiT.py:148 / :155),   u bf16 [M,ldu] = LayerNorm(out) * gamma + beta  (eps 1e-5; the norm of :152 / the
@@ -295,18 +295,6 @@ int ditto_gemm_ln_bf16(const void* A, int lda, const void* W, const float* bias,
 int ditto_gemm_lnq_bf16(const void* h, int ldh, int h_is_bf16, const float* gamma, const float* beta, const void* W,
                         const float* bias, void* out_bf16, int ldo, int M, int d, int mfma_shape, void* w_scratch,
                         ditto_stream_t stream);
-
-/* OPT-IN A/B KERNEL (DITTO_EXPERIMENTAL builds; otherwise DITTO_ERR_ARG): the cross out-projection + residual + the LayerNorm behind it
- * ON THE BF16 RESIDUAL STREAM on the fused q-projection kernel's skeleton (csrc/gemm_lnq.hip, out-projection form; src/components/
- * DiT.py:148 + :152; "frq" selects it in the model).  Measured slower than csrc/gemm_frd.hip in the model (74.0 / 65.8 us): not a default.
- *   h bf16 [M, ldh] (in place) = h + A[M, 768] (bf16) W[768, 768]^T + bias;  u bf16 [M, ldu] = LayerNorm(h) * gamma + beta (eps 1e-5,
- *   on the UNROUNDED fp32 row; gamma = beta = u = NULL: no LayerNorm output).  64-row tiles whose A rows stay in the LDS, eight
- *   waves (two per SIMD) side by side in N, W streamed straight into registers.  W: bf16, nn.Linear layout [768 out, 768 in];
- * w_scratch: 768 * 768 * 2 bytes, 256-byte aligned (receives the stage-major image; the model keeps it in its arena).
- * rot_period_tiles > 0: tiles t and t + period start their K loop at the same place (the model passes the 64-row tiles per utterance). */
-int ditto_gemm_resln_bf16(const void* A, int lda, const void* W, const float* bias, void* h_bf16, int ldh, const float* gamma,
-                          const float* beta, void* u_bf16, int ldu, int M, int rot_period_tiles, void* w_scratch,
-                          ditto_stream_t stream);
 
 /* Weight-gradient GEMM of the backward pass (csrc/gemm_tn.hip): out fp32 [Mo, No] = X[K, Mo]^T Y[K, No], both operands
  * K-major bf16 (rows = the contraction index, as activations and their gradients lie in memory), i.e. dW = dY^T X of
@@ -332,9 +320,8 @@ int ditto_gemm_tn_bf16(const void* X, int ldx, const void* Y, int ldy, float* ou
  * over several launches or GPUs sets this to the rows (B * N) of the unsplit batch: every launch then decides as that batch
  * would and sharding changes no bit (ditto_tts_amd/dist.py sample_sharded does).  0 (default) = each launch on its own rows.
  * "fr_tile": which N = 768 full-row kernel: 0 (default) / 130 = 128-row tiles with the weights fetched straight from L2 into
- * registers (csrc/gemm_frd.hip); 128 = 128-row tiles with the weights through an LDS ring (csrc/gemm_fr.hip); 64 = 64-row tiles,
- * two workgroups per CU (csrc/gemm_fr64.hip) for launches with K <= "fr64_maxk".  All three produce the same fp32 result bit
- * for bit; the LayerNorm output of 128 and 64 is bit-identical, that of 0 / 130 may differ from it in the last bf16 bit of a few
+ * registers (csrc/gemm_frd.hip); 64 = 64-row tiles, two workgroups per CU (csrc/gemm_fr64.hip) for launches with
+ * K <= "fr64_maxk".  Both produce the same fp32 result bit for bit; the LayerNorm output may differ in the last bf16 bit of a few
  * elements (other association of the row statistics).  "fr_stagger": start delay of a CU's second workgroup in the 64-row
  * kernel, 10 ns ticks.  (N = 1024 always runs csrc/gemm_fr64.hip.)
  * "fr_u_fp8": TEST HOOK: ditto_gemm_ln_bf16 at N = 1024 writes u as fp8 e4m3 bytes ([M, ldu] bytes), the form the fp8 linear
@@ -363,9 +350,7 @@ int ditto_gemm_tn_bf16(const void* X, int ldx, const void* Y, int ldy, float* ou
  * "residual_bf16": 1 = the residual stream h between the segments of a block lives in HBM as bf16 (fp32 only inside the
  * accumulators and the LayerNorm statistics) for launches of the full-row class at d = 768 / head_dim 64; 0 = fp32 stream.
  * The sampler state x and eps stay fp32 either way.  (DITTO_RESIDUAL_BF16 in the environment sets the initial value.)
- * "frq": 1 (DITTO_EXPERIMENTAL builds only; default 0) = the cross out-projection + residual + norm3 of launches on the bf16 residual
- * stream on the fused q-projection kernel's skeleton (csrc/gemm_lnq.hip: 64-row tiles, two waves per SIMD) instead of csrc/gemm_frd.hip's
- * 128-row tile — measured slower, an A/B switch.  "lnq_waves": 8 (default) / 4 = waves per workgroup of the fused norm2 + q-projection (bit-identical).
+ * "lnq_waves": 8 (default) / 4 = waves per workgroup of the fused norm2 + q-projection (bit-identical).
  * "lnq": norm2 fused into the cross-attention q-projection (csrc/gemm_lnq.hip) for launches of the full-row class at d = 768:
  * 0 = LayerNorm launch + tiled GEMM, 32 / 16 = fused, on that MFMA shape.  (DITTO_LNQ sets the initial value.)
  * "splitk_wgs": K-splitting of the long-K GEMMs (fc2, final projection) of small batches, with an ordered fp32 reduce.
@@ -378,13 +363,10 @@ int ditto_gemm_tn_bf16(const void* X, int ldx, const void* Y, int ldy, float* ou
  * rounds of 256 x 256 tiles on the CUs, for launches of at most that many rounds (d = 768: B = 8, 16 at N = 1024); bit-identical.
  * "ll_mask" (default 3): the other launch forms of the low-latency class, each a function of the class and of K / Skv only:
  * bit 0 = fc2's split-K finish also writes the next block's norm1 (no bit changes), bit 1 = the cross out-projection as two
- * K-splits whose finish writes norm3, bit 2 (round 5; off by default: measured slower, an A/B switch) = the fused head_dim-64 attention split over the keys (Skv a multiple of
- * 512 and >= 1024: 4 splits; of 256 and >= 512: 2) with an ordered merge launch that for the self-attention also writes norm2.
- * Bits 1 and 2 change a summation order: they are part of what defines the class (pin it with class_rows as usual). */
+ * K-splits whose finish writes norm3.  Bit 1 changes a summation order: it is part of what defines the class (pin it with
+ * class_rows as usual).  (ABI 9's bit 2, split-KV attention, measured slower and was removed in ABI 10.) */
 int ditto_set_option(const char* name, int value);
-/* Reads a switch back (callers that change one temporarily restore what they found: ditto_tts_amd/hip.py batch_class).
- * Also "experimental": 1 when the library contains the opt-in A/B kernels of csrc/experimental/ ("gemm_tile" 130,
- * "attn_flags" bit 12 — refused by ditto_set_option otherwise). */
+/* Reads a switch back (callers that change one temporarily restore what they found: ditto_tts_amd/hip.py batch_class). */
 int ditto_get_option(const char* name, int* value);
 
 /* Which launches of one DiT block (reference src/components/DiT.py:148+152, :155+:105) a forward over B utterances of N

@@ -27,16 +27,3 @@ def asym(shape, seed, scale=1.0):
     """asymmetric, full-rank, sign-varying test data (guide: never check tile maps with symmetric data)"""
     from ditto_tts_amd.synth import hash_normal
     return hash_normal(shape, "asym", seed) * scale
-
-
-def skip_unless_experimental(gemm_tile=0, attn_flags=0, fr_tile=0):
-    """gemm_tile 130 (csrc/experimental/gemm_o3.hip), attn_flags bit 12 (attention_v4.hip) / bits 14, 15 (attention_w4.hip) and
-    fr_tile 128 (gemm_fr128.hip) select opt-in A/B kernels that the default library is built without
-    (DITTO_EXPERIMENTAL=1 python -m ditto_tts_amd.build --force)."""
-    import pytest
-    if (gemm_tile == 130 or (attn_flags & (4096 | 16384 | 32768)) or fr_tile == 128) and not hip.get_option("experimental"):
-        pytest.skip("needs the csrc/experimental/ kernels (DITTO_EXPERIMENTAL=1 build)")
-
-
-def experimental() -> bool:
-    return bool(hip.get_option("experimental"))

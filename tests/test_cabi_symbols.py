@@ -25,7 +25,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, n), f"{n} declared in ditto_hip.h but not exported by libditto_hip.so"
         assert n in hip.SYMBOLS, f"{n} has no ctypes prototype in ditto_tts_amd/hip.py"
     assert sorted(hip.SYMBOLS) == names
-    assert lib.ditto_abi_version() == 9
+    assert lib.ditto_abi_version() == 10
 
 
 def test_struct_layout_matches_header():
