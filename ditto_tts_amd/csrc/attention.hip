@@ -764,7 +764,7 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
                 const long wgs = (rows_cls / 256) * a.H;
                 const bool wide_ok = a.ldo % 8 == 0 && (!a.resid_f32 || a.ldr % 8 == 0);   // 16-byte row pieces in the epilogue
                 if (wide_ok && !(g_attn_flags & 131072) && (wgs >= g_attn64p_min_wgs || (g_attn_flags & 262144)))
-                    return launch_attn64p(p, a.resid_f32 != nullptr, s);
+                    return launch_attn64p(p, a.resid_f32 != nullptr, s, (g_attn_flags & 524288) != 0);
             }
             const dim3 gridv(p.nqb * a.H * a.B);
             // whole pairs of key tiles: the software-pipelined, hand-interleaved kernel where it measures faster — small grids

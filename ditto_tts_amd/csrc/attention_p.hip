@@ -14,12 +14,17 @@ namespace {
 }  // namespace
 
 // p.nqb is set here: blocks of 256 queries
-hipError_t launch_attn64p(const AttnParams& p_in, bool resid, hipStream_t s) {
+hipError_t launch_attn64p(const AttnParams& p_in, bool resid, hipStream_t s, bool ring3) {
     AttnParams p = p_in;
     p.nqb = (p.Sq + 255) / 256;
     const dim3 grid(p.nqb * p.H * p.B), block(256);
-    if (resid) hipLaunchKernelGGL((attn64p_kernel<true>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((attn64p_kernel<false>), grid, block, 0, s, p);
+    if (ring3) {   // A/B (attn_flags 524288): a ring of 3 tile pairs (48 KiB) instead of 4: same bits, same speed in the model
+        if (resid) hipLaunchKernelGGL((attn64p_kernel<true, 3>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((attn64p_kernel<false, 3>), grid, block, 0, s, p);
+    } else {
+        if (resid) hipLaunchKernelGGL((attn64p_kernel<true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((attn64p_kernel<false>), grid, block, 0, s, p);
+    }
     return hipGetLastError();
 }
 

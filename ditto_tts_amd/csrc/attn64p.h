@@ -18,7 +18,9 @@
 //     workgroup's K / V tile serves 256 queries: half the LDS-DMA pieces, ring writes and barriers per FLOP;
 //   * 32 MFMAs per 64 queries x 64 keys, not 40: the row sum is fp32 adds on the lane's own probabilities (attn64v2 spent four
 //     all-ones MFMAs per block on it: 20 % of the matrix pipe's time at a point where that pipe is not the idle one);
-//   * the row maximum as two chains of v_max3_f32 (hipcc pairs the operands with v_max_f32 first: 48 instructions for 32);
+//   * NO row maximum on the common path: the raise of the running maximum is decided by the tile's row SUMS (see tile_body), which
+//     the kernel needs anyway — the maximum (two chains of v_max3_f32 + a lane exchange per block, a sixth of the vector work) is
+//     taken on the first tile and on the rare tile whose sums say a raise is due;
 //   * the eight K fragments of a tile requested together ahead of the sixteen score MFMAs (left alone hipcc issues read, wait,
 //     MFMA, read ... and every MFMA pays an LDS round trip);
 //   * the epilogue trades 4-column groups between the two halves of a query (v_permlane32_swap) so that every lane stores 16
@@ -47,6 +49,8 @@ DITTO_DEV float max3f(float a, float b, float c) {
     return r;
 }
 
+constexpr float SUM_RAISE_THR = 8192.0f;   // 2^13: a lane's 32 probabilities of a tile may sum to this before the tile is redone with a raise
+
 // DIAG (tools/probe_attn64p.hip only; wrong results by design, every knock-out computes on VALID data): bit 0 = no softmax arithmetic
 // (P = the packed scores), bit 1 = no K/V DMA after the prologue (every ring slot holds a tile), bit 2 = no barrier / DMA wait in the
 // loop (with bit 1), bit 3 = no LDS fragment reads (Q fragments stand in), bit 4 = the exponentials replaced by adds, bit 7 = no MFMAs
@@ -70,16 +74,18 @@ __global__ __launch_bounds__(256, 2) void attn64p_kernel(AttnParams p) {
         qvalid[x] = qrow[x] < p.Sq;
         qrow[x] = qvalid[x] ? qrow[x] : p.Sq - 1;
     }
-    bf16x8 qf[2][4];   // Q^T B-operand fragments: lane holds Q[query ql of block x][d = 16 ks + 8 hh + 0..7]
-#pragma unroll
-    for (int x = 0; x < 2; ++x) {
-        const bf16* qp = p.q + ((size_t)b * p.Sq + qrow[x]) * p.ldq + h * DH + 8 * hh;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[x][ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
-    }
     const int nkt = (p.Skv + KBLK - 1) / KBLK;
     const bool ragged = (p.Skv & (KBLK - 1)) != 0;
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+    bf16x8 qf[2][4];   // Q^T B-operand fragments: lane holds Q[query ql of block x][d = 16 ks + 8 hh + 0..7]
+    {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const bf16* qp = p.q + ((size_t)b * p.Sq + qrow[x]) * p.ldq + h * DH + 8 * hh;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qf[x][ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+        }
+    }
     // this lane's two (row, chunk) DMA sources of tile 0 (LDS swizzles applied on the source); tile kt is + kt * 64 rows
     const bf16 *ksrc[2], *vsrc[2];
 #pragma unroll
@@ -134,15 +140,19 @@ __global__ __launch_bounds__(256, 2) void attn64p_kernel(AttnParams p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) { ot[x][0][i] = 0.f; ot[x][1][i] = 0.f; cneg[x][i] = 0.f; }
 
-    // ---- prologue: tiles 0 .. NBUF-2 in flight, tile 0 landed ----
+    // ---- prologue: tile 0 ALONE first, then tiles 1 .. NBUF-2.  The workgroups of a launch start together (512 resident, three
+    //      rounds at C2): with all three tiles of every workgroup requested at once the FIRST tiles queue behind 32 KiB more per
+    //      workgroup and nothing computes meanwhile (probe, same process: 121.0 -> 114.7 us warm, 130.4 -> 123.8 from HBM) ----
+    dma_kv(0, 0);
+    wait_groups(0);
+    if constexpr (DIAG & 2) {   // (knock-out: every slot holds a tile, no traffic in the loop)
 #pragma unroll
-    for (int t0 = 0; t0 < NBUF - 1; ++t0)
-        if (t0 < nkt) dma_kv(t0, t0);
-    if constexpr (DIAG & 2) {
-        dma_kv(NBUF - 1 < nkt ? NBUF - 1 : 0, NBUF - 1);
+        for (int t0 = 1; t0 < NBUF; ++t0) dma_kv(t0 < nkt ? t0 : 0, t0);
         wait_groups(0);
     } else {
-        wait_groups((nkt < NBUF - 1 ? nkt : NBUF - 1) - 1);   // the groups younger than tile 0
+#pragma unroll
+        for (int t0 = 1; t0 < NBUF - 1; ++t0)
+            if (t0 < nkt) dma_kv(t0, t0);
     }
     __syncthreads();
 
@@ -155,10 +165,12 @@ __global__ __launch_bounds__(256, 2) void attn64p_kernel(AttnParams p) {
             dma_kv(kt + NBUF - 1, ns);
         }
 
+        f32x16 st[2][2];
+        u32x4 pa[4], pb[4];
+        float lt[2];   // this lane's sums of the tile's probabilities, per block
         // ---- S'^T[key][query] = K Q'^T - m for both blocks: every K fragment feeds two MFMAs.  The eight fragments are requested
         //      together, ahead of the first MFMA (the registers exist: S', P and the V fragments are dead here) ----
-        f32x16 st[2][2];
-        {
+        auto scores = [&]() {
             bf16x8 kf[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i)
@@ -178,39 +190,35 @@ __global__ __launch_bounds__(256, 2) void attn64p_kernel(AttnParams p) {
                     }
                 }
             __builtin_amdgcn_sched_barrier(0);
-        }
-        if constexpr (decltype(MASKED)::value) {   // ragged last tile only: keys >= Skv never contribute
-            const int kbase_idx = kt * KBLK + 4 * hh;
+            if constexpr (decltype(MASKED)::value) {   // ragged last tile only: keys >= Skv never contribute
+                const int kbase_idx = kt * KBLK + 4 * hh;
 #pragma unroll
-            for (int x = 0; x < 2; ++x)
+                for (int x = 0; x < 2; ++x)
 #pragma unroll
-                for (int kb2 = 0; kb2 < 2; ++kb2)
+                    for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = kbase_idx + kb2 * 32 + (r & 3) + 8 * (r >> 2);
-                        if (key >= p.Skv) st[x][kb2][r] = -1e30f;
-                    }
-        }
-
-        // ---- row maxima relative to the running ones; raise them (rarely; one wave-uniform decision for both blocks, taken BEFORE
-        //      any P of this tile is exponentiated and with the previous tile's P V complete: guide T13 safe order) ----
-        if constexpr (!(DIAG & 1)) {
-            float dm[2];
-#pragma unroll
-            for (int x = 0; x < 2; ++x) {
-                float c0 = max3f(st[x][0][0], st[x][0][1], st[x][0][2]), c1 = max3f(st[x][1][0], st[x][1][1], st[x][1][2]);
-#pragma unroll
-                for (int r = 3; r < 15; r += 2) { c0 = max3f(c0, st[x][0][r], st[x][0][r + 1]); c1 = max3f(c1, st[x][1][r], st[x][1][r + 1]); }
-                const float a = max3f(c0, c1, fmaxf(st[x][0][15], st[x][1][15]));
-                float s0, s1;
-                swap32(a, s0, s1);
-                dm[x] = fmaxf(s0, s1);
+                        for (int r = 0; r < 16; ++r) {
+                            const int key = kbase_idx + kb2 * 32 + (r & 3) + 8 * (r >> 2);
+                            if (key >= p.Skv) st[x][kb2][r] = -1e30f;
+                        }
             }
-            if (kt == 0 || !__all(fmaxf(dm[0], dm[1]) <= RESCALE_THR_LOG2)) {
+        };
+        // ---- the exact row maxima relative to the running ones, and the raise: the running maximum moves to (at least) the tile's, in
+        //      whole octaves (the factors are powers of two); S', -m, O and l are rescaled together, BEFORE any P of this tile exists and
+        //      with the previous tile's P V complete (guide T13 safe order) ----
+        auto raise_exact = [&]() {
+            if constexpr (!(DIAG & 1)) {
 #pragma unroll
                 for (int x = 0; x < 2; ++x) {
-                    // first tile: the running maximum IS this tile's.  Whole octaves: the factors are powers of two
-                    const float up = ceilf(kt == 0 ? dm[x] : fmaxf(dm[x], 0.f));
+                    float c0 = max3f(st[x][0][0], st[x][0][1], st[x][0][2]), c1 = max3f(st[x][1][0], st[x][1][1], st[x][1][2]);
+#pragma unroll
+                    for (int r = 3; r < 15; r += 2) { c0 = max3f(c0, st[x][0][r], st[x][0][r + 1]); c1 = max3f(c1, st[x][1][r], st[x][1][r + 1]); }
+                    const float a = max3f(c0, c1, fmaxf(st[x][0][15], st[x][1][15]));
+                    float s0, s1;
+                    swap32(a, s0, s1);
+                    const float dm = fmaxf(s0, s1);
+                    // first tile: the running maximum IS this tile's; later: it only ever rises
+                    const float up = ceilf(kt == 0 ? dm : fmaxf(dm, 0.f));
 #pragma unroll
                     for (int i = 0; i < 16; ++i) { st[x][0][i] -= up; st[x][1][i] -= up; cneg[x][i] -= up; }
                     if (kt > 0) {   // (first tile: O and l are zero, and 2^-up may be infinite)
@@ -221,31 +229,50 @@ __global__ __launch_bounds__(256, 2) void attn64p_kernel(AttnParams p) {
                     }
                 }
             }
-        }
-
-        // ---- P = exp2(S'); l += P (fp32, this lane's keys); both blocks' probabilities first, then every V^T fragment feeds two MFMAs ----
-        auto exp8 = [&](int x, int s2, float& l0, float& l1) {   // the 8 probabilities of k-step s2 -> one packed B operand
-            u32x4 pk;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float e0 = st[x][s2 >> 1][8 * (s2 & 1) + 2 * j], e1 = st[x][s2 >> 1][8 * (s2 & 1) + 2 * j + 1];
-                if constexpr (!(DIAG & 1)) {
-                    if constexpr (DIAG & 16) { e0 += 1.0f; e1 += 1.0f; }
-                    else { e0 = __builtin_amdgcn_exp2f(e0); e1 = __builtin_amdgcn_exp2f(e1); }
-                    l0 += e0; l1 += e1;
-                }
-                pk[j] = pack_bf16x2(e0, e1);
-            }
-            return pk;
         };
-        u32x4 pa[4], pb[4];
-        float la0 = 0.f, la1 = 0.f, lb0 = 0.f, lb1 = 0.f;
+        // ---- P = exp2(S') as packed bf16 pairs (the B operands of O += V P); lt = this lane's fp32 sum of the probabilities
+        //      (v_dot2c_f32_bf16 on the packed pairs was tried for it: not faster than the two adds it replaces, and hipcc 7.2 miscompiles
+        //      the builtin on two accumulator chains) ----
+        auto exp_all = [&]() {
 #pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) pa[s2] = exp8(0, s2, la0, la1);
-        lrun[0] += la0 + la1;
+            for (int x = 0; x < 2; ++x) {
+                float l0 = 0.f, l1 = 0.f;
 #pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) pb[s2] = exp8(1, s2, lb0, lb1);
-        lrun[1] += lb0 + lb1;
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    u32x4 pk;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float e0 = st[x][s2 >> 1][8 * (s2 & 1) + 2 * j], e1 = st[x][s2 >> 1][8 * (s2 & 1) + 2 * j + 1];
+                        if constexpr (!(DIAG & 1)) {
+                            if constexpr (DIAG & 16) { e0 += 1.0f; e1 += 1.0f; }
+                            else { e0 = __builtin_amdgcn_exp2f(e0); e1 = __builtin_amdgcn_exp2f(e1); }
+                        }
+                        pk[j] = pack_bf16x2(e0, e1);
+                        if constexpr (!(DIAG & 1)) { l0 += e0; l1 += e1; }
+                    }
+                    if (x == 0) pa[s2] = pk; else pb[s2] = pk;
+                }
+                lt[x] = l0 + l1;
+            }
+        };
+        // The raise is decided by the SUMS, not by a row maximum taken on every tile (16 v_max3_f32 + a lane exchange per block and
+        // tile: a sixth of the vector work): the probabilities are computed against the running maximum as it stands, and only if
+        // some lane's 32 of them sum to more than 2^13 (so: every P of the tile <= 2^13, exact in bf16's exponent range, fp32
+        // accumulation) — or to inf / NaN — the tile is redone the exact way: scores again (its K tile is still in LDS), the true row
+        // maxima, the raise, the exponentials.  Wave-uniform and rare (a key that beats the running maximum by more than 2^8 .. 2^13);
+        // the first tile always takes the exact path (it establishes the running maximum).
+        scores();
+        if (kt == 0) raise_exact();
+        exp_all();
+        if constexpr (!(DIAG & 1)) {
+            if (kt > 0 && !__all(lt[0] <= SUM_RAISE_THR && lt[1] <= SUM_RAISE_THR)) {
+                scores();
+                raise_exact();
+                exp_all();
+            }
+        }
+        lrun[0] += lt[0];
+        lrun[1] += lt[1];
         // ---- O^T[d][query] += V^T[d][key] P^T[key][query] ----
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2)

@@ -47,6 +47,10 @@ constexpr int WAVE = 64;
 // would (likewise the row mirror for i ^ 8), and (R1 + R0), then (R3 + R2) + (R1 + R0) across the four rows is the butterfly's
 // (R0 + R1) + (R2 + R3) by commutativity: every kernel that normalises rows through these helpers (ln_kernel, the AdaLN kernel's
 // norm1, the split-K finish, gemm_lnq) still produces the SAME bits as the others.
+// PRECONDITION: whole 64-lane waves (EXEC all ones) — the total is read from lane 63 and the row broadcasts read lanes 15 / 31 / 47,
+// so an inactive lane there gives garbage (the ds_bpermute butterflies of rounds 1-4 summed the active lanes only).  Every call
+// site runs 256-thread workgroups with wave-uniform control flow around it.  The association is near-to-far, so LayerNorm bits
+// differ from ABI-8 libraries ("bit changes between library versions").
 template <int CTRL, int ROW_MASK = 0xF>
 DITTO_DEV float dpp_f32(float v, float masked = 0.0f) {   // lanes of masked-off rows read `masked`
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, masked), __builtin_bit_cast(int, v), CTRL,

@@ -283,9 +283,9 @@ int ditto_train_forward_opts(ditto_model_t m, const float* x, const float* text,
     }
     HIP_TRY(launch_text_mod(text, m->wx, m->bx, pooled, tmod, B, T, c.text_dim, d, s));
     const bool hb = train_stream_bf16(m, M);
-    {
+    {   // a tape whose forward fails half-way must not look written: drop any older record of this address now, record at the end
         std::lock_guard<std::mutex> lk(m->tape_mu);
-        m->tapes[tape] = ditto_model::TapeRec{B, N, T, hb};
+        m->tapes.erase(tape);
     }
     if (hb)   // bf16 h0 + block 0's norm1 from the same kernel, as the inference forward
         HIP_TRY(launch_adaln(x, m->ttab, tmod, t, c.diffusion_steps, hs(0), xcat, 2 * d, B, N, d, s, true, m->layers[0].g1,
@@ -393,6 +393,12 @@ int ditto_train_forward_opts(ditto_model_t m, const float* x, const float* text,
         g.A = xcat; g.lda = 2 * d; g.W = m->Wfin; g.bias = m->bfin; g.out = eps_out; g.ldo = d; g.M = M; g.N = d;
         g.K = 2 * d;
         HIP_TRY(launch_gemm(g, EPI_BIAS_F32, s));
+    }
+    {   // every launch of the forward is enqueued: the tape is this handle's.  The map is bounded: a caller that allocates
+        // a fresh tape per step would otherwise grow it for ever, and a tape is gigabytes — nobody holds 64 live ones
+        std::lock_guard<std::mutex> lk(m->tape_mu);
+        if (m->tapes.size() >= 64) m->tapes.clear();
+        m->tapes[tape] = ditto_model::TapeRec{B, N, T, hb};
     }
     return DITTO_OK;
 }

@@ -253,6 +253,16 @@ class GradSync:
         if self._open_bytes >= self.bucket_bytes:
             self._flush()
 
+    def abort(self):
+        """Drop the step's open state after an exception in the backward or in a collective: the tensors of the dead step must not
+        join the next step's buckets (another size than the other ranks' -> a collective mismatch or silently averaged stale
+        gradients).  The compute stream still waits for whatever exchange was enqueued, so buffers are not reused under it."""
+        self._open, self._open_bytes = [], 0
+        if self._comm is not None and self._keep:
+            torch.cuda.current_stream(self._keep[0][0].device).wait_stream(self._comm)
+        self._keep = []
+        self.buckets = 0
+
     def finish(self) -> int:
         self._flush()
         if self._comm is not None and self._keep:

@@ -69,9 +69,14 @@ class _DiTTOTrainFn(torch.autograd.Function):
             raise RuntimeError("backward through the same DiTTO.forward twice (the activation tape was released)")
         sd = {k: v for k, v in model.state_dict(keep_vars=True).items() if not k.startswith("nac.")}
         sync = getattr(model, "_grad_sync", None)      # dist.GradSync: the gradient exchange overlapped with this backward
-        grads = eng.train_backward(sd, grad_out, ctx.xf, ctx.tt, ctx.T, ctx.tape, ctx.dropout_p, ctx.seed, opts=ctx.opts,
-                                   piece_cb=sync.reduce if sync is not None else None,
-                                   layers_per_piece=getattr(model, "_grad_sync_layers", 1))
+        try:
+            grads = eng.train_backward(sd, grad_out, ctx.xf, ctx.tt, ctx.T, ctx.tape, ctx.dropout_p, ctx.seed, opts=ctx.opts,
+                                       piece_cb=sync.reduce if sync is not None else None,
+                                       layers_per_piece=getattr(model, "_grad_sync_layers", 1))
+        except BaseException:
+            if sync is not None:
+                sync.abort()                           # no stale tensors in the next step's buckets
+            raise
         if sync is not None:
             sync.finish()                              # the compute stream waits for the exchange: the gradients returned are the means
         B, N, _ = ctx.xf.shape

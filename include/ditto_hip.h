@@ -464,7 +464,12 @@ int ditto_train_backward_opts(ditto_model_t m, const ditto_weights* w, const flo
  * call runs layers layer_from, layer_from - 1, ..., layer_to (num_layers > layer_from >= layer_to >= 0) and writes THEIR gradients
  * (grads->layers[l]); the call with layer_from == num_layers - 1 also runs the head (proj_in / proj_out gradients), the call with
  * layer_to == 0 the tail (GlobalAdaLN, time embedding).  Successive calls, top layer first, on ONE stream with ONE workspace (it
- * carries the stream gradient between them) are bit-identical to ditto_train_backward, which is the call (num_layers - 1, 0). */
+ * carries the stream gradient between them) are bit-identical to ditto_train_backward, which is the call (num_layers - 1, 0).
+ * ONE gradient crosses a piece boundary: grads->layers[l].mlp_fc2_bias is the column sum taken by the LayerNorm backward of layer
+ * l + 1's norm1 (the fused fc2 + norm1 launch of the forward), so it is written by the piece that CONTAINS LAYER l + 1 — the call
+ * with layer_to == l + 1 writes layers[l].mlp_fc2_bias as well, and a piece's own top layer's fc2 bias gradient was written by the
+ * piece above it (the top layer's: by the call with layer_from == num_layers - 1 itself).  A caller that allocates, zeroes or
+ * exchanges gradient buffers per piece must treat layers[layer_to - 1].mlp_fc2_bias as part of the piece (dist.py GradSync does). */
 int ditto_train_backward_layers(ditto_model_t m, const ditto_weights* w, const float* grad_eps, const float* x,
                                 const int64_t* t, int B, int N, int T, const float* rope_cos, const float* rope_sin,
                                 float dropout_p, uint64_t seed, const void* tape, size_t tape_bytes, const ditto_grads* grads,
