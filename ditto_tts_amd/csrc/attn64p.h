@@ -27,7 +27,11 @@
 //     contiguous bytes per row instead of 8 (guide T21: the store tail of a workgroup is issue-bound).
 // The running maximum stays the score chains' initial accumulator (-m in a 16-register block per query block: no per-element
 // subtract).  Two waves per SIMD, not one: attn64v4's lone wave issued one vector instruction per 4 cycles with nobody to cover
-// its LDS and DMA waits.
+// its LDS and DMA waits.  Tried on this kernel and NOT kept (profiles/r06_attn_probe.txt): block B's exponentials placed between
+// block A's O += V P MFMAs by scheduling-group barriers (equal or slower at 3 spilled registers), Q^T re-read from LDS to free 32
+// registers for that (slower), s_setprio around the MFMA clusters (+8 %), 512-query workgroups (slower at Sq = 1024: nothing covers
+// a workgroup's prologue and epilogue), a start stagger of the CU's second workgroup (no effect), warm-up loads for the block that
+// takes the slot next (-4 % from HBM in isolation, +1 % in the model), v_dot2c_f32_bf16 for the row sum (not faster than two adds).
 //
 // LDS: a ring of NBUF {K, V} tile pairs (4 x 16 KiB per workgroup).  Tile t + NBUF - 1 is issued at the top of iteration t into the
 // slot of tile t - 1 (free: every wave passed the barrier that ended iteration t - 1), and the counted wait in front of the barrier
@@ -206,55 +210,53 @@ __global__ __launch_bounds__(256, 2) void attn64p_kernel(AttnParams p) {
         // ---- the exact row maxima relative to the running ones, and the raise: the running maximum moves to (at least) the tile's, in
         //      whole octaves (the factors are powers of two); S', -m, O and l are rescaled together, BEFORE any P of this tile exists and
         //      with the previous tile's P V complete (guide T13 safe order) ----
-        auto raise_exact = [&]() {
+        auto raise_blk = [&](int x) {
             if constexpr (!(DIAG & 1)) {
+                float c0 = max3f(st[x][0][0], st[x][0][1], st[x][0][2]), c1 = max3f(st[x][1][0], st[x][1][1], st[x][1][2]);
 #pragma unroll
-                for (int x = 0; x < 2; ++x) {
-                    float c0 = max3f(st[x][0][0], st[x][0][1], st[x][0][2]), c1 = max3f(st[x][1][0], st[x][1][1], st[x][1][2]);
+                for (int r = 3; r < 15; r += 2) { c0 = max3f(c0, st[x][0][r], st[x][0][r + 1]); c1 = max3f(c1, st[x][1][r], st[x][1][r + 1]); }
+                const float a = max3f(c0, c1, fmaxf(st[x][0][15], st[x][1][15]));
+                float s0, s1;
+                swap32(a, s0, s1);
+                const float dm = fmaxf(s0, s1);
+                // first tile: the running maximum IS this tile's; later: it only ever rises
+                const float up = ceilf(kt == 0 ? dm : fmaxf(dm, 0.f));
 #pragma unroll
-                    for (int r = 3; r < 15; r += 2) { c0 = max3f(c0, st[x][0][r], st[x][0][r + 1]); c1 = max3f(c1, st[x][1][r], st[x][1][r + 1]); }
-                    const float a = max3f(c0, c1, fmaxf(st[x][0][15], st[x][1][15]));
-                    float s0, s1;
-                    swap32(a, s0, s1);
-                    const float dm = fmaxf(s0, s1);
-                    // first tile: the running maximum IS this tile's; later: it only ever rises
-                    const float up = ceilf(kt == 0 ? dm : fmaxf(dm, 0.f));
+                for (int i = 0; i < 16; ++i) { st[x][0][i] -= up; st[x][1][i] -= up; cneg[x][i] -= up; }
+                if (kt > 0) {   // (first tile: O and l are zero, and 2^-up may be infinite)
+                    const float alpha = __builtin_amdgcn_exp2f(-up);
+                    lrun[x] *= alpha;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) { st[x][0][i] -= up; st[x][1][i] -= up; cneg[x][i] -= up; }
-                    if (kt > 0) {   // (first tile: O and l are zero, and 2^-up may be infinite)
-                        const float alpha = __builtin_amdgcn_exp2f(-up);
-                        lrun[x] *= alpha;
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) { ot[x][0][i] *= alpha; ot[x][1][i] *= alpha; }
-                    }
+                    for (int i = 0; i < 16; ++i) { ot[x][0][i] *= alpha; ot[x][1][i] *= alpha; }
                 }
             }
         };
+        auto raise_exact = [&]() { raise_blk(0); raise_blk(1); };
         // ---- P = exp2(S') as packed bf16 pairs (the B operands of O += V P); lt = this lane's fp32 sum of the probabilities
         //      (v_dot2c_f32_bf16 on the packed pairs was tried for it: not faster than the two adds it replaces, and hipcc 7.2 miscompiles
         //      the builtin on two accumulator chains) ----
-        auto exp_all = [&]() {
+        float el0 = 0.f, el1 = 0.f;   // the two partial sums of the block being exponentiated
+        auto exp8 = [&](int x, int s2) {   // the 8 probabilities of k-step s2 of block x -> one packed B operand
+            u32x4 pk;
 #pragma unroll
-            for (int x = 0; x < 2; ++x) {
-                float l0 = 0.f, l1 = 0.f;
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) {
-                    u32x4 pk;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float e0 = st[x][s2 >> 1][8 * (s2 & 1) + 2 * j], e1 = st[x][s2 >> 1][8 * (s2 & 1) + 2 * j + 1];
-                        if constexpr (!(DIAG & 1)) {
-                            if constexpr (DIAG & 16) { e0 += 1.0f; e1 += 1.0f; }
-                            else { e0 = __builtin_amdgcn_exp2f(e0); e1 = __builtin_amdgcn_exp2f(e1); }
-                        }
-                        pk[j] = pack_bf16x2(e0, e1);
-                        if constexpr (!(DIAG & 1)) { l0 += e0; l1 += e1; }
-                    }
-                    if (x == 0) pa[s2] = pk; else pb[s2] = pk;
+            for (int j = 0; j < 4; ++j) {
+                float e0 = st[x][s2 >> 1][8 * (s2 & 1) + 2 * j], e1 = st[x][s2 >> 1][8 * (s2 & 1) + 2 * j + 1];
+                if constexpr (!(DIAG & 1)) {
+                    if constexpr (DIAG & 16) { e0 += 1.0f; e1 += 1.0f; }
+                    else { e0 = __builtin_amdgcn_exp2f(e0); e1 = __builtin_amdgcn_exp2f(e1); }
+                    el0 += e0; el1 += e1;
                 }
-                lt[x] = l0 + l1;
+                pk[j] = pack_bf16x2(e0, e1);
             }
+            if (x == 0) pa[s2] = pk; else pb[s2] = pk;
         };
+        auto exp_blk = [&](int x) {
+            el0 = 0.f; el1 = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) exp8(x, s2);
+            lt[x] = el0 + el1;
+        };
+        auto exp_all = [&]() { exp_blk(0); exp_blk(1); };
         // The raise is decided by the SUMS, not by a row maximum taken on every tile (16 v_max3_f32 + a lane exchange per block and
         // tile: a sixth of the vector work): the probabilities are computed against the running maximum as it stands, and only if
         // some lane's 32 of them sum to more than 2^13 (so: every P of the tile <= 2^13, exact in bf16's exponent range, fp32
