@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--no-sweep", action="store_true", help="skip the B in {1, 8, 32} sweep (N = 1 only)")
     ap.add_argument("--global-batch", type=int, default=256, help="C3 strong-scaling point: utterances held by rank 0")
     ap.add_argument("--no-c3", action="store_true", help="skip the C3 strong-scaling point")
+    ap.add_argument("--write-c3-expect", action="store_true",
+                    help="N = 1 only: record this tree's C3 latents digest in profiles/c3_digest_expect.json (what N = 2 / 4 / 8 must reproduce)")
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run oracle parity check of the timed shape")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the C4 / C5 / training-step side measurements (N = 1 runs of the default config only)")
@@ -186,6 +188,12 @@ def step_min_seconds(cfg, B, N, T, one_off_per_step):
     return sec
 
 
+# the kernel this tree launches per class at C2, B = 32 (what a committed PMC pass must have measured to be quoted)
+TRAFFIC_KERNEL = {"gemm_gated_mlp": "gemm256_kernel<3", "gemm_qkv_rope": "gemm256_kernel<2", "gemm_q_proj": "gemm_lnq_kernel<32, 4, true, 768, 8",
+                  "gemm_out_proj": "gemm_frd_kernel", "gemm_fc2": "gemm_frd_kernel", "gemm_final": "gemm192_kernel<4",
+                  "attn_self": "attn64p_kernel<true", "attn_cross": "attn64p_kernel<false"}
+
+
 def pmc_traffic(kernel_class, B, N, T, cfg):
     """(HBM bytes per launch of `kernel_class`, where the figure comes from): the committed rocprofv3 PMC passes
     (profiles/*_pmc_traffic.json, tools/pmc_traffic.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command,
@@ -199,13 +207,33 @@ def pmc_traffic(kernel_class, B, N, T, cfg):
         names = sorted((f for f in os.listdir(pdir) if f.endswith("pmc_traffic.json")), reverse=True)  # newest first
     except OSError:
         return None, None
+    want = TRAFFIC_KERNEL.get(kernel_class)
     for name in names:
         try:
             d = json.load(open(os.path.join(pdir, name)))
-            return d[kernel_class]["traffic_bytes"], f"offline PMC pass profiles/{name} (not this run)"
+            rec = d[kernel_class]
+            # a pass taken on another build's kernel says nothing about this one: the recorded kernel name must be the one this
+            # tree launches for the class, else the figure is refused, not quietly reused
+            if want and want not in rec.get("kernel", ""):
+                return None, f"refused: profiles/{name} measured {rec.get('kernel', '?')[:60]!r}, this tree launches {want!r} for {kernel_class}"
+            return rec["traffic_bytes"], f"offline PMC pass profiles/{name} (not this run)"
         except (OSError, KeyError, ValueError, TypeError):
             continue
     return None, None
+
+
+def tree_sha16():
+    """sha256 (first 16 hex digits) over the kernel sources and the C-ABI header: identifies the code that decides the bits
+    (a rebuilt .so is not byte-identical, the sources are)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "ditto_tts_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "ditto_hip.h"), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def usable_cores():
@@ -249,19 +277,26 @@ def cpu_baseline(cfg, N, T):
                 x = O.p_sample_update(x, eps, t, betas, alphas, acp, z)
                 ts.append(time.perf_counter() - t0)
         ts = sorted(ts[1:])
-        return ts[len(ts) // 2]
+        return ts[len(ts) // 2], ts[0], ts[-1]
 
-    med1 = run(1, 12)
+    med1, min1, max1 = run(1, 12)
+    try:
+        quota = open("/sys/fs/cgroup/cpu.max").read().strip()
+    except OSError:
+        quota = None
     out = {"value": 1.0 / med1, "unit": "utterance-steps/s", "cores": torch.get_num_threads(), "kind": "port",
            "sample": f"B=1, 12 steps (median) after 1 warm-up of the same {cfg.num_layers}L/d={cfg.hidden_dim}/"
                      f"N={N}/T={T} step, fp32 torch-CPU oracle (uncached text K/V, as the reference)",
-           "s_per_step": med1, "gflops": cfg.flops_per_utt_step(N, T, cached_kv=False) / med1 / 1e9}
+           "s_per_step": med1, "gflops": cfg.flops_per_utt_step(N, T, cached_kv=False) / med1 / 1e9,
+           # the host is a shared, quota-limited cgroup: the figure moved 2.2x between rounds with identical code, so it carries its
+           # spread: the fastest and slowest of the 12 steps and the quota it ran under
+           "s_per_step_min": min1, "s_per_step_max": max1, "value_best": 1.0 / min1, "spread": max1 / min1, "cgroup_cpu_max": quota}
     try:
         cpu_name = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except (OSError, IndexError):
         cpu_name = None
     out["cpu_model"] = cpu_name
-    med4 = run(4, 3)
+    med4 = run(4, 3)[0]
     out["b4"] = {"value": 4.0 / med4, "s_per_step": med4, "sample": "B=4, 3 steps (median) after 1 warm-up",
                  "gflops": 4 * cfg.flops_per_utt_step(N, T, cached_kv=False) / med4 / 1e9}
     return out
@@ -723,7 +758,25 @@ def main():
                 # a world-size-independent fingerprint of the gathered latents (same value at N = 1, 2, 4, 8 <=> sharding
                 # changed no bit): the sum of the fp32 bit patterns, mod 2^63
                 digest = int(lat.view(torch.int32).to(torch.int64).sum().item() & 0x7FFFFFFFFFFFFFFF)
+            # the checkable prediction: sharding changes no bit, so the digest at N = 2 / 4 / 8 must be the N = 1
+            # value of the SAME source tree; the N = 1 run of the final tree recorded it (--write-c3-expect)
+            tree = tree_sha16()
+            expect = None
+            try:
+                e = json.load(open(os.path.join(ROOT, "profiles", "c3_digest_expect.json")))
+                if e.get("tree_sha16") == tree and e.get("global_batch") == G and e.get("steps") == S:
+                    expect = int(e["latents_digest"])
+            except (OSError, ValueError, KeyError, TypeError):
+                pass
+            if rank == 0 and world == 1 and args.write_c3_expect:
+                json.dump({"tree_sha16": tree, "global_batch": G, "steps": S, "latents_digest": digest,
+                           "note": "bench.py --write-c3-expect at N = 1: the C3 latents digest every N must reproduce for this source tree"},
+                          open(os.path.join(ROOT, "profiles", "c3_digest_expect.json"), "w"), indent=1)
+                expect = digest
             c3 = {"global_batch": G, "micro_batch": mb, "steps": S, "scaling": "strong", "n_gpus": world,
+                  "tree_sha16": tree, "digest_expected_from_n1": expect,
+                  "digest_matches_n1": (None if expect is None or digest is None else bool(digest == expect)),
+                  "prediction": "latents_digest(N) == latents_digest(1) of the same tree; value(N) >= 0.9 * N * value(1) of the weak-scaling line",
                   "value": G * S / total, "unit": "utterance-steps/s", "total_s": total, **ph,
                   "comm_bytes_per_peer": (G // world) * (T * cfg.text_dim * 2 + 2 * N * cfg.hidden_dim * 4) if world > 1 else 0,
                   "latents_finite_and_complete": ok, "latents_digest": digest,

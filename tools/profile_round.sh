@@ -3,13 +3,16 @@
 #   1. --kernel-trace --stats (+ a marker-trace run with DITTO_ROCTX=1: roctx ranges per kernel class)
 #   2. --pmc FETCH_SIZE, 3. --pmc WRITE_SIZE (separate passes), 4. --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES
 # Counter passes carry NO trace flags (gpurun refuses the combination); the program follows `--` directly.
+#   tools/profile_round.sh r06_c5 C5     # the same passes for another bench configuration (no per-class traffic table: the class map
+#                                        # of tools/pmc_traffic.py is C2's; the raw counter csvs, kernel stats and MFMA-busy are kept)
 set -u
 TAG=$1
+CFG=${2:-C2}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-BENCH="python3 bench.py --no-cpu-baseline --profile-steps 0 --loops 0 --no-sweep --no-c3 --no-other-configs --no-parity"   # (--no-parity since round 5: the parity leg now runs 12 more B = 32 steps between seconds of CPU work, whose cold-clock launches do not belong in the average)
-python bench.py > $OUT/bench.json 2> $OUT/bench.err
+BENCH="python3 bench.py --config $CFG --no-cpu-baseline --profile-steps 0 --loops 0 --no-sweep --no-c3 --no-other-configs --no-parity"   # (--no-parity since round 5: the parity leg now runs 12 more B = 32 steps between seconds of CPU work, whose cold-clock launches do not belong in the average)
+if [ "$CFG" = C2 ]; then python bench.py > $OUT/bench.json 2> $OUT/bench.err; else python bench.py --config $CFG --no-cpu-baseline --no-sweep --no-c3 --no-other-configs > $OUT/bench.json 2> $OUT/bench.err; fi
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $BENCH --steps 10 --warmup 2 > $OUT/kt.log 2>&1
 DITTO_ROCTX=1 timeout 600 rocprofv3 --kernel-trace --marker-trace --output-format csv -d $OUT/mk -o mk -- $BENCH --steps 2 --warmup 1 > $OUT/mk.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -25,7 +28,7 @@ cp $(find $OUT/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) $OUT/ke
 cp $(find $OUT/pmc_mfma -name "*counter_collection.csv" | head -1) $OUT/keep/${TAG}_pmc_mfma.csv 2>/dev/null
 cp $(find $OUT/mk -name "*marker_api_trace.csv" | head -1) $OUT/keep/${TAG}_marker_trace.csv 2>/dev/null
 cp $OUT/bench.json $OUT/keep/${TAG}_bench.json
-python tools/pmc_traffic.py $OUT/keep/${TAG}_pmc_FETCH_SIZE.csv $OUT/keep/${TAG}_pmc_WRITE_SIZE.csv $OUT/keep/${TAG}_pmc_traffic.json > /dev/null
+[ "$CFG" = C2 ] && python tools/pmc_traffic.py $OUT/keep/${TAG}_pmc_FETCH_SIZE.csv $OUT/keep/${TAG}_pmc_WRITE_SIZE.csv $OUT/keep/${TAG}_pmc_traffic.json > /dev/null
 python tools/pmc_mfma.py $OUT/keep/${TAG}_pmc_mfma.csv > $OUT/keep/${TAG}_mfma_busy.txt
 rm -rf $OUT/kt $OUT/mk $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_mfma
 ls -la $OUT/keep; head -12 $OUT/keep/${TAG}_mfma_busy.txt; head -8 $OUT/keep/${TAG}_kernel_stats.csv | cut -c1-150
