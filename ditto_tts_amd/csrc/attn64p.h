@@ -235,28 +235,33 @@ __global__ __launch_bounds__(256, 2) void attn64p_kernel(AttnParams p) {
         // ---- P = exp2(S') as packed bf16 pairs (the B operands of O += V P); lt = this lane's fp32 sum of the probabilities
         //      (v_dot2c_f32_bf16 on the packed pairs was tried for it: not faster than the two adds it replaces, and hipcc 7.2 miscompiles
         //      the builtin on two accumulator chains) ----
-        float el0 = 0.f, el1 = 0.f;   // the two partial sums of the block being exponentiated
-        auto exp8 = [&](int x, int s2) {   // the 8 probabilities of k-step s2 of block x -> one packed B operand
-            u32x4 pk;
+        // (tools/probe_coissue.hip, profiles/r06_coissue.txt: a vector instruction that CONSUMES a transcendental's result makes no
+        // progress while the other wave of the SIMD streams MFMAs back to back — pure v_exp / v_add / v_cvt streams lose 25 % there, a
+        // stream in which adds or converts read v_exp results waits out the partner's whole burst.  That is why the softmax and the
+        // MFMAs of two waves add up rather than overlap, whatever the wave structure.  Putting all 64 exponentials first, as one pure
+        // transcendental stream, and the 96 consumers behind it measured SLOWER in this kernel — 121 against 114 us — and was not kept.)
+        auto exp_all = [&]() {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float e0 = st[x][s2 >> 1][8 * (s2 & 1) + 2 * j], e1 = st[x][s2 >> 1][8 * (s2 & 1) + 2 * j + 1];
-                if constexpr (!(DIAG & 1)) {
-                    if constexpr (DIAG & 16) { e0 += 1.0f; e1 += 1.0f; }
-                    else { e0 = __builtin_amdgcn_exp2f(e0); e1 = __builtin_amdgcn_exp2f(e1); }
-                    el0 += e0; el1 += e1;
+            for (int x = 0; x < 2; ++x) {
+                float l0 = 0.f, l1 = 0.f;
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    u32x4 pk;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float e0 = st[x][s2 >> 1][8 * (s2 & 1) + 2 * j], e1 = st[x][s2 >> 1][8 * (s2 & 1) + 2 * j + 1];
+                        if constexpr (!(DIAG & 1)) {
+                            if constexpr (DIAG & 16) { e0 += 1.0f; e1 += 1.0f; }
+                            else { e0 = __builtin_amdgcn_exp2f(e0); e1 = __builtin_amdgcn_exp2f(e1); }
+                            l0 += e0; l1 += e1;
+                        }
+                        pk[j] = pack_bf16x2(e0, e1);
+                    }
+                    if (x == 0) pa[s2] = pk; else pb[s2] = pk;
                 }
-                pk[j] = pack_bf16x2(e0, e1);
+                lt[x] = l0 + l1;
             }
-            if (x == 0) pa[s2] = pk; else pb[s2] = pk;
         };
-        auto exp_blk = [&](int x) {
-            el0 = 0.f; el1 = 0.f;
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) exp8(x, s2);
-            lt[x] = el0 + el1;
-        };
-        auto exp_all = [&]() { exp_blk(0); exp_blk(1); };
         // The raise is decided by the SUMS, not by a row maximum taken on every tile (16 v_max3_f32 + a lane exchange per block and
         // tile: a sixth of the vector work): the probabilities are computed against the running maximum as it stands, and only if
         // some lane's 32 of them sum to more than 2^13 (so: every P of the tile <= 2^13, exact in bf16's exponent range, fp32
