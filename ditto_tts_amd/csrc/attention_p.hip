@@ -1,5 +1,5 @@
-// attention_p.hip — the translation unit of attn64p (attn64p.h): the head_dim-64 attention forward of the inference path at 64
-// queries per wave (reference src/components/DiT.py:131-139 self-attention, :144-148 cross-attention).  Its own file because it is
+// attention_p.hip — the translation unit of attn64p / attn64q (attn64p.h, attn64q.h): the head_dim-64 attention forward of the
+// inference path at 64 queries per wave (reference src/components/DiT.py:131-139 self-attention, :144-148 cross-attention).  Its own file because it is
 // compiled without the SLP vectoriser (build.py EXTRA: -fno-honor-nans -fno-slp-vectorize; packed fp32 adds cost it 40 registers)
 // and because co-compiled kernel templates perturb one another's register allocation (guide rule 19).
 #include <type_traits>
@@ -11,13 +11,21 @@ namespace ditto {
 namespace {
 #include "attn64v2.h"   // the tile constants (the kernel itself is instantiated in attention.hip / attention_train.hip)
 #include "attn64p.h"
+#include "attn64q.h"
 }  // namespace
 
 // p.nqb is set here: blocks of 256 queries
-hipError_t launch_attn64p(const AttnParams& p_in, bool resid, hipStream_t s, bool ring3) {
+hipError_t launch_attn64p(const AttnParams& p_in, bool resid, hipStream_t s, bool ring3, bool no_q) {
     AttnParams p = p_in;
     p.nqb = (p.Sq + 255) / 256;
     const dim3 grid(p.nqb * p.H * p.B), block(256);
+    // whole key tiles, at least two: attn64q (attn64q.h: one software-pipelined stream per wave, optimistic softmax with attn64p's
+    // loop as the exact path of a workgroup whose rows left the range).  A rule on the SHAPE only.  attn_flags 1048576 = never.
+    if (!no_q && !ring3 && p.Skv % KBLK == 0 && p.Skv >= 2 * KBLK) {
+        if (resid) hipLaunchKernelGGL((attn64q_kernel<true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((attn64q_kernel<false>), grid, block, 0, s, p);
+        return hipGetLastError();
+    }
     if (ring3) {   // A/B (attn_flags 524288): a ring of 3 tile pairs (48 KiB) instead of 4: same bits, same speed in the model
         if (resid) hipLaunchKernelGGL((attn64p_kernel<true, 3>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((attn64p_kernel<false, 3>), grid, block, 0, s, p);

@@ -47,22 +47,23 @@ DITTO_DEV void swap32(float a, float& lo, float& hi) {
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
     lo = x; hi = y;   // x = {a[0..31], a[0..31]}, y = {a[32..63], a[32..63]}
 }
-DITTO_DEV float max3f(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
+// v_max3_f32 through the builtins (the backend fuses the pair under -fno-honor-nans), NOT an asm statement: its operands are MFMA
+// results, and the wait states gfx950 needs between an MFMA's write and a vector read of the register are inserted by the compiler
+// for its own instructions only — an asm statement scheduled right behind the last MFMA of a score block reads the accumulator one
+// MFMA short (found in attn64q.h's first prologue, round 6).
+DITTO_DEV float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
 constexpr float SUM_RAISE_THR = 8192.0f;   // 2^13: a lane's 32 probabilities of a tile may sum to this before the tile is redone with a raise
 
 // DIAG (tools/probe_attn64p.hip only; wrong results by design, every knock-out computes on VALID data): bit 0 = no softmax arithmetic
 // (P = the packed scores), bit 1 = no K/V DMA after the prologue (every ring slot holds a tile), bit 2 = no barrier / DMA wait in the
 // loop (with bit 1), bit 3 = no LDS fragment reads (Q fragments stand in), bit 4 = the exponentials replaced by adds, bit 7 = no MFMAs
-template <bool RESID, int NBUF = 4, int DIAG = 0>
-__global__ __launch_bounds__(256, 2) void attn64p_kernel(AttnParams p) {
+// the workgroup's whole job as a device function over a ring of NBUF x 16 KiB of LDS that is free on entry (attn64q.h runs it as
+// its exact path)
+template <bool RESID, int NBUF, int DIAG>
+DITTO_DEV void attn64p_body(const AttnParams& p, char* smem) {
     static_assert(NBUF >= 2 && NBUF <= 4, "ring depth");
     constexpr int QWG = 256;                                      // queries per workgroup (p.nqb counts blocks of this size)
-    __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * KV_TILE_BYTES];  // [slot][K|V]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nwg = p.nqb * p.H * p.B;
@@ -363,4 +364,10 @@ __global__ __launch_bounds__(256, 2) void attn64p_kernel(AttnParams p) {
                 }
             }
     }
+}
+
+template <bool RESID, int NBUF = 4, int DIAG = 0>
+__global__ __launch_bounds__(256, 2) void attn64p_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * KV_TILE_BYTES];  // [slot][K|V]
+    attn64p_body<RESID, NBUF, DIAG>(p, smem);
 }

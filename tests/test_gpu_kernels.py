@@ -284,11 +284,12 @@ def test_attention_pipelined_kernel_is_bitwise_the_tile_loop_kernel(lib, B, H, S
 @pytest.mark.parametrize("B,H,Sq,Skv", [(1, 2, 128, 128), (2, 3, 200, 256), (1, 12, 1024, 1024), (1, 2, 333, 2048),
                                         (2, 2, 1000, 1000), (1, 1, 40, 1), (3, 12, 512, 96), (8, 12, 1024, 1024)])
 def test_attention_64_queries_per_wave_kernel(lib, B, H, Sq, Skv):
-    """attn64p (round 6, csrc/attn64p.h: 64 queries per wave, K / V fragments shared by two query blocks, fp32 row sums, the wide
-    epilogue) against attn64v2 on the same operands — same products, another association of the row sum only: within bf16-output
-    noise — against torch, and against itself (bitwise repeatable).  Ragged query and key counts, rows with forced raises of the
-    running maximum.  (Its two residual epilogues — the self-attention's in-place update on the fp32 and on the bf16 stream — run
-    in the model tests: tests/test_gpu_model.py taps `after_self` of G1 and the full-size checks.)"""
+    """attn64p and attn64q (round 6, csrc/attn64p.h / attn64q.h: 64 queries per wave, fp32 row sums, the wide epilogue; attn64q = one
+    software-pipelined stream per wave with the optimistic softmax, where Skv is whole tiles) against attn64v2 on the same operands
+    — same products, other associations of the row sum only: within bf16-output noise — against torch, and against themselves
+    (bitwise repeatable).  Ragged query and key counts, rows with forced raises of the running maximum (for attn64q: logits of
+    ~ 30 .. 60 in log2 units, still inside its range).  (The residual epilogues — the self-attention's in-place update on the fp32
+    and on the bf16 stream — run in the model tests: tests/test_gpu_model.py taps `after_self` of G1 and the full-size checks.)"""
     dh, d = 64, H * 64
     q = asym((B * Sq, d), 51) * 0.7
     k = asym((B * Skv, d), 52) * 0.7
@@ -302,7 +303,8 @@ def test_attention_64_queries_per_wave_kernel(lib, B, H, Sq, Skv):
     k, v = bf16(k.to(DEV)), bf16(v.to(DEV))
     outs = []
     try:
-        for flags in (16 + 256 + 131072, 16 + 262144, 16 + 262144):
+        # attn64v2; the round-6 kernels as dispatched (attn64q where Skv % 64 == 0 and Skv >= 128, else attn64p), twice; attn64p always
+        for flags in (16 + 256 + 131072, 16 + 262144, 16 + 262144, 16 + 262144 + 1048576):
             hip.check(lib.ditto_set_option(b"attn_flags", flags))
             out = torch.full((B * Sq, d), float("nan"), dtype=torch.bfloat16, device=DEV)
             hip.check(lib.ditto_attention_bf16(qs.data_ptr(), d, k.data_ptr(), d, v.data_ptr(), d, out.data_ptr(), d, B, H, Sq,
@@ -314,8 +316,67 @@ def test_attention_64_queries_per_wave_kernel(lib, B, H, Sq, Skv):
     for o in outs:
         assert torch.isfinite(o.float()).all()
         assert rel_l2(o.float(), want) < 1.5e-2 and max_abs(o.float(), want) < 6e-2
-    assert torch.equal(outs[1], outs[2]), "attn64p is not repeatable"
-    assert rel_l2(outs[1].float(), outs[0].float()) < 4e-3
+    assert torch.equal(outs[1], outs[2]), "not repeatable"
+    assert rel_l2(outs[1].float(), outs[0].float()) < 4e-3 and rel_l2(outs[3].float(), outs[0].float()) < 4e-3
+    if Skv % 64 or Skv < 128:
+        assert torch.equal(outs[1], outs[3]), "ragged key counts run attn64p"
+
+
+@pytest.mark.parametrize("case", ["overflow", "underflow", "nan", "mixed"])
+def test_attention_optimistic_softmax_leaves_its_range(lib, case):
+    """attn64q keeps no running maximum: P = exp2(S) unshifted, and a workgroup whose row sums left [2^-100, 2^100] (or are NaN) starts
+    over on attn64p's exact loop before it stores anything.  Logits far above the range (every probability overflows), far below
+    (every probability underflows: l = 0), NaN inputs, and a batch in which only some workgroups leave the range: the result is
+    attn64p's, bit for bit where the workgroup fell back, and within rounding of it elsewhere."""
+    B, H, Sq, Skv, dh = 2, 4, 512, 512, 64
+    d = H * dh
+    q = asym((B * Sq, d), 61) * 0.7
+    k = asym((B * Skv, d), 62) * 0.7
+    v = asym((B * Skv, d), 63)
+    scale = 1.0 / math.sqrt(dh)
+    qs = q * (1.4426950408889634 * scale)
+    u = torch.full((dh,), 0.125)                           # |u|^2 = 1
+    fell_back = torch.zeros(B, H, Sq // 256, dtype=torch.bool)     # workgroups (256 queries of one head) that must take the exact path
+    if case == "overflow":
+        qs = qs * 60.0                                      # row maxima of some hundreds of octaves
+        fell_back[:] = True
+    elif case == "underflow":
+        k[:, :] = (u.repeat(H) + 0.02 * k)                  # every key ~ u, every query ~ -150 u: logits ~ -150 (log2 units), spread ~ 1
+        qs = -150.0 * u.repeat(H) + 0.3 * qs
+        fell_back[:] = True
+    elif case == "nan":
+        qs[300, dh:2 * dh] = float("nan")                   # one query row of head 1, batch 0: its workgroup only
+        fell_back[0, 1, 1] = True
+    else:
+        qs[Sq + 256:Sq + 512, 2 * dh:3 * dh] *= 60.0        # batch 1, head 2, queries 256.. : one workgroup overflows
+        qs[10, :dh] = -150.0 * u                            # batch 0, head 0, one row underflows against keys ~ u
+        k[:Skv, :dh] = u + 0.02 * k[:Skv, :dh]
+        fell_back[1, 2, 1] = True
+        fell_back[0, 0, 0] = True
+    qs, k, v = bf16(qs.to(DEV)), bf16(k.to(DEV)), bf16(v.to(DEV))
+    outs = []
+    try:
+        for flags in (16 + 262144, 16 + 262144 + 1048576):   # attn64q (this shape), attn64p
+            hip.check(lib.ditto_set_option(b"attn_flags", flags))
+            out = torch.full((B * Sq, d), float("nan"), dtype=torch.bfloat16, device=DEV)
+            hip.check(lib.ditto_attention_bf16(qs.data_ptr(), d, k.data_ptr(), d, v.data_ptr(), d, out.data_ptr(), d, B, H, Sq,
+                                               Skv, dh, scale, None, 0, stream()))
+            outs.append(out.float().view(B, Sq // 256, 256, H, dh).permute(0, 3, 1, 2, 4))   # [B, H, workgroup, 256, dh]
+    finally:
+        hip.check(lib.ditto_set_option(b"attn_flags", 3))
+    got, exact = outs
+    fb = fell_back.to(DEV)
+    if case != "nan":
+        assert torch.isfinite(exact).all() and torch.isfinite(got).all()
+        want = _attn_ref(qs.float() / (1.4426950408889634 * scale), k, v, B, H, Sq, Skv, dh, scale)
+        want = want.view(B, Sq // 256, 256, H, dh).permute(0, 3, 1, 2, 4)
+        assert rel_l2(got, want) < 1.5e-2
+    assert torch.equal(got[fb].nan_to_num(nan=7.0), exact[fb].nan_to_num(nan=7.0)), "a workgroup out of range is not the exact path's"
+    ok = ~fb
+    assert torch.isfinite(got[ok]).all()
+    assert rel_l2(got[ok], exact[ok]) < 4e-3
+    if case in ("nan", "mixed"):
+        assert not torch.equal(got[ok], exact[ok]), "expected the optimistic path on the workgroups inside the range"
 
 
 @pytest.mark.parametrize("attn_flags", [3, 16, 16 + 64, 16 + 128, 16 + 256, 16 + 512, 16 + 262144])

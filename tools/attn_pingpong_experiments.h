@@ -27,10 +27,13 @@
 // wave waits for its own pieces with a counted vmcnt in front of that barrier (group 0: the one that ends VV(j+NB); group 1: the one
 // that ends MM(j+NB-1)), leaving the NB-2 younger bundles in flight.
 // ------------------------------------------------------------------------------------------------
+#ifndef DITTO_STATIC_FOR
+#define DITTO_STATIC_FOR
 template <typename F, int... I>
 DITTO_DEV void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, typename F>
 DITTO_DEV void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+#endif
 // the last fragment (its index in the matrix phase's fetch order) that MFMA m of the phase reads
 constexpr int mm_need(int m) { return m < 16 ? (m >> 1) : 8 + 4 * ((m - 16) >> 2) + (((m - 16) & 3) == 0 ? 1 : ((m - 16) & 3) == 1 ? 2 : 3); }
 

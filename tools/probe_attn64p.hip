@@ -19,6 +19,7 @@ namespace ditto {
 namespace {
 #include "attn64v2.h"
 #include "attn64p.h"
+#include "attn64q.h"
 #include "../../tools/attn_pingpong_experiments.h"
 }  // namespace
 }  // namespace ditto
@@ -49,12 +50,14 @@ int main(int argc, char** argv) {
     const int Sq = argc > 3 ? atoi(argv[3]) : 1024, Skv = argc > 4 ? atoi(argv[4]) : 1024;
     const int rounds = argc > 5 ? atoi(argv[5]) : 7, iters = argc > 6 ? atoi(argv[6]) : 20;
     const int nset = argc > 7 ? atoi(argv[7]) : 1;   // > 1: rotate over that many copies of q / k / v (operands from HBM, as in the model)
+    const float big = argc > 8 ? atof(argv[8]) : 0.f;   // > 0: the queries of the LAST batch item are scaled by this (logits out of attn64q's optimistic range)
     const int d = H * 64;
     const size_t nq = (size_t)B * Sq * d, nk = (size_t)B * Skv * d;
     std::vector<unsigned short> hq(nq), hk(nk), hv(nk);
     unsigned long long s = 12345;
     const float qs = 1.4426950408889634f / 8.0f;
     for (auto& x : hq) x = f2bf(gauss(s) * qs);
+    if (big > 0.f) for (size_t i = (size_t)(B - 1) * Sq * d; i < nq; ++i) hq[i] = f2bf(bf2f(hq[i]) * big);
     for (auto& x : hk) x = f2bf(gauss(s));
     for (auto& x : hv) x = f2bf(gauss(s));
     bf16 *q, *k, *v, *o[6], *rin;
@@ -76,30 +79,30 @@ int main(int argc, char** argv) {
     p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv; p.scale_log2 = 1.0f;
     hipStream_t st = nullptr;
     const int NV = 14;
-    const char* names[NV] = {"attn64v2 (3 waves/SIMD, 32 q/wave)", "attn64p (NBUF = 4)", "attn64p NBUF = 3",
-                             "attn64pp (ping-pong, 8 waves x 64 q)", "attn32pp (ping-pong, 16 waves x 32 q)",
-                             "attn64p: no softmax", "attn64p: exponentials -> adds", "attn64p: no DMA", "attn64p: no DMA, no barrier",
-                             "attn64p: no LDS fragment reads", "attn64p: MFMA + softmax only", "attn64p: MFMA only",
+    const char* names[NV] = {"attn64v2 (3 waves/SIMD, 32 q/wave)", "attn64p (NBUF = 4)", "attn64q (pipelined, optimistic)",
+                             "attn64q, queue restarts per tile", "attn64q, fragments 6 slots ahead",
+                             "attn64q: no softmax", "attn64q: no row-sum adds", "attn64q: no DMA", "attn64q: no DMA, no barrier",
+                             "attn64q: no DMA, no barrier, no adds", "attn64q: no DMA, no barrier, no softmax", "attn64p: MFMA only",
                              "attn64p: softmax only (no MFMA)", "attn64p: no MFMA (DMA, LDS, softmax)"};
     auto launch = [&](int var) {
         AttnParams pp = p;
         rot = rot + 1 == nset ? 0 : rot + 1;
         pp.q = qset[rot]; pp.k = kset[rot]; pp.v = vset[rot];
         pp.out = o[var < 5 ? var : 5];
-        pp.nqb = var == 0 ? (Sq + 127) / 128 : (var == 3 || var == 4) ? (Sq + 511) / 512 : (Sq + 255) / 256;
-        const dim3 grid(pp.nqb * H * B), blk(var == 3 ? 512 : var == 4 ? 1024 : 256);
+        pp.nqb = var == 0 ? (Sq + 127) / 128 : (Sq + 255) / 256;
+        const dim3 grid(pp.nqb * H * B), blk(256);
         switch (var) {
             case 0: hipLaunchKernelGGL((attn64v2_kernel<false, 3>), grid, blk, 0, st, pp); break;
             case 1: hipLaunchKernelGGL((attn64p_kernel<false, 4>), grid, blk, 0, st, pp); break;
-            case 2: hipLaunchKernelGGL((attn64p_kernel<false, 3>), grid, blk, 0, st, pp); break;
-            case 3: hipLaunchKernelGGL((attn64pp_kernel<false, 4, 32 + 64>), grid, blk, 0, st, pp); break;
-            case 4: hipLaunchKernelGGL((attn32pp_kernel<false, 4, 0>), grid, blk, 0, st, pp); break;
-            case 5: hipLaunchKernelGGL((attn64p_kernel<false, 4, 1>), grid, blk, 0, st, pp); break;
-            case 6: hipLaunchKernelGGL((attn64p_kernel<false, 4, 16>), grid, blk, 0, st, pp); break;
-            case 7: hipLaunchKernelGGL((attn64p_kernel<false, 4, 2>), grid, blk, 0, st, pp); break;
-            case 8: hipLaunchKernelGGL((attn64p_kernel<false, 4, 6>), grid, blk, 0, st, pp); break;
-            case 9: hipLaunchKernelGGL((attn64p_kernel<false, 4, 8>), grid, blk, 0, st, pp); break;
-            case 10: hipLaunchKernelGGL((attn64p_kernel<false, 4, 14>), grid, blk, 0, st, pp); break;
+            case 2: hipLaunchKernelGGL((attn64q_kernel<false>), grid, blk, 0, st, pp); break;
+            case 3: hipLaunchKernelGGL((attn64q_kernel<false, 0, 4, false>), grid, blk, 0, st, pp); break;
+            case 4: hipLaunchKernelGGL((attn64q_kernel<false, 0, 6>), grid, blk, 0, st, pp); break;
+            case 5: hipLaunchKernelGGL((attn64q_kernel<false, 1>), grid, blk, 0, st, pp); break;
+            case 6: hipLaunchKernelGGL((attn64q_kernel<false, 16>), grid, blk, 0, st, pp); break;
+            case 7: hipLaunchKernelGGL((attn64q_kernel<false, 2>), grid, blk, 0, st, pp); break;
+            case 8: hipLaunchKernelGGL((attn64q_kernel<false, 6>), grid, blk, 0, st, pp); break;
+            case 9: hipLaunchKernelGGL((attn64q_kernel<false, 22>), grid, blk, 0, st, pp); break;
+            case 10: hipLaunchKernelGGL((attn64q_kernel<false, 7>), grid, blk, 0, st, pp); break;
             case 11: hipLaunchKernelGGL((attn64p_kernel<false, 4, 15>), grid, blk, 0, st, pp); break;
             case 12: hipLaunchKernelGGL((attn64p_kernel<false, 4, 128 + 14>), grid, blk, 0, st, pp); break;
             default: hipLaunchKernelGGL((attn64p_kernel<false, 4, 128>), grid, blk, 0, st, pp); break;
@@ -123,6 +126,20 @@ int main(int argc, char** argv) {
             mx = fmax(mx, fabs(a - c));
         }
         printf("%-40s vs attn64v2: rel-L2 %.3e  max-abs %.3e  NaN %zu\n", names[var], sqrt(se / sr), mx, bad);
+        if (getenv("PROBE_DUMP") && var == 2) {   // where: per block of 32 queries x 32 columns of head 0, batch 0
+            for (int qb = 0; qb < Sq / 32 && qb < 16; ++qb) {
+                printf("  q %4d..:", qb * 32);
+                for (int cb = 0; cb < 2; ++cb) {
+                    double m2 = 0;
+                    for (int r = 0; r < 32; ++r) for (int c = 0; c < 32; ++c) {
+                        const size_t i = (size_t)(qb * 32 + r) * d + cb * 32 + c;
+                        m2 = fmax(m2, fabs(bf2f(h0[i]) - bf2f(h1[i])));
+                    }
+                    printf(" %.2e", m2);
+                }
+                printf("\n");
+            }
+        }
     }
     // ---- a direct fp64 check of a few rows of (b, h) = (B-1, H-1) ----
     {

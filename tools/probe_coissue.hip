@@ -146,6 +146,65 @@ __global__ __launch_bounds__(512, 2) void k(float* out, unsigned long long* cyc,
     if (lane == 0) cyc[blockIdx.x * 8 + wid] = t1 - t0;
 }
 
+// the SAME wave issues both: one pair step of the vector mix behind every MFMA
+template <int VMIX>
+__global__ __launch_bounds__(512, 2) void ksame(float* out, unsigned long long* cyc, const float* in, int iters) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    float seed = in[tid & 511];
+    bf16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(seed + i); b[i] = (__bf16)(seed * 0.5f - i); }
+    f32x16 c0, c1, c2, c3;
+    for (int i = 0; i < 16; ++i) { c0[i] = 0.f; c1[i] = 0.f; c2[i] = 0.f; c3[i] = 0.f; }
+    float x[8], l0 = 0.f, l1 = 0.f;
+    unsigned pk = 0;
+    for (int i = 0; i < 8; ++i) x[i] = seed * (i + 1) * 1e-3f;
+    unsigned long long t0, t1;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0));
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            pair_step<VMIX>(x[0], x[1], l0, l1, pk);
+            __builtin_amdgcn_sched_barrier(0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            pair_step<VMIX>(x[2], x[3], l0, l1, pk);
+            __builtin_amdgcn_sched_barrier(0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c2, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            pair_step<VMIX>(x[4], x[5], l0, l1, pk);
+            __builtin_amdgcn_sched_barrier(0);
+            c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c3, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            pair_step<VMIX>(x[6], x[7], l0, l1, pk);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1));
+    out[blockIdx.x * 512 + tid] = c0[0] + c1[1] + c2[2] + c3[3] + l0 + l1 + __builtin_bit_cast(float, pk);
+    if (lane == 0) cyc[blockIdx.x * 8 + wid] = t1 - t0;
+}
+
+template <int VMIX>
+void run_same(const char* name, float* out, unsigned long long* cyc, const float* in) {
+    const int nblk = 256, iters = 2000;
+    std::vector<unsigned long long> hc(nblk * 8);
+    double r[2];
+    for (int two = 0; two < 2; ++two) {
+        CK(hipMemset(cyc, 0, nblk * 8 * 8));
+        for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((ksame<VMIX>), dim3(nblk), dim3(two ? 512 : 256), 0, 0, out, cyc, in, iters);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(hc.data(), cyc, nblk * 8 * 8, hipMemcpyDeviceToHost));
+        std::vector<double> m;
+        for (int b = 0; b < nblk; ++b)
+            for (int w = 0; w < (two ? 8 : 4); ++w) m.push_back((double)hc[b * 8 + w] / iters / 16);
+        std::sort(m.begin(), m.end());
+        r[two] = m[m.size() / 2];
+    }
+    printf("SAME wave, 1 MFMA + 1 pair step of %-40s: %5.1f cycles per pair at one wave per SIMD, %5.1f at two (per wave; %5.1f per SIMD)\n", name, r[0], r[1], r[1] / 2);
+}
+
 template <int VMIX>
 void run(const char* name, float* out, unsigned long long* cyc, const float* in) {
     const int nblk = 256, iters = 2000;
@@ -190,5 +249,9 @@ int main() {
     run<20>("32 v_exp | 16 x (2 add + cvt) | 32 v_mul", out, cyc, in);
     run<21>("32 v_exp | 32 add | 16 cvt | 32 v_mul", out, cyc, in);
     run<22>("32 v_exp | 32 indep v_mul | 16 x (2 add + cvt) | 32 v_mul", out, cyc, in);
+    run_same<0>("2 v_exp + 2 v_add + v_cvt_pk_bf16_f32", out, cyc, in);
+    run_same<3>("2 v_exp + 2 v_add", out, cyc, in);
+    run_same<1>("4 v_add", out, cyc, in);
+    run_same<2>("2 v_exp", out, cyc, in);
     return 0;
 }
