@@ -38,7 +38,8 @@ namespace ditto {
 // workgroup) form always, bit 11 (2048): never; bit 13 (8192): the training forward on the older kernel (attn64_kernel<.., TRAIN>)
 // instead of attn64v2's TRAIN instantiations (attention_train.hip) — A/B only; bit 17 (131072): never attn64p (attention_p.hip, the
 // 64-queries-per-wave kernel of round 6), bit 18 (262144): attn64p whatever the grid, bit 19 (524288): its ring of 3 tile pairs, bit 20 (1048576): never attn64q (the
-// pipelined, optimistic form that runs wherever attn64p would and Skv is whole tiles: attn64q.h).  (Bits 12, 14, 15, 16 selected the round-3 /
+// pipelined, optimistic form that runs wherever attn64p would and Skv is whole tiles: attn64q.h), bit 21 (2097152): attn64q's two forms (K fragments held for
+// block B or not) swapped between the residual and the plain epilogue (A/B).  (Bits 12, 14, 15, 16 selected the round-3 /
 // round-5 experiments attn64v4 / attn64w4 / KPF, measured equal or slower and deleted in round 6: DESIGN.md "tried".)
 // ditto_set_option("attn_flags")
 int g_attn_flags = 3;
@@ -765,7 +766,8 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
                 const long wgs = (rows_cls / 256) * a.H;
                 const bool wide_ok = a.ldo % 8 == 0 && (!a.resid_f32 || a.ldr % 8 == 0);   // 16-byte row pieces in the epilogue
                 if (wide_ok && !(g_attn_flags & 131072) && (wgs >= g_attn64p_min_wgs || (g_attn_flags & 262144)))
-                    return launch_attn64p(p, a.resid_f32 != nullptr, s, (g_attn_flags & 524288) != 0, (g_attn_flags & 1048576) != 0);
+                    return launch_attn64p(p, a.resid_f32 != nullptr, s, (g_attn_flags & 524288) != 0,
+                                          (g_attn_flags & 1048576) ? 1 : (g_attn_flags & 2097152) ? 2 : 0);
             }
             const dim3 gridv(p.nqb * a.H * a.B);
             // whole pairs of key tiles: the software-pipelined, hand-interleaved kernel where it measures faster — small grids

@@ -61,13 +61,13 @@ constexpr float SUM_RAISE_THR = 8192.0f;   // 2^13: a lane's 32 probabilities of
 // the workgroup's whole job as a device function over a ring of NBUF x 16 KiB of LDS that is free on entry (attn64q.h runs it as
 // its exact path)
 template <bool RESID, int NBUF, int DIAG>
-DITTO_DEV void attn64p_body(const AttnParams& p, char* smem) {
+DITTO_DEV void attn64p_body(const AttnParams& p, char* smem, int tid, int bid) {
     static_assert(NBUF >= 2 && NBUF <= 4, "ring depth");
     constexpr int QWG = 256;                                      // queries per workgroup (p.nqb counts blocks of this size)
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nwg = p.nqb * p.H * p.B;
-    const int id = xcd_remap(blockIdx.x, nwg);
+    const int id = xcd_remap(bid, nwg);
     const int qb = id % p.nqb, bh = id / p.nqb;
     const int h = bh % p.H, b = bh / p.H;
     const int ql = lane & 31, hh = lane >> 5;
@@ -369,5 +369,5 @@ DITTO_DEV void attn64p_body(const AttnParams& p, char* smem) {
 template <bool RESID, int NBUF = 4, int DIAG = 0>
 __global__ __launch_bounds__(256, 2) void attn64p_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * KV_TILE_BYTES];  // [slot][K|V]
-    attn64p_body<RESID, NBUF, DIAG>(p, smem);
+    attn64p_body<RESID, NBUF, DIAG>(p, smem, threadIdx.x, blockIdx.x);
 }

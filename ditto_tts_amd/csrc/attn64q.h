@@ -31,6 +31,10 @@
 #pragma once
 
 constexpr int Q_QD = 4;   // fragments are requested this many slots ahead of their MFMA
+#ifndef Q_HOLD_DEFAULT
+#define Q_HOLD_DEFAULT 1
+#endif
+constexpr int Q_HOLD = Q_HOLD_DEFAULT;   // 0: every fragment read per use; 1: K fragments held for block B; 2: K and V fragments held
 constexpr int Q_QN = 8;   // queue registers (a power of two that divides 32, > Q_QD)
 
 #ifndef DITTO_STATIC_FOR
@@ -41,7 +45,7 @@ template <int N, class F>
 DITTO_DEV void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 #endif
 
-template <bool RESID, int DIAG = 0, int QD = Q_QD, bool WRAP = true>
+template <bool RESID, int DIAG = 0, int QD = Q_QD, bool WRAP = true, int HOLD = Q_HOLD>
 __global__ __launch_bounds__(256, 2) void attn64q_kernel(AttnParams p) {
     constexpr int NBUF = 4, QWG = 256;
     __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * KV_TILE_BYTES];  // [slot][K|V]
@@ -153,6 +157,9 @@ __global__ __launch_bounds__(256, 2) void attn64q_kernel(AttnParams p) {
         pp[x][2 * kb2 + (i >> 2)][i & 3] = pack_bf16x2(e0, e1);
     };
 
+    // HOLD: a tile's 8 K fragments stay in registers from S_A's slot to S_B's (16 slots on), its 8 V fragments from O_A's slot to O_B's
+    // (16 slots on, across the loop's back edge): 16 LDS fragment reads per tile instead of 32
+    bf16x8 kh[HOLD ? 8 : 1], vh[HOLD == 2 ? 8 : 1];
     // ---- prologue: tiles 0, 1, 2 in flight (tile 0 alone first); S_A(0), S_B(0); P_A(0); O_A += V(0) P_A(0); first half of P_B(0) ----
     dma_kv(0, 0);
     wait_groups(0);
@@ -178,8 +185,11 @@ __global__ __launch_bounds__(256, 2) void attn64q_kernel(AttnParams p) {
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2)
 #pragma unroll
-            for (int db = 0; db < 2; ++db)
-                ot[0][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(vb, s2, db), __builtin_bit_cast(bf16x8, pp[0][s2]), ot[0][db], 0, 0, 0);
+            for (int db = 0; db < 2; ++db) {
+                const bf16x8 vf = vfrag(vb, s2, db);
+                if constexpr (HOLD == 2) vh[s2 * 2 + db] = vf;
+                ot[0][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pp[0][s2]), ot[0][db], 0, 0, 0);
+            }
         static_for<8>([&](auto I) { pair_step_c(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, I); });
     }
     // tile 1 landed for everyone (the groups of tile 2 may stay in flight)
@@ -192,7 +202,11 @@ __global__ __launch_bounds__(256, 2) void attn64q_kernel(AttnParams p) {
     bf16x8 fq[Q_QN];     // the fragment queue: slot m's fragment in fq[m % Q_QN], requested QD slots ahead
     {
         const char* kb1 = smem + 2 * KV_TILE_BYTES;
-        static_for<QD>([&](auto M_) { constexpr int m = decltype(M_)::value; fq[m % Q_QN] = kfrag(kb1, m >> 2, m & 3); });
+        static_for<QD>([&](auto M_) {
+            constexpr int m = decltype(M_)::value;
+            if constexpr (HOLD) kh[m] = kfrag(kb1, m >> 2, m & 3);
+            else fq[m % Q_QN] = kfrag(kb1, m >> 2, m & 3);
+        });
     }
     for (int t = 1; t < nkt; ++t) {
         const char* kb = smem + slot * 2 * KV_TILE_BYTES;
@@ -202,7 +216,16 @@ __global__ __launch_bounds__(256, 2) void attn64q_kernel(AttnParams p) {
         const char* kbn = smem + nslot * 2 * KV_TILE_BYTES;   // K(t+1): the fragment queue runs on into the next iteration's first slots
         auto fetch = [&](auto M_) {
             constexpr int m = decltype(M_)::value, mm = m & 31, j = mm & 7;
-            if constexpr (m >= 32) fq[m % Q_QN] = kfrag(kbn, j >> 2, j & 3);
+            if constexpr (HOLD == 2) {
+                if constexpr (m >= 32) kh[j] = kfrag(kbn, j >> 2, j & 3);
+                else if constexpr (mm < 8) kh[j] = kfrag(kb, j >> 2, j & 3);
+                else if constexpr (mm >= 24) vh[j] = vfrag(vb, j >> 1, j & 1);
+            } else if constexpr (HOLD == 1) {      // V fragments through the queue, K fragments held
+                if constexpr (m >= 32) kh[j] = kfrag(kbn, j >> 2, j & 3);
+                else if constexpr (mm < 8) kh[j] = kfrag(kb, j >> 2, j & 3);
+                else if constexpr (mm >= 24) fq[m % Q_QN] = vfrag(vb, j >> 1, j & 1);
+                else if constexpr (mm >= 8 && mm < 16) fq[m % Q_QN] = vfrag(vprev, j >> 1, j & 1);
+            } else if constexpr (m >= 32) fq[m % Q_QN] = kfrag(kbn, j >> 2, j & 3);
             else if constexpr (mm < 8) fq[m % Q_QN] = kfrag(kb, j >> 2, j & 3);
             else if constexpr (mm < 16) fq[m % Q_QN] = vfrag(vprev, j >> 1, j & 1);
             else if constexpr (mm < 24) fq[m % Q_QN] = kfrag(kb, j >> 2, j & 3);
@@ -222,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void attn64q_kernel(AttnParams p) {
                 if (t + 3 < nkt) dma_kv(t + 3, slot == 0 ? NBUF - 1 : slot - 1);
             }
             if constexpr (WRAP && m + QD >= 32) fetch(std::integral_constant<int, m + QD>{});   // (past the last tile: a read of a dead slot)
-            const bf16x8 f = fq[m % Q_QN];
+            const bf16x8 f = HOLD == 2 ? ((m & 8) ? vh[j] : kh[j]) : HOLD == 1 ? ((m & 8) ? fq[m % Q_QN] : kh[j]) : fq[m % Q_QN];
             if constexpr (m < 8) {
                 f32x16 z;
 #pragma unroll
@@ -255,11 +278,16 @@ __global__ __launch_bounds__(256, 2) void attn64q_kernel(AttnParams p) {
         for (int s2 = 0; s2 < 4; ++s2)
 #pragma unroll
             for (int db = 0; db < 2; ++db)
-                ot[1][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(vb, s2, db), __builtin_bit_cast(bf16x8, pp[1][s2]), ot[1][db], 0, 0, 0);
+                ot[1][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(HOLD == 2 ? vh[s2 * 2 + db] : vfrag(vb, s2, db), __builtin_bit_cast(bf16x8, pp[1][s2]), ot[1][db], 0, 0, 0);
     }
 
     // ---- did every row stay inside fp32's comfortable range?  l in [2^-100, 2^100]: no probability overflowed, and every one that
     // matters (2^-26 of the row's sum) was a normal number.  Otherwise (or NaN) the workgroup starts over on the exact path. ----
+    // (the row indices pass through an asm statement here so that none of the epilogue's address arithmetic is hoisted above the loop
+    // and kept in registers across it: one spilled register in the loop costs a scratch reload per tile, which counts on vmcnt with
+    // the LDS-DMA loads and turns the counted waits into full drains — measured 165 against 117 us)
+#pragma unroll
+    for (int x = 0; x < 2; ++x) asm volatile("" : "+v"(qrow[x]));
     float linv[2];
     {
         bool bad = false;
@@ -277,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void attn64q_kernel(AttnParams p) {
             if (__any(bad) && lane == 0) redo = 1;
             __syncthreads();
             if (redo) {
-                attn64p_body<RESID, NBUF, 0>(p, smem);
+                attn64p_body<RESID, NBUF, 0>(p, smem, threadIdx.x, blockIdx.x);
                 return;
             }
         }

@@ -24,7 +24,7 @@ struct AttnParams {
 };
 
 hipError_t launch_attention_train64(const AttnParams& p, bool resid, hipStream_t s);   // attention_train.hip
-hipError_t launch_attn64p(const AttnParams& p, bool resid, hipStream_t s, bool ring3 = false, bool no_q = false);   // attention_p.hip: 64 queries per wave (round 6: attn64p, attn64q)
+hipError_t launch_attn64p(const AttnParams& p, bool resid, hipStream_t s, bool ring3 = false, int no_q = 0);   // attention_p.hip: 64 queries per wave (round 6: attn64p, attn64q)
 
 // the self-attention epilogue's stream update  h[row, col .. col+3] = h_in[...] + o  (src/components/DiT.py:139: no out-proj),
 // on an fp32 stream or a bf16 one (wave-uniform branch, outside every loop)

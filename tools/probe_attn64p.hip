@@ -80,7 +80,7 @@ int main(int argc, char** argv) {
     hipStream_t st = nullptr;
     const int NV = 14;
     const char* names[NV] = {"attn64v2 (3 waves/SIMD, 32 q/wave)", "attn64p (NBUF = 4)", "attn64q (pipelined, optimistic)",
-                             "attn64q, queue restarts per tile", "attn64q, fragments 6 slots ahead",
+                             "attn64q, fragments held for block B", "attn64q, held, 6 slots ahead",
                              "attn64q: no softmax", "attn64q: no row-sum adds", "attn64q: no DMA", "attn64q: no DMA, no barrier",
                              "attn64q: no DMA, no barrier, no adds", "attn64q: no DMA, no barrier, no softmax", "attn64p: MFMA only",
                              "attn64p: softmax only (no MFMA)", "attn64p: no MFMA (DMA, LDS, softmax)"};
@@ -95,8 +95,8 @@ int main(int argc, char** argv) {
             case 0: hipLaunchKernelGGL((attn64v2_kernel<false, 3>), grid, blk, 0, st, pp); break;
             case 1: hipLaunchKernelGGL((attn64p_kernel<false, 4>), grid, blk, 0, st, pp); break;
             case 2: hipLaunchKernelGGL((attn64q_kernel<false>), grid, blk, 0, st, pp); break;
-            case 3: hipLaunchKernelGGL((attn64q_kernel<false, 0, 4, false>), grid, blk, 0, st, pp); break;
-            case 4: hipLaunchKernelGGL((attn64q_kernel<false, 0, 6>), grid, blk, 0, st, pp); break;
+            case 3: hipLaunchKernelGGL((attn64q_kernel<false, 0, 4, true, true>), grid, blk, 0, st, pp); break;
+            case 4: hipLaunchKernelGGL((attn64q_kernel<false, 0, 6, true, true>), grid, blk, 0, st, pp); break;
             case 5: hipLaunchKernelGGL((attn64q_kernel<false, 1>), grid, blk, 0, st, pp); break;
             case 6: hipLaunchKernelGGL((attn64q_kernel<false, 16>), grid, blk, 0, st, pp); break;
             case 7: hipLaunchKernelGGL((attn64q_kernel<false, 2>), grid, blk, 0, st, pp); break;
