@@ -46,6 +46,9 @@ int g_attn_flags = 3;
 // attn64p from this many of its 256-query workgroups on (by class rows): 768 = three per CU, i.e. B >= 16 at N = 1024, 12 heads (in-model
 // A/B, profiles/r06_attn_ab.txt: B = 12 loses 3 % of its attention time, B = 16 gains 9 %).  ditto_set_option("attn64p_min_wgs")
 int g_attn64p_min_wgs = [] { const char* e = getenv("DITTO_ATTN64P_MIN_WGS"); const int v = e ? atoi(e) : 768; return v > 0 ? v : 768; }();
+// ... and without a residual epilogue (the cross-attention) from this many: in-model at B = 4 / 8 / 12 the plain form gains 8 / 6 / 4 %
+// of its launch where the residual form ties or loses (profiles/r06_attn64q.txt).  ditto_set_option("attn64p_min_wgs_plain")
+int g_attn64p_min_wgs_plain = [] { const char* e = getenv("DITTO_ATTN64P_MIN_WGS_PLAIN"); const int v = e ? atoi(e) : 192; return v > 0 ? v : 192; }();
 
 namespace {
 
@@ -765,7 +768,7 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
                 const long rows_cls = opt_class_rows() > 0 ? opt_class_rows() : (long)a.B * a.Sq;
                 const long wgs = (rows_cls / 256) * a.H;
                 const bool wide_ok = a.ldo % 8 == 0 && (!a.resid_f32 || a.ldr % 8 == 0);   // 16-byte row pieces in the epilogue
-                if (wide_ok && !(g_attn_flags & 131072) && (wgs >= g_attn64p_min_wgs || (g_attn_flags & 262144)))
+                if (wide_ok && !(g_attn_flags & 131072) && (wgs >= (a.resid_f32 ? g_attn64p_min_wgs : g_attn64p_min_wgs_plain) || (g_attn_flags & 262144)))
                     return launch_attn64p(p, a.resid_f32 != nullptr, s, (g_attn_flags & 524288) != 0,
                                           (g_attn_flags & 1048576) ? 1 : (g_attn_flags & 2097152) ? 2 : 0);
             }

@@ -1131,7 +1131,7 @@ static int* option_slot(const char* name) {
         {"pp_mask", &g_pp_mask}, {"fr_mask", &g_fr_mask}, {"fr_class_rows", &g_fr_class_rows}, {"fr_dgrad", &g_fr_dgrad},
         {"train_flags", &g_train_flags}, {"fr_u_fp8", &g_fr_u_fp8}, {"fr_tile", &g_fr_tile}, {"fr64_maxk", &g_fr64_maxk},
         {"fr_stagger", &g_fr_stagger}, {"fr_rot", &g_fr_rot}, {"pp_nb", &g_pp_nb}, {"pp_stagger", &g_pp_stagger},
-        {"splitk_wgs", &g_splitk_wgs}, {"residual_bf16", &g_resid_bf16}, {"lnq", &g_lnq}, {"lnq_ring", &g_lnq_ring}, {"lnq_waves", &g_lnq_waves}, {"qkv_split", &g_qkv_split}, {"ll_mask", &g_ll_mask}, {"lnq_min_rows", &g_lnq_min_rows}, {"attn64p_min_wgs", &g_attn64p_min_wgs}};
+        {"splitk_wgs", &g_splitk_wgs}, {"residual_bf16", &g_resid_bf16}, {"lnq", &g_lnq}, {"lnq_ring", &g_lnq_ring}, {"lnq_waves", &g_lnq_waves}, {"qkv_split", &g_qkv_split}, {"ll_mask", &g_ll_mask}, {"lnq_min_rows", &g_lnq_min_rows}, {"attn64p_min_wgs", &g_attn64p_min_wgs}, {"attn64p_min_wgs_plain", &g_attn64p_min_wgs_plain}};
     for (auto& e : tab) if (!strcmp(name, e.n)) return e.p;
     return nullptr;
 }
@@ -1234,9 +1234,9 @@ int ditto_set_option(const char* name, int value) {
         g_lnq_min_rows = value;
         return DITTO_OK;
     }
-    if (!strcmp(name, "attn64p_min_wgs")) {
-        if (value < 1) return fail(DITTO_ERR_ARG, "attn64p_min_wgs must be >= 1");
-        g_attn64p_min_wgs = value;
+    if (!strcmp(name, "attn64p_min_wgs") || !strcmp(name, "attn64p_min_wgs_plain")) {
+        if (value < 1) return fail(DITTO_ERR_ARG, "attn64p_min_wgs[_plain] must be >= 1");
+        (name[15] ? g_attn64p_min_wgs_plain : g_attn64p_min_wgs) = value;
         return DITTO_OK;
     }
     if (!strcmp(name, "ll_mask")) {

@@ -72,7 +72,7 @@ hipError_t launch_repack_bf16_stage_major(const void* src_bf16, void* dst, int N
 // reaches HBM).  h fp32 or bf16 rows; Wp = stage-major image of W_q for the MFMA `shape`: 32 -> group 16, 16 -> group 32.
 hipError_t launch_gemm_lnq(const void* h, int ldh, bool h_bf16, const float* gamma, const float* beta, const void* Wp,
                            const float* bias, void* out_bf16, int ldo, int M, int d, int shape, int rot_period, hipStream_t s);
-extern int g_attn64p_min_wgs;   // attention.hip
+extern int g_attn64p_min_wgs, g_attn64p_min_wgs_plain;   // attention.hip
 extern int g_lnq_waves;  // gemm_lnq.hip: waves per workgroup of the d = 768 / shape-32 kernel: 4 (one per SIMD) or 8 (two per SIMD)
 extern int g_lnq_ring;   // gemm_lnq.hip: depth of the W register ring in stages (0 = default: 4 for shape 32, 2 for shape 16; 8 / 4 = the deep rings)
 // The full-row kernel runs ONE 128-row tile per workgroup, so it needs enough rows to fill the chip: measured in the
