@@ -191,7 +191,7 @@ def step_min_seconds(cfg, B, N, T, one_off_per_step):
 # the kernel this tree launches per class at C2, B = 32 (what a committed PMC pass must have measured to be quoted)
 TRAFFIC_KERNEL = {"gemm_gated_mlp": "gemm256_kernel<3", "gemm_qkv_rope": "gemm256_kernel<2", "gemm_q_proj": "gemm_lnq_kernel<32, 4, true, 768, 8",
                   "gemm_out_proj": "gemm_frd_kernel", "gemm_fc2": "gemm_frd_kernel", "gemm_final": "gemm192_kernel<4",
-                  "attn_self": "attn64p_kernel<true", "attn_cross": "attn64p_kernel<false"}
+                  "attn_self": "attn64q_kernel<true", "attn_cross": "attn64q_kernel<false"}
 
 
 def pmc_traffic(kernel_class, B, N, T, cfg):

@@ -17,8 +17,20 @@
 //   24 .. 31                  O_A     += V(t) P_A(t)                P_B(t),   first half
 //
 // (the half-tile skew of round 3's attn64v4, at two waves per SIMD and with a third fewer vector instructions).  LDS fragments are
-// read per slot, QD slots ahead of the MFMA that takes them (no fragment is held for the other block: 32 reads per tile); the
-// per-tile barrier sits at slot 28 so that the fragment queue can run on into the next tile's K.
+// requested QD slots ahead of the MFMA that takes them, through a queue of registers that runs on over the loop's back edge (the
+// per-tile barrier sits at slot 32 - QD, so that the first K fragments of the next tile are requested behind it).  HOLD = 1 keeps a
+// tile's 8 K fragments in registers from S_A's slot to S_B's (24 LDS fragment reads per tile instead of 32; the plain form), HOLD
+// = 0 reads every fragment per use (the residual form: its epilogue needs the registers; HOLD = 2, V fragments held as well,
+// spills one fragment there, and one scratch reload in the loop counts on vmcnt with the LDS-DMA loads — every counted wait
+// becomes a drain: 165 against 117 us).  Measured (profiles/r06_attn64q.txt): C2 B = 32 in isolation 104-106 us against 117-122
+// (attn64p) and 125 (attn64v2); in the model self 110.6 / cross 104.0 against 117.0 / 116.2 (attn64p) on one box.
+//
+// ASM PAIR STEPS AND THE MFMA HAZARD.  The pair step of the steady loop is ONE asm statement (order = schedule; the compiler can
+// neither sink the adds out of the block nor pack them).  gfx950 needs software wait states between an MFMA's write of a register
+// and a vector instruction's read of it; hipcc inserts them for its own instructions and NOT for an asm statement's.  In the loop
+// every slot is pinned by sched_barriers and an asm step reads a score block whose last MFMA lies >= 4 slots (128 cycles) back.
+// The prologue and the drain, which the compiler schedules freely, use the same step written in builtins (pair_step_c): the first
+// version's asm steps there read their accumulators one MFMA short (rel-L2 2e-2, block A only).
 //
 // OPTIMISTIC SOFTMAX.  There is no running maximum: P = exp2(S) as it leaves the MFMA (q is pre-scaled: log2 units), O and l
 // accumulate unshifted and O / l at the end is the softmax — the same arithmetic as the shifted form as long as nothing leaves
@@ -236,11 +248,11 @@ __global__ __launch_bounds__(256, 2) void attn64q_kernel(AttnParams p) {
             constexpr int m = decltype(M_)::value, j = m & 7;
             if constexpr (m + QD < 32) fetch(std::integral_constant<int, m + QD>{});
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (m == ((DIAG & 64) ? 24 : 32 - QD)) {
+            if constexpr (m == 32 - QD) {
                 // tile t+1 landed (this wave's pieces; the groups of tiles t+2, t+3 may stay in flight), then for everyone; everyone is
                 // past block 2 of this iteration, so the slot of tile t-1 is free for tile t+3
                 const int last = t + 2 < nkt ? t + 2 : nkt - 1;
-                wait_groups((DIAG & 32) ? 0 : last - (t + 1));
+                wait_groups(last - (t + 1));
                 if constexpr (!(DIAG & 4)) __syncthreads();
                 if (t + 3 < nkt) dma_kv(t + 3, slot == 0 ? NBUF - 1 : slot - 1);
             }

@@ -13,6 +13,7 @@ CLASSES = [("gemm_gated_mlp", "gemm256_kernel<3"), ("gemm_qkv_rope", "gemm256_ke
            ("gemm_q_proj", "gemm_lnq_kernel"),      # round 4: norm2 fused into the q-projection (the class keeps its name)
            ("gemm_final", "gemm192_kernel<4"), ("attn_self", "attn64v2_kernel<true"), ("attn_cross", "attn64v2_kernel<false"),
            ("attn_self", "attn64p_kernel<true"), ("attn_cross", "attn64p_kernel<false"),   # round 6 (a later match overrides an earlier one)
+           ("attn_self", "attn64q_kernel<true"), ("attn_cross", "attn64q_kernel<false"),
            ("layernorm", "ln_kernel<3, 0>"), ("adaln", "ln_kernel<3, 1>"), ("p_sample_update", "p_sample_update_seeded_kernel")]
 # the cross out-projection (+ norm3) and fc2 (+ next norm1) are the SAME kernel (gemm_fr_kernel<true, true>) at K = d and
 # K = 4d: its launches are told apart by their own read traffic (fc2 reads a 4x wider A), position by position in both passes
