@@ -220,7 +220,26 @@ __global__ __launch_bounds__(256, 2) void attn64q_kernel(AttnParams p) {
             else fq[m % Q_QN] = kfrag(kb1, m >> 2, m & 3);
         });
     }
+    // The residual form on the bf16 stream fetches its rows of the stream by LDS-DMA at the top of the LAST tile, into the two ring
+    // slots that no tile will use any more (4 waves x 64 rows x 128 B = 32 KiB = two slots; every wave its own 8 KiB, chunk c of row
+    // r at position c ^ (r & 7)): the epilogue then reads data that have had a tile's time to arrive instead of issuing global
+    // loads behind the last MFMA, and no register lives across the loop for it (as prefetched VALUES the compiler spilled them to
+    // scratch on the spot).  The last tile's barrier waits with vmcnt(0) anyway.  A workgroup that falls back discards them.
     for (int t = 1; t < nkt; ++t) {
+        if constexpr (RESID && !(DIAG & 31)) {
+            if (t == nkt - 1 && p.resid_bf16) {
+                const int rs = (slot + (wid < 2 ? 1 : 2)) & (NBUF - 1);
+                const unsigned rdst = lds_base + (unsigned)(rs * 2 * KV_TILE_BYTES + (wid & 1) * KV_TILE_BYTES);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int row = 8 * i + (lane >> 3);
+                    int qr = qb * QWG + wid * 64 + row;
+                    qr = qr < p.Sq ? qr : p.Sq - 1;
+                    glds16(reinterpret_cast<const bf16*>(p.resid_in) + ((size_t)b * p.Sq + qr) * p.ldr + h * DH + (((lane & 7) ^ (row & 7)) << 3),
+                           rdst + (unsigned)(i * 1024));
+                }
+            }
+        }
         const char* kb = smem + slot * 2 * KV_TILE_BYTES;
         const char* vb = kb + KV_TILE_BYTES;
         const char* vprev = smem + (slot == 0 ? NBUF - 1 : slot - 1) * 2 * KV_TILE_BYTES + KV_TILE_BYTES;
@@ -340,7 +359,9 @@ __global__ __launch_bounds__(256, 2) void attn64q_kernel(AttnParams p) {
                 const int col = h * DH + 32 * db + 16 * k2 + 8 * hh;
                 if constexpr (RESID) {
                     if (p.resid_bf16) {
-                        const u32x4 w = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16*>(p.resid_in) + grow * p.ldr + col);
+                        const int rs = (slot + (wid < 2 ? 0 : 1)) & (NBUF - 1);     // (slot has moved on by one since the last tile's top)
+                        const int rr = 32 * x + ql, ch = 4 * db + 2 * k2 + hh;
+                        const u32x4 w = *reinterpret_cast<const u32x4*>(smem + rs * 2 * KV_TILE_BYTES + (wid & 1) * KV_TILE_BYTES + rr * 128 + ((ch ^ (rr & 7)) << 4));
                         u32x4 o4;
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
