@@ -141,6 +141,24 @@ def test_full_row_plan_is_judged_per_launch_and_pinnable():
         hip.set_option("fr_class_rows", -1)
 
 
+def test_attention_kernel_thresholds_are_validated_options():
+    """Round 6: the grids from which the 64-queries-per-wave attention kernels run (attn64p / attn64q) are two process defaults,
+    one for the residual form (self-attention) and one for the plain form (cross-attention); both are read back, both refuse
+    values below 1.  Host arithmetic only: no GPU call."""
+    a, b = hip.get_option("attn64p_min_wgs"), hip.get_option("attn64p_min_wgs_plain")
+    assert (a, b) == (768, 192) or "DITTO_ATTN64P_MIN_WGS" in "".join(__import__("os").environ)
+    try:
+        hip.set_option("attn64p_min_wgs", 512)
+        hip.set_option("attn64p_min_wgs_plain", 96)
+        assert hip.get_option("attn64p_min_wgs") == 512 and hip.get_option("attn64p_min_wgs_plain") == 96
+        for name in ("attn64p_min_wgs", "attn64p_min_wgs_plain"):
+            with pytest.raises(hip.DittoHipError):
+                hip.set_option(name, 0)
+    finally:
+        hip.set_option("attn64p_min_wgs", a)
+        hip.set_option("attn64p_min_wgs_plain", b)
+
+
 def test_call_options_are_per_call_and_per_thread():
     """ABI 9: the switches that decide which bits an utterance gets — kernel class pin, residual-stream
     type, fused launches — are a ditto_call_opts ARGUMENT or a scope of the CALLING THREAD (ditto_call_opts_push / _pop), not
