@@ -25,6 +25,13 @@
 // becomes a drain: 165 against 117 us).  Measured (profiles/r06_attn64q.txt): C2 B = 32 in isolation 104-106 us against 117-122
 // (attn64p) and 125 (attn64v2); in the model self 110.6 / cross 104.0 against 117.0 / 116.2 (attn64p) on one box.
 //
+// WHAT BOUNDS IT.  v_exp_f32 is quarter rate (16 cycles per wave64 instruction): a pair step is 2 x 16 + 3 x 4 = 44 cycles of vector
+// issue against the MFMA's 32, so the stream is bound by the vector pipe, 73 % of it transcendentals (measured 42.6 per SIMD).  Tried
+// on top (profiles/r06_coissue.txt, r06_attn64q.txt): the row sums on the matrix pipe (8 all-ones MFMAs per tile, pair step of
+// {exp, exp, cvt} = 35 cycles, 40 slots): 111 against 105 us — the other per-slot costs scale with the MFMA count; v_dot2(c)_f32_bf16
+// for the sums: waits for the matrix pipe (49 cycles per step); consumers one step behind their exponentials: -3 % in the
+// microbenchmark, not built.
+//
 // ASM PAIR STEPS AND THE MFMA HAZARD.  The pair step of the steady loop is ONE asm statement (order = schedule; the compiler can
 // neither sink the adds out of the block nor pack them).  gfx950 needs software wait states between an MFMA's write of a register
 // and a vector instruction's read of it; hipcc inserts them for its own instructions and NOT for an asm statement's.  In the loop

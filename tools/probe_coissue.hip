@@ -47,6 +47,17 @@ __device__ __forceinline__ void pair_step(float& x0, float& x1, float& l0, float
         asm volatile("v_add_f32 %0, 1.5, %0\n\tv_add_f32 %1, 2.5, %1" : "+v"(l0), "+v"(l1));
         asm volatile("" : "+v"(e0), "+v"(e1));
         p = __builtin_bit_cast(unsigned, e0) & __builtin_bit_cast(unsigned, e1);
+    } else if constexpr (VMIX == 10) {  // 2 exp, cvt_pk, row sum of the ROUNDED pair by v_dot2c_f32_bf16
+        e0 = __builtin_amdgcn_exp2f(x0); e1 = __builtin_amdgcn_exp2f(x1);
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p) : "v"(e0), "v"(e1));
+        asm volatile("v_dot2c_f32_bf16 %0, 0x3f803f80, %1" : "+v"(l0) : "v"(p));
+    } else if constexpr (VMIX == 11) {  // the same with the three-operand v_dot2_f32_bf16
+        e0 = __builtin_amdgcn_exp2f(x0); e1 = __builtin_amdgcn_exp2f(x1);
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p) : "v"(e0), "v"(e1));
+        asm volatile("v_dot2_f32_bf16 %0, %1, %2, %0" : "+v"(l0) : "v"(p), "v"(0x3f803f80u));
+    } else if constexpr (VMIX == 12) {  // 2 exp, cvt_pk (no row sum)
+        e0 = __builtin_amdgcn_exp2f(x0); e1 = __builtin_amdgcn_exp2f(x1);
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p) : "v"(e0), "v"(e1));
     } else if constexpr (VMIX == 8) {   // 2 exp, 2 add, truncating pack by v_perm_b32
         e0 = __builtin_amdgcn_exp2f(x0); e1 = __builtin_amdgcn_exp2f(x1);
         l0 += e0; l1 += e1;
@@ -146,6 +157,23 @@ __global__ __launch_bounds__(512, 2) void k(float* out, unsigned long long* cyc,
     if (lane == 0) cyc[blockIdx.x * 8 + wid] = t1 - t0;
 }
 
+// the pair step with its consumers one step late: this step's exponentials, then the adds and the convert of the PREVIOUS step's
+// results (no instruction waits for a transcendental issued just before it).  ORDER 0: exps first; 1: consumers first
+template <int ORDER>
+__device__ __forceinline__ void pair_step_late(float& x0, float& x1, float& l0, float& l1, unsigned& pk, float& ep0, float& ep1) {
+    float n0, n1;
+    unsigned p;
+    if constexpr (ORDER == 0)
+        asm volatile("v_exp_f32 %0, %5\n\tv_exp_f32 %1, %6\n\tv_add_f32 %2, %2, %7\n\tv_add_f32 %3, %3, %8\n\tv_cvt_pk_bf16_f32 %4, %7, %8"
+                     : "=&v"(n0), "=&v"(n1), "+v"(l0), "+v"(l1), "=&v"(p) : "v"(x0), "v"(x1), "v"(ep0), "v"(ep1));
+    else
+        asm volatile("v_add_f32 %2, %2, %7\n\tv_add_f32 %3, %3, %8\n\tv_cvt_pk_bf16_f32 %4, %7, %8\n\tv_exp_f32 %0, %5\n\tv_exp_f32 %1, %6"
+                     : "=&v"(n0), "=&v"(n1), "+v"(l0), "+v"(l1), "=&v"(p) : "v"(x0), "v"(x1), "v"(ep0), "v"(ep1));
+    ep0 = n0; ep1 = n1;
+    pk ^= p;
+    asm volatile("" : "+v"(x0), "+v"(x1));
+}
+
 // the SAME wave issues both: one pair step of the vector mix behind every MFMA
 template <int VMIX>
 __global__ __launch_bounds__(512, 2) void ksame(float* out, unsigned long long* cyc, const float* in, int iters) {
@@ -155,9 +183,14 @@ __global__ __launch_bounds__(512, 2) void ksame(float* out, unsigned long long* 
     for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(seed + i); b[i] = (__bf16)(seed * 0.5f - i); }
     f32x16 c0, c1, c2, c3;
     for (int i = 0; i < 16; ++i) { c0[i] = 0.f; c1[i] = 0.f; c2[i] = 0.f; c3[i] = 0.f; }
-    float x[8], l0 = 0.f, l1 = 0.f;
+    float x[8], l0 = 0.f, l1 = 0.f, ep0 = 1.f, ep1 = 1.f;
     unsigned pk = 0;
     for (int i = 0; i < 8; ++i) x[i] = seed * (i + 1) * 1e-3f;
+    auto step = [&](float& a0, float& a1) {
+        if constexpr (VMIX == 13) pair_step_late<0>(a0, a1, l0, l1, pk, ep0, ep1);
+        else if constexpr (VMIX == 14) pair_step_late<1>(a0, a1, l0, l1, pk, ep0, ep1);
+        else pair_step<VMIX>(a0, a1, l0, l1, pk);
+    };
     unsigned long long t0, t1;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0));
     for (int it = 0; it < iters; ++it) {
@@ -165,24 +198,24 @@ __global__ __launch_bounds__(512, 2) void ksame(float* out, unsigned long long* 
         for (int u = 0; u < 4; ++u) {
             c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            pair_step<VMIX>(x[0], x[1], l0, l1, pk);
+            step(x[0], x[1]);
             __builtin_amdgcn_sched_barrier(0);
             c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c1, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            pair_step<VMIX>(x[2], x[3], l0, l1, pk);
+            step(x[2], x[3]);
             __builtin_amdgcn_sched_barrier(0);
             c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c2, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            pair_step<VMIX>(x[4], x[5], l0, l1, pk);
+            step(x[4], x[5]);
             __builtin_amdgcn_sched_barrier(0);
             c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c3, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            pair_step<VMIX>(x[6], x[7], l0, l1, pk);
+            step(x[6], x[7]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1));
-    out[blockIdx.x * 512 + tid] = c0[0] + c1[1] + c2[2] + c3[3] + l0 + l1 + __builtin_bit_cast(float, pk);
+    out[blockIdx.x * 512 + tid] = c0[0] + c1[1] + c2[2] + c3[3] + l0 + l1 + ep0 + ep1 + __builtin_bit_cast(float, pk);
     if (lane == 0) cyc[blockIdx.x * 8 + wid] = t1 - t0;
 }
 
@@ -253,5 +286,11 @@ int main() {
     run_same<3>("2 v_exp + 2 v_add", out, cyc, in);
     run_same<1>("4 v_add", out, cyc, in);
     run_same<2>("2 v_exp", out, cyc, in);
+    run_same<12>("2 v_exp + v_cvt_pk", out, cyc, in);
+    run_same<10>("2 v_exp + v_cvt_pk + v_dot2c_f32_bf16", out, cyc, in);
+    run_same<11>("2 v_exp + v_cvt_pk + v_dot2_f32_bf16", out, cyc, in);
+    run_same<7>("v_dot2c_f32_bf16", out, cyc, in);
+    run_same<13>("2 v_exp | add, add, cvt of the PREVIOUS pair", out, cyc, in);
+    run_same<14>("add, add, cvt of the PREVIOUS pair | 2 v_exp", out, cyc, in);
     return 0;
 }
