@@ -19,9 +19,9 @@ hipError_t launch_attn64p(const AttnParams& p_in, bool resid, hipStream_t s, boo
     AttnParams p = p_in;
     p.nqb = (p.Sq + 255) / 256;
     const dim3 grid(p.nqb * p.H * p.B), block(256);
-    // whole key tiles, at least two: attn64q (attn64q.h: one software-pipelined stream per wave, optimistic softmax with attn64p's
+    // at least two key tiles (the last may be partial): attn64q (attn64q.h: one software-pipelined stream per wave, optimistic softmax with attn64p's
     // loop as the exact path of a workgroup whose rows left the range).  A rule on the SHAPE only.  attn_flags 1048576 = never.
-    if (no_q != 1 && !ring3 && p.Skv % KBLK == 0 && p.Skv >= 2 * KBLK) {
+    if (no_q != 1 && !ring3 && p.Skv > KBLK) {
         // K fragments held for block B (24 LDS fragment reads per tile instead of 32) in the plain form, not in the residual form:
         // in-model A/B at C2, self (residual form) 110.6 against 116.5 us without them, cross (plain) 104.0 against 106.0 with
         // them (profiles/r06_attn64q.txt).  A rule on the instantiation, not on the data.  attn_flags 2097152 swaps the two (A/B).

@@ -46,7 +46,8 @@
 // agrees through one LDS word, and if any row failed the WHOLE workgroup redoes its block with the exact tile loop (attn64p's:
 // running maximum, deferred raise) before anything is stored.  Fast path and exact path differ only by fp32 rounding.
 //
-// Contract: as attn64p, plus Skv % 64 == 0 and Skv >= 128 (whole tiles, at least two); the launcher sends other shapes to attn64p.
+// Contract: as attn64p, plus Skv >= 65 (at least two tiles; the last may be partial: its iteration is a second copy of the loop body
+// whose score chains start from -inf on the missing key rows); the launcher sends shorter key sequences to attn64p.
 #pragma once
 
 constexpr int Q_QD = 4;   // fragments are requested this many slots ahead of their MFMA
@@ -85,7 +86,8 @@ __global__ __launch_bounds__(256, 2) void attn64q_kernel(AttnParams p) {
         qvalid[x] = qrow[x] < p.Sq;
         qrow[x] = qvalid[x] ? qrow[x] : p.Sq - 1;
     }
-    const int nkt = p.Skv / KBLK;
+    const int nkt = (p.Skv + KBLK - 1) / KBLK;
+    const bool ragged = (p.Skv % KBLK) != 0;       // the last tile is partial: its DMA rows are clamped, its scores start from -inf
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
     bf16x8 qf[2][4];
 #pragma unroll
@@ -104,6 +106,21 @@ __global__ __launch_bounds__(256, 2) void attn64q_kernel(AttnParams p) {
     const size_t kstep = (size_t)KBLK * p.ldk, vstep = (size_t)KBLK * p.ldv;
     auto dma_kv = [&](int kt, int slot) {   // 4 loads per wave
         if constexpr (DIAG & 2) return;
+        if (ragged && kt == nkt - 1) {      // rows past Skv are clamped (never read out of bounds; finite values under P = 0)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int piece = wid * 2 + i;
+                const int row = piece * 8 + (lane >> 3), cpos = lane & 7;
+                int key = kt * KBLK + row;
+                key = key < p.Skv ? key : p.Skv - 1;
+                const int ck = cpos ^ ((row >> 1) & 7), cv = cpos ^ (((row >> 1) & 1) << 2);
+                glds16(p.k + ((size_t)b * p.Skv + key) * p.ldk + h * DH + ck * 8,
+                       lds_base + (unsigned)(slot * 2 * KV_TILE_BYTES + piece * 1024));
+                glds16(p.v + ((size_t)b * p.Skv + key) * p.ldv + h * DH + cv * 8,
+                       lds_base + (unsigned)(slot * 2 * KV_TILE_BYTES + KV_TILE_BYTES + piece * 1024));
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int piece = wid * 2 + i;
@@ -232,7 +249,18 @@ __global__ __launch_bounds__(256, 2) void attn64q_kernel(AttnParams p) {
     // r at position c ^ (r & 7)): the epilogue then reads data that have had a tile's time to arrive instead of issuing global
     // loads behind the last MFMA, and no register lives across the loop for it (as prefetched VALUES the compiler spilled them to
     // scratch on the spot).  The last tile's barrier waits with vmcnt(0) anyway.  A workgroup that falls back discards them.
-    for (int t = 1; t < nkt; ++t) {
+    auto iteration = [&](auto MASKED_, const int t) {
+        constexpr bool MASKED = decltype(MASKED_)::value;
+        // the partial last tile: its score chains start from -inf on the key rows past Skv (P = exp2(-inf) = 0: no instruction in the
+        // pair steps, 32 registers that exist in this copy of the iteration only)
+        f32x16 zmask[MASKED ? 2 : 1];
+        if constexpr (MASKED) {
+            const int rem = p.Skv - (nkt - 1) * KBLK;
+#pragma unroll
+            for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) zmask[kb2][i] = (32 * kb2 + 8 * (i >> 2) + 4 * hh + (i & 3)) < rem ? 0.f : -__builtin_inff();
+        }
         if constexpr (RESID && !(DIAG & 31)) {
             if (t == nkt - 1 && p.resid_bf16) {
                 const int rs = (slot + (wid < 2 ? 1 : 2)) & (NBUF - 1);
@@ -288,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void attn64q_kernel(AttnParams p) {
                 f32x16 z;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) z[i] = 0.f;
-                st[0][j >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, qf[0][j & 3], (j & 3) == 0 ? z : st[0][j >> 2], 0, 0, 0);
+                st[0][j >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, qf[0][j & 3], (j & 3) == 0 ? (MASKED ? zmask[MASKED ? (j >> 2) : 0] : z) : st[0][j >> 2], 0, 0, 0);
                 pair_step(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, j>{});
             } else if constexpr (m < 16) {
                 ot[1][j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, __builtin_bit_cast(bf16x8, pp[1][j >> 1]), ot[1][j & 1], 0, 0, 0);
@@ -297,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void attn64q_kernel(AttnParams p) {
                 f32x16 z;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) z[i] = 0.f;
-                st[1][j >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, qf[1][j & 3], (j & 3) == 0 ? z : st[1][j >> 2], 0, 0, 0);
+                st[1][j >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, qf[1][j & 3], (j & 3) == 0 ? (MASKED ? zmask[MASKED ? (j >> 2) : 0] : z) : st[1][j >> 2], 0, 0, 0);
                 pair_step(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, j>{});
             } else {
                 ot[0][j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, __builtin_bit_cast(bf16x8, pp[0][j >> 1]), ot[0][j & 1], 0, 0, 0);
@@ -306,7 +334,9 @@ __global__ __launch_bounds__(256, 2) void attn64q_kernel(AttnParams p) {
             __builtin_amdgcn_sched_barrier(0);
         });
         slot = nslot;
-    }
+    };
+    for (int t = 1; t < nkt - (ragged ? 1 : 0); ++t) iteration(std::false_type{}, t);
+    if (ragged) iteration(std::true_type{}, nkt - 1);
     // ---- drain: second half of P_B(last), O_B += V(last) P_B(last) ----
     {
         const int ls = slot == 0 ? NBUF - 1 : slot - 1;

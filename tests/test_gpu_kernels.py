@@ -282,10 +282,11 @@ def test_attention_pipelined_kernel_is_bitwise_the_tile_loop_kernel(lib, B, H, S
 
 
 @pytest.mark.parametrize("B,H,Sq,Skv", [(1, 2, 128, 128), (2, 3, 200, 256), (1, 12, 1024, 1024), (1, 2, 333, 2048),
-                                        (2, 2, 1000, 1000), (1, 1, 40, 1), (3, 12, 512, 96), (8, 12, 1024, 1024)])
+                                        (2, 2, 1000, 1000), (1, 1, 40, 1), (3, 12, 512, 96), (8, 12, 1024, 1024),
+                                        (2, 3, 300, 65), (1, 2, 256, 127), (2, 2, 100, 129), (1, 3, 512, 191), (1, 4, 700, 1023)])
 def test_attention_64_queries_per_wave_kernel(lib, B, H, Sq, Skv):
     """attn64p and attn64q (round 6, csrc/attn64p.h / attn64q.h: 64 queries per wave, fp32 row sums, the wide epilogue; attn64q = one
-    software-pipelined stream per wave with the optimistic softmax, where Skv is whole tiles) against attn64v2 on the same operands
+    software-pipelined stream per wave with the optimistic softmax, from two key tiles on, the last one possibly partial) against attn64v2 on the same operands
     — same products, other associations of the row sum only: within bf16-output noise — against torch, and against themselves
     (bitwise repeatable).  Ragged query and key counts, rows with forced raises of the running maximum (for attn64q: logits of
     ~ 30 .. 60 in log2 units, still inside its range).  (The residual epilogues — the self-attention's in-place update on the fp32
@@ -303,7 +304,7 @@ def test_attention_64_queries_per_wave_kernel(lib, B, H, Sq, Skv):
     k, v = bf16(k.to(DEV)), bf16(v.to(DEV))
     outs = []
     try:
-        # attn64v2; the round-6 kernels as dispatched (attn64q where Skv % 64 == 0 and Skv >= 128, else attn64p), twice; attn64p always
+        # attn64v2; the round-6 kernels as dispatched (attn64q from 65 keys on — a partial last tile included —, else attn64p), twice; attn64p always
         for flags in (16 + 256 + 131072, 16 + 262144, 16 + 262144, 16 + 262144 + 1048576):
             hip.check(lib.ditto_set_option(b"attn_flags", flags))
             out = torch.full((B * Sq, d), float("nan"), dtype=torch.bfloat16, device=DEV)
@@ -318,17 +319,18 @@ def test_attention_64_queries_per_wave_kernel(lib, B, H, Sq, Skv):
         assert rel_l2(o.float(), want) < 1.5e-2 and max_abs(o.float(), want) < 6e-2
     assert torch.equal(outs[1], outs[2]), "not repeatable"
     assert rel_l2(outs[1].float(), outs[0].float()) < 4e-3 and rel_l2(outs[3].float(), outs[0].float()) < 4e-3
-    if Skv % 64 or Skv < 128:
-        assert torch.equal(outs[1], outs[3]), "ragged key counts run attn64p"
+    if Skv <= 64:
+        assert torch.equal(outs[1], outs[3]), "a single key tile runs attn64p"
 
 
+@pytest.mark.parametrize("Skv", [512, 471])
 @pytest.mark.parametrize("case", ["overflow", "underflow", "nan", "mixed"])
-def test_attention_optimistic_softmax_leaves_its_range(lib, case):
+def test_attention_optimistic_softmax_leaves_its_range(lib, case, Skv):
     """attn64q keeps no running maximum: P = exp2(S) unshifted, and a workgroup whose row sums left [2^-100, 2^100] (or are NaN) starts
     over on attn64p's exact loop before it stores anything.  Logits far above the range (every probability overflows), far below
     (every probability underflows: l = 0), NaN inputs, and a batch in which only some workgroups leave the range: the result is
     attn64p's, bit for bit where the workgroup fell back, and within rounding of it elsewhere."""
-    B, H, Sq, Skv, dh = 2, 4, 512, 512, 64
+    B, H, Sq, dh = 2, 4, 512, 64       # Skv = 471: the partial last tile's copy of the loop (masked score chains) on both paths
     d = H * dh
     q = asym((B * Sq, d), 61) * 0.7
     k = asym((B * Skv, d), 62) * 0.7
