@@ -408,6 +408,12 @@ class DenoiseEngine:
         if piece_cb is None:
             self._call("ditto_train_backward", *args, opts=opts)
             return grads
+        if not hip._has_call_opts():
+            # a frozen pre-ABI-9 library (DITTO_HIP_LIB) has no ditto_train_backward_layers: one call, then every tensor as one piece
+            # (the caller's exchange then simply runs after the backward instead of under it)
+            self._call("ditto_train_backward", *args, opts=opts)
+            piece_cb(list(grads.values()))
+            return grads
         head = ("proj_in.weight", "proj_in.bias", "proj_out.weight", "proj_out.bias")     # written by the piece that starts at the top
         tail = [k for f, k in hip.GLOBAL_KEY.items() if f != "rotary_inv_freq" and k not in head]   # ... that ends at layer 0
         step = max(int(layers_per_piece), 1)
