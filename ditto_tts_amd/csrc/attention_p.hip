@@ -26,7 +26,10 @@ hipError_t launch_attn64p(const AttnParams& p_in, bool resid, hipStream_t s, boo
         // in-model A/B at C2, self (residual form) 110.6 against 116.5 us without them, cross (plain) 104.0 against 106.0 with
         // them (profiles/r06_attn64q.txt).  A rule on the instantiation, not on the data.  attn_flags 2097152 swaps the two (A/B).
         const bool hold = (no_q == 2) ? resid : !resid;
-        if (resid) {
+        if (p.Skv % KBLK) {     // a partial last tile: the instantiation with the masked copy of the loop body (no fragment held)
+            if (resid) hipLaunchKernelGGL((attn64q_kernel<true, 0, Q_QD, true, 0, true>), grid, block, 0, s, p);
+            else hipLaunchKernelGGL((attn64q_kernel<false, 0, Q_QD, true, 0, true>), grid, block, 0, s, p);
+        } else if (resid) {
             if (hold) hipLaunchKernelGGL((attn64q_kernel<true, 0, Q_QD, true, 1>), grid, block, 0, s, p);
             else hipLaunchKernelGGL((attn64q_kernel<true, 0, Q_QD, true, 0>), grid, block, 0, s, p);
         } else {

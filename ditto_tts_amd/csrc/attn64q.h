@@ -65,7 +65,7 @@ template <int N, class F>
 DITTO_DEV void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 #endif
 
-template <bool RESID, int DIAG = 0, int QD = Q_QD, bool WRAP = true, int HOLD = Q_HOLD>
+template <bool RESID, int DIAG = 0, int QD = Q_QD, bool WRAP = true, int HOLD = Q_HOLD, bool RAGGED = false>
 __global__ __launch_bounds__(256, 2) void attn64q_kernel(AttnParams p) {
     constexpr int NBUF = 4, QWG = 256;
     __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * KV_TILE_BYTES];  // [slot][K|V]
@@ -87,7 +87,10 @@ __global__ __launch_bounds__(256, 2) void attn64q_kernel(AttnParams p) {
         qrow[x] = qvalid[x] ? qrow[x] : p.Sq - 1;
     }
     const int nkt = (p.Skv + KBLK - 1) / KBLK;
-    const bool ragged = (p.Skv % KBLK) != 0;       // the last tile is partial: its DMA rows are clamped, its scores start from -inf
+    // RAGGED instantiation: the last tile may be partial — its DMA rows are clamped, its scores start from -inf.  (Its own instantiation:
+    // the second copy of the loop body raises the register pressure in front of the loop, and in the plain form that put a scratch
+    // reload there whose vmcnt wait hipcc then keeps INSIDE the loop — a drain of the LDS-DMA pipeline per tile, 145 against 102 us.)
+    const bool ragged = RAGGED && (p.Skv % KBLK) != 0;
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
     bf16x8 qf[2][4];
 #pragma unroll
@@ -311,24 +314,35 @@ __global__ __launch_bounds__(256, 2) void attn64q_kernel(AttnParams p) {
                 if (t + 3 < nkt) dma_kv(t + 3, slot == 0 ? NBUF - 1 : slot - 1);
             }
             if constexpr (WRAP && m + QD >= 32) fetch(std::integral_constant<int, m + QD>{});   // (past the last tile: a read of a dead slot)
-            const bf16x8 f = HOLD == 2 ? ((m & 8) ? vh[j] : kh[j]) : HOLD == 1 ? ((m & 8) ? fq[m % Q_QN] : kh[j]) : fq[m % Q_QN];
+            bf16x8 f;
+            if constexpr (HOLD == 2) { if constexpr ((m & 8) != 0) f = vh[j]; else f = kh[j]; }
+            else if constexpr (HOLD == 1) { if constexpr ((m & 8) != 0) f = fq[m % Q_QN]; else f = kh[j]; }
+            else f = fq[m % Q_QN];
             if constexpr (m < 8) {
                 f32x16 z;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) z[i] = 0.f;
                 st[0][j >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, qf[0][j & 3], (j & 3) == 0 ? (MASKED ? zmask[MASKED ? (j >> 2) : 0] : z) : st[0][j >> 2], 0, 0, 0);
+
+                __builtin_amdgcn_sched_barrier(0);      // the MFMA first: the pair step issues under it
                 pair_step(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, j>{});
             } else if constexpr (m < 16) {
                 ot[1][j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, __builtin_bit_cast(bf16x8, pp[1][j >> 1]), ot[1][j & 1], 0, 0, 0);
+
+                __builtin_amdgcn_sched_barrier(0);      // the MFMA first: the pair step issues under it
                 pair_step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, j>{});
             } else if constexpr (m < 24) {
                 f32x16 z;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) z[i] = 0.f;
                 st[1][j >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, qf[1][j & 3], (j & 3) == 0 ? (MASKED ? zmask[MASKED ? (j >> 2) : 0] : z) : st[1][j >> 2], 0, 0, 0);
+
+                __builtin_amdgcn_sched_barrier(0);      // the MFMA first: the pair step issues under it
                 pair_step(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, j>{});
             } else {
                 ot[0][j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, __builtin_bit_cast(bf16x8, pp[0][j >> 1]), ot[0][j & 1], 0, 0, 0);
+
+                __builtin_amdgcn_sched_barrier(0);      // the MFMA first: the pair step issues under it
                 pair_step(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, j>{});
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -336,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void attn64q_kernel(AttnParams p) {
         slot = nslot;
     };
     for (int t = 1; t < nkt - (ragged ? 1 : 0); ++t) iteration(std::false_type{}, t);
-    if (ragged) iteration(std::true_type{}, nkt - 1);
+    if constexpr (RAGGED) { if (ragged) iteration(std::true_type{}, nkt - 1); }
     // ---- drain: second half of P_B(last), O_B += V(last) P_B(last) ----
     {
         const int ls = slot == 0 ? NBUF - 1 : slot - 1;
@@ -346,7 +360,11 @@ __global__ __launch_bounds__(256, 2) void attn64q_kernel(AttnParams p) {
         for (int s2 = 0; s2 < 4; ++s2)
 #pragma unroll
             for (int db = 0; db < 2; ++db)
-                ot[1][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(HOLD == 2 ? vh[s2 * 2 + db] : vfrag(vb, s2, db), __builtin_bit_cast(bf16x8, pp[1][s2]), ot[1][db], 0, 0, 0);
+            {
+                bf16x8 vf;
+                if constexpr (HOLD == 2) vf = vh[(s2 * 2 + db) & (HOLD == 2 ? 7 : 0)]; else vf = vfrag(vb, s2, db);
+                ot[1][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pp[1][s2]), ot[1][db], 0, 0, 0);
+            }
     }
 
     // ---- did every row stay inside fp32's comfortable range?  l in [2^-100, 2^100]: no probability overflowed, and every one that

@@ -94,7 +94,9 @@ int main(int argc, char** argv) {
         switch (var) {
             case 0: hipLaunchKernelGGL((attn64v2_kernel<false, 3>), grid, blk, 0, st, pp); break;
             case 1: hipLaunchKernelGGL((attn64p_kernel<false, 4>), grid, blk, 0, st, pp); break;
-            case 2: hipLaunchKernelGGL((attn64q_kernel<false>), grid, blk, 0, st, pp); break;
+            case 2: if (Skv % 64) hipLaunchKernelGGL((attn64q_kernel<false, 0, 4, true, 0, true>), grid, blk, 0, st, pp);
+                    else hipLaunchKernelGGL((attn64q_kernel<false>), grid, blk, 0, st, pp);
+                    break;
             case 3: hipLaunchKernelGGL((attn64q_kernel<false, 0, 4, true, true>), grid, blk, 0, st, pp); break;
             case 4: hipLaunchKernelGGL((attn64q_kernel<false, 0, 6, true, true>), grid, blk, 0, st, pp); break;
             case 5: hipLaunchKernelGGL((attn64q_kernel<false, 1>), grid, blk, 0, st, pp); break;
