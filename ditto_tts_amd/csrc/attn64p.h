@@ -150,6 +150,13 @@ DITTO_DEV void attn64p_body(const AttnParams& p, char* smem, int tid, int bid) {
     //      workgroup and nothing computes meanwhile (probe, same process: 121.0 -> 114.7 us warm, 130.4 -> 123.8 from HBM) ----
     dma_kv(0, 0);
     wait_groups(0);
+    // The Q fragments are global loads whose first use is INSIDE the tile loop: hipcc then keeps their `s_waitcnt vmcnt(3) .. (0)` in
+    // the loop body, where they drain the LDS-DMA pipeline once per tile (rounds 6's first builds ran that way: tools/check_attn_loop.py).
+    // A use in front of the loop moves the compiler's wait here, next to the vmcnt(0) above.
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[x][ks]));
     if constexpr (DIAG & 2) {   // (knock-out: every slot holds a tile, no traffic in the loop)
 #pragma unroll
         for (int t0 = 1; t0 < NBUF; ++t0) dma_kv(t0 < nkt ? t0 : 0, t0);
